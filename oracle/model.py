@@ -1,0 +1,237 @@
+"""Oracle restatement of the reference FastSpeech2 module tree (default branch only).
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.  Plain eager PyTorch, same state_dict keys and
+registration order as the reference, so the fixture weights load into it unchanged.
+Citations are file:line of /root/reference (syoamakase/Transformer_TTS).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def positional_table(d_model, max_seq_len=5000):
+    """Models/modules.py:97-105: pe[pos,i]=sin(pos/10000^(2i/d)), pe[pos,i+1]=cos(pos/10000^(2(i+1)/d))
+    for even i (the exponent uses 2*i, not i), evaluated in Python floats and stored as fp32."""
+    pos = np.arange(max_seq_len, dtype=np.float64)[:, None]
+    i = np.arange(0, d_model, 2, dtype=np.float64)[None, :]
+    pe = np.zeros((max_seq_len, d_model), np.float64)
+    pe[:, 0::2] = np.sin(pos / (10000.0 ** ((2.0 * i) / d_model)))
+    pe[:, 1::2] = np.cos(pos / (10000.0 ** ((2.0 * (i + 1.0)) / d_model)))
+    return torch.from_numpy(pe.astype(np.float32))
+
+
+class PositionalEncoder(nn.Module):
+    """Models/modules.py:90-111: x + alpha * pe[:t], then dropout; pe is not a buffer."""
+
+    def __init__(self, d_model, max_seq_len=5000, dropout=0.1):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(1))
+        self.drop = dropout
+        self.pe = positional_table(d_model, max_seq_len)
+
+    def forward(self, x):
+        pe = self.pe[: x.shape[1]].to(x.dtype)
+        return F.dropout(x + self.alpha * pe, self.drop, self.training)
+
+
+def attention(q, k, v, d_k, key_mask, p_drop):
+    """Models/modules.py:7-21.  key_mask (B,1,t) bool; -1e4 fill on masked KEYS only; the dropout on
+    the probabilities is F.dropout with its default training=True, i.e. active even in eval()."""
+    s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(d_k)
+    s = s.masked_fill(key_mask.unsqueeze(1) == 0, -1e4)
+    p = torch.softmax(s, dim=-1)
+    p = F.dropout(p, p_drop, True)
+    return torch.matmul(p, v), p
+
+
+class MultiHeadAttention(nn.Module):
+    """Models/modules.py:23-70 (concat_after=False).  Registration order q, v, k, out (:32-41)."""
+
+    def __init__(self, heads, d_model, dropout):
+        super().__init__()
+        self.h, self.d_k, self.p = heads, d_model // heads, dropout
+        self.q_linear = nn.Linear(d_model, d_model)
+        self.v_linear = nn.Linear(d_model, d_model)
+        self.k_linear = nn.Linear(d_model, d_model)
+        self.out = nn.Linear(d_model, d_model)
+
+    def forward(self, x, key_mask):
+        b, t, d = x.shape
+        split = lambda y: y.view(b, t, self.h, self.d_k).transpose(1, 2)
+        o, p = attention(split(self.q_linear(x)), split(self.k_linear(x)), split(self.v_linear(x)),
+                         self.d_k, key_mask, self.p)
+        return self.out(o.transpose(1, 2).reshape(b, t, d)), p
+
+
+class FeedForward(nn.Module):
+    """Models/modules.py:72-88: LN(dropout(conv2(relu(conv1(x))) + x)) -- its own residual and LN."""
+
+    def __init__(self, d_model, k, dropout):
+        super().__init__()
+        self.f_1 = nn.Conv1d(d_model, 4 * d_model, k, padding=k // 2)
+        self.f_2 = nn.Conv1d(4 * d_model, d_model, k, padding=k // 2)
+        self.layer_norm = nn.LayerNorm(d_model)
+        self.p = dropout
+
+    def forward(self, x):
+        y = self.f_2(F.relu(self.f_1(x.transpose(1, 2)))).transpose(1, 2)
+        return self.layer_norm(F.dropout(y + x, self.p, self.training))
+
+
+class EncoderLayer(nn.Module):
+    """Models/layers.py:8-41 (single speaker): pre-LN attention and FFN blocks with outer residuals."""
+
+    def __init__(self, d_model, heads, k, dropout):
+        super().__init__()
+        self.norm_1 = nn.LayerNorm(d_model)
+        self.norm_2 = nn.LayerNorm(d_model)
+        self.attn = MultiHeadAttention(heads, d_model, dropout)
+        self.ff = FeedForward(d_model, k, dropout)
+        self.p = dropout
+
+    def forward(self, x, key_mask):
+        a, p = self.attn(self.norm_1(x), key_mask)
+        x = x + F.dropout(a, self.p, self.training)
+        x = x + F.dropout(self.ff(self.norm_2(x)), self.p, self.training)
+        return x, p
+
+
+class Encoder(nn.Module):
+    """Models/encoder.py:31-112: embed (Embedding pad 0 | Linear) -> PE -> N layers -> LayerNorm;
+    attention maps of all layers stacked to (B,N,H,t,t) (:97,105)."""
+
+    def __init__(self, vocab, d_model, N, heads, k, dropout, embedding=True):
+        super().__init__()
+        self.embed = nn.Embedding(vocab, d_model, padding_idx=0) if embedding else nn.Linear(vocab, d_model)
+        self.pe = PositionalEncoder(d_model, dropout=dropout)
+        self.layers = nn.ModuleList([EncoderLayer(d_model, heads, k, dropout) for _ in range(N)])
+        self.norm = nn.LayerNorm(d_model)
+
+    def forward(self, src, key_mask):
+        x = self.pe(self.embed(src))
+        attns = []
+        for layer in self.layers:
+            x, p = layer(x, key_mask)
+            attns.append(p)
+        return self.norm(x), torch.stack(attns, dim=1)
+
+
+class VariancePredictor(nn.Module):
+    """Models/varianceadaptor.py:186-231: conv3-ReLU-LN-drop, conv3-ReLU-LN-drop, Linear(256->1),
+    masked_fill(mask==0, 0)."""
+
+    def __init__(self, d_in, filt=256, k=3, dropout=0.5):
+        super().__init__()
+        self.conv1 = nn.Conv1d(d_in, filt, k, padding=1)
+        self.layer_norm1 = nn.LayerNorm(filt)
+        self.conv2 = nn.Conv1d(filt, filt, k, padding=1)
+        self.layer_norm2 = nn.LayerNorm(filt)
+        self.linear_layer = nn.Linear(filt, 1)
+        self.p = dropout
+
+    def forward(self, x, mask):
+        x = F.relu(self.conv1(x.transpose(1, 2))).transpose(1, 2)
+        x = F.dropout(self.layer_norm1(x), self.p, self.training)
+        x = F.relu(self.conv2(x.transpose(1, 2))).transpose(1, 2)
+        x = F.dropout(self.layer_norm2(x), self.p, self.training)
+        out = self.linear_layer(x).squeeze(-1)
+        return out.masked_fill(mask.squeeze(1) == 0, 0.0)
+
+
+def length_regulate(x, dur, max_len):
+    """Models/varianceadaptor.py:141-184,233-249: repeat phoneme vector i dur[i] times, then zero-pad
+    (or crop: F.pad with a negative amount) each utterance to max_len."""
+    out = x.new_zeros(x.shape[0], max_len, x.shape[2])
+    for b in range(x.shape[0]):
+        rep = torch.repeat_interleave(x[b], dur[b].long().clamp(min=0), dim=0)[:max_len]
+        out[b, : rep.shape[0]] = rep
+    return out
+
+
+class VarianceAdaptor(nn.Module):
+    """Models/varianceadaptor.py:34-129, teacher-forced branch (duration/pitch/energy targets given)."""
+
+    def __init__(self, d_model, n_bins, f0_min, f0_max, energy_min, energy_max, dropout):
+        super().__init__()
+        self.duration_predictor = VariancePredictor(d_model, dropout=dropout)
+        self.pitch_predictor = VariancePredictor(d_model, dropout=dropout)
+        # :56,61 -- fp32 boundaries, plain attributes
+        self.pitch_bins = torch.exp(torch.linspace(np.log(f0_min), np.log(f0_max), n_bins - 1))
+        self.pitch_embedding = nn.Embedding(n_bins, d_model)
+        self.energy_predictor = VariancePredictor(d_model, dropout=dropout)
+        self.energy_bins = torch.linspace(energy_min, energy_max, n_bins - 1)
+        self.energy_embedding = nn.Embedding(n_bins, d_model)
+
+    def forward(self, x, src_mask, mel_mask, d_target, p_target, e_target):
+        log_d = self.duration_predictor(x, src_mask)                       # :69
+        x = length_regulate(x, d_target, mel_mask.shape[2])                # :71-73
+        p = self.pitch_predictor(x, mel_mask)                              # :95
+        pe = self.pitch_embedding(torch.bucketize(p_target, self.pitch_bins.to(p_target.dtype)))   # :100
+        e = self.energy_predictor(x, mel_mask)                             # :114
+        ee = self.energy_embedding(torch.bucketize(e_target, self.energy_bins.to(e_target.dtype)))  # :116
+        return x + pe + ee, log_d, p, e, x                                 # :122-129
+
+
+class PostConvNet(nn.Module):
+    """Models/postnets.py:13-79 (prev_version=True): Linear(d->mel) then 5 causal convs (k=5, pad 4,
+    crop the last 4), BatchNorm(batch stats)+tanh+dropout after the first four, residual to mel_pred."""
+
+    def __init__(self, num_hidden, mel_dim, dropout):
+        super().__init__()
+        self.conv1 = nn.Conv1d(mel_dim, num_hidden, 5, padding=4)
+        self.conv_list = nn.ModuleList([nn.Conv1d(num_hidden, num_hidden, 5, padding=4) for _ in range(3)])
+        self.conv2 = nn.Conv1d(num_hidden, mel_dim, 5, padding=4)
+        self.out = nn.Linear(num_hidden, mel_dim)
+        self.batch_norm_list = nn.ModuleList([nn.BatchNorm1d(num_hidden) for _ in range(3)])
+        self.pre_batchnorm = nn.BatchNorm1d(num_hidden)
+        self.p = dropout
+
+    def forward(self, x):
+        mel_pred = self.out(x).transpose(1, 2)
+        h = F.dropout(torch.tanh(self.pre_batchnorm(self.conv1(mel_pred)[:, :, :-4])), self.p, self.training)
+        for bn, conv in zip(self.batch_norm_list, self.conv_list):
+            h = F.dropout(torch.tanh(bn(conv(h)[:, :, :-4])), self.p, self.training)
+        post = self.conv2(h)[:, :, :-4] + mel_pred
+        return mel_pred.transpose(1, 2), post.transpose(1, 2)
+
+
+class FastSpeech2(nn.Module):
+    """Models/fastspeech2.py:38-116 (ctor) and :118-241 (forward), default options only:
+    transformer encoder/decoder, postnet_pred=True, no speaker / sq-vae / hop / fix_mask / debug."""
+
+    def __init__(self, vocab, mel_dim, d_model, N_e, H_e, k_e, N_d, H_d, k_d, dropout, dropout_postnet,
+                 dropout_variance_adaptor, n_bins, f0_min, f0_max, energy_min, energy_max):
+        super().__init__()
+        self.encoder = Encoder(vocab, d_model, N_e, H_e, k_e, dropout, embedding=True)
+        self.variance_adaptor = VarianceAdaptor(d_model, n_bins, f0_min, f0_max, energy_min, energy_max,
+                                                dropout_variance_adaptor)
+        self.decoder = Encoder(d_model, d_model, N_d, H_d, k_d, dropout, embedding=False)
+        self.postnet = PostConvNet(d_model, mel_dim, dropout_postnet)
+
+    @classmethod
+    def from_hp(cls, hp, dropout=None, dropout_postnet=0.5, dropout_variance_adaptor=None):
+        """Argument wiring of train_fastspeech2.py:381-389."""
+        return cls(hp.vocab_size, hp.mel_dim, hp.d_model_encoder, hp.n_layer_encoder, hp.n_head_encoder,
+                   hp.ff_conv_kernel_size_encoder, hp.n_layer_decoder, hp.n_head_decoder,
+                   hp.ff_conv_kernel_size_decoder, hp.dropout if dropout is None else dropout, dropout_postnet,
+                   getattr(hp, "dropout_variance_adaptor", 0.5) if dropout_variance_adaptor is None
+                   else dropout_variance_adaptor, hp.nbins, hp.f0_min, hp.f0_max, hp.energy_min, hp.energy_max)
+
+    def double(self):
+        """fp64 reference: also cast the plain-attribute tables."""
+        super().double()
+        va = self.variance_adaptor
+        va.pitch_bins, va.energy_bins = va.pitch_bins.double(), va.energy_bins.double()
+        return self
+
+    def forward(self, src, src_mask, mel_mask, d_target, p_target, e_target):
+        e_out, attn_enc = self.encoder(src, src_mask)
+        va_out, log_d, p_pred, e_pred, text_dur = self.variance_adaptor(e_out, src_mask, mel_mask, d_target,
+                                                                         p_target, e_target)
+        d_out, attn_dec = self.decoder(va_out, mel_mask)
+        mel_before, mel_after = self.postnet(d_out)
+        return (mel_before, mel_after, log_d, p_pred, e_pred, va_out, text_dur, attn_enc, attn_dec,
+                None, None, None, None, None)

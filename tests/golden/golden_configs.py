@@ -1,0 +1,60 @@
+"""Configurations of the golden fixtures (shared by make_golden.py and the tests).
+
+hparams keys are the working set of SURVEY.md Appendix A (the reference ships no hparams file).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from transformer_tts_amd import synthetic
+
+_BASE = dict(
+    architecture="text-mel", model="Fastspeech2", comment="", save_dir="/tmp/fs2_golden_ckpt",
+    train_script="", test_script="", lengths_file="", mean_file=None, var_file=None, spm_model=None,
+    mel_dim=80, amp=False, optimizer="Noam", warmup_step=4000, warmup_factor=1.0, max_seqlen=None,
+    max_epoch=100, save_per_epoch=50, clip=1.0, loaded_epoch=None, loaded_dir=None,
+    encoder_type="transformer", decoder_type="transformer", concat_after_encoder=False,
+    concat_after_decoder=False, postnet_pred=True, reduction_rate=1, dropout=0.0, nbins=256,
+    f0_min=71.0, f0_max=799.8, energy_min=0.0, energy_max=403.8, pitch_pred=True, energy_pred=True,
+    is_multi_speaker=False, different_spk_emb_samespeaker=False)
+
+CONFIGS = {
+    # d=32, 2+2 FFT layers, k 3/1: every kernel family at the smallest aligned sizes; ragged batch
+    # with zero durations.
+    "tiny": dict(hp=dict(vocab_size=40, batch_size=3, d_model_encoder=32, n_layer_encoder=2, n_head_encoder=2,
+                         ff_conv_kernel_size_encoder=3, d_model_decoder=32, n_layer_decoder=2, n_head_decoder=2,
+                         ff_conv_kernel_size_decoder=1),
+                 weight_seed=11, batch=lambda: synthetic.tiny_batch(seed=7, batch_size=3, vocab=40),
+                 train_steps=3, start_step=4000),
+    # d=64, 1+1 layers, 4 heads, k 9/5: the wide-kernel conv geometry of the benchmark encoder.
+    "small": dict(hp=dict(vocab_size=60, batch_size=4, d_model_encoder=64, n_layer_encoder=1, n_head_encoder=4,
+                          ff_conv_kernel_size_encoder=9, d_model_decoder=64, n_layer_decoder=1, n_head_decoder=4,
+                          ff_conv_kernel_size_decoder=5),
+                  weight_seed=12, batch=lambda: synthetic.make_batch(8, 4, l_range=(9, 20), dur_range=(1, 9), vocab=60),
+                  train_steps=3, start_step=4000),
+    # BASELINE.json configs[1]: scalar anchors + digests only.
+    "bench": dict(hp=dict(vocab_size=152, batch_size=48, d_model_encoder=256, n_layer_encoder=4, n_head_encoder=2,
+                          ff_conv_kernel_size_encoder=9, d_model_decoder=256, n_layer_decoder=4, n_head_decoder=2,
+                          ff_conv_kernel_size_decoder=1),
+                  weight_seed=13, batch=lambda: synthetic.benchmark_batch(2024, 48),
+                  train_steps=1, start_step=4000),
+}
+
+
+def hp_namespace(cfg):
+    d = dict(_BASE)
+    d.update(cfg["hp"])
+    return SimpleNamespace(**d)
+
+
+def sample_index(n, k=64):
+    return np.unique(np.linspace(0, max(n - 1, 0), num=min(n, k)).astype(np.int64))
+
+
+def digest(t):
+    """[sum, sum|x|, l2, n, samples...] in float64: a compact pin for a large tensor."""
+    x = torch.as_tensor(t).detach().double().reshape(-1)
+    n = x.numel()
+    head = [float(x.sum()), float(x.abs().sum()), float((x * x).sum().sqrt()), float(n)]
+    return np.asarray(head + x[torch.from_numpy(sample_index(n))].tolist(), np.float64)
