@@ -1,0 +1,204 @@
+/*
+ * fs2_hip.h -- C ABI of libfs2_hip.so: the MI355X (gfx950) kernels of the FastSpeech2 training path.
+ *
+ * The reference (syoamakase/Transformer_TTS) is pure Python/PyTorch and has NO plugin / operator /
+ * FFI interface: its hot path calls stock PyTorch ops.  This header is the
+ * boundary the build defines in their place; every entry point cites the reference call site whose
+ * arithmetic it replaces.  INTEGRATION.md shows the ctypes binding a maintainer of the reference
+ * would add.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; every pointer is DEVICE memory owned by the caller;
+ *  - no allocation, no ownership transfer, no host synchronisation, no host reads of device data:
+ *    every call only enqueues kernels on `stream` (a hipStream_t) and is graph-capturable;
+ *  - stateless and re-entrant; return 0, or a negative FS2_E* code with text in fs2_last_error();
+ *  - activations are channels-last [rows = (batch, time)][channels], row-major;
+ *  - dtype codes: FS2_F32 = 0 (exact-fp32 mode: f32-input MFMA), FS2_BF16 = 1 (bf16 MFMA, fp32 accumulate);
+ *  - dropout: Philox4x32-10 keyed by the device-resident {seed, offset} pair `rng` and a per call
+ *    site id `site`; the backward entry point regenerates the mask from the same triple.
+ */
+#ifndef FS2_HIP_H
+#define FS2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS2_F32 0
+#define FS2_BF16 1
+
+#define FS2_OK 0
+#define FS2_EINVAL (-1)   /* bad shape / alignment / argument */
+#define FS2_ELAUNCH (-2)  /* hipLaunchKernel failed */
+
+const char* fs2_last_error(void);
+int fs2_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM family (MFMA).  C[M,N] = alpha * sum_k A(m,k) * B(n,k)  (+bias[n]) (ReLU) (*relu_mask>0) (+residual)
+ *
+ * Replaces: nn.Linear (Models/modules.py:32-41,49-51,68; Models/encoder.py:57; Models/postnets.py:43,67),
+ * nn.Conv1d as implicit GEMM (Models/modules.py:76-84; Models/varianceadaptor.py:203-209,216-221;
+ * Models/postnets.py:28-39,71-75), torch.matmul in attention() (Models/modules.py:8,20) and the autograd
+ * backward of all of them (dgrad = same kernel on a transposed/flipped weight shadow, wgrad = k-major form).
+ *
+ *  a_kmajor = 0: A stored [M][K] (lda = row stride);  a_kmajor = 1: A stored [K][M].  Same for B / N.
+ *  conv = 1 (A row-major only): rows are (b,t) with t = m % seq_len; the reduction runs over `taps`
+ *      x K with A row m+tap-pad (zero outside [0,seq_len)) and B column tap*K + k  (B is [N][taps*K]).
+ *  conv = 2 (A and B k-major, wgrad): reduction rows are (b,t); B row r is read at r + batch2_index - pad
+ *      (zero outside the sequence); batch2 enumerates the taps (use sB2 = 0, sC2 = K_in).
+ *  Row strides and the contiguous-dim extents must be multiples of 16 bytes (8 bf16 / 4 f32).
+ *  Kb = valid reduction extent of B when it differs from K (0 = K): rows >= Kb of a k-major B read as 0.
+ *  accumulate = 1: C is fp32 and results are atomically added (split_k > 1 requires it).
+ *  colstats != NULL: per-column sum and sum of squares of the stored values are atomically added to
+ *      colstats[0..N) and colstats[N..2N)  (BatchNorm batch statistics, Models/postnets.py:58-59).
+ */
+typedef struct FS2Gemm {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias;
+    const void* residual;
+    const void* relu_mask;
+    float* colstats;
+    int64_t lda, ldb, ldc, ldr, ldm;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2; /* batch strides in elements (C strides also apply to residual/mask) */
+    int32_t M, N, K, Kb;
+    int32_t a_kmajor, b_kmajor;
+    int32_t dtype;      /* of A and B */
+    int32_t c_dtype;    /* of C */
+    int32_t res_dtype;  /* of residual */
+    int32_t relu;
+    int32_t accumulate;
+    int32_t split_k;
+    int32_t batch1, batch2;
+    int32_t conv, taps, pad, seq_len;
+    float alpha;
+    int32_t reserved;
+} FS2Gemm;
+
+int fs2_gemm(const FS2Gemm* g, void* stream);
+
+/* Weight shadows (fp32 master (O, I, k) as in the reference state_dict -> kernel layout, dtype `dtype`):
+ *  mode 0 (forward):  dst[o*dld + j*I + i]       = src[o][i][j]
+ *  mode 1 (dgrad):    dst[i*dld + j*O + o]       = src[o][i][k-1-j]
+ * and the inverse for weight gradients: grad[o][i][j] += scratch[o*(k*I) + j*I + i].          */
+int fs2_cast_permute(const float* src, void* dst, int O, int I, int k, int64_t dld, int mode, int dtype, void* stream);
+int fs2_permute_add(const float* scratch, float* grad, int O, int I, int k, void* stream);
+int fs2_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* out[n] += sum_m x[m][n]   (bias gradients); x is [M][N] with row stride ldx */
+int fs2_colsum(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, void* stream);
+
+/* nn.Embedding gather / scatter-add (Models/encoder.py:55,84; Models/varianceadaptor.py:57,62). */
+int fs2_embedding_fwd(const int64_t* ids, const float* table, void* out, int out_dtype, int64_t n, int d, void* stream);
+int fs2_embedding_bwd(const int64_t* ids, const void* dout, int dout_dtype, float* dtable, int64_t n, int d,
+                      int64_t padding_idx, void* stream);
+
+/* PositionalEncoder (Models/modules.py:107-111): out = dropout(a + alpha * pe[t]);  backward gives da and dalpha. */
+int fs2_pe_add_fwd(const void* a, int a_dtype, const float* pe, const float* alpha, float* out, int B, int t, int d,
+                   float p, const uint64_t* rng, uint32_t site, void* stream);
+int fs2_pe_add_bwd(const float* dout, const float* pe, void* da, int da_dtype, float* dalpha, int B, int t, int d,
+                   float p, const uint64_t* rng, uint32_t site, void* stream);
+
+/* nn.LayerNorm over the last dim (eps 1e-5), optionally followed by dropout (Models/varianceadaptor.py:219,222)
+ * and, in backward, by the ReLU mask of its input (x > 0).  dx_accumulate: dx += instead of dx =.        */
+int fs2_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                      float* mean, float* rstd, int64_t M, int d, float eps, float p, const uint64_t* rng,
+                      uint32_t site, void* stream);
+int fs2_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
+                      const float* rstd, void* dx, int dx_dtype, float* dgamma, float* dbeta, int64_t M, int d,
+                      float p, const uint64_t* rng, uint32_t site, int relu_mask, int dx_accumulate, void* stream);
+
+/* Residual + dropout + LayerNorm (Models/layers.py:31-35,40 with the next norm fused):
+ *   s = r + dropout_p(a);  y = LN(s)      r,s fp32 [M][d];  a,y dtype `dtype`.
+ * backward: ds_total = ds_down (may be NULL) + LNbwd(dy);  dr = ds_total;  da = dropout'(ds_total).  */
+int fs2_add_ln_fwd(const float* r, const void* a, int dtype, float* s, const float* gamma, const float* beta, void* y,
+                   float* mean, float* rstd, int64_t M, int d, float eps, float p, const uint64_t* rng, uint32_t site,
+                   void* stream);
+int fs2_add_ln_bwd(const float* ds_down, const void* dy, int dtype, const float* s, const float* gamma,
+                   const float* mean, const float* rstd, float* dr, void* da, float* dgamma, float* dbeta, int64_t M,
+                   int d, float p, const uint64_t* rng, uint32_t site, void* stream);
+
+/* FeedForward tail (Models/modules.py:85-87): y = LN(dropout_p(f2 + h)) ;  backward returns g = d(f2) = d(h). */
+int fs2_ffn_ln_fwd(const void* f2, const void* h, int dtype, const float* gamma, const float* beta, void* y,
+                   float* mean, float* rstd, int64_t M, int d, float eps, float p, const uint64_t* rng, uint32_t site,
+                   void* stream);
+int fs2_ffn_ln_bwd(const void* dy, const void* f2, const void* h, int dtype, const float* gamma, const float* mean,
+                   const float* rstd, void* g, float* dgamma, float* dbeta, int64_t M, int d, float p,
+                   const uint64_t* rng, uint32_t site, void* stream);
+
+/* attention() softmax (Models/modules.py:9-19): in place on S [rows = B*H*t][ld = tp >= t]:
+ *   P = softmax(mask_keys(S, -1e4));  P_drop = dropout_p(P) (always on).  S already holds QK^T/sqrt(d_k).
+ * key_mask [B][t] bytes (0 = padded key).  Columns [t, tp) are written as 0.  p_drop may alias p_out when p == 0.
+ * backward: dS = P * (dP' - sum_j dP'_j P_j), dP' = dropout'(dP), written in place over dP.           */
+int fs2_softmax_fwd(void* s_inout_p, void* p_drop, int dtype, const uint8_t* key_mask, int B, int H, int t, int tp,
+                    int64_t batch_stride, float p, const uint64_t* rng, uint32_t site, void* stream);
+int fs2_softmax_bwd(void* dp_inout_ds, const void* p_saved, int dtype, int B, int H, int t, int tp,
+                    int64_t batch_stride, float p, const uint64_t* rng, uint32_t site, void* stream);
+
+/* LengthRegulator (Models/varianceadaptor.py:141-184,233-249): out[b][f] = x[b][i] for the phoneme i whose
+ * duration interval contains frame f, 0 beyond sum(dur) or max_len.  starts is a [B][L+1] int32 workspace
+ * (exclusive prefix sums) produced by forward and consumed by backward (segmented sum).               */
+int fs2_length_regulate_fwd(const void* x, int dtype, const int64_t* dur, void* out, int32_t* starts, int B, int L,
+                            int T, int d, void* stream);
+int fs2_length_regulate_bwd(const void* dout, int dtype, const int32_t* starts, void* dx, int B, int L, int T, int d,
+                            int accumulate, void* stream);
+
+/* torch.bucketize + nn.Embedding adds (Models/varianceadaptor.py:100,116,123-126):
+ *   out = x + Ep[#bins_p < f0] + Ee[#bins_e < energy];  idx (int32 [2][M]) saved for the scatter-add backward. */
+int fs2_bucket_embed_add_fwd(const void* x, int dtype, const float* f0, const float* energy, const float* pbins,
+                             const float* ebins, int nbins, const float* Ep, const float* Ee, void* out, int32_t* idx,
+                             int64_t M, int d, void* stream);
+int fs2_bucket_embed_bwd(const void* dout, int dtype, const int32_t* idx, float* dEp, float* dEe, int64_t M, int d,
+                         void* stream);
+
+/* VariancePredictor head (Models/varianceadaptor.py:223-229): out[m] = mask[m] ? x[m].w + b : 0. */
+int fs2_linear1_fwd(const void* x, int dtype, const float* w, const float* b, const uint8_t* mask, float* out,
+                    int64_t M, int d, void* stream);
+int fs2_linear1_bwd(const float* dout, const void* x, int dtype, const float* w, const uint8_t* mask, void* dx,
+                    float* dw, float* db, int64_t M, int d, void* stream);
+
+/* BatchNorm1d(batch statistics) + tanh + dropout (Models/postnets.py:71-73).
+ *  colstats: x [M][C] -> sums[0..C) += sum, sums[C..2C) += sum of squares (also available fused in fs2_gemm)
+ *  finalize: mean/rstd from the (possibly all-reduced) sums and count; running stats updated with
+ *            momentum (unbiased variance), num_batches_tracked += 1
+ *  fwd: y = dropout(tanh((x-mean)*rstd*gamma+beta))
+ *  bwd_reduce: red[0..C) += sum dz, red[C..2C) += sum dz*xhat   (dz = dropout'(dy) * (1 - tanh^2))
+ *  bwd_apply: dx = gamma*rstd*(dz - red0/count - xhat*red1/count);  dgamma += red1, dbeta += red0        */
+int fs2_colstats(const void* x, int dtype, int64_t M, int C, float* sums, void* stream);
+int fs2_bn_finalize(const float* sums, float count, float eps, float momentum, float* mean, float* rstd,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked, int C, void* stream);
+int fs2_bn_tanh_fwd(const void* x, int dtype, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, void* y, int64_t M, int C, float p, const uint64_t* rng, uint32_t site,
+                    void* stream);
+int fs2_bn_tanh_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, float* red, int64_t M, int C, float p,
+                           const uint64_t* rng, uint32_t site, void* stream);
+int fs2_bn_tanh_bwd_apply(const void* dy, const void* x, int dtype, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, const float* red, float count, void* dx,
+                          float* dgamma, float* dbeta, int64_t M, int C, float p, const uint64_t* rng, uint32_t site,
+                          void* stream);
+
+/* nn.L1Loss (train_fastspeech2.py:212-259): loss[0] += sum|pred - tgt| / n.  target_mode 1: tgt = log(int64 tgt + 1).
+ * backward: dpred = sign(pred - tgt) * (*gscale) / n  (gscale: device scalar, upstream gradient).          */
+int fs2_l1_fwd(const void* pred, int pred_dtype, const void* target, int target_mode, int64_t n, float* loss,
+               void* stream);
+int fs2_l1_bwd(const void* pred, int pred_dtype, const void* target, int target_mode, int64_t n, const float* gscale,
+               void* dpred, int dpred_dtype, void* stream);
+
+/* clip_grad_norm_(1.0) + Adam (train_fastspeech2.py:304-315,416), flat arenas of n fp32 elements.
+ *  sqnorm: out[0] += sum x^2.   adam: coef = min(1, max_norm / (sqrt(*gsq * gscale^2) + 1e-6));
+ *  hyper (device float[4]) = {lr, 1-beta1^t, 1-beta2^t, grad_scale (e.g. 1/world)}.                     */
+int fs2_sqnorm(const float* x, int64_t n, float* out, void* stream);
+int fs2_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* gsq,
+                  float beta1, float beta2, float eps, float max_norm, void* stream);
+
+/* rng[1] += 1 (one step of the dropout stream). */
+int fs2_rng_advance(uint64_t* rng, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FS2_HIP_H */

@@ -1,0 +1,453 @@
+"""CPU restatement of every tensor-level op of transformer_tts_amd/ops.py (same names, same
+signatures), in plain PyTorch.  TEST INFRASTRUCTURE -- see oracle/__init__.py.
+
+Two uses, both in tests/: (1) the per-kernel parity reference for the HIP kernels
+(tests/test_kernels_gpu.py runs ops.X on the GPU and primitives.X on CPU copies); (2) a fake
+backend that tests monkeypatch over ``transformer_tts_amd.ops`` so the host-side forward/backward
+composition in transformer_tts_amd/Models can be checked on a machine without a GPU.
+
+Each op cites the reference arithmetic it stands for (file:line of syoamakase/Transformer_TTS).
+Dropout masks reproduce the kernels' Philox4x32-10 stream bit for bit (``drop_scale``), so
+dropout-on comparisons are exact rather than statistical.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+F32, BF16 = 0, 1
+_COMPUTE = torch.float64   # internal precision of the restatement; results are cast to the output dtype
+
+
+def lib():
+    raise RuntimeError("oracle.primitives has no native library")
+
+
+class Rng:
+    def __init__(self, seed, device="cpu"):
+        self.state = torch.tensor([seed, 0], dtype=torch.int64)
+
+    def advance(self):
+        self.state[1] += 1
+
+
+# ------------------------------------------------------------------------------------------------ Philox dropout
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+    mask = np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(x, np.uint64) for x in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0, k1 = (k0 + W0) & mask, (k1 + W1) & mask
+    return c0, c1, c2, c3
+
+
+def drop_scale(shape, p, rng, site, base_index=None):
+    """Per-element factors (0 or 1/(1-p)) of the kernels' dropout stream for a tensor whose element
+    index (row-major, or ``base_index`` if given as an int64 array of that shape) is the Philox counter."""
+    if p <= 0.0:
+        return torch.ones(shape, dtype=_COMPUTE)
+    seed, off = int(rng.state[0]) & (2 ** 64 - 1), int(rng.state[1]) & (2 ** 64 - 1)
+    n = int(np.prod(shape))
+    idx = np.arange(n, dtype=np.uint64) if base_index is None else np.asarray(base_index, np.uint64).reshape(-1)
+    q = idx >> np.uint64(2)
+    k0 = seed & 0xFFFFFFFF
+    k1 = ((seed >> 32) ^ (off >> 32)) & 0xFFFFFFFF
+    r = _philox4x32_10(q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.full(n, site, np.uint64),
+                       np.full(n, off & 0xFFFFFFFF, np.uint64), k0, k1)
+    lane = (idx & np.uint64(3)).astype(np.int64)
+    bits = np.stack(r, axis=1)[np.arange(n), lane].astype(np.uint32)
+    u = bits.astype(np.float32) * np.float32(2.3283064365386963e-10)
+    keep = u >= np.float32(p)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy(np.where(keep, scale, np.float32(0)).astype(np.float64).reshape(shape))
+
+
+def _f(t):
+    return t.to(_COMPUTE)
+
+
+def _out(v, dtype):
+    return v.to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM family
+def _epi(v, bias, relu, residual, relu_mask, colstats, out, out_dtype, alpha=1.0):
+    v = v * alpha
+    if bias is not None:
+        v = v + _f(bias)
+    if relu:
+        v = torch.relu(v)
+    if relu_mask is not None:
+        v = torch.where(_f(relu_mask) > 0, v, torch.zeros_like(v))
+    if residual is not None:
+        v = v + _f(residual)
+    dt = out.dtype if out is not None else out_dtype
+    r = v.to(dt)
+    if colstats is not None:
+        n = r.shape[-1]
+        rr = _f(r).reshape(-1, n)
+        colstats[:n] += rr.sum(0).float()
+        colstats[n:] += (rr * rr).sum(0).float()
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, out_dtype=None,
+           alpha=1.0):
+    """nn.Linear: Models/modules.py:32-41,49-51,68; Models/encoder.py:57; Models/postnets.py:43,67."""
+    return _epi(_f(x) @ _f(w).t(), bias, relu, residual, relu_mask, colstats, out, out_dtype or x.dtype, alpha)
+
+
+def _unfold(x, taps, pad):
+    """(B,t,C) -> (B,t,taps*C) with column j*C+c = x[b, t+j-pad, c] (zero outside the sequence)."""
+    B, t, C = x.shape
+    cols = []
+    for j in range(taps):
+        s = j - pad
+        sh = torch.zeros_like(x)
+        lo, hi = max(0, -s), min(t, t - s)
+        if hi > lo:
+            sh[:, lo:hi] = x[:, lo + s:hi + s]
+        cols.append(sh)
+    return torch.cat(cols, dim=2)
+
+
+def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None,
+         out_dtype=None):
+    """nn.Conv1d over time (Models/modules.py:76-84; varianceadaptor.py:203-209; postnets.py:28-39,71-75)
+    in channels-last form; w is the kernel-layout shadow [n][j*C + c] = weight[n][c][j]."""
+    return _epi(_unfold(_f(x), taps, pad) @ _f(w).t(), bias, relu, residual, relu_mask, colstats, out,
+                out_dtype or x.dtype)
+
+
+def wgrad(dy, x, out):
+    out += (_f(dy).t() @ _f(x)).float()
+    return out
+
+
+def conv_wgrad(dy, x, taps, pad, out):
+    B, t, N = dy.shape
+    out += (_f(dy).reshape(B * t, N).t() @ _unfold(_f(x), taps, pad).reshape(B * t, -1)).float()
+    return out
+
+
+def bmm(a, b, out, trans_a=False, trans_b=True, alpha=1.0):
+    """torch.matmul of attention() (Models/modules.py:8,20) and its backward products."""
+    M, N = out.shape[2], out.shape[3]
+    if trans_a:
+        v = _f(a)[..., :M].transpose(-1, -2) @ _f(b)
+    elif trans_b:
+        v = _f(a) @ _f(b).transpose(-1, -2)
+    else:
+        v = _f(a)[..., : b.shape[2]] @ _f(b)
+    out.copy_((alpha * v[..., :M, :N]).to(out.dtype))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ shadows / casts
+def cast_permute(src, dst, mode):
+    s = src if src.dim() == 3 else src.unsqueeze(-1)
+    O, I, k = s.shape
+    if mode == 0:
+        v = s.permute(0, 2, 1).reshape(O, k * I)
+    else:
+        v = s.flip(2).permute(1, 2, 0).reshape(I, k * O)
+    dst[:, : v.shape[1]] = v.to(dst.dtype)
+    return dst
+
+
+def permute_add(scratch, grad):
+    g = grad if grad.dim() == 3 else grad.unsqueeze(-1)
+    O, I, k = g.shape
+    g += scratch.reshape(O, k, I).permute(0, 2, 1)
+
+
+def cast(src, dtype, out=None):
+    if out is None:
+        return src.to(dtype)
+    out.copy_(src.to(out.dtype))
+    return out
+
+
+def colsum(x, out):
+    out += _f(x).sum(0).float()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ embedding / PE
+def embedding_fwd(ids, table, out_dtype):
+    """nn.Embedding (Models/encoder.py:55,84)."""
+    return table[ids].to(out_dtype)
+
+
+def embedding_bwd(ids, dout, dtable, padding_idx=-1):
+    flat, g = ids.reshape(-1), dout.reshape(-1, dout.shape[-1]).float()
+    keep = flat != padding_idx
+    dtable.index_add_(0, flat[keep], g[keep])
+
+
+def pe_add_fwd(a, pe, alpha, p, rng, site):
+    """PositionalEncoder.forward (Models/modules.py:107-111)."""
+    B, t, d = a.shape
+    v = (_f(a) + _f(alpha) * _f(pe[:t])) * drop_scale((B, t, d), p, rng, site)
+    return v.float()
+
+
+def pe_add_bwd(dout, pe, da_dtype, dalpha, p, rng, site, need_da=True):
+    B, t, d = dout.shape
+    g = _f(dout) * drop_scale((B, t, d), p, rng, site)
+    dalpha += (g * _f(pe[:t])).sum().float()
+    return g.to(da_dtype) if need_da else None
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm family
+def _ln(x, gamma, beta, eps):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    return (x - mu) * rstd * _f(gamma) + _f(beta), mu.squeeze(-1), rstd.squeeze(-1)
+
+
+def _ln_bwd(dy, x, gamma, mean, rstd):
+    xh = (x - _f(mean).unsqueeze(-1)) * _f(rstd).unsqueeze(-1)
+    dg = dy * _f(gamma)
+    c1 = dg.mean(-1, keepdim=True)
+    c2 = (dg * xh).mean(-1, keepdim=True)
+    dx = _f(rstd).unsqueeze(-1) * (dg - c1 - xh * c2)
+    d = x.shape[-1]
+    return dx, (dy * xh).reshape(-1, d).sum(0), dy.reshape(-1, d).sum(0)
+
+
+def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5, p=0.0, rng=None, site=0):
+    """nn.LayerNorm (+ nn.Dropout after it: Models/varianceadaptor.py:219,222)."""
+    y, mu, rstd = _ln(_f(x), gamma, beta, eps)
+    y = y * drop_scale(tuple(x.shape), p, rng, site)
+    return y.to(out_dtype), mu.reshape(-1).float(), rstd.reshape(-1).float()
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, relu_mask=False, dx=None):
+    g = _f(dy) * drop_scale(tuple(x.shape), p, rng, site)
+    v, dg, db = _ln_bwd(g, _f(x), gamma, mean.reshape(x.shape[:-1]), rstd.reshape(x.shape[:-1]))
+    dgamma += dg.float()
+    dbeta += db.float()
+    if relu_mask:
+        v = torch.where(_f(x) > 0, v, torch.zeros_like(v))
+    if dx is not None:
+        dx.copy_((_f(dx) + v).to(dx.dtype))
+        return dx
+    return v.to(x.dtype)
+
+
+def add_ln_fwd(r, a, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
+    """x = x + dropout(branch); norm(x)  (Models/layers.py:31-35,40 with the following norm)."""
+    s = (_f(r) + _f(a) * drop_scale(tuple(a.shape), p, rng, site)).float()
+    y, mu, rstd = _ln(_f(s), gamma, beta, eps)
+    return s, y.to(a.dtype), mu.reshape(-1).float(), rstd.reshape(-1).float()
+
+
+def add_ln_bwd(ds_down, dy, s, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0):
+    v, dg, db = _ln_bwd(_f(dy), _f(s), gamma, mean.reshape(s.shape[:-1]), rstd.reshape(s.shape[:-1]))
+    dgamma += dg.float()
+    dbeta += db.float()
+    if ds_down is not None:
+        v = v + _f(ds_down)
+    dr = v.float()
+    da = (_f(dr) * drop_scale(tuple(s.shape), p, rng, site)).to(dy.dtype)
+    return dr, da
+
+
+def ffn_ln_fwd(f2, h, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
+    """FeedForward tail: layer_norm(dropout(x + res)) (Models/modules.py:85-87)."""
+    u = (_f(f2) + _f(h)) * drop_scale(tuple(h.shape), p, rng, site)
+    y, mu, rstd = _ln(u, gamma, beta, eps)
+    return y.to(h.dtype), mu.reshape(-1).float(), rstd.reshape(-1).float()
+
+
+def ffn_ln_bwd(dy, f2, h, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0):
+    ds = drop_scale(tuple(h.shape), p, rng, site)
+    u = (_f(f2) + _f(h)) * ds
+    v, dg, db = _ln_bwd(_f(dy), u, gamma, mean.reshape(h.shape[:-1]), rstd.reshape(h.shape[:-1]))
+    dgamma += dg.float()
+    dbeta += db.float()
+    return (v * ds).to(h.dtype)
+
+
+# ------------------------------------------------------------------------------------------------ attention softmax
+def _strided_index(t):
+    """element offsets (relative to the view's first element) of a strided view, as int64 array"""
+    idx = torch.zeros(t.shape, dtype=torch.int64)
+    for dim, (n, s) in enumerate(zip(t.shape, t.stride())):
+        shape = [1] * t.dim()
+        shape[dim] = n
+        idx = idx + (torch.arange(n, dtype=torch.int64) * s).view(shape)
+    return idx.numpy()
+
+
+def softmax_fwd(s, p_drop, key_mask, t, p=0.0, rng=None, site=0):
+    """attention() of Models/modules.py:9-19: masked_fill(mask==0, -1e4) on keys, softmax, F.dropout
+    (training=True always).  s already holds QK^T/sqrt(d_k); in place; pad columns [t,tp) -> 0."""
+    B, H, _, tp = s.shape
+    v = _f(s)[..., :t]
+    v = v.masked_fill(key_mask.view(B, 1, 1, t) == 0, -1e4)
+    pr = torch.softmax(v, dim=-1)
+    full = torch.zeros((B, H, t, tp), dtype=_COMPUTE)
+    full[..., :t] = pr
+    s.copy_(full.to(s.dtype))
+    if p_drop.data_ptr() != s.data_ptr() or p > 0:
+        sc = drop_scale((B, H, t, tp), p, rng, site, base_index=_strided_index(s))
+        p_drop.copy_((_f(s) * sc).to(s.dtype))
+
+
+def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
+    B, H, _, tp = dp.shape
+    sc = drop_scale((B, H, t, tp), p, rng, site, base_index=_strided_index(dp))
+    g = torch.zeros((B, H, t, tp), dtype=_COMPUTE)
+    g[..., :t] = (_f(dp) * sc)[..., :t]          # pad columns of dP are undefined on input
+    pr = torch.zeros_like(g)
+    pr[..., :t] = _f(p_saved)[..., :t]
+    dot = (g * pr).sum(-1, keepdim=True)
+    dp.copy_((pr * (g - dot)).to(dp.dtype))
+
+
+# ------------------------------------------------------------------------------------------------ variance adaptor
+def length_regulate_fwd(x, dur, T):
+    """LengthRegulator.LR/expand + pad (Models/varianceadaptor.py:141-184,233-249)."""
+    B, L, d = x.shape
+    out = torch.zeros((B, T, d), dtype=x.dtype)
+    starts = torch.zeros((B, L + 1), dtype=torch.int32)
+    dd = dur.clamp(min=0)
+    starts[:, 1:] = torch.cumsum(dd, dim=1).to(torch.int32)
+    for b in range(B):
+        rep = torch.repeat_interleave(x[b], dd[b], dim=0)[:T]
+        out[b, : rep.shape[0]] = rep
+    return out, starts
+
+
+def length_regulate_bwd(dout, starts, L, dx=None):
+    B, T, d = dout.shape
+    v = torch.zeros((B, L, d), dtype=_COMPUTE)
+    for b in range(B):
+        for i in range(L):
+            f0, f1 = int(starts[b, i]), min(int(starts[b, i + 1]), T)
+            if f1 > f0:
+                v[b, i] = _f(dout[b, f0:f1]).sum(0)
+    if dx is not None:
+        dx.copy_((_f(dx) + v).to(dx.dtype))
+        return dx
+    return v.to(dout.dtype)
+
+
+def bucket_embed_add_fwd(x, f0, energy, pbins, ebins, Ep, Ee):
+    """x + pitch_embedding(bucketize(f0)) + energy_embedding(bucketize(e)) (varianceadaptor.py:100,116,123-126)."""
+    ip, ie = torch.bucketize(f0, pbins), torch.bucketize(energy, ebins)
+    out = ((_f(x) + _f(Ep[ip])) + _f(Ee[ie])).to(x.dtype)
+    return out, torch.stack([ip.reshape(-1), ie.reshape(-1)]).to(torch.int32)
+
+
+def bucket_embed_bwd(dout, idx, dEp, dEe):
+    g = dout.reshape(-1, dout.shape[-1]).float()
+    dEp.index_add_(0, idx[0].long(), g)
+    dEe.index_add_(0, idx[1].long(), g)
+
+
+def linear1_fwd(x, w, b, mask):
+    """linear_layer + squeeze + masked_fill(mask==0, 0) (Models/varianceadaptor.py:223-229)."""
+    out = _f(x) @ _f(w).reshape(-1) + _f(b)
+    return out.masked_fill(mask.reshape(out.shape) == 0, 0.0).float()
+
+
+def linear1_bwd(dout, x, w, mask, dw, db):
+    g = _f(dout) * (mask.reshape(dout.shape) != 0)
+    dw += (g.unsqueeze(-1) * _f(x)).reshape(-1, x.shape[-1]).sum(0).float().reshape(dw.shape)
+    db += g.sum().float()
+    return (g.unsqueeze(-1) * _f(w).reshape(-1)).to(x.dtype)
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm + tanh
+def colstats(x, sums):
+    C = x.shape[-1]
+    v = _f(x).reshape(-1, C)
+    sums[:C] += v.sum(0).float()
+    sums[C:] += (v * v).sum(0).float()
+
+
+def bn_finalize(sums, count, eps, momentum, running_mean, running_var, num_batches_tracked):
+    """nn.BatchNorm1d in training mode (Models/postnets.py:58-59): biased batch variance for the
+    normalisation, unbiased for running_var, momentum 0.1."""
+    C = sums.numel() // 2
+    mu = _f(sums[:C]) / count
+    var = (_f(sums[C:]) / count - mu * mu).clamp(min=0)
+    if running_mean is not None:
+        unb = var * count / (count - 1) if count > 1 else var
+        running_mean.copy_(((1 - momentum) * _f(running_mean) + momentum * mu).float())
+        running_var.copy_(((1 - momentum) * _f(running_var) + momentum * unb).float())
+    if num_batches_tracked is not None:
+        num_batches_tracked += 1
+    return mu.float(), (1.0 / torch.sqrt(var + eps)).float()
+
+
+def _bn_z(x, mean, rstd, gamma, beta):
+    xh = (_f(x) - _f(mean)) * _f(rstd)
+    return xh, torch.tanh(xh * _f(gamma) + _f(beta))
+
+
+def bn_tanh_fwd(x, mean, rstd, gamma, beta, p=0.0, rng=None, site=0):
+    """dropout(tanh(batch_norm(x))) (Models/postnets.py:71-73)."""
+    _, th = _bn_z(x, mean, rstd, gamma, beta)
+    return (th * drop_scale(tuple(x.shape), p, rng, site)).to(x.dtype)
+
+
+def bn_tanh_bwd_reduce(dy, x, mean, rstd, gamma, beta, red, p=0.0, rng=None, site=0):
+    C = x.shape[-1]
+    xh, th = _bn_z(x, mean, rstd, gamma, beta)
+    dz = _f(dy) * drop_scale(tuple(x.shape), p, rng, site) * (1 - th * th)
+    red[:C] += dz.reshape(-1, C).sum(0).float()
+    red[C:] += (dz * xh).reshape(-1, C).sum(0).float()
+
+
+def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta, p=0.0, rng=None, site=0):
+    C = x.shape[-1]
+    xh, th = _bn_z(x, mean, rstd, gamma, beta)
+    dz = _f(dy) * drop_scale(tuple(x.shape), p, rng, site) * (1 - th * th)
+    r0, r1 = _f(red[:C]) / count, _f(red[C:]) / count
+    if dgamma is not None:
+        dbeta += red[:C]
+        dgamma += red[C:]
+    return (_f(gamma) * _f(rstd) * (dz - r0 - xh * r1)).to(x.dtype)
+
+
+# ------------------------------------------------------------------------------------------------ losses / optimizer
+def _l1_target(target, log1p_int_target):
+    return torch.log(target.float() + 1) if log1p_int_target else target
+
+
+def l1_fwd(pred, target, loss, log1p_int_target=False):
+    """nn.L1Loss() over every element (train_fastspeech2.py:212-259)."""
+    loss += (_f(pred) - _f(_l1_target(target, log1p_int_target))).abs().mean().float()
+
+
+def l1_bwd(pred, target, gscale, dpred_dtype, log1p_int_target=False):
+    d = _f(pred) - _f(_l1_target(target, log1p_int_target))
+    return (torch.sign(d) * _f(gscale) / pred.numel()).to(dpred_dtype)
+
+
+def sqnorm(x, out):
+    out += (_f(x) ** 2).sum().float()
+
+
+def adam_step(p, g, m, v, hyper, gsq, beta1, beta2, eps, max_norm):
+    """clip_grad_norm_ + torch.optim.Adam.step (train_fastspeech2.py:312-315,416)."""
+    lr, bc1, bc2, gs = (float(h) for h in hyper)
+    gmul = gs
+    if max_norm > 0 and gsq is not None:
+        gmul *= min(1.0, max_norm / (float(gsq[0]) ** 0.5 * gs + 1e-6))
+    gg = g * gmul
+    m.lerp_(gg, 1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    denom = v.sqrt() / (bc2 ** 0.5) + eps
+    p.addcdiv_(m, denom, value=-lr / bc1)

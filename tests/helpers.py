@@ -55,3 +55,34 @@ def is_null_gradient_param(key):
     Adam's g/(sqrt(v)+1e-9) turns into +-lr steps: chaotic in the reference itself, so the values
     after an optimizer step are not pinned for them."""
     return _NULL_GRAD.search(key) is not None
+
+
+def product_model(name, amp=False, dropout=0.0, device="cpu", return_attn=True):
+    """The HIP-backed FastSpeech2 (transformer_tts_amd) with the fixture weights of config `name`."""
+    from transformer_tts_amd.Models.fastspeech2 import FastSpeech2
+    from transformer_tts_amd.utils.utils import fill_variables
+    cfg = CONFIGS[name]
+    hp = hp_namespace(cfg)
+    hp.amp = amp
+    hp.return_attn = return_attn
+    fill_variables(hp, verbose=False)
+    g = load_golden(name)
+    m = FastSpeech2(hp=hp, src_vocab=hp.vocab_size, trg_vocab=hp.mel_dim, d_model_encoder=hp.d_model_encoder,
+                    N_e=hp.n_layer_encoder, n_head_encoder=hp.n_head_encoder,
+                    ff_conv_kernel_size_encoder=hp.ff_conv_kernel_size_encoder,
+                    concat_after_encoder=hp.concat_after_encoder, d_model_decoder=hp.d_model_decoder,
+                    N_d=hp.n_layer_decoder, n_head_decoder=hp.n_head_decoder,
+                    ff_conv_kernel_size_decoder=hp.ff_conv_kernel_size_decoder,
+                    concat_after_decoder=hp.concat_after_decoder, dropout_variance_adaptor=dropout,
+                    reduction_rate=hp.reduction_rate, dropout=dropout, dropout_postnet=dropout, n_bins=hp.nbins,
+                    f0_min=hp.f0_min, f0_max=hp.f0_max, energy_min=hp.energy_min, energy_max=hp.energy_max,
+                    pitch_pred=hp.pitch_pred, energy_pred=hp.energy_pred, accent_emb=hp.accent_emb,
+                    output_type=hp.output_type, num_group=hp.num_group, multi_speaker=hp.is_multi_speaker,
+                    spk_emb_dim=hp.spk_emb_dim, spk_emb_architecture=hp.spk_emb_architecture)
+    m.load_state_dict(synthetic.recipe_state_dict(golden_shapes(g), cfg["weight_seed"]))
+    m.train()
+    return m.to(device), hp, g
+
+
+def batch_to(batch, device):
+    return tuple(b.to(device) if torch.is_tensor(b) else b for b in batch)

@@ -1,0 +1,481 @@
+"""Forward/backward composition of the FastSpeech2 blocks out of the HIP ops (transformer_tts_amd.ops).
+
+Each block of the reference model (FFT stack, variance predictor, length regulator, bucket
+embedding add, PostNet, L1 loss) is ONE torch.autograd.Function whose forward and backward are
+explicit sequences of kernel launches: nothing is traced, no torch compute op runs in between, and
+the activations each backward needs are kept as plain tensors on the ctx.  Parameter gradients are
+accumulated by the kernels straight into ``param.grad`` (views of one flat fp32 arena when the
+optimizer is ``FusedAdam``), so the Functions return None for their parameter inputs.
+
+Layout: activations are channels-last (B, t, C); `T` below is the compute dtype (torch.bfloat16 in
+bf16 mode, torch.float32 in the exact-fp32 parity mode); the residual stream is always fp32.
+"""
+import math
+
+import torch
+
+from .. import ops
+
+_site_counter = [0]
+
+
+def next_site():
+    """Unique id of a dropout call site (selects its Philox stream)."""
+    _site_counter[0] += 1
+    return _site_counter[0]
+
+
+class Runtime:
+    """Per-model runtime state shared by all blocks: compute dtype, dropout RNG, weight shadows,
+    optional data-parallel communicator."""
+
+    def __init__(self, compute_dtype=torch.float32, seed=1234):
+        self.dtype = compute_dtype
+        self.seed = seed
+        self.rng = None          # ops.Rng, created lazily on the model's device
+        self.shadows = {}
+        self.epoch = 0           # bumped by the optimizer after an in-place (raw pointer) parameter update
+        self.scratch = {}
+        self.dp = None           # parallel.DataParallel or None
+        self.return_attn = True
+
+    def get_rng(self, device):
+        if self.rng is None:
+            self.rng = ops.Rng(self.seed, device)
+        return self.rng
+
+    def invalidate(self):
+        self.epoch += 1
+
+    # ---- weight shadows: fp32 master (reference layout) -> compute dtype, kernel layout
+    def _cached(self, key, params, build):
+        ver = tuple(p._version for p in params) + (self.epoch,)
+        hit = self.shadows.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        val = build(hit[1] if hit is not None else None)
+        self.shadows[key] = (ver, val)
+        return val
+
+    def w_fwd(self, weight):
+        """(O,I[,k]) -> [o][j*I+i] in compute dtype"""
+        O, I = weight.shape[0], weight.shape[1]
+        k = weight.shape[2] if weight.dim() == 3 else 1
+        if k == 1 and self.dtype == torch.float32:
+            return weight.detach().view(O, I)
+
+        def build(old):
+            dst = old if old is not None else torch.empty((O, k * I), dtype=self.dtype, device=weight.device)
+            return ops.cast_permute(weight.detach(), dst, 0)
+        return self._cached((id(weight), "f"), (weight,), build)
+
+    def w_dgrad(self, weight):
+        """(O,I[,k]) -> [i][j*O+o] with flipped taps (the operand of the data-gradient GEMM)"""
+        O, I = weight.shape[0], weight.shape[1]
+        k = weight.shape[2] if weight.dim() == 3 else 1
+
+        def build(old):
+            dst = old if old is not None else torch.empty((I, k * O), dtype=self.dtype, device=weight.device)
+            return ops.cast_permute(weight.detach(), dst, 1)
+        return self._cached((id(weight), "d"), (weight,), build)
+
+    def qkv(self, attn):
+        """fused [q;k;v] projection: forward shadow (3d,d), dgrad shadow (d,3d), bias (3d)"""
+        ws = (attn.q_linear.weight, attn.k_linear.weight, attn.v_linear.weight)
+        bs = (attn.q_linear.bias, attn.k_linear.bias, attn.v_linear.bias)
+        d = ws[0].shape[0]
+
+        def build(old):
+            if old is None:
+                dev = ws[0].device
+                old = (torch.empty((3 * d, d), dtype=self.dtype, device=dev),
+                       torch.empty((d, 3 * d), dtype=self.dtype, device=dev),
+                       torch.empty((3 * d,), dtype=torch.float32, device=dev))
+            wf, wd, bias = old
+            for j, (w, b) in enumerate(zip(ws, bs)):
+                ops.cast_permute(w.detach(), wf[j * d:(j + 1) * d], 0)
+                ops.cast_permute(w.detach(), wd[:, j * d:(j + 1) * d], 1)
+                ops.cast(b.detach(), torch.float32, out=bias[j * d:(j + 1) * d])
+            return old
+        return self._cached((id(attn), "qkv"), ws + bs, build)
+
+    def zeros(self, key, shape, dtype, device):
+        """persistent zero-filled scratch (re-zeroed on every request)"""
+        buf = self.scratch.get(key)
+        if buf is None or buf.shape != torch.Size(shape) or buf.dtype != dtype or buf.device != device:
+            buf = torch.zeros(shape, dtype=dtype, device=device)
+            self.scratch[key] = buf
+        else:
+            buf.zero_()
+        return buf
+
+
+def grad_of(p):
+    """fp32 buffer the kernels accumulate d(loss)/dp into (the arena view when FusedAdam owns it)."""
+    if p.grad is None:
+        g = getattr(p, "_fs2_grad", None)
+        if g is None:
+            g = torch.zeros_like(p)
+        else:
+            g.zero_()
+        p.grad = g
+    return p.grad
+
+
+def _conv_wgrad(rt, dy, x, conv, pad):
+    """accumulate weight and bias gradients of an nn.Conv1d (weight (O,I,k)) from dy (B,t,O), x (B,t,I)"""
+    w = conv.weight
+    O, I, k = w.shape
+    gw = grad_of(w)
+    if k == 1:
+        ops.conv_wgrad(dy, x, 1, 0, gw.view(O, I))
+    else:
+        scratch = rt.zeros(("wg", O, I, k), (O, k * I), torch.float32, w.device)
+        ops.conv_wgrad(dy, x, k, pad, scratch)
+        ops.permute_add(scratch, gw)
+    ops.colsum(dy.view(-1, O), grad_of(conv.bias))
+
+
+def _linear_wgrad(dy2, x2, lin):
+    ops.wgrad(dy2, x2, grad_of(lin.weight))
+    ops.colsum(dy2, grad_of(lin.bias))
+
+
+def _tp(t):
+    return (t + 7) // 8 * 8
+
+
+# ================================================================================================ FFT stack
+class EncoderStackFunction(torch.autograd.Function):
+    """Models/encoder.py:83-112 (Encoder.forward) with N x Models/layers.py:29-41 (EncoderLayer.forward),
+    Models/modules.py:43-70 (MultiHeadAttention), :7-21 (attention) and :81-88 (FeedForward)."""
+
+    @staticmethod
+    def forward(ctx, enc, src, key_mask, *params):
+        rt = enc.rt
+        T = rt.dtype
+        dev = src.device
+        rng = rt.get_rng(dev)
+        p = enc.dropout
+        N, H, d = enc.N, enc.heads, enc.d_model
+        dk = d // H
+        B, t = src.shape[0], src.shape[1]
+        M = B * t
+        tp = _tp(t)
+        km = key_mask.reshape(B, t).contiguous()
+        sv = {}
+
+        if enc.embedding:
+            a0 = ops.embedding_fwd(src, enc.embed.weight.detach(), torch.float32)              # encoder.py:84
+        else:
+            a0 = ops.linear(src.reshape(M, -1), rt.w_fwd(enc.embed.weight), enc.embed.bias.detach()).view(B, t, d)
+        pe = enc.pe.table(dev)
+        x = ops.pe_add_fwd(a0, pe, enc.pe.alpha.detach(), p, rng, enc.pe.site)                  # modules.py:107-111
+        n1 = enc.layers[0].norm_1
+        h, mean0, rstd0 = ops.layernorm_fwd(x, n1.weight.detach(), n1.bias.detach(), T)         # layers.py:31
+        sv["x0"], sv["mean0"], sv["rstd0"] = x, mean0, rstd0
+
+        attn = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
+        attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if p > 0 else attn
+        layers = []
+        scale = 1.0 / math.sqrt(dk)
+        for i, layer in enumerate(enc.layers):
+            L = {}
+            wf, _, bqkv = rt.qkv(layer.attn)
+            qkv = ops.linear(h.view(M, d), wf, bqkv)                                             # modules.py:49-51
+            q5 = qkv.view(B, t, 3, H, dk)
+            q, k, v = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))                        # (B,H,t,dk) views
+            S, Pd = attn[:, i], attn_drop[:, i]
+            ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)                                 # modules.py:8-9
+            ops.softmax_fwd(S, Pd, km, t, p, rng, layer.site_attn)                               # modules.py:11-19
+            O = torch.empty((B, t, H, dk), dtype=T, device=dev)
+            ops.bmm(Pd, v, O.permute(0, 2, 1, 3), trans_b=False)                                 # modules.py:20
+            a = ops.linear(O.view(M, d), rt.w_fwd(layer.attn.out.weight), layer.attn.out.bias.detach())  # :68
+            n2 = layer.norm_2
+            x1, h2, m2, r2 = ops.add_ln_fwd(x, a.view(B, t, d), n2.weight.detach(), n2.bias.detach(), 1e-5, p, rng,
+                                            layer.site_res1)                                    # layers.py:33-35
+            ff = layer.ff
+            kk = ff.f_1.weight.shape[2]
+            f1 = ops.conv(h2, rt.w_fwd(ff.f_1.weight), kk, kk // 2, ff.f_1.bias.detach(), relu=True)   # modules.py:83
+            f2 = ops.conv(f1, rt.w_fwd(ff.f_2.weight), kk, kk // 2, ff.f_2.bias.detach())              # modules.py:84
+            lnf = ff.layer_norm
+            yff, mf, rf = ops.ffn_ln_fwd(f2, h2, lnf.weight.detach(), lnf.bias.detach(), 1e-5, p, rng,
+                                         layer.site_ffn)                                        # modules.py:85-87
+            nn_ = enc.layers[i + 1].norm_1 if i + 1 < N else enc.norm
+            x2, hn, mn, rn = ops.add_ln_fwd(x1, yff, nn_.weight.detach(), nn_.bias.detach(), 1e-5, p, rng,
+                                            layer.site_res2)                                    # layers.py:40,31 / encoder.py:112
+            L.update(h=h, qkv=qkv, O=O, x1=x1, h2=h2, m2=m2, r2=r2, f1=f1, f2=f2, mf=mf, rf=rf, x2=x2, mn=mn, rn=rn)
+            layers.append(L)
+            x, h = x2, hn
+
+        ctx.enc, ctx.sv, ctx.layers, ctx.attn, ctx.attn_drop = enc, sv, layers, attn, attn_drop
+        ctx.src, ctx.km = src, km
+        ctx.set_materialize_grads(False)
+        attn_out = attn_drop[..., :t]
+        ctx.mark_non_differentiable(attn_out)
+        return h, attn_out
+
+    @staticmethod
+    def backward(ctx, dh, _dattn):
+        enc, sv, layers = ctx.enc, ctx.sv, ctx.layers
+        rt = enc.rt
+        T = rt.dtype
+        rng = rt.rng
+        p = enc.dropout
+        N, H, d = enc.N, enc.heads, enc.d_model
+        dk = d // H
+        src = ctx.src
+        B, t = src.shape[0], src.shape[1]
+        M = B * t
+        tp = _tp(t)
+        dev = dh.device
+        scale = 1.0 / math.sqrt(dk)
+        dh = dh.contiguous()
+        dx = None                       # fp32 gradient w.r.t. the residual stream coming from above
+        dP = torch.empty((B, H, t, tp), dtype=T, device=dev)
+        for i in reversed(range(N)):
+            layer, L = enc.layers[i], layers[i]
+            nn_ = enc.layers[i + 1].norm_1 if i + 1 < N else enc.norm
+            dx1, dyff = ops.add_ln_bwd(dx, dh, L["x2"], nn_.weight.detach(), L["mn"], L["rn"], grad_of(nn_.weight),
+                                       grad_of(nn_.bias), p, rng, layer.site_res2)
+            ff = layer.ff
+            lnf = ff.layer_norm
+            g = ops.ffn_ln_bwd(dyff, L["f2"], L["h2"], lnf.weight.detach(), L["mf"], L["rf"], grad_of(lnf.weight),
+                               grad_of(lnf.bias), p, rng, layer.site_ffn)
+            kk = ff.f_1.weight.shape[2]
+            pad = kk // 2
+            _conv_wgrad(rt, g, L["f1"], ff.f_2, pad)
+            dz1 = ops.conv(g, rt.w_dgrad(ff.f_2.weight), kk, kk - 1 - pad, relu_mask=L["f1"])
+            _conv_wgrad(rt, dz1, L["h2"], ff.f_1, pad)
+            dh2 = ops.conv(dz1, rt.w_dgrad(ff.f_1.weight), kk, kk - 1 - pad, residual=g)
+            n2 = layer.norm_2
+            dx, da = ops.add_ln_bwd(dx1, dh2, L["x1"], n2.weight.detach(), L["m2"], L["r2"], grad_of(n2.weight),
+                                    grad_of(n2.bias), p, rng, layer.site_res1)
+            at = layer.attn
+            da2 = da.view(M, d)
+            _linear_wgrad(da2, L["O"].view(M, d), at.out)
+            dO = ops.linear(da2, rt.w_dgrad(at.out.weight))
+            dO4 = dO.view(B, t, H, dk).permute(0, 2, 1, 3)
+            qkv = L["qkv"]
+            q5 = qkv.view(B, t, 3, H, dk)
+            q, k, v = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+            dqkv = torch.empty((B, t, 3 * d), dtype=T, device=dev)
+            d5 = dqkv.view(B, t, 3, H, dk)
+            dq, dk_, dv = (d5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+            P, Pd = ctx.attn[:, i], ctx.attn_drop[:, i]
+            ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)                 # dV = Pd^T dO
+            ops.bmm(dO4, v, dP[..., :t], trans_b=True)                        # dP = dO V^T
+            ops.softmax_bwd(dP, P, t, p, rng, layer.site_attn)                # -> dS (pad columns 0)
+            ops.bmm(dP, k, dq, trans_b=False, alpha=scale)                    # dQ = dS K / sqrt(dk)
+            ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale)     # dK = dS^T Q / sqrt(dk)
+            dqkv2, h2d = dqkv.view(M, 3 * d), L["h"].view(M, d)
+            for j, lin in enumerate((at.q_linear, at.k_linear, at.v_linear)):
+                _linear_wgrad(dqkv2[:, j * d:(j + 1) * d], h2d, lin)
+            _, wd, _ = rt.qkv(at)
+            dh = ops.linear(dqkv2, wd).view(B, t, d)
+
+        n1 = enc.layers[0].norm_1
+        dx0 = ops.layernorm_bwd(dh, sv["x0"], n1.weight.detach(), sv["mean0"], sv["rstd0"], grad_of(n1.weight),
+                                grad_of(n1.bias), dx=dx)
+        pe = enc.pe.table(dev)
+        if enc.embedding:
+            da0 = ops.pe_add_bwd(dx0, pe, torch.float32, grad_of(enc.pe.alpha), p, rng, enc.pe.site)
+            ops.embedding_bwd(src, da0, grad_of(enc.embed.weight), padding_idx=0)
+            dsrc = None
+        else:
+            da0 = ops.pe_add_bwd(dx0, pe, T, grad_of(enc.pe.alpha), p, rng, enc.pe.site)
+            _linear_wgrad(da0.view(M, d), src.reshape(M, -1), enc.embed)
+            dsrc = ops.linear(da0.view(M, d), rt.w_dgrad(enc.embed.weight)).view(src.shape)
+        if rt.dp is not None:
+            rt.dp.grads_ready(enc)
+        return (None, dsrc, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+# ================================================================================================ variance predictor
+class VariancePredictorFunction(torch.autograd.Function):
+    """Models/varianceadaptor.py:216-231."""
+
+    @staticmethod
+    def forward(ctx, mod, x, mask, *params):
+        rt = mod.rt
+        T = rt.dtype
+        rng = rt.get_rng(x.device)
+        p = mod.dropout
+        B, t, _ = x.shape
+        km = mask.reshape(B, t).contiguous()
+        c1 = ops.conv(x, rt.w_fwd(mod.conv1.weight), 3, 1, mod.conv1.bias.detach(), relu=True)
+        l1 = mod.layer_norm1
+        n1, m1, r1 = ops.layernorm_fwd(c1, l1.weight.detach(), l1.bias.detach(), T, 1e-5, p, rng, mod.site1)
+        c2 = ops.conv(n1, rt.w_fwd(mod.conv2.weight), 3, 1, mod.conv2.bias.detach(), relu=True)
+        l2 = mod.layer_norm2
+        n2, m2, r2 = ops.layernorm_fwd(c2, l2.weight.detach(), l2.bias.detach(), T, 1e-5, p, rng, mod.site2)
+        lin = mod.linear_layer
+        out = ops.linear1_fwd(n2, lin.weight.detach().view(-1), lin.bias.detach(), km)
+        ctx.mod, ctx.sv = mod, dict(x=x, km=km, c1=c1, n1=n1, m1=m1, r1=r1, c2=c2, n2=n2, m2=m2, r2=r2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod, s = ctx.mod, ctx.sv
+        rt = mod.rt
+        rng, p = rt.rng, mod.dropout
+        lin, l1, l2 = mod.linear_layer, mod.layer_norm1, mod.layer_norm2
+        dn2 = ops.linear1_bwd(dout.contiguous(), s["n2"], lin.weight.detach().view(-1), s["km"],
+                              grad_of(lin.weight).view(-1), grad_of(lin.bias))
+        dz2 = ops.layernorm_bwd(dn2, s["c2"], l2.weight.detach(), s["m2"], s["r2"], grad_of(l2.weight),
+                                grad_of(l2.bias), p, rng, mod.site2, relu_mask=True)
+        _conv_wgrad(rt, dz2, s["n1"], mod.conv2, 1)
+        dn1 = ops.conv(dz2, rt.w_dgrad(mod.conv2.weight), 3, 1)
+        dz1 = ops.layernorm_bwd(dn1, s["c1"], l1.weight.detach(), s["m1"], s["r1"], grad_of(l1.weight),
+                                grad_of(l1.bias), p, rng, mod.site1, relu_mask=True)
+        _conv_wgrad(rt, dz1, s["x"], mod.conv1, 1)
+        dx = ops.conv(dz1, rt.w_dgrad(mod.conv1.weight), 3, 1)
+        return (None, dx, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+
+
+# ================================================================================================ length regulator
+class LengthRegulatorFunction(torch.autograd.Function):
+    """Models/varianceadaptor.py:141-184 (+pad :233-249): on-device scan + gather instead of the
+    reference's per-phoneme Python loop with .item()."""
+
+    @staticmethod
+    def forward(ctx, x, dur, max_len):
+        out, starts = ops.length_regulate_fwd(x.contiguous(), dur.contiguous(), max_len)
+        ctx.starts, ctx.L = starts, x.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.length_regulate_bwd(dout.contiguous(), ctx.starts, ctx.L), None, None
+
+
+class BucketEmbedAddFunction(torch.autograd.Function):
+    """Models/varianceadaptor.py:100,116,123-126."""
+
+    @staticmethod
+    def forward(ctx, va, x, f0, energy, *params):
+        out, idx = ops.bucket_embed_add_fwd(x.contiguous(), f0.contiguous(), energy.contiguous(), va.pitch_bins_dev(x.device),
+                                            va.energy_bins_dev(x.device), va.pitch_embedding.weight.detach(),
+                                            va.energy_embedding.weight.detach())
+        ctx.va, ctx.idx = va, idx
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        va = ctx.va
+        dout = dout.contiguous()
+        ops.bucket_embed_bwd(dout, ctx.idx, grad_of(va.pitch_embedding.weight), grad_of(va.energy_embedding.weight))
+        return (None, dout, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+# ================================================================================================ PostNet
+class PostNetFunction(torch.autograd.Function):
+    """Models/postnets.py:64-79 (prev_version=True)."""
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        rt = mod.rt
+        T = rt.dtype
+        rng = rt.get_rng(x.device)
+        p = mod.dropout
+        B, t, d = x.shape
+        M = B * t
+        mel_dim = mod.out.weight.shape[0]
+        mel_pred = ops.linear(x.reshape(M, d), rt.w_fwd(mod.out.weight), mod.out.bias.detach(),
+                              out_dtype=torch.float32).view(B, t, mel_dim)                       # postnets.py:67
+        mel_T = mel_pred if T == torch.float32 else ops.cast(mel_pred, T)
+        convs = [mod.conv1] + list(mod.conv_list)
+        bns = [mod.pre_batchnorm] + list(mod.batch_norm_list)
+        inputs, cs, stats = [], [], []
+        h = mel_T
+        count = M
+        for li, (cv, bn) in enumerate(zip(convs, bns)):
+            C = cv.weight.shape[0]
+            sums = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+            c = ops.conv(h, rt.w_fwd(cv.weight), 5, 4, cv.bias.detach(), colstats=sums)          # causal: pad 4, crop 4
+            if rt.dp is not None:
+                count = rt.dp.allreduce_stats(sums, M)
+            mean, rstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                         bn.num_batches_tracked)
+            inputs.append(h)
+            h = ops.bn_tanh_fwd(c, mean, rstd, bn.weight.detach(), bn.bias.detach(), p, rng, mod.sites[li])  # :71-73
+            cs.append(c)
+            stats.append((mean, rstd, count))
+        post = ops.conv(h, rt.w_fwd(mod.conv2.weight), 5, 4, mod.conv2.bias.detach(), residual=mel_pred,
+                        out_dtype=torch.float32)                                                # :74-75
+        ctx.mod, ctx.sv = mod, dict(x=x, mel_T=mel_T, inputs=inputs, cs=cs, stats=stats, h_last=h)
+        ctx.set_materialize_grads(False)
+        return mel_pred, post
+
+    @staticmethod
+    def backward(ctx, dmel, dpost):
+        mod, s = ctx.mod, ctx.sv
+        rt = mod.rt
+        T = rt.dtype
+        rng, p = rt.rng, mod.dropout
+        x = s["x"]
+        B, t, d = x.shape
+        M = B * t
+        convs = [mod.conv1] + list(mod.conv_list)
+        bns = [mod.pre_batchnorm] + list(mod.batch_norm_list)
+        dmel_conv = None
+        if dpost is not None:
+            dpost = dpost.contiguous()
+            dpost_T = dpost if T == torch.float32 else ops.cast(dpost, T)
+            _conv_wgrad(rt, dpost_T, s["h_last"], mod.conv2, 4)
+            dh = ops.conv(dpost_T, rt.w_dgrad(mod.conv2.weight), 5, 0)
+            for li in reversed(range(4)):
+                cv, bn = convs[li], bns[li]
+                C = cv.weight.shape[0]
+                mean, rstd, count = s["stats"][li]
+                red = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+                ops.bn_tanh_bwd_reduce(dh, s["cs"][li], mean, rstd, bn.weight.detach(), bn.bias.detach(), red, p, rng,
+                                       mod.sites[li])
+                # affine grads come from the LOCAL sums (as SyncBatchNorm does; the DP gradient average
+                # handles the ranks); colsum over a 1-row matrix is the accumulate-add
+                ops.colsum(red[:C].view(1, C), grad_of(bn.bias))
+                ops.colsum(red[C:].view(1, C), grad_of(bn.weight))
+                if rt.dp is not None:
+                    rt.dp.allreduce_sum(red)
+                dc = ops.bn_tanh_bwd_apply(dh, s["cs"][li], mean, rstd, bn.weight.detach(), bn.bias.detach(), red, count,
+                                           None, None, p, rng, mod.sites[li])
+                _conv_wgrad(rt, dc, s["inputs"][li], cv, 4)
+                if li > 0:
+                    dh = ops.conv(dc, rt.w_dgrad(cv.weight), 5, 0)
+                else:   # gradient w.r.t. mel_pred through conv1, plus the residual path of `post`
+                    dmel_conv = ops.conv(dc, rt.w_dgrad(cv.weight), 5, 0, residual=dpost, out_dtype=torch.float32)
+        # mel_pred = out(x): d(mel_pred) = dmel (direct) + dmel_conv; the Linear is linear, so run it per term
+        x2 = x.reshape(M, d)
+        dx = None
+        for term in (dmel_conv, dmel):
+            if term is None:
+                continue
+            term = term.contiguous()
+            term_T = (term if T == torch.float32 else ops.cast(term, T)).view(M, -1)
+            _linear_wgrad(term_T, x2, mod.out)
+            dx = ops.linear(term_T, rt.w_dgrad(mod.out.weight), residual=dx)
+        if rt.dp is not None:
+            rt.dp.grads_ready(mod)
+        return (None, None if dx is None else dx.view(B, t, d)) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+# ================================================================================================ L1 loss
+class L1LossFunction(torch.autograd.Function):
+    """nn.L1Loss() of train_fastspeech2.py:212-259 (mean over every element, padding included)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, log1p_int_target):
+        pred = pred.contiguous()
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        ops.l1_fwd(pred, target.contiguous(), loss, log1p_int_target)
+        ctx.pred, ctx.target, ctx.mode = pred, target, log1p_int_target
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        return ops.l1_bwd(ctx.pred, ctx.target.contiguous(), gs, ctx.pred.dtype, ctx.mode), None, None
+
+
+def l1_loss(pred, target, log1p_int_target=False):
+    return L1LossFunction.apply(pred, target, log1p_int_target)

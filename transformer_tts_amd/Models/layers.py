@@ -1,0 +1,20 @@
+"""EncoderLayer parameter container (reference: Models/layers.py:8-41, single-speaker branch)."""
+import torch.nn as nn
+
+from .functional import next_site
+from .modules import FeedForward, MultiHeadAttention
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d_model, heads, ff_conv_kernel_size, dropout=0.1, concat_after=False, multi_speaker=False,
+                 spk_emb_dim=None):
+        super().__init__()
+        assert not multi_speaker, "multi-speaker conditioning is outside the accelerated path"
+        self.norm_1 = nn.LayerNorm(d_model)
+        self.norm_2 = nn.LayerNorm(d_model)
+        self.attn = MultiHeadAttention(heads, d_model, d_model, d_model, d_model, dropout=dropout,
+                                       concat_after=concat_after)
+        self.ff = FeedForward(d_model, ff_conv_kernel_size, dropout=dropout)
+        self.multi_speaker = multi_speaker
+        # dropout call sites: attention probabilities, dropout_1, FeedForward.dropout, dropout_2
+        self.site_attn, self.site_res1, self.site_ffn, self.site_res2 = (next_site() for _ in range(4))

@@ -1,0 +1,23 @@
+"""PostConvNet: Linear(d -> mel) + 5 causal Conv1d with BatchNorm/tanh/dropout (reference: Models/postnets.py:13-79)."""
+import torch.nn as nn
+
+from .functional import PostNetFunction, Runtime, next_site
+
+
+class PostConvNet(nn.Module):
+    def __init__(self, hp, num_hidden, mel_dim, reduction_rate, dropout=0.5, prev_version=True, runtime=None):
+        super().__init__()
+        assert prev_version and reduction_rate == 1
+        self.prev_version = prev_version
+        self.dropout = dropout
+        self.conv1 = nn.Conv1d(mel_dim * reduction_rate, num_hidden, kernel_size=5, padding=4)
+        self.conv_list = nn.ModuleList([nn.Conv1d(num_hidden, num_hidden, kernel_size=5, padding=4) for _ in range(3)])
+        self.conv2 = nn.Conv1d(num_hidden, mel_dim * reduction_rate, kernel_size=5, padding=4)
+        self.out = nn.Linear(num_hidden, mel_dim * reduction_rate)
+        self.batch_norm_list = nn.ModuleList([nn.BatchNorm1d(num_hidden) for _ in range(3)])
+        self.pre_batchnorm = nn.BatchNorm1d(num_hidden)
+        self.sites = [next_site() for _ in range(4)]
+        self.rt = runtime if runtime is not None else Runtime()
+
+    def forward(self, input_, mask=None):
+        return PostNetFunction.apply(self, input_, *self.parameters())

@@ -1,0 +1,14 @@
+// Error reporting and ABI version of libfs2_hip.so.
+#include "common.cuh"
+
+static thread_local char g_err[512] = "";
+
+void fs2_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* fs2_last_error(void) { return g_err; }
+extern "C" int fs2_abi_version(void) { return 1; }

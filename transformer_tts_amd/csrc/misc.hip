@@ -1,0 +1,438 @@
+// Gather / scatter / scan / reduction / optimizer kernels of the FastSpeech2 path for gfx950:
+// embedding, length regulator (wave scan + gather, segmented-sum backward), bucketize + embedding add,
+// L1 losses, weight-shadow cast/permute, global grad-norm and fused clip + Adam over flat fp32 arenas.
+#include "common.cuh"
+
+namespace {
+
+constexpr int TPB = 256;
+
+#define CHECK_DT(name, dt) FS2_REQUIRE((dt) == FS2_F32 || (dt) == FS2_BF16, "%s: bad dtype %d", name, (int)(dt))
+#define T_DISPATCH(dtype, T, ...)                                     \
+    do {                                                              \
+        if ((dtype) == FS2_F32) { typedef float T; __VA_ARGS__; }     \
+        else { typedef bf16_t T; __VA_ARGS__; }                       \
+    } while (0)
+
+static inline int wave_rows_grid(int64_t rows) {  // 4 waves per block, one row per wave at a time
+    int64_t b = (rows + 3) / 4;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+static inline int flat_grid(int64_t n_vec) {
+    int64_t b = (n_vec + TPB - 1) / TPB;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+__device__ __forceinline__ float block_sum(float v, float* lds4) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds4[wave] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+// ------------------------------------------------------------------ embedding
+template <typename T>
+__global__ __launch_bounds__(TPB) void embedding_fwd_k(const int64_t* __restrict__ ids, const float* __restrict__ table,
+        T* __restrict__ out, int64_t n, int d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+        const float* src = table + ids[r] * d;
+        for (int c = lane * 4; c < d; c += 256) store4<T>(out + r * d + c, load4<float>(src + c));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(TPB) void embedding_bwd_k(const int64_t* __restrict__ ids, const T* __restrict__ dout,
+        float* __restrict__ dtable, int64_t n, int d, int64_t padding_idx) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+        const int64_t id = ids[r];
+        if (id == padding_idx) continue;
+        float* dst = dtable + id * d;
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 g = load4<T>(dout + r * d + c);
+            atomicAdd(dst + c, g.x); atomicAdd(dst + c + 1, g.y); atomicAdd(dst + c + 2, g.z); atomicAdd(dst + c + 3, g.w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ length regulator
+// one wave per utterance: exclusive prefix sums of max(dur, 0) -> starts[b][0..L]
+__global__ __launch_bounds__(64) void lr_scan_k(const int64_t* __restrict__ dur, int32_t* __restrict__ starts, int L) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < L; base += 64) {
+        const int i = base + lane;
+        int v = 0;
+        if (i < L) { const int64_t x = dur[(int64_t)b * L + i]; v = x > 0 ? (int)x : 0; }
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        if (i < L) starts[(int64_t)b * (L + 1) + i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) starts[(int64_t)b * (L + 1) + L] = carry;
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void lr_gather_k(const T* __restrict__ x, const int32_t* __restrict__ starts,
+        T* __restrict__ out, int B, int L, int Tn, int d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t rows = (int64_t)B * Tn;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+        const int b = (int)(r / Tn), f = (int)(r - (int64_t)b * Tn);
+        const int32_t* st = starts + (int64_t)b * (L + 1);
+        T* dst = out + r * d;
+        if (f >= st[L]) {   // beyond the utterance: zero padding
+            for (int c = lane * 4; c < d; c += 256) store4<T>(dst + c, make_float4(0.f, 0.f, 0.f, 0.f));
+            continue;
+        }
+        // largest i with st[i] <= f  (phonemes of zero duration are skipped automatically)
+        int lo = 0, hi = L;   // invariant: st[lo] <= f < st[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (st[mid] <= f) lo = mid; else hi = mid;
+        }
+        const T* src = x + ((int64_t)b * L + lo) * d;
+        for (int c = lane * 4; c < d; c += 256) store4<T>(dst + c, load4<T>(src + c));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void lr_bwd_k(const T* __restrict__ dout, const int32_t* __restrict__ starts,
+        T* __restrict__ dx, int B, int L, int Tn, int d, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t rows = (int64_t)B * L;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+        const int b = (int)(r / L), i = (int)(r - (int64_t)b * L);
+        const int32_t* st = starts + (int64_t)b * (L + 1);
+        const int f0 = st[i];
+        const int f1 = min(st[i + 1], Tn);   // frames cropped by max_len get no gradient
+        for (int c = lane * 4; c < d; c += 256) {
+            float4 acc = accumulate ? load4<T>(dx + r * d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int f = f0; f < f1; ++f) {
+                const float4 g = load4<T>(dout + ((int64_t)b * Tn + f) * d + c);
+                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+            }
+            store4<T>(dx + r * d + c, acc);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ bucketize + embedding add
+__device__ __forceinline__ int bucketize(const float* __restrict__ bins, int nb, float v) {
+    // number of boundaries strictly below v (torch.bucketize, right=False)
+    int lo = 0, hi = nb;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (bins[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <typename T>
+__global__ __launch_bounds__(TPB) void bucket_embed_add_fwd_k(const T* __restrict__ x, const float* __restrict__ f0,
+        const float* __restrict__ en, const float* __restrict__ pbins, const float* __restrict__ ebins, int nb,
+        const float* __restrict__ Ep, const float* __restrict__ Ee, T* __restrict__ out, int32_t* __restrict__ idx,
+        int64_t M, int d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < M; r += (int64_t)gridDim.x * 4) {
+        const int ip = bucketize(pbins, nb, f0[r]);
+        const int ie = bucketize(ebins, nb, en[r]);
+        if (lane == 0) { idx[r] = ip; idx[M + r] = ie; }
+        const float* ep = Ep + (int64_t)ip * d;
+        const float* ee = Ee + (int64_t)ie * d;
+        for (int c = lane * 4; c < d; c += 256) {
+            float4 v = load4<T>(x + r * d + c);
+            const float4 a = load4<float>(ep + c), b = load4<float>(ee + c);
+            // same association as the reference: (x + pitch_embedding) + energy_embedding
+            v.x = (v.x + a.x) + b.x; v.y = (v.y + a.y) + b.y; v.z = (v.z + a.z) + b.z; v.w = (v.w + a.w) + b.w;
+            store4<T>(out + r * d + c, v);
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(TPB) void bucket_embed_bwd_k(const T* __restrict__ dout, const int32_t* __restrict__ idx,
+        float* __restrict__ dEp, float* __restrict__ dEe, int64_t M, int d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < M; r += (int64_t)gridDim.x * 4) {
+        float* dp = dEp + (int64_t)idx[r] * d;
+        float* de = dEe + (int64_t)idx[M + r] * d;
+        for (int c = lane * 4; c < d; c += 256) {
+            const float4 g = load4<T>(dout + r * d + c);
+            atomicAdd(dp + c, g.x); atomicAdd(dp + c + 1, g.y); atomicAdd(dp + c + 2, g.z); atomicAdd(dp + c + 3, g.w);
+            atomicAdd(de + c, g.x); atomicAdd(de + c + 1, g.y); atomicAdd(de + c + 2, g.z); atomicAdd(de + c + 3, g.w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ L1 loss
+template <typename T> __device__ __forceinline__ float l1_target(const void* tgt, int mode, int64_t i) {
+    if (mode == 1) return logf((float)reinterpret_cast<const int64_t*>(tgt)[i] + 1.0f);
+    return reinterpret_cast<const float*>(tgt)[i];
+}
+template <typename T>
+__global__ __launch_bounds__(TPB) void l1_fwd_k(const T* __restrict__ pred, const void* __restrict__ tgt, int mode,
+        int64_t n, float* __restrict__ loss) {
+    __shared__ float lds4[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+        acc += fabsf(to_f32<T>(pred[i]) - l1_target<T>(tgt, mode, i));
+    const float s = block_sum(acc, lds4);
+    if (threadIdx.x == 0) atomicAdd(loss, s / (float)n);
+}
+template <typename T, typename TG>
+__global__ __launch_bounds__(TPB) void l1_bwd_k(const T* __restrict__ pred, const void* __restrict__ tgt, int mode,
+        int64_t n, const float* __restrict__ gscale, TG* __restrict__ dpred) {
+    const float g = gscale[0] / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const float df = to_f32<T>(pred[i]) - l1_target<T>(tgt, mode, i);
+        dpred[i] = from_f32<TG>(df > 0.f ? g : (df < 0.f ? -g : 0.f));
+    }
+}
+
+// ------------------------------------------------------------------ casts / weight shadows
+template <typename TS, typename TD>
+__global__ __launch_bounds__(TPB) void cast_k(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+        dst[i] = from_f32<TD>(to_f32<TS>(src[i]));
+}
+// src (O, I, k) fp32 -> dst; one thread per destination element (destination-contiguous)
+template <typename T>
+__global__ __launch_bounds__(TPB) void cast_permute_k(const float* __restrict__ src, T* __restrict__ dst, int O, int I,
+        int k, int64_t dld, int mode) {
+    const int64_t n = (int64_t)O * I * k;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        if (mode == 0) {          // dst[o][j*I + i] = src[o][i][j]
+            const int i = (int)(e % I); const int j = (int)((e / I) % k); const int o = (int)(e / ((int64_t)I * k));
+            dst[(int64_t)o * dld + (int64_t)j * I + i] = from_f32<T>(src[((int64_t)o * I + i) * k + j]);
+        } else {                  // dst[i][j*O + o] = src[o][i][k-1-j]
+            const int o = (int)(e % O); const int j = (int)((e / O) % k); const int i = (int)(e / ((int64_t)O * k));
+            dst[(int64_t)i * dld + (int64_t)j * O + o] = from_f32<T>(src[((int64_t)o * I + i) * k + (k - 1 - j)]);
+        }
+    }
+}
+__global__ __launch_bounds__(TPB) void permute_add_k(const float* __restrict__ scratch, float* __restrict__ grad, int O,
+        int I, int k) {
+    const int64_t n = (int64_t)O * I * k;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        const int j = (int)(e % k); const int i = (int)((e / k) % I); const int o = (int)(e / ((int64_t)I * k));
+        grad[e] += scratch[((int64_t)o * k + j) * I + i];
+    }
+}
+
+// out[n] += sum_m x[m][n]: block = 64 column-groups of 4 x 4 row-slabs
+template <typename T>
+__global__ __launch_bounds__(TPB) void colsum_k(const T* __restrict__ x, int64_t M, int N, int64_t ldx,
+        float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + lane * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < N)
+        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < M; r += (int64_t)gridDim.y * 4) {
+            const float4 v = load4<T>(x + r * ldx + col);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    *reinterpret_cast<float4*>(red + wave * 256 + lane * 4) = acc;
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < N) atomicAdd(out + c, red[threadIdx.x] + red[256 + threadIdx.x] + red[512 + threadIdx.x] + red[768 + threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ optimizer
+__global__ __launch_bounds__(TPB) void sqnorm_k(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float lds4[4];
+    float acc = 0.f;
+    const int64_t nv = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[(nv << 2) + threadIdx.x]; acc += v * v; }
+    const float s = block_sum(acc, lds4);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float gmul, float b1, float b2,
+                                       float step_size, float bc2s, float eps) {
+    g *= gmul;
+    m = m + (g - m) * (1.f - b1);            // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * b2 + (1.f - b2) * g * g;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(v) / bc2s + eps;
+    p = p - step_size * (m / denom);
+}
+__global__ __launch_bounds__(TPB) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+        float* __restrict__ v, int64_t n, const float* __restrict__ hyper, const float* __restrict__ gsq, float b1,
+        float b2, float eps, float max_norm) {
+    const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gs = hyper[3];
+    float gmul = gs;
+    if (max_norm > 0.f && gsq != nullptr) {
+        const float total = sqrtf(gsq[0]) * gs;
+        gmul *= fminf(1.f, max_norm / (total + 1e-6f));   // clip_grad_norm_
+    }
+    const float step_size = lr / bc1, bc2s = sqrtf(bc2);
+    const int64_t nv = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, gmul, b1, b2, step_size, bc2s, eps);
+        adam1(pp.y, gg.y, mm.y, vv.y, gmul, b1, b2, step_size, bc2s, eps);
+        adam1(pp.z, gg.z, mm.z, vv.z, gmul, b1, b2, step_size, bc2s, eps);
+        adam1(pp.w, gg.w, mm.w, vv.w, gmul, b1, b2, step_size, bc2s, eps);
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nv << 2) + threadIdx.x;
+        adam1(p[i], g[i], m[i], v[i], gmul, b1, b2, step_size, bc2s, eps);
+    }
+}
+
+__global__ void rng_advance_k(uint64_t* rng) { rng[1] += 1; }
+
+}  // namespace
+
+// ==================================================================== host launchers
+extern "C" int fs2_embedding_fwd(const int64_t* ids, const float* table, void* out, int out_dtype, int64_t n, int d,
+                                 void* stream) {
+    CHECK_DT("fs2_embedding_fwd", out_dtype);
+    FS2_REQUIRE(d > 0 && d % 4 == 0, "fs2_embedding_fwd: d=%d must be a multiple of 4", d);
+    if (n <= 0) return FS2_OK;
+    T_DISPATCH(out_dtype, T, { hipLaunchKernelGGL((embedding_fwd_k<T>), dim3(wave_rows_grid(n)), dim3(TPB), 0, (hipStream_t)stream, ids, table, (T*)out, n, d); });
+    FS2_CHECK_LAUNCH("fs2_embedding_fwd");
+    return FS2_OK;
+}
+extern "C" int fs2_embedding_bwd(const int64_t* ids, const void* dout, int dout_dtype, float* dtable, int64_t n, int d,
+                                 int64_t padding_idx, void* stream) {
+    CHECK_DT("fs2_embedding_bwd", dout_dtype);
+    FS2_REQUIRE(d > 0 && d % 4 == 0, "fs2_embedding_bwd: d=%d must be a multiple of 4", d);
+    if (n <= 0) return FS2_OK;
+    T_DISPATCH(dout_dtype, T, { hipLaunchKernelGGL((embedding_bwd_k<T>), dim3(wave_rows_grid(n)), dim3(TPB), 0, (hipStream_t)stream, ids, (const T*)dout, dtable, n, d, padding_idx); });
+    FS2_CHECK_LAUNCH("fs2_embedding_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_length_regulate_fwd(const void* x, int dtype, const int64_t* dur, void* out, int32_t* starts, int B,
+                                       int L, int T, int d, void* stream) {
+    CHECK_DT("fs2_length_regulate_fwd", dtype);
+    FS2_REQUIRE(B > 0 && L > 0 && T > 0 && d > 0 && d % 4 == 0, "fs2_length_regulate_fwd: bad shape B=%d L=%d T=%d d=%d", B, L, T, d);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lr_scan_k, dim3(B), dim3(64), 0, st, dur, starts, L);
+    FS2_CHECK_LAUNCH("fs2_length_regulate_fwd(scan)");
+    T_DISPATCH(dtype, TT, { hipLaunchKernelGGL((lr_gather_k<TT>), dim3(wave_rows_grid((int64_t)B * T)), dim3(TPB), 0, st, (const TT*)x, starts, (TT*)out, B, L, T, d); });
+    FS2_CHECK_LAUNCH("fs2_length_regulate_fwd(gather)");
+    return FS2_OK;
+}
+extern "C" int fs2_length_regulate_bwd(const void* dout, int dtype, const int32_t* starts, void* dx, int B, int L, int T,
+                                       int d, int accumulate, void* stream) {
+    CHECK_DT("fs2_length_regulate_bwd", dtype);
+    FS2_REQUIRE(B > 0 && L > 0 && T > 0 && d > 0 && d % 4 == 0, "fs2_length_regulate_bwd: bad shape");
+    T_DISPATCH(dtype, TT, { hipLaunchKernelGGL((lr_bwd_k<TT>), dim3(wave_rows_grid((int64_t)B * L)), dim3(TPB), 0, (hipStream_t)stream, (const TT*)dout, starts, (TT*)dx, B, L, T, d, accumulate); });
+    FS2_CHECK_LAUNCH("fs2_length_regulate_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_bucket_embed_add_fwd(const void* x, int dtype, const float* f0, const float* energy, const float* pbins,
+                                        const float* ebins, int nbins, const float* Ep, const float* Ee, void* out,
+                                        int32_t* idx, int64_t M, int d, void* stream) {
+    CHECK_DT("fs2_bucket_embed_add_fwd", dtype);
+    FS2_REQUIRE(d > 0 && d % 4 == 0 && nbins > 0, "fs2_bucket_embed_add_fwd: bad d/nbins");
+    if (M <= 0) return FS2_OK;
+    T_DISPATCH(dtype, T, { hipLaunchKernelGGL((bucket_embed_add_fwd_k<T>), dim3(wave_rows_grid(M)), dim3(TPB), 0, (hipStream_t)stream, (const T*)x, f0, energy, pbins, ebins, nbins, Ep, Ee, (T*)out, idx, M, d); });
+    FS2_CHECK_LAUNCH("fs2_bucket_embed_add_fwd");
+    return FS2_OK;
+}
+extern "C" int fs2_bucket_embed_bwd(const void* dout, int dtype, const int32_t* idx, float* dEp, float* dEe, int64_t M,
+                                    int d, void* stream) {
+    CHECK_DT("fs2_bucket_embed_bwd", dtype);
+    FS2_REQUIRE(d > 0 && d % 4 == 0, "fs2_bucket_embed_bwd: bad d");
+    if (M <= 0) return FS2_OK;
+    T_DISPATCH(dtype, T, { hipLaunchKernelGGL((bucket_embed_bwd_k<T>), dim3(wave_rows_grid(M)), dim3(TPB), 0, (hipStream_t)stream, (const T*)dout, idx, dEp, dEe, M, d); });
+    FS2_CHECK_LAUNCH("fs2_bucket_embed_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_l1_fwd(const void* pred, int pred_dtype, const void* target, int target_mode, int64_t n, float* loss,
+                          void* stream) {
+    CHECK_DT("fs2_l1_fwd", pred_dtype);
+    FS2_REQUIRE(n > 0 && (target_mode == 0 || target_mode == 1), "fs2_l1_fwd: bad n/target_mode");
+    T_DISPATCH(pred_dtype, T, { hipLaunchKernelGGL((l1_fwd_k<T>), dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, (const T*)pred, target, target_mode, n, loss); });
+    FS2_CHECK_LAUNCH("fs2_l1_fwd");
+    return FS2_OK;
+}
+extern "C" int fs2_l1_bwd(const void* pred, int pred_dtype, const void* target, int target_mode, int64_t n,
+                          const float* gscale, void* dpred, int dpred_dtype, void* stream) {
+    CHECK_DT("fs2_l1_bwd", pred_dtype); CHECK_DT("fs2_l1_bwd", dpred_dtype);
+    FS2_REQUIRE(n > 0 && (target_mode == 0 || target_mode == 1), "fs2_l1_bwd: bad n/target_mode");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(flat_grid(n)), block(TPB);
+    if (pred_dtype == FS2_F32 && dpred_dtype == FS2_F32) hipLaunchKernelGGL((l1_bwd_k<float, float>), grid, block, 0, st, (const float*)pred, target, target_mode, n, gscale, (float*)dpred);
+    else if (pred_dtype == FS2_F32) hipLaunchKernelGGL((l1_bwd_k<float, bf16_t>), grid, block, 0, st, (const float*)pred, target, target_mode, n, gscale, (bf16_t*)dpred);
+    else if (dpred_dtype == FS2_F32) hipLaunchKernelGGL((l1_bwd_k<bf16_t, float>), grid, block, 0, st, (const bf16_t*)pred, target, target_mode, n, gscale, (float*)dpred);
+    else hipLaunchKernelGGL((l1_bwd_k<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)pred, target, target_mode, n, gscale, (bf16_t*)dpred);
+    FS2_CHECK_LAUNCH("fs2_l1_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+    CHECK_DT("fs2_cast", src_dtype); CHECK_DT("fs2_cast", dst_dtype);
+    if (n <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(flat_grid(n)), block(TPB);
+    if (src_dtype == FS2_F32 && dst_dtype == FS2_BF16) hipLaunchKernelGGL((cast_k<float, bf16_t>), grid, block, 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == FS2_BF16 && dst_dtype == FS2_F32) hipLaunchKernelGGL((cast_k<bf16_t, float>), grid, block, 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == FS2_F32) hipLaunchKernelGGL((cast_k<float, float>), grid, block, 0, st, (const float*)src, (float*)dst, n);
+    else hipLaunchKernelGGL((cast_k<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    FS2_CHECK_LAUNCH("fs2_cast");
+    return FS2_OK;
+}
+extern "C" int fs2_cast_permute(const float* src, void* dst, int O, int I, int k, int64_t dld, int mode, int dtype,
+                                void* stream) {
+    CHECK_DT("fs2_cast_permute", dtype);
+    FS2_REQUIRE(O > 0 && I > 0 && k > 0 && (mode == 0 || mode == 1), "fs2_cast_permute: bad shape/mode");
+    FS2_REQUIRE(dld >= (int64_t)k * (mode == 0 ? I : O), "fs2_cast_permute: dld too small");
+    const int64_t n = (int64_t)O * I * k;
+    T_DISPATCH(dtype, T, { hipLaunchKernelGGL((cast_permute_k<T>), dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, src, (T*)dst, O, I, k, dld, mode); });
+    FS2_CHECK_LAUNCH("fs2_cast_permute");
+    return FS2_OK;
+}
+extern "C" int fs2_permute_add(const float* scratch, float* grad, int O, int I, int k, void* stream) {
+    FS2_REQUIRE(O > 0 && I > 0 && k > 0, "fs2_permute_add: bad shape");
+    const int64_t n = (int64_t)O * I * k;
+    hipLaunchKernelGGL(permute_add_k, dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, scratch, grad, O, I, k);
+    FS2_CHECK_LAUNCH("fs2_permute_add");
+    return FS2_OK;
+}
+extern "C" int fs2_colsum(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, void* stream) {
+    CHECK_DT("fs2_colsum", dtype);
+    FS2_REQUIRE(N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N, "fs2_colsum: N and ldx must be multiples of 4");
+    if (M <= 0) return FS2_OK;
+    int64_t slabs = (M + 3) / 4;
+    if (slabs > 512) slabs = 512;
+    dim3 grid((N + 255) / 256, (unsigned)slabs);
+    T_DISPATCH(dtype, T, { hipLaunchKernelGGL((colsum_k<T>), grid, dim3(TPB), 0, (hipStream_t)stream, (const T*)x, M, N, ldx, out); });
+    FS2_CHECK_LAUNCH("fs2_colsum");
+    return FS2_OK;
+}
+
+extern "C" int fs2_sqnorm(const float* x, int64_t n, float* out, void* stream) {
+    FS2_REQUIRE(n > 0 && fs2_aligned16(x), "fs2_sqnorm: n > 0 and 16-byte aligned x required");
+    hipLaunchKernelGGL(sqnorm_k, dim3(flat_grid(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, x, n, out);
+    FS2_CHECK_LAUNCH("fs2_sqnorm");
+    return FS2_OK;
+}
+extern "C" int fs2_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* gsq,
+                             float beta1, float beta2, float eps, float max_norm, void* stream) {
+    FS2_REQUIRE(n > 0 && fs2_aligned16(p) && fs2_aligned16(g) && fs2_aligned16(m) && fs2_aligned16(v), "fs2_adam_step: arenas must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_k, dim3(flat_grid(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, hyper, gsq, beta1, beta2, eps, max_norm);
+    FS2_CHECK_LAUNCH("fs2_adam_step");
+    return FS2_OK;
+}
+extern "C" int fs2_rng_advance(uint64_t* rng, void* stream) {
+    hipLaunchKernelGGL(rng_advance_k, dim3(1), dim3(1), 0, (hipStream_t)stream, rng);
+    FS2_CHECK_LAUNCH("fs2_rng_advance");
+    return FS2_OK;
+}

@@ -1,0 +1,928 @@
+// Row-wise (one 64-lane wave per row) HBM-bound kernels of the FastSpeech2 path for gfx950:
+// LayerNorm family with fused residual / dropout, attention softmax, positional-encoding add,
+// the variance-predictor head and BatchNorm+tanh.  Every lane moves 16-byte (f32) / 8-byte (bf16)
+// groups of 4 consecutive channels, so a wave-instruction covers 1 KiB / 512 B contiguous bytes.
+// A block is 4 waves; waves stride over rows, and per-channel reductions over rows (dgamma, dbeta,
+// BatchNorm sums) are kept in registers, combined across the 4 waves in LDS and flushed with one
+// float atomic per channel per block.
+#include "common.cuh"
+
+namespace {
+
+constexpr int ROW_BLOCK = 256;  // 4 waves
+constexpr int ROW_WAVES = 4;
+
+static inline int row_grid(int64_t rows) {
+    int64_t b = (rows + ROW_WAVES - 1) / ROW_WAVES;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+#define ROW_LOOP(M)                                                                          \
+    const int lane = threadIdx.x & 63;                                                       \
+    const int wave = threadIdx.x >> 6;                                                       \
+    for (int64_t row = (int64_t)blockIdx.x * ROW_WAVES + wave; row < (M); row += (int64_t)gridDim.x * ROW_WAVES)
+
+// column of group g for this lane, and whether it is inside the row
+#define GCOL(g) (4 * (lane + 64 * (g)))
+
+template <int NG, typename T>
+__device__ __forceinline__ void row_load(const T* p, int d, int lane, float4 (&v)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) v[g] = (GCOL(g) < d) ? load4<T>(p + GCOL(g)) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+template <int NG, typename T>
+__device__ __forceinline__ void row_store(T* p, int d, int lane, const float4 (&v)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+        if (GCOL(g) < d) store4<T>(p + GCOL(g), v[g]);
+}
+__device__ __forceinline__ float sum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+
+// mean and 1/sqrt(var+eps) of a row held in registers (two-pass, as torch's LayerNorm does)
+template <int NG>
+__device__ __forceinline__ void row_stats(const float4 (&v)[NG], int d, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) s += sum4(v[g]);  // out-of-row groups are zero
+    mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+        if (GCOL(g) < d) {
+            float4 c = make_float4(v[g].x - mean, v[g].y - mean, v[g].z - mean, v[g].w - mean);
+            q += sum4(mul4(c, c));
+        }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+}
+
+// flush per-lane per-channel partial sums: LDS across the 4 waves, then one atomic per channel
+template <int NG>
+__device__ __forceinline__ void flush_channel_sums(const float4 (&acc)[NG], float* out, int d, float* lds /* [4][NG*256] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) *reinterpret_cast<float4*>(lds + wave * NG * 256 + GCOL(g)) = acc[g];
+    __syncthreads();
+    for (int c = threadIdx.x; c < NG * 256; c += ROW_BLOCK) {
+        if (c < d) {
+            float s = lds[c] + lds[NG * 256 + c] + lds[2 * NG * 256 + c] + lds[3 * NG * 256 + c];
+            atomicAdd(out + c, s);
+        }
+    }
+}
+
+// ================================================================ LayerNorm (+dropout)
+template <typename TX, typename TY, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void layernorm_fwd_k(const TX* __restrict__ x, const float* __restrict__ gamma,
+        const float* __restrict__ beta, TY* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+        int64_t M, int d, float eps, float p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 gm[NG], bt[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm);
+        row_load<NG, float>(beta, d, lane, bt);
+    }
+    ROW_LOOP(M) {
+        float4 v[NG];
+        row_load<NG, TX>(x + row * d, d, lane, v);
+        float mu, rs;
+        row_stats<NG>(v, d, lane, eps, mu, rs);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float4 o;
+            o.x = (v[g].x - mu) * rs * gm[g].x + bt[g].x; o.y = (v[g].y - mu) * rs * gm[g].y + bt[g].y;
+            o.z = (v[g].z - mu) * rs * gm[g].z + bt[g].z; o.w = (v[g].w - mu) * rs * gm[g].w + bt[g].w;
+            if (dc.on && GCOL(g) < d) o = mul4(o, drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+            v[g] = o;
+        }
+        row_store<NG, TY>(y + row * d, d, lane, v);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <typename TDY, typename TX, typename TDX, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void layernorm_bwd_k(const TDY* __restrict__ dy, const TX* __restrict__ x,
+        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+        TDX* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M, int d, float p,
+        const uint64_t* rng, uint32_t site, int relu_mask, int dx_accumulate) {
+    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 gm[NG], ag[NG], ab[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float invd = 1.f / (float)d;
+    ROW_LOOP(M) {
+        float4 g_[NG], xv[NG];
+        row_load<NG, TDY>(dy + row * d, d, lane, g_);
+        row_load<NG, TX>(x + row * d, d, lane, xv);
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+        unsigned pos[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            pos[g] = 0xFu;
+            if (GCOL(g) < d) {
+                if (dc.on) g_[g] = mul4(g_[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+                if (relu_mask)  // the LayerNorm input was relu(z): remember where z > 0
+                    pos[g] = (xv[g].x > 0.f ? 1u : 0u) | (xv[g].y > 0.f ? 2u : 0u) | (xv[g].z > 0.f ? 4u : 0u) | (xv[g].w > 0.f ? 8u : 0u);
+                float4 xh = make_float4((xv[g].x - mu) * rs, (xv[g].y - mu) * rs, (xv[g].z - mu) * rs, (xv[g].w - mu) * rs);
+                ag[g] = add4(ag[g], mul4(g_[g], xh));
+                ab[g] = add4(ab[g], g_[g]);
+                float4 dg = mul4(g_[g], gm[g]);
+                c1 += sum4(dg);
+                c2 += sum4(mul4(dg, xh));
+                g_[g] = dg;   // dy * gamma
+                xv[g] = xh;
+            }
+        }
+        c1 = wave_sum(c1) * invd;
+        c2 = wave_sum(c2) * invd;
+        float4 o[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2); o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2);
+            o[g].z = rs * (g_[g].z - c1 - xv[g].z * c2); o[g].w = rs * (g_[g].w - c1 - xv[g].w * c2);
+            if (relu_mask) {
+                o[g].x = (pos[g] & 1u) ? o[g].x : 0.f; o[g].y = (pos[g] & 2u) ? o[g].y : 0.f;
+                o[g].z = (pos[g] & 4u) ? o[g].z : 0.f; o[g].w = (pos[g] & 8u) ? o[g].w : 0.f;
+            }
+        }
+        if (dx_accumulate) {
+            float4 old[NG];
+            row_load<NG, TDX>(dx + row * d, d, lane, old);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) o[g] = add4(o[g], old[g]);
+        }
+        row_store<NG, TDX>(dx + row * d, d, lane, o);
+    }
+    flush_channel_sums<NG>(ag, dgamma, d, red);
+    flush_channel_sums<NG>(ab, dbeta, d, red);
+}
+
+// ================================================================ s = r + dropout(a); y = LN(s)
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void add_ln_fwd_k(const float* __restrict__ r, const T* __restrict__ a,
+        float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+        float* __restrict__ mean, float* __restrict__ rstd, int64_t M, int d, float eps, float p, const uint64_t* rng,
+        uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 gm[NG], bt[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm);
+        row_load<NG, float>(beta, d, lane, bt);
+    }
+    ROW_LOOP(M) {
+        float4 v[NG], av[NG];
+        row_load<NG, float>(r + row * d, d, lane, v);
+        row_load<NG, T>(a + row * d, d, lane, av);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (dc.on && GCOL(g) < d) av[g] = mul4(av[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+            v[g] = add4(v[g], av[g]);
+        }
+        row_store<NG, float>(s + row * d, d, lane, v);
+        float mu, rs;
+        row_stats<NG>(v, d, lane, eps, mu, rs);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g].x = (v[g].x - mu) * rs * gm[g].x + bt[g].x; v[g].y = (v[g].y - mu) * rs * gm[g].y + bt[g].y;
+            v[g].z = (v[g].z - mu) * rs * gm[g].z + bt[g].z; v[g].w = (v[g].w - mu) * rs * gm[g].w + bt[g].w;
+        }
+        row_store<NG, T>(y + row * d, d, lane, v);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void add_ln_bwd_k(const float* __restrict__ ds_down, const T* __restrict__ dy,
+        const float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ mean,
+        const float* __restrict__ rstd, float* __restrict__ dr, T* __restrict__ da, float* __restrict__ dgamma,
+        float* __restrict__ dbeta, int64_t M, int d, float p, const uint64_t* rng, uint32_t site) {
+    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 gm[NG], ag[NG], ab[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float invd = 1.f / (float)d;
+    ROW_LOOP(M) {
+        float4 g_[NG], xv[NG];
+        row_load<NG, T>(dy + row * d, d, lane, g_);
+        row_load<NG, float>(s + row * d, d, lane, xv);
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (GCOL(g) < d) {
+                float4 xh = make_float4((xv[g].x - mu) * rs, (xv[g].y - mu) * rs, (xv[g].z - mu) * rs, (xv[g].w - mu) * rs);
+                ag[g] = add4(ag[g], mul4(g_[g], xh));
+                ab[g] = add4(ab[g], g_[g]);
+                float4 dg = mul4(g_[g], gm[g]);
+                c1 += sum4(dg);
+                c2 += sum4(mul4(dg, xh));
+                g_[g] = dg;
+                xv[g] = xh;
+            }
+        }
+        c1 = wave_sum(c1) * invd;
+        c2 = wave_sum(c2) * invd;
+        float4 o[NG], dn[NG];
+        if (ds_down != nullptr) row_load<NG, float>(ds_down + row * d, d, lane, dn);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2); o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2);
+            o[g].z = rs * (g_[g].z - c1 - xv[g].z * c2); o[g].w = rs * (g_[g].w - c1 - xv[g].w * c2);
+            if (ds_down != nullptr) o[g] = add4(o[g], dn[g]);
+        }
+        row_store<NG, float>(dr + row * d, d, lane, o);
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            if (dc.on && GCOL(g) < d) o[g] = mul4(o[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+        row_store<NG, T>(da + row * d, d, lane, o);
+    }
+    flush_channel_sums<NG>(ag, dgamma, d, red);
+    flush_channel_sums<NG>(ab, dbeta, d, red);
+}
+
+// ================================================================ y = LN(dropout(f2 + h))
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void ffn_ln_fwd_k(const T* __restrict__ f2, const T* __restrict__ h,
+        const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
+        float* __restrict__ rstd, int64_t M, int d, float eps, float p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 gm[NG], bt[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm);
+        row_load<NG, float>(beta, d, lane, bt);
+    }
+    ROW_LOOP(M) {
+        float4 v[NG], hv[NG];
+        row_load<NG, T>(f2 + row * d, d, lane, v);
+        row_load<NG, T>(h + row * d, d, lane, hv);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g] = add4(v[g], hv[g]);
+            if (dc.on && GCOL(g) < d) v[g] = mul4(v[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+        }
+        float mu, rs;
+        row_stats<NG>(v, d, lane, eps, mu, rs);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g].x = (v[g].x - mu) * rs * gm[g].x + bt[g].x; v[g].y = (v[g].y - mu) * rs * gm[g].y + bt[g].y;
+            v[g].z = (v[g].z - mu) * rs * gm[g].z + bt[g].z; v[g].w = (v[g].w - mu) * rs * gm[g].w + bt[g].w;
+        }
+        row_store<NG, T>(y + row * d, d, lane, v);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void ffn_ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ f2,
+        const T* __restrict__ h, const float* __restrict__ gamma, const float* __restrict__ mean,
+        const float* __restrict__ rstd, T* __restrict__ gout, float* __restrict__ dgamma, float* __restrict__ dbeta,
+        int64_t M, int d, float p, const uint64_t* rng, uint32_t site) {
+    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 gm[NG], ag[NG], ab[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float invd = 1.f / (float)d;
+    ROW_LOOP(M) {
+        float4 g_[NG], xv[NG], hv[NG], ds[NG];
+        row_load<NG, T>(dy + row * d, d, lane, g_);
+        row_load<NG, T>(f2 + row * d, d, lane, xv);
+        row_load<NG, T>(h + row * d, d, lane, hv);
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            ds[g] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (GCOL(g) < d) {
+                if (dc.on) ds[g] = drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2);
+                float4 u = mul4(add4(xv[g], hv[g]), ds[g]);
+                float4 xh = make_float4((u.x - mu) * rs, (u.y - mu) * rs, (u.z - mu) * rs, (u.w - mu) * rs);
+                ag[g] = add4(ag[g], mul4(g_[g], xh));
+                ab[g] = add4(ab[g], g_[g]);
+                float4 dg = mul4(g_[g], gm[g]);
+                c1 += sum4(dg);
+                c2 += sum4(mul4(dg, xh));
+                g_[g] = dg;
+                xv[g] = xh;
+            }
+        }
+        c1 = wave_sum(c1) * invd;
+        c2 = wave_sum(c2) * invd;
+        float4 o[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2) * ds[g].x; o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2) * ds[g].y;
+            o[g].z = rs * (g_[g].z - c1 - xv[g].z * c2) * ds[g].z; o[g].w = rs * (g_[g].w - c1 - xv[g].w * c2) * ds[g].w;
+        }
+        row_store<NG, T>(gout + row * d, d, lane, o);
+    }
+    flush_channel_sums<NG>(ag, dgamma, d, red);
+    flush_channel_sums<NG>(ab, dbeta, d, red);
+}
+
+// ================================================================ attention softmax (in place) + dropout
+// rows = (b, h, i); S row = base + b*batch_stride + (h*t + i)*tp; keys j < t; pad columns [t,tp) -> 0
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd_k(T* __restrict__ s, T* __restrict__ pd,
+        const uint8_t* __restrict__ key_mask, int B, int H, int t, int tp, int64_t batch_stride, float p,
+        const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    const int64_t rows = (int64_t)B * H * t;
+    ROW_LOOP(rows) {
+        const int b = (int)(row / ((int64_t)H * t));
+        const int64_t inb = row - (int64_t)b * H * t;   // h*t + i
+        const int64_t off = b * batch_stride + inb * tp;
+        const uint8_t* km = key_mask + (int64_t)b * t;
+        float4 v[NG];
+        row_load<NG, T>(s + off, tp, lane, v);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float* e = &v[g].x;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = GCOL(g) + c;
+                if (j < t) {
+                    if (km[j] == 0) e[c] = -1e4f;     // masked_fill(mask == 0, -1e4) on keys
+                    mx = fmaxf(mx, e[c]);
+                } else e[c] = -3.0e38f;
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float* e = &v[g].x;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = GCOL(g) + c;
+                e[c] = (j < t) ? __expf(e[c] - mx) : 0.f;
+                sum += e[c];
+            }
+        }
+        const float inv = 1.f / wave_sum(sum);
+        float4 o[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g] = scale4(v[g], inv);
+            o[g] = v[g];
+            if (dc.on && GCOL(g) < tp) o[g] = mul4(o[g], drop_scale4(dc, (uint64_t)(off + GCOL(g)) >> 2));
+        }
+        row_store<NG, T>(s + off, tp, lane, v);
+        if (pd != s) row_store<NG, T>(pd + off, tp, lane, o);
+    }
+}
+
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void softmax_bwd_k(T* __restrict__ dp, const T* __restrict__ ps, int B, int H,
+        int t, int tp, int64_t batch_stride, float p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    const int64_t rows = (int64_t)B * H * t;
+    ROW_LOOP(rows) {
+        const int b = (int)(row / ((int64_t)H * t));
+        const int64_t inb = row - (int64_t)b * H * t;
+        const int64_t off = b * batch_stride + inb * tp;
+        float4 g_[NG], pv[NG];
+        row_load<NG, T>(dp + off, tp, lane, g_);
+        row_load<NG, T>(ps + off, tp, lane, pv);
+        float dot = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            // pad columns [t,tp) of dP were never written by the GEMM: force them (and P's) to 0
+            float* ge = &g_[g].x; float* pe_ = &pv[g].x;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (GCOL(g) + c >= t) { ge[c] = 0.f; pe_[c] = 0.f; }
+            if (dc.on && GCOL(g) < tp) g_[g] = mul4(g_[g], drop_scale4(dc, (uint64_t)(off + GCOL(g)) >> 2));
+            dot += sum4(mul4(g_[g], pv[g]));
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            g_[g].x = pv[g].x * (g_[g].x - dot); g_[g].y = pv[g].y * (g_[g].y - dot);
+            g_[g].z = pv[g].z * (g_[g].z - dot); g_[g].w = pv[g].w * (g_[g].w - dot);
+        }
+        row_store<NG, T>(dp + off, tp, lane, g_);
+    }
+}
+
+// ================================================================ positional encoding add
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void pe_add_fwd_k(const T* __restrict__ a, const float* __restrict__ pe,
+        const float* __restrict__ alpha, float* __restrict__ out, int64_t M, int t, int d, float p,
+        const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    const float al = alpha[0];
+    ROW_LOOP(M) {
+        const int pos = (int)(row % t);
+        float4 v[NG], pv[NG];
+        row_load<NG, T>(a + row * d, d, lane, v);
+        row_load<NG, float>(pe + (int64_t)pos * d, d, lane, pv);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g] = add4(v[g], scale4(pv[g], al));
+            if (dc.on && GCOL(g) < d) v[g] = mul4(v[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+        }
+        row_store<NG, float>(out + row * d, d, lane, v);
+    }
+}
+
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void pe_add_bwd_k(const float* __restrict__ dout, const float* __restrict__ pe,
+        T* __restrict__ da, float* __restrict__ dalpha, int64_t M, int t, int d, float p, const uint64_t* rng,
+        uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float acc = 0.f;
+    ROW_LOOP(M) {
+        const int pos = (int)(row % t);
+        float4 v[NG], pv[NG];
+        row_load<NG, float>(dout + row * d, d, lane, v);
+        row_load<NG, float>(pe + (int64_t)pos * d, d, lane, pv);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (dc.on && GCOL(g) < d) v[g] = mul4(v[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+            acc += sum4(mul4(v[g], pv[g]));
+        }
+        if (da != nullptr) row_store<NG, T>(da + row * d, d, lane, v);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dalpha, acc);
+}
+
+// ================================================================ Linear(d -> 1) + masked_fill(0)
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void linear1_fwd_k(const T* __restrict__ x, const float* __restrict__ w,
+        const float* __restrict__ b, const uint8_t* __restrict__ mask, float* __restrict__ out, int64_t M, int d) {
+    float4 wv[NG];
+    { const int lane = threadIdx.x & 63; row_load<NG, float>(w, d, lane, wv); }
+    const float bias = b[0];
+    ROW_LOOP(M) {
+        float4 v[NG];
+        row_load<NG, T>(x + row * d, d, lane, v);
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) s += sum4(mul4(v[g], wv[g]));
+        s = wave_sum(s);
+        if (lane == 0) out[row] = mask[row] ? s + bias : 0.f;
+    }
+}
+
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void linear1_bwd_k(const float* __restrict__ dout, const T* __restrict__ x,
+        const float* __restrict__ w, const uint8_t* __restrict__ mask, T* __restrict__ dx, float* __restrict__ dw,
+        float* __restrict__ db, int64_t M, int d) {
+    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    float4 wv[NG], aw[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(w, d, lane, wv);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) aw[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float ab = 0.f;
+    ROW_LOOP(M) {
+        const float go = mask[row] ? dout[row] : 0.f;
+        float4 v[NG], o[NG];
+        row_load<NG, T>(x + row * d, d, lane, v);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            aw[g] = add4(aw[g], scale4(v[g], go));
+            o[g] = scale4(wv[g], go);
+        }
+        row_store<NG, T>(dx + row * d, d, lane, o);
+        if (lane == 0) ab += go;
+    }
+    flush_channel_sums<NG>(aw, dw, d, red);
+    if ((threadIdx.x & 63) == 0 && ab != 0.f) atomicAdd(db, ab);
+}
+
+// ================================================================ BatchNorm(batch stats) + tanh + dropout
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void colstats_k(const T* __restrict__ x, int64_t M, int C, float* __restrict__ sums) {
+    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    float4 a1[NG], a2[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a1[g] = a2[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ROW_LOOP(M) {
+        float4 v[NG];
+        row_load<NG, T>(x + row * C, C, lane, v);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { a1[g] = add4(a1[g], v[g]); a2[g] = add4(a2[g], mul4(v[g], v[g])); }
+    }
+    flush_channel_sums<NG>(a1, sums, C, red);
+    flush_channel_sums<NG>(a2, sums + C, C, red);
+}
+
+__global__ void bn_finalize_k(const float* __restrict__ sums, float count, float eps, float momentum,
+        float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+        float* __restrict__ running_var, int64_t* __restrict__ nbt, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const double mud = (double)sums[c] / (double)count;
+        const float mu = (float)mud;
+        float var = (float)((double)sums[C + c] / (double)count - mud * mud);   // biased batch variance
+        var = fmaxf(var, 0.f);
+        mean[c] = mu;
+        rstd[c] = 1.0f / sqrtf(var + eps);
+        if (running_mean != nullptr) {
+            const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+    if (c == 0 && nbt != nullptr) nbt[0] += 1;
+}
+
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_fwd_k(const T* __restrict__ x, const float* __restrict__ mean,
+        const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+        T* __restrict__ y, int64_t M, int C, float p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 sc[NG], sh[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        float4 mu[NG], rs[NG], gm[NG], bt[NG];
+        row_load<NG, float>(mean, C, lane, mu); row_load<NG, float>(rstd, C, lane, rs);
+        row_load<NG, float>(gamma, C, lane, gm); row_load<NG, float>(beta, C, lane, bt);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            sc[g] = mul4(rs[g], gm[g]);
+            sh[g] = make_float4(bt[g].x - mu[g].x * sc[g].x, bt[g].y - mu[g].y * sc[g].y,
+                                bt[g].z - mu[g].z * sc[g].z, bt[g].w - mu[g].w * sc[g].w);
+        }
+    }
+    ROW_LOOP(M) {
+        float4 v[NG];
+        row_load<NG, T>(x + row * C, C, lane, v);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g].x = tanhf(v[g].x * sc[g].x + sh[g].x); v[g].y = tanhf(v[g].y * sc[g].y + sh[g].y);
+            v[g].z = tanhf(v[g].z * sc[g].z + sh[g].z); v[g].w = tanhf(v[g].w * sc[g].w + sh[g].w);
+            if (dc.on && GCOL(g) < C) v[g] = mul4(v[g], drop_scale4(dc, (uint64_t)(row * C + GCOL(g)) >> 2));
+        }
+        row_store<NG, T>(y + row * C, C, lane, v);
+    }
+}
+
+// MODE 0: accumulate red[0..C) += sum dz, red[C..2C) += sum dz*xhat.   MODE 1: write dx.
+template <typename T, int NG, int MODE>
+__global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
+        const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+        const float* __restrict__ beta, float* __restrict__ red_io, float count, T* __restrict__ dx,
+        float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M, int C, float p, const uint64_t* rng,
+        uint32_t site) {
+    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 mu[NG], rs[NG], gm[NG], bt[NG], a1[NG], a2[NG], r0[NG], r1[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(mean, C, lane, mu); row_load<NG, float>(rstd, C, lane, rs);
+        row_load<NG, float>(gamma, C, lane, gm); row_load<NG, float>(beta, C, lane, bt);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) a1[g] = a2[g] = r0[g] = r1[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1) {
+            row_load<NG, float>(red_io, C, lane, r0);
+            row_load<NG, float>(red_io + C, C, lane, r1);
+            const float ic = 1.f / count;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { r0[g] = scale4(r0[g], ic); r1[g] = scale4(r1[g], ic); }
+        }
+    }
+    ROW_LOOP(M) {
+        float4 g_[NG], xv[NG];
+        row_load<NG, T>(dy + row * C, C, lane, g_);
+        row_load<NG, T>(x + row * C, C, lane, xv);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (dc.on && GCOL(g) < C) g_[g] = mul4(g_[g], drop_scale4(dc, (uint64_t)(row * C + GCOL(g)) >> 2));
+            float4 xh = make_float4((xv[g].x - mu[g].x) * rs[g].x, (xv[g].y - mu[g].y) * rs[g].y,
+                                    (xv[g].z - mu[g].z) * rs[g].z, (xv[g].w - mu[g].w) * rs[g].w);
+            float4 th = make_float4(tanhf(xh.x * gm[g].x + bt[g].x), tanhf(xh.y * gm[g].y + bt[g].y),
+                                    tanhf(xh.z * gm[g].z + bt[g].z), tanhf(xh.w * gm[g].w + bt[g].w));
+            float4 dz = make_float4(g_[g].x * (1.f - th.x * th.x), g_[g].y * (1.f - th.y * th.y),
+                                    g_[g].z * (1.f - th.z * th.z), g_[g].w * (1.f - th.w * th.w));
+            if (MODE == 0) {
+                a1[g] = add4(a1[g], dz);
+                a2[g] = add4(a2[g], mul4(dz, xh));
+            } else {
+                g_[g].x = gm[g].x * rs[g].x * (dz.x - r0[g].x - xh.x * r1[g].x);
+                g_[g].y = gm[g].y * rs[g].y * (dz.y - r0[g].y - xh.y * r1[g].y);
+                g_[g].z = gm[g].z * rs[g].z * (dz.z - r0[g].z - xh.z * r1[g].z);
+                g_[g].w = gm[g].w * rs[g].w * (dz.w - r0[g].w - xh.w * r1[g].w);
+            }
+        }
+        if (MODE == 1) row_store<NG, T>(dx + row * C, C, lane, g_);
+    }
+    if (MODE == 0) {
+        flush_channel_sums<NG>(a1, red_io, C, red);
+        flush_channel_sums<NG>(a2, red_io + C, C, red);
+    } else if (blockIdx.x == 0 && dgamma != nullptr) {
+        // dbeta += sum dz, dgamma += sum dz*xhat (already reduced over rows -- and over ranks -- in red_io)
+        for (int c = threadIdx.x; c < C; c += ROW_BLOCK) {
+            atomicAdd(dbeta + c, red_io[c]);
+            atomicAdd(dgamma + c, red_io[C + c]);
+        }
+    }
+}
+
+}  // namespace
+
+// ================================================================ host launchers
+#define NG_DISPATCH(d, NGV, ...)                                             \
+    do {                                                                     \
+        if ((d) <= 256) { constexpr int NGV = 1; __VA_ARGS__; }              \
+        else if ((d) <= 512) { constexpr int NGV = 2; __VA_ARGS__; }         \
+        else if ((d) <= 1024) { constexpr int NGV = 4; __VA_ARGS__; }        \
+        else { constexpr int NGV = 8; __VA_ARGS__; }                         \
+    } while (0)
+
+#define CHECK_ROW(name, d, maxd)                                                                     \
+    FS2_REQUIRE((d) > 0 && (d) % 4 == 0 && (d) <= (maxd), "%s: row length %d must be a multiple of 4 and <= %d", name, (int)(d), (int)(maxd))
+#define CHECK_DT(name, dt) FS2_REQUIRE((dt) == FS2_F32 || (dt) == FS2_BF16, "%s: bad dtype %d", name, (int)(dt))
+
+extern "C" int fs2_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                                 float* mean, float* rstd, int64_t M, int d, float eps, float p, const uint64_t* rng,
+                                 uint32_t site, void* stream) {
+    CHECK_ROW("fs2_layernorm_fwd", d, 2048); CHECK_DT("fs2_layernorm_fwd", x_dtype); CHECK_DT("fs2_layernorm_fwd", y_dtype);
+    FS2_REQUIRE(!(x_dtype == FS2_BF16 && y_dtype == FS2_F32), "fs2_layernorm_fwd: bf16 -> f32 is not provided");
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_layernorm_fwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, {
+        if (x_dtype == FS2_F32 && y_dtype == FS2_F32)
+            hipLaunchKernelGGL((layernorm_fwd_k<float, float, NG>), grid, block, 0, st, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, d, eps, p, rng, site);
+        else if (x_dtype == FS2_F32)
+            hipLaunchKernelGGL((layernorm_fwd_k<float, bf16_t, NG>), grid, block, 0, st, (const float*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, d, eps, p, rng, site);
+        else
+            hipLaunchKernelGGL((layernorm_fwd_k<bf16_t, bf16_t, NG>), grid, block, 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, d, eps, p, rng, site);
+    });
+    FS2_CHECK_LAUNCH("fs2_layernorm_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
+                                 const float* mean, const float* rstd, void* dx, int dx_dtype, float* dgamma,
+                                 float* dbeta, int64_t M, int d, float p, const uint64_t* rng, uint32_t site,
+                                 int relu_mask, int dx_accumulate, void* stream) {
+    CHECK_ROW("fs2_layernorm_bwd", d, 1024);
+    FS2_REQUIRE(x_dtype == dx_dtype, "fs2_layernorm_bwd: dx dtype must equal x dtype");
+    FS2_REQUIRE(!(dy_dtype == FS2_F32 && x_dtype == FS2_BF16), "fs2_layernorm_bwd: f32 dy with bf16 x is not provided");
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_layernorm_bwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, {
+        if constexpr (NG <= 4) {
+            if (dy_dtype == FS2_F32)
+                hipLaunchKernelGGL((layernorm_bwd_k<float, float, float, NG>), grid, block, 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, d, p, rng, site, relu_mask, dx_accumulate);
+            else if (x_dtype == FS2_F32)
+                hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, float, float, NG>), grid, block, 0, st, (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, d, p, rng, site, relu_mask, dx_accumulate);
+            else
+                hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, bf16_t, bf16_t, NG>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, d, p, rng, site, relu_mask, dx_accumulate);
+        }
+    });
+    FS2_CHECK_LAUNCH("fs2_layernorm_bwd");
+    return FS2_OK;
+}
+
+#define T_DISPATCH(dtype, T, ...)                                     \
+    do {                                                              \
+        if ((dtype) == FS2_F32) { typedef float T; __VA_ARGS__; }     \
+        else { typedef bf16_t T; __VA_ARGS__; }                       \
+    } while (0)
+
+extern "C" int fs2_add_ln_fwd(const float* r, const void* a, int dtype, float* s, const float* gamma, const float* beta,
+                              void* y, float* mean, float* rstd, int64_t M, int d, float eps, float p,
+                              const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_add_ln_fwd", d, 1024); CHECK_DT("fs2_add_ln_fwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_add_ln_fwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((add_ln_fwd_k<T, NG>), grid, block, 0, st, r, (const T*)a, s, gamma, beta, (T*)y, mean, rstd, M, d, eps, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_add_ln_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_add_ln_bwd(const float* ds_down, const void* dy, int dtype, const float* s, const float* gamma,
+                              const float* mean, const float* rstd, float* dr, void* da, float* dgamma, float* dbeta,
+                              int64_t M, int d, float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_add_ln_bwd", d, 1024); CHECK_DT("fs2_add_ln_bwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_add_ln_bwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((add_ln_bwd_k<T, NG>), grid, block, 0, st, ds_down, (const T*)dy, s, gamma, mean, rstd, dr, (T*)da, dgamma, dbeta, M, d, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_add_ln_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_ffn_ln_fwd(const void* f2, const void* h, int dtype, const float* gamma, const float* beta, void* y,
+                              float* mean, float* rstd, int64_t M, int d, float eps, float p, const uint64_t* rng,
+                              uint32_t site, void* stream) {
+    CHECK_ROW("fs2_ffn_ln_fwd", d, 1024); CHECK_DT("fs2_ffn_ln_fwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ffn_ln_fwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((ffn_ln_fwd_k<T, NG>), grid, block, 0, st, (const T*)f2, (const T*)h, gamma, beta, (T*)y, mean, rstd, M, d, eps, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_ffn_ln_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_ffn_ln_bwd(const void* dy, const void* f2, const void* h, int dtype, const float* gamma,
+                              const float* mean, const float* rstd, void* g, float* dgamma, float* dbeta, int64_t M,
+                              int d, float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_ffn_ln_bwd", d, 1024); CHECK_DT("fs2_ffn_ln_bwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ffn_ln_bwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((ffn_ln_bwd_k<T, NG>), grid, block, 0, st, (const T*)dy, (const T*)f2, (const T*)h, gamma, mean, rstd, (T*)g, dgamma, dbeta, M, d, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_ffn_ln_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_softmax_fwd(void* s, void* pd, int dtype, const uint8_t* key_mask, int B, int H, int t, int tp,
+                               int64_t batch_stride, float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_DT("fs2_softmax_fwd", dtype);
+    FS2_REQUIRE(t > 0 && tp >= t && tp % 8 == 0 && tp <= 2048, "fs2_softmax_fwd: need 0 < t <= tp <= 2048, tp %% 8 == 0 (t=%d tp=%d)", t, tp);
+    FS2_REQUIRE(batch_stride % 4 == 0, "fs2_softmax_fwd: batch_stride must be a multiple of 4");
+    FS2_REQUIRE(p == 0.f || (rng != nullptr && pd != s), "fs2_softmax_fwd: dropout needs rng and a separate p_drop buffer");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid((int64_t)B * H * t)), block(ROW_BLOCK);
+    NG_DISPATCH(tp, NG, { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((softmax_fwd_k<T, NG>), grid, block, 0, st, (T*)s, (T*)pd, key_mask, B, H, t, tp, batch_stride, p, rng, site);
+    }); });
+    FS2_CHECK_LAUNCH("fs2_softmax_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_softmax_bwd(void* dp, const void* ps, int dtype, int B, int H, int t, int tp, int64_t batch_stride,
+                               float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_DT("fs2_softmax_bwd", dtype);
+    FS2_REQUIRE(t > 0 && tp >= t && tp % 8 == 0 && tp <= 2048, "fs2_softmax_bwd: need 0 < t <= tp <= 2048, tp %% 8 == 0");
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_softmax_bwd: dropout needs rng");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid((int64_t)B * H * t)), block(ROW_BLOCK);
+    NG_DISPATCH(tp, NG, { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((softmax_bwd_k<T, NG>), grid, block, 0, st, (T*)dp, (const T*)ps, B, H, t, tp, batch_stride, p, rng, site);
+    }); });
+    FS2_CHECK_LAUNCH("fs2_softmax_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_pe_add_fwd(const void* a, int a_dtype, const float* pe, const float* alpha, float* out, int B, int t,
+                              int d, float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_pe_add_fwd", d, 1024); CHECK_DT("fs2_pe_add_fwd", a_dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_pe_add_fwd: dropout needs rng");
+    const int64_t M = (int64_t)B * t;
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(a_dtype, T, {
+        hipLaunchKernelGGL((pe_add_fwd_k<T, NG>), grid, block, 0, st, (const T*)a, pe, alpha, out, M, t, d, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_pe_add_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_pe_add_bwd(const float* dout, const float* pe, void* da, int da_dtype, float* dalpha, int B, int t,
+                              int d, float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_pe_add_bwd", d, 1024); CHECK_DT("fs2_pe_add_bwd", da_dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_pe_add_bwd: dropout needs rng");
+    const int64_t M = (int64_t)B * t;
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(da_dtype, T, {
+        hipLaunchKernelGGL((pe_add_bwd_k<T, NG>), grid, block, 0, st, dout, pe, (T*)da, dalpha, M, t, d, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_pe_add_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_linear1_fwd(const void* x, int dtype, const float* w, const float* b, const uint8_t* mask, float* out,
+                               int64_t M, int d, void* stream) {
+    CHECK_ROW("fs2_linear1_fwd", d, 1024); CHECK_DT("fs2_linear1_fwd", dtype);
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((linear1_fwd_k<T, NG>), grid, block, 0, st, (const T*)x, w, b, mask, out, M, d);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_linear1_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_linear1_bwd(const float* dout, const void* x, int dtype, const float* w, const uint8_t* mask, void* dx,
+                               float* dw, float* db, int64_t M, int d, void* stream) {
+    CHECK_ROW("fs2_linear1_bwd", d, 1024); CHECK_DT("fs2_linear1_bwd", dtype);
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((linear1_bwd_k<T, NG>), grid, block, 0, st, dout, (const T*)x, w, mask, (T*)dx, dw, db, M, d);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_linear1_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_colstats(const void* x, int dtype, int64_t M, int C, float* sums, void* stream) {
+    CHECK_ROW("fs2_colstats", C, 1024); CHECK_DT("fs2_colstats", dtype);
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((colstats_k<T, NG>), grid, block, 0, st, (const T*)x, M, C, sums);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_colstats");
+    return FS2_OK;
+}
+
+extern "C" int fs2_bn_finalize(const float* sums, float count, float eps, float momentum, float* mean, float* rstd,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, int C,
+                               void* stream) {
+    FS2_REQUIRE(C > 0 && count > 0.f, "fs2_bn_finalize: bad C/count");
+    hipLaunchKernelGGL(bn_finalize_k, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, eps,
+                       momentum, mean, rstd, running_mean, running_var, num_batches_tracked, C);
+    FS2_CHECK_LAUNCH("fs2_bn_finalize");
+    return FS2_OK;
+}
+
+extern "C" int fs2_bn_tanh_fwd(const void* x, int dtype, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, void* y, int64_t M, int C, float p, const uint64_t* rng,
+                               uint32_t site, void* stream) {
+    CHECK_ROW("fs2_bn_tanh_fwd", C, 1024); CHECK_DT("fs2_bn_tanh_fwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_bn_tanh_fwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((bn_tanh_fwd_k<T, NG>), grid, block, 0, st, (const T*)x, mean, rstd, gamma, beta, (T*)y, M, C, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_bn_tanh_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_bn_tanh_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, float* red, int64_t M, int C, float p,
+                                      const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_bn_tanh_bwd_reduce", C, 1024); CHECK_DT("fs2_bn_tanh_bwd_reduce", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_bn_tanh_bwd_reduce: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 0>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, red, 1.f, (T*)nullptr, (float*)nullptr, (float*)nullptr, M, C, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_bn_tanh_bwd_reduce");
+    return FS2_OK;
+}
+
+extern "C" int fs2_bn_tanh_bwd_apply(const void* dy, const void* x, int dtype, const float* mean, const float* rstd,
+                                     const float* gamma, const float* beta, const float* red, float count, void* dx,
+                                     float* dgamma, float* dbeta, int64_t M, int C, float p, const uint64_t* rng,
+                                     uint32_t site, void* stream) {
+    CHECK_ROW("fs2_bn_tanh_bwd_apply", C, 1024); CHECK_DT("fs2_bn_tanh_bwd_apply", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_bn_tanh_bwd_apply: dropout needs rng");
+    FS2_REQUIRE(count > 0.f, "fs2_bn_tanh_bwd_apply: count must be positive");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 1>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, const_cast<float*>(red), count, (T*)dx, dgamma, dbeta, M, C, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_bn_tanh_bwd_apply");
+    return FS2_OK;
+}

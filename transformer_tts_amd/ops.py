@@ -1,0 +1,540 @@
+"""Tensor-level bindings of the C ABI in include/fs2_hip.h (ctypes -> libfs2_hip.so).
+
+PyTorch is used only as the owner of device memory and of the current HIP stream: every function
+takes CUDA(=HIP) tensors, passes raw pointers / sizes / strides to the extern "C" launchers and
+returns without synchronising.  There is NO CPU fallback: if the library is missing or a tensor is
+not on the GPU the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+_lib = None
+
+
+class FS2Gemm(ctypes.Structure):
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p), ("relu_mask", ctypes.c_void_p), ("colstats", ctypes.c_void_p),
+        ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldc", ctypes.c_int64), ("ldr", ctypes.c_int64),
+        ("ldm", ctypes.c_int64),
+        ("sA1", ctypes.c_int64), ("sA2", ctypes.c_int64), ("sB1", ctypes.c_int64), ("sB2", ctypes.c_int64),
+        ("sC1", ctypes.c_int64), ("sC2", ctypes.c_int64),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("Kb", ctypes.c_int32),
+        ("a_kmajor", ctypes.c_int32), ("b_kmajor", ctypes.c_int32), ("dtype", ctypes.c_int32),
+        ("c_dtype", ctypes.c_int32), ("res_dtype", ctypes.c_int32), ("relu", ctypes.c_int32),
+        ("accumulate", ctypes.c_int32), ("split_k", ctypes.c_int32), ("batch1", ctypes.c_int32),
+        ("batch2", ctypes.c_int32), ("conv", ctypes.c_int32), ("taps", ctypes.c_int32), ("pad", ctypes.c_int32),
+        ("seq_len", ctypes.c_int32), ("alpha", ctypes.c_float), ("reserved", ctypes.c_int32),
+    ]
+
+
+# name -> argtypes (restype is always int unless noted); mirrors include/fs2_hip.h one to one
+_P, _I, _L, _F, _U32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
+SIGNATURES = {
+    "fs2_gemm": [ctypes.POINTER(FS2Gemm), _P],
+    "fs2_cast_permute": [_P, _P, _I, _I, _I, _L, _I, _I, _P],
+    "fs2_permute_add": [_P, _P, _I, _I, _I, _P],
+    "fs2_cast": [_P, _I, _P, _I, _L, _P],
+    "fs2_colsum": [_P, _I, _L, _I, _L, _P, _P],
+    "fs2_embedding_fwd": [_P, _P, _P, _I, _L, _I, _P],
+    "fs2_embedding_bwd": [_P, _P, _I, _P, _L, _I, _L, _P],
+    "fs2_pe_add_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _U32, _P],
+    "fs2_pe_add_bwd": [_P, _P, _P, _I, _P, _I, _I, _I, _F, _P, _U32, _P],
+    "fs2_layernorm_fwd": [_P, _I, _P, _P, _P, _I, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
+    "fs2_layernorm_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _L, _I, _F, _P, _U32, _I, _I, _P],
+    "fs2_add_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
+    "fs2_add_ln_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_ffn_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
+    "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
+    "fs2_softmax_bwd": [_P, _P, _I, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
+    "fs2_length_regulate_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "fs2_length_regulate_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "fs2_bucket_embed_add_fwd": [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
+    "fs2_bucket_embed_bwd": [_P, _I, _P, _P, _P, _L, _I, _P],
+    "fs2_linear1_fwd": [_P, _I, _P, _P, _P, _P, _L, _I, _P],
+    "fs2_linear1_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _P],
+    "fs2_colstats": [_P, _I, _L, _I, _P, _P],
+    "fs2_bn_finalize": [_P, _F, _F, _F, _P, _P, _P, _P, _P, _I, _P],
+    "fs2_bn_tanh_fwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_bn_tanh_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_bn_tanh_bwd_apply": [_P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_l1_fwd": [_P, _I, _P, _I, _L, _P, _P],
+    "fs2_l1_bwd": [_P, _I, _P, _I, _L, _P, _P, _I, _P],
+    "fs2_sqnorm": [_P, _L, _P, _P],
+    "fs2_adam_step": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P],
+    "fs2_rng_advance": [_P, _P],
+}
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """Load libfs2_hip.so (once).  Raises if it has not been built -- there is no fallback."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `python -m transformer_tts_amd.build` "
+                               "(hipcc --offload-arch=gfx950).  transformer_tts_amd has no CPU fallback.")
+        l = ctypes.CDLL(path)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        l.fs2_last_error.restype = ctypes.c_char_p
+        l.fs2_abi_version.restype = ctypes.c_int
+        _lib = l
+    return _lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib().fs2_last_error().decode()}")
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("transformer_tts_amd ops need GPU tensors (no CPU fallback)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t):
+    return _DT[t.dtype]
+
+
+def _c(t):
+    assert t.is_contiguous(), "contiguous tensor required"
+    return t
+
+
+class Rng:
+    """Device-resident {seed, offset} pair of the dropout streams; `advance()` once per step."""
+
+    def __init__(self, seed, device):
+        self.state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+
+    def advance(self):
+        _check(lib().fs2_rng_advance(_p(self.state), _stream()), "fs2_rng_advance")
+
+
+def _rng_ptr(rng, p):
+    if p > 0.0 and rng is None:
+        raise RuntimeError("dropout p > 0 needs an ops.Rng")
+    return _p(rng.state) if rng is not None else None
+
+
+# ------------------------------------------------------------------------------------------------ GEMM family
+def _ld(t):
+    """row stride of a matrix view whose last dim is contiguous"""
+    assert t.stride(-1) == 1 or t.shape[-1] == 1, f"last dim must be contiguous, strides {t.stride()}"
+    return t.stride(-2)
+
+
+def _gemm_call(g):
+    _check(lib().fs2_gemm(ctypes.byref(g), _stream()), "fs2_gemm")
+
+
+def _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha):
+    g.C, g.ldc, g.c_dtype = _p(out), _ld(out), _dt(out)
+    g.bias = _p(bias)
+    g.relu = int(relu)
+    g.alpha = float(alpha)
+    if residual is not None:
+        g.residual, g.ldr, g.res_dtype = _p(residual), _ld(residual), _dt(residual)
+    if relu_mask is not None:
+        g.relu_mask, g.ldm = _p(relu_mask), _ld(relu_mask)
+    if colstats is not None:
+        g.colstats = _p(colstats)
+
+
+def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, out_dtype=None,
+           alpha=1.0):
+    """out[M,N] = alpha * x[M,K] @ w[N,K]^T (+bias)(ReLU)(*mask>0)(+residual).  x, w: same dtype (f32 | bf16)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or x.dtype, device=x.device)
+    g = FS2Gemm()
+    g.A, g.B, g.lda, g.ldb = _p(x), _p(w), _ld(x), _ld(w)
+    g.M, g.N, g.K, g.dtype = M, N, K, _dt(x)
+    g.split_k = g.batch1 = g.batch2 = 1
+    _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha)
+    _gemm_call(g)
+    return out
+
+
+def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None,
+         out_dtype=None):
+    """Conv1d over time as implicit GEMM: x (B,t,C) channels-last, w (N, taps*C) [n][j*C + c];
+    out[b,t,n] = sum_{j,c} x[b, t+j-pad, c] * w[n, j*C+c]  (zero outside the sequence)."""
+    B, t, C = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == taps * C
+    if out is None:
+        out = torch.empty((B, t, N), dtype=out_dtype or x.dtype, device=x.device)
+    x2, o2 = x.view(B * t, C), out.view(B * t, N)
+    g = FS2Gemm()
+    g.A, g.B, g.lda, g.ldb = _p(x2), _p(w), _ld(x2), _ld(w)
+    g.M, g.N, g.K, g.dtype = B * t, N, C, _dt(x)
+    g.split_k = g.batch1 = g.batch2 = 1
+    g.conv, g.taps, g.pad, g.seq_len = 1, taps, pad, t
+    r2 = residual.view(B * t, N) if residual is not None else None
+    m2 = relu_mask.view(B * t, N) if relu_mask is not None else None
+    _epilogue(g, o2, bias, relu, r2, m2, colstats, 1.0)
+    _gemm_call(g)
+    return out
+
+
+def _pick_split(M_out, N_out, K_red, batch):
+    tiles = ((M_out + 127) // 128) * ((N_out + 127) // 128) * batch
+    ktiles = max(1, (K_red + 63) // 64)
+    want = max(1, 512 // max(tiles, 1))
+    return int(max(1, min(want, ktiles, 64)))
+
+
+def wgrad(dy, x, out):
+    """out[N,K] (fp32) += dy[M,N]^T @ x[M,K]  (k-major operands, split-K with fp32 atomics)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert out.dtype == torch.float32 and out.shape == (N, K)
+    g = FS2Gemm()
+    g.A, g.B, g.lda, g.ldb = _p(dy), _p(x), _ld(dy), _ld(x)
+    g.a_kmajor = g.b_kmajor = 1
+    g.M, g.N, g.K, g.dtype = N, K, M, _dt(x)
+    g.batch1 = g.batch2 = 1
+    g.split_k = _pick_split(N, K, M, 1)
+    g.accumulate = 1
+    _epilogue(g, out, None, False, None, None, None, 1.0)
+    _gemm_call(g)
+    return out
+
+
+def conv_wgrad(dy, x, taps, pad, out):
+    """out[N, taps*C] (fp32) += sum_{b,t} dy[b,t,n] * x[b, t+j-pad, c]   (kernel layout [n][j*C+c])."""
+    B, t, N = dy.shape
+    C = x.shape[2]
+    assert out.dtype == torch.float32 and out.shape == (N, taps * C)
+    dy2, x2 = dy.view(B * t, N), x.view(B * t, C)
+    g = FS2Gemm()
+    g.A, g.B, g.lda, g.ldb = _p(dy2), _p(x2), _ld(dy2), _ld(x2)
+    g.a_kmajor = g.b_kmajor = 1
+    g.M, g.N, g.K, g.dtype = N, C, B * t, _dt(x)
+    g.batch1, g.batch2 = 1, taps
+    g.sC2 = C
+    g.conv, g.taps, g.pad, g.seq_len = 2, taps, pad, t
+    g.split_k = _pick_split(N, C, B * t, taps)
+    g.accumulate = 1
+    _epilogue(g, out, None, False, None, None, None, 1.0)
+    _gemm_call(g)
+    return out
+
+
+def bmm(a, b, out, trans_a=False, trans_b=True, alpha=1.0):
+    """Batched product over two leading batch dims of 4-D strided views (last dim contiguous):
+       trans_b=True  (NT): out[..,M,N] = a[..,M,K] @ b[..,N,K]^T
+       trans_b=False (NN): out[..,M,N] = a[..,M,Ka>=Kb] @ b[..,Kb,N]      (a's extra columns must be 0)
+       trans_a=True  (TN): out[..,M,N] = a[..,K,Ma>=M]^T @ b[..,K,N]      (requires trans_b=False)"""
+    assert a.dim() == 4 and b.dim() == 4 and out.dim() == 4
+    g = FS2Gemm()
+    g.A, g.B = _p(a), _p(b)
+    g.lda, g.ldb = _ld(a), _ld(b)
+    g.sA1, g.sA2, g.sB1, g.sB2, g.sC1, g.sC2 = a.stride(0), a.stride(1), b.stride(0), b.stride(1), out.stride(0), out.stride(1)
+    g.batch1, g.batch2 = out.shape[0], out.shape[1]
+    g.M, g.N = out.shape[2], out.shape[3]
+    g.dtype = _dt(a)
+    g.split_k = 1
+    if trans_a:
+        assert not trans_b
+        g.a_kmajor = g.b_kmajor = 1
+        g.K = a.shape[2]
+        assert b.shape[2] == g.K
+    elif trans_b:
+        g.K = a.shape[3]
+        assert b.shape[3] == g.K
+    else:
+        g.b_kmajor = 1
+        g.K, g.Kb = a.shape[3], b.shape[2]
+    _epilogue(g, out, None, False, None, None, None, alpha)
+    _gemm_call(g)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ shadows / casts
+def cast_permute(src, dst, mode):
+    """src fp32 (O,I,k) or (O,I); dst 2-D view (rows, >= k*I | k*O) with contiguous last dim."""
+    O, I = src.shape[0], src.shape[1]
+    k = src.shape[2] if src.dim() == 3 else 1
+    _check(lib().fs2_cast_permute(_p(_c(src)), _p(dst), O, I, k, _ld(dst), mode, _dt(dst), _stream()), "fs2_cast_permute")
+    return dst
+
+
+def permute_add(scratch, grad):
+    """grad (O,I,k) fp32 += scratch (O, k*I) laid out [o][j*I+i]"""
+    O, I = grad.shape[0], grad.shape[1]
+    k = grad.shape[2] if grad.dim() == 3 else 1
+    _check(lib().fs2_permute_add(_p(_c(scratch)), _p(_c(grad)), O, I, k, _stream()), "fs2_permute_add")
+
+
+def cast(src, dtype, out=None):
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    _check(lib().fs2_cast(_p(_c(src)), _dt(src), _p(_c(out)), _dt(out), src.numel(), _stream()), "fs2_cast")
+    return out
+
+
+def colsum(x, out):
+    """out[N] (fp32) += sum over rows of x[M,N] (row stride may exceed N)."""
+    M, N = x.shape
+    _check(lib().fs2_colsum(_p(x), _dt(x), M, N, _ld(x), _p(out), _stream()), "fs2_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ embedding / PE
+def embedding_fwd(ids, table, out_dtype):
+    out = torch.empty(tuple(ids.shape) + (table.shape[1],), dtype=out_dtype, device=table.device)
+    _check(lib().fs2_embedding_fwd(_p(_c(ids)), _p(_c(table)), _p(out), _dt(out), ids.numel(), table.shape[1], _stream()),
+           "fs2_embedding_fwd")
+    return out
+
+
+def embedding_bwd(ids, dout, dtable, padding_idx=-1):
+    _check(lib().fs2_embedding_bwd(_p(_c(ids)), _p(_c(dout)), _dt(dout), _p(_c(dtable)), ids.numel(), dtable.shape[1],
+                                   padding_idx, _stream()), "fs2_embedding_bwd")
+
+
+def pe_add_fwd(a, pe, alpha, p, rng, site):
+    B, t, d = a.shape
+    out = torch.empty((B, t, d), dtype=torch.float32, device=a.device)
+    _check(lib().fs2_pe_add_fwd(_p(_c(a)), _dt(a), _p(pe), _p(alpha), _p(out), B, t, d, p, _rng_ptr(rng, p), site,
+                                _stream()), "fs2_pe_add_fwd")
+    return out
+
+
+def pe_add_bwd(dout, pe, da_dtype, dalpha, p, rng, site, need_da=True):
+    B, t, d = dout.shape
+    da = torch.empty((B, t, d), dtype=da_dtype, device=dout.device) if need_da else None
+    _check(lib().fs2_pe_add_bwd(_p(_c(dout)), _p(pe), _p(da), _DT[da_dtype], _p(dalpha), B, t, d, p,
+                                _rng_ptr(rng, p), site, _stream()), "fs2_pe_add_bwd")
+    return da
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm family
+def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5, p=0.0, rng=None, site=0):
+    d = x.shape[-1]
+    M = x.numel() // d
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    _check(lib().fs2_layernorm_fwd(_p(_c(x)), _dt(x), _p(gamma), _p(beta), _p(y), _dt(y), _p(mean), _p(rstd), M, d, eps,
+                                   p, _rng_ptr(rng, p), site, _stream()), "fs2_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, relu_mask=False, dx=None):
+    """dx (dtype of x) = LNbwd(dropout'(dy)) (* (x > 0) when relu_mask); with dx given: dx += ..."""
+    d = x.shape[-1]
+    M = x.numel() // d
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty_like(x)
+    _check(lib().fs2_layernorm_bwd(_p(_c(dy)), _dt(dy), _p(_c(x)), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(_c(dx)),
+                                   _dt(dx), _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, int(relu_mask),
+                                   int(acc), _stream()), "fs2_layernorm_bwd")
+    return dx
+
+
+def add_ln_fwd(r, a, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
+    """s = r + dropout(a) (fp32);  y = LN(s) (dtype of a).  returns s, y, mean, rstd"""
+    d = r.shape[-1]
+    M = r.numel() // d
+    s = torch.empty_like(r)
+    y = torch.empty_like(a)
+    mean = torch.empty(M, dtype=torch.float32, device=r.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=r.device)
+    _check(lib().fs2_add_ln_fwd(_p(_c(r)), _p(_c(a)), _dt(a), _p(s), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d,
+                                eps, p, _rng_ptr(rng, p), site, _stream()), "fs2_add_ln_fwd")
+    return s, y, mean, rstd
+
+
+def add_ln_bwd(ds_down, dy, s, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0):
+    """returns dr (fp32, = ds_down + LNbwd(dy)) and da (dtype of dy, = dropout'(dr))"""
+    d = s.shape[-1]
+    M = s.numel() // d
+    dr = torch.empty_like(s)
+    da = torch.empty_like(dy)
+    _check(lib().fs2_add_ln_bwd(_p(ds_down), _p(_c(dy)), _dt(dy), _p(_c(s)), _p(gamma), _p(mean), _p(rstd), _p(dr),
+                                _p(da), _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, _stream()),
+           "fs2_add_ln_bwd")
+    return dr, da
+
+
+def ffn_ln_fwd(f2, h, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
+    d = h.shape[-1]
+    M = h.numel() // d
+    y = torch.empty_like(h)
+    mean = torch.empty(M, dtype=torch.float32, device=h.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=h.device)
+    _check(lib().fs2_ffn_ln_fwd(_p(_c(f2)), _p(_c(h)), _dt(h), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d, eps,
+                                p, _rng_ptr(rng, p), site, _stream()), "fs2_ffn_ln_fwd")
+    return y, mean, rstd
+
+
+def ffn_ln_bwd(dy, f2, h, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0):
+    d = h.shape[-1]
+    M = h.numel() // d
+    g = torch.empty_like(h)
+    _check(lib().fs2_ffn_ln_bwd(_p(_c(dy)), _p(_c(f2)), _p(_c(h)), _dt(h), _p(gamma), _p(mean), _p(rstd), _p(g),
+                                _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, _stream()), "fs2_ffn_ln_bwd")
+    return g
+
+
+# ------------------------------------------------------------------------------------------------ attention softmax
+def softmax_fwd(s, p_drop, key_mask, t, p=0.0, rng=None, site=0):
+    """s, p_drop: (B,H,t,tp) views (row stride tp, contiguous over (H,t,tp)); in place on s."""
+    B, H, _, tp = s.shape
+    assert s.stride(3) == 1 and s.stride(2) == tp and s.stride(1) == t * tp
+    assert p_drop.stride() == s.stride()
+    _check(lib().fs2_softmax_fwd(_p(s), _p(p_drop), _dt(s), _p(_c(key_mask)), B, H, t, tp, s.stride(0), p,
+                                 _rng_ptr(rng, p), site, _stream()), "fs2_softmax_fwd")
+
+
+def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
+    B, H, _, tp = dp.shape
+    assert dp.stride(3) == 1 and dp.stride(2) == tp and dp.stride(1) == t * tp
+    assert p_saved.stride() == dp.stride()
+    _check(lib().fs2_softmax_bwd(_p(dp), _p(p_saved), _dt(dp), B, H, t, tp, dp.stride(0), p, _rng_ptr(rng, p), site,
+                                 _stream()), "fs2_softmax_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ variance adaptor
+def length_regulate_fwd(x, dur, T):
+    B, L, d = x.shape
+    out = torch.empty((B, T, d), dtype=x.dtype, device=x.device)
+    starts = torch.empty((B, L + 1), dtype=torch.int32, device=x.device)
+    _check(lib().fs2_length_regulate_fwd(_p(_c(x)), _dt(x), _p(_c(dur)), _p(out), _p(starts), B, L, T, d, _stream()),
+           "fs2_length_regulate_fwd")
+    return out, starts
+
+
+def length_regulate_bwd(dout, starts, L, dx=None):
+    B, T, d = dout.shape
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty((B, L, d), dtype=dout.dtype, device=dout.device)
+    _check(lib().fs2_length_regulate_bwd(_p(_c(dout)), _dt(dout), _p(starts), _p(_c(dx)), B, L, T, d, int(acc), _stream()),
+           "fs2_length_regulate_bwd")
+    return dx
+
+
+def bucket_embed_add_fwd(x, f0, energy, pbins, ebins, Ep, Ee):
+    d = x.shape[-1]
+    M = x.numel() // d
+    out = torch.empty_like(x)
+    idx = torch.empty((2, M), dtype=torch.int32, device=x.device)
+    _check(lib().fs2_bucket_embed_add_fwd(_p(_c(x)), _dt(x), _p(_c(f0)), _p(_c(energy)), _p(pbins), _p(ebins),
+                                          pbins.numel(), _p(_c(Ep)), _p(_c(Ee)), _p(out), _p(idx), M, d, _stream()),
+           "fs2_bucket_embed_add_fwd")
+    return out, idx
+
+
+def bucket_embed_bwd(dout, idx, dEp, dEe):
+    d = dout.shape[-1]
+    M = dout.numel() // d
+    _check(lib().fs2_bucket_embed_bwd(_p(_c(dout)), _dt(dout), _p(idx), _p(dEp), _p(dEe), M, d, _stream()),
+           "fs2_bucket_embed_bwd")
+
+
+def linear1_fwd(x, w, b, mask):
+    d = x.shape[-1]
+    M = x.numel() // d
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    _check(lib().fs2_linear1_fwd(_p(_c(x)), _dt(x), _p(_c(w)), _p(b), _p(_c(mask)), _p(out), M, d, _stream()),
+           "fs2_linear1_fwd")
+    return out
+
+
+def linear1_bwd(dout, x, w, mask, dw, db):
+    d = x.shape[-1]
+    M = x.numel() // d
+    dx = torch.empty_like(x)
+    _check(lib().fs2_linear1_bwd(_p(_c(dout)), _p(_c(x)), _dt(x), _p(_c(w)), _p(_c(mask)), _p(dx), _p(dw), _p(db), M, d,
+                                 _stream()), "fs2_linear1_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm + tanh
+def colstats(x, sums):
+    C = x.shape[-1]
+    _check(lib().fs2_colstats(_p(_c(x)), _dt(x), x.numel() // C, C, _p(sums), _stream()), "fs2_colstats")
+
+
+def bn_finalize(sums, count, eps, momentum, running_mean, running_var, num_batches_tracked):
+    C = sums.numel() // 2
+    mean = torch.empty(C, dtype=torch.float32, device=sums.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=sums.device)
+    _check(lib().fs2_bn_finalize(_p(sums), float(count), eps, momentum, _p(mean), _p(rstd), _p(running_mean),
+                                 _p(running_var), _p(num_batches_tracked), C, _stream()), "fs2_bn_finalize")
+    return mean, rstd
+
+
+def bn_tanh_fwd(x, mean, rstd, gamma, beta, p=0.0, rng=None, site=0):
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    _check(lib().fs2_bn_tanh_fwd(_p(_c(x)), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), x.numel() // C, C, p,
+                                 _rng_ptr(rng, p), site, _stream()), "fs2_bn_tanh_fwd")
+    return y
+
+
+def bn_tanh_bwd_reduce(dy, x, mean, rstd, gamma, beta, red, p=0.0, rng=None, site=0):
+    C = x.shape[-1]
+    _check(lib().fs2_bn_tanh_bwd_reduce(_p(_c(dy)), _p(_c(x)), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(red),
+                                        x.numel() // C, C, p, _rng_ptr(rng, p), site, _stream()),
+           "fs2_bn_tanh_bwd_reduce")
+
+
+def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta, p=0.0, rng=None, site=0):
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    _check(lib().fs2_bn_tanh_bwd_apply(_p(_c(dy)), _p(_c(x)), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(red),
+                                       float(count), _p(dx), _p(dgamma), _p(dbeta), x.numel() // C, C, p,
+                                       _rng_ptr(rng, p), site, _stream()), "fs2_bn_tanh_bwd_apply")
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ losses / optimizer
+def l1_fwd(pred, target, loss, log1p_int_target=False):
+    """loss[0] (fp32, zeroed by the caller) += mean |pred - target|"""
+    _check(lib().fs2_l1_fwd(_p(_c(pred)), _dt(pred), _p(_c(target)), int(log1p_int_target), pred.numel(), _p(loss),
+                            _stream()), "fs2_l1_fwd")
+
+
+def l1_bwd(pred, target, gscale, dpred_dtype, log1p_int_target=False):
+    dpred = torch.empty(pred.shape, dtype=dpred_dtype, device=pred.device)
+    _check(lib().fs2_l1_bwd(_p(_c(pred)), _dt(pred), _p(_c(target)), int(log1p_int_target), pred.numel(), _p(gscale),
+                            _p(dpred), _dt(dpred), _stream()), "fs2_l1_bwd")
+    return dpred
+
+
+def sqnorm(x, out):
+    _check(lib().fs2_sqnorm(_p(_c(x)), x.numel(), _p(out), _stream()), "fs2_sqnorm")
+
+
+def adam_step(p, g, m, v, hyper, gsq, beta1, beta2, eps, max_norm):
+    _check(lib().fs2_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(gsq), beta1, beta2, eps, max_norm,
+                               _stream()), "fs2_adam_step")
