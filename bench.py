@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/sec of a FastSpeech2 train step (d_model=256, 4+4 FFT layers, 80 mel,
+batch 48 per GPU, bf16) on 1/2/4/8 MI355X  --  BASELINE.json `metric`, configs[1] (configs[2] for N > 1).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
+forward + 5 L1 losses + backward + global-norm clip + Adam (+ gradient all-reduce and SyncBatchNorm
+statistics over RCCL when N > 1), with the reference's dropout rates (0.1 / 0.5 / 0.5, attention dropout
+always on).  `value` = valid (un-padded) mel frames of all ranks / wall time of K steps bracketed by
+barrier + synchronize, MAX over ranks.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel family (the MFMA GEMM), achieved = algorithmic FLOPs of its launches /
+                  their summed duration measured with HIP events on the launch stream inside the timed
+                  region; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md); traffic from profiles/ if collected.
+  cpu_baseline -- the oracle (CPU restatement of the reference step, kind "port") timed on this host's cores
+                  on one full config-2 batch; a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+POOL = 8                        # pre-built batches cycled
+
+
+def bench_hp(amp=True):
+    from types import SimpleNamespace
+    from golden_configs import _BASE, CONFIGS
+    from transformer_tts_amd.utils.utils import fill_variables
+    d = dict(_BASE)
+    d.update(CONFIGS["bench"]["hp"])
+    hp = SimpleNamespace(**d)
+    hp.amp, hp.dropout, hp.dropout_variance_adaptor = amp, 0.1, 0.5
+    fill_variables(hp, verbose=False)
+    return hp
+
+
+class GemmTimer:
+    """Wraps ops._gemm_call: a HIP event pair on the launch stream around every fs2_gemm launch."""
+
+    def __init__(self):
+        self.records = []      # (key, flops, start, end)
+
+    def install(self):
+        from transformer_tts_amd import ops
+        self._orig = ops._gemm_call
+
+        def timed(g):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self._orig(g)
+            e.record()
+            taps = g.taps if g.conv == 1 else 1
+            flops = 2.0 * g.M * g.N * g.K * taps * max(1, g.batch1) * max(1, g.batch2)
+            key = ("bf16" if g.dtype == 1 else "f32", "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm")
+            self.records.append((key, flops, s, e))
+        ops._gemm_call = timed
+
+    def remove(self):
+        from transformer_tts_amd import ops
+        ops._gemm_call = self._orig
+
+    def summary(self):
+        agg = {}
+        for key, flops, s, e in self.records:
+            ms = s.elapsed_time(e)
+            a = agg.setdefault(key, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += ms; a[2] += 1
+        return agg
+
+
+def cpu_baseline(hp, batch):
+    """Oracle train step (fp32 eager PyTorch, reference dropout rates) on this host's cores."""
+    from oracle import train as otrain
+    from oracle.model import FastSpeech2 as OracleFS2
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = OracleFS2.from_hp(hp, dropout=hp.dropout, dropout_postnet=0.5, dropout_variance_adaptor=hp.dropout_variance_adaptor)
+    m.train()
+    opt = otrain.make_optimizer(m)
+    small = tuple(b[:2] if torch.is_tensor(b) else b for b in batch)
+    otrain.train_step(m, opt, 1, small, hp.d_model_decoder)           # untimed warm-up on 2 utterances
+    t0 = time.perf_counter()
+    otrain.train_step(m, opt, 2, batch, hp.d_model_decoder)
+    dt = time.perf_counter() - t0
+    frames = int(batch[5].sum())
+    return dict(value=frames / dt, unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 train step (fwd+bwd+clip+Adam, fp32) of the config-2 batch: {batch[0].shape[0]} utterances, "
+                       f"{frames} valid mel frames, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32", action="store_true", help="exact-fp32 parity mode instead of bf16 (not the headline)")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from transformer_tts_amd import ops, synthetic
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.train_fastspeech2 import build_model, train_step
+    from transformer_tts_amd.utils.utils import init_weight
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (the product has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl")
+    ops.lib()
+
+    hp = bench_hp(amp=not args.fp32)
+    torch.manual_seed(1234)
+    model = build_model(hp)
+    model.apply(init_weight)
+    model.train()
+    model = model.to(dev)
+    opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=1.0)
+    if world > 1:
+        from transformer_tts_amd.parallel import DataParallel
+        opt.dp = DataParallel(model, opt.arena)
+
+    # synthetic batches, resident in HBM before the timed region; different data on every rank
+    pool = [tuple(b.to(dev) if torch.is_tensor(b) else b for b in synthetic.benchmark_batch(2024 + 1000 * rank + i, 48))
+            for i in range(POOL)]
+    frames = [int(b[5].sum()) for b in pool]
+
+    step = 1
+    for i in range(args.warmup):
+        train_step(model, opt, step, pool[i % POOL], hp)
+        step += 1
+    timer = GemmTimer()
+    timer.install()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(args.steps):
+        train_step(model, opt, step, pool[(args.warmup + i) % POOL], hp)
+        done += frames[(args.warmup + i) % POOL]
+        step += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timer.remove()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        n = torch.tensor([float(done)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        dt, done = float(t.item()), float(n.item())
+
+    if rank == 0:
+        agg = timer.summary()
+        roof = None
+        if agg:
+            key, (fl, ms, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+            achieved = fl / (ms * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            roof = dict(bound="mfma", kernel=f"gemm_kernel<{key[0]}> A {key[1]} B {key[2]}", achieved=round(achieved, 2),
+                        peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
+                        traffic=traffic, launches=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
+                        gemm_share_of_step=round(sum(v[1] for v in agg.values()) / (dt * 1e3), 3),
+                        all_variants={"/".join(k): dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), ms=round(v[1], 2),
+                                                         launches=v[2]) for k, v in agg.items()})
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(hp, synthetic.benchmark_batch(2024, 48))
+        line = {
+            "metric": "mel-frames/sec (train step) FastSpeech2 d_model=256", "value": round(done / dt, 1),
+            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: FastSpeech2 d_model=256, 4+4 FFT layers (H=2, k_enc=9, k_dec=1), "
+                                   "80-mel, batch 48/GPU (L_pad<=128, T_pad~925), fwd+bwd+clip+Adam, dropout 0.1/0.5/0.5",
+                       "global_batch": 48 * world, "parallelism": f"dp{world}", "padded_frames_per_step": 48 * 925},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

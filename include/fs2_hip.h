@@ -135,8 +135,8 @@ int fs2_ffn_ln_bwd(const void* dy, const void* f2, const void* h, int dtype, con
  * backward: dS = P * (dP' - sum_j dP'_j P_j), dP' = dropout'(dP), written in place over dP.           */
 int fs2_softmax_fwd(void* s_inout_p, void* p_drop, int dtype, const uint8_t* key_mask, int B, int H, int t, int tp,
                     int64_t batch_stride, float p, const uint64_t* rng, uint32_t site, void* stream);
-int fs2_softmax_bwd(void* dp_inout_ds, const void* p_saved, int dtype, int B, int H, int t, int tp,
-                    int64_t batch_stride, float p, const uint64_t* rng, uint32_t site, void* stream);
+int fs2_softmax_bwd(void* dp_inout_ds, int64_t dp_batch_stride, const void* p_saved, int64_t p_batch_stride, int dtype,
+                    int B, int H, int t, int tp, float p, const uint64_t* rng, uint32_t site, void* stream);
 
 /* LengthRegulator (Models/varianceadaptor.py:141-184,233-249): out[b][f] = x[b][i] for the phoneme i whose
  * duration interval contains frame f, 0 beyond sum(dur) or max_len.  starts is a [B][L+1] int32 workspace
@@ -163,13 +163,15 @@ int fs2_linear1_bwd(const float* dout, const void* x, int dtype, const float* w,
 /* BatchNorm1d(batch statistics) + tanh + dropout (Models/postnets.py:71-73).
  *  colstats: x [M][C] -> sums[0..C) += sum, sums[C..2C) += sum of squares (also available fused in fs2_gemm)
  *  finalize: mean/rstd from the (possibly all-reduced) sums and count; running stats updated with
- *            momentum (unbiased variance), num_batches_tracked += 1
+ *            momentum (unbiased variance), num_batches_tracked += 1.  count_dev != NULL: the row count is read
+ *            from device memory (all-reduced together with the sums under data parallelism), `count` ignored
  *  fwd: y = dropout(tanh((x-mean)*rstd*gamma+beta))
  *  bwd_reduce: red[0..C) += sum dz, red[C..2C) += sum dz*xhat   (dz = dropout'(dy) * (1 - tanh^2))
  *  bwd_apply: dx = gamma*rstd*(dz - red0/count - xhat*red1/count);  dgamma += red1, dbeta += red0        */
 int fs2_colstats(const void* x, int dtype, int64_t M, int C, float* sums, void* stream);
-int fs2_bn_finalize(const float* sums, float count, float eps, float momentum, float* mean, float* rstd,
-                    float* running_mean, float* running_var, int64_t* num_batches_tracked, int C, void* stream);
+int fs2_bn_finalize(const float* sums, float count, const float* count_dev, float eps, float momentum, float* mean,
+                    float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int C,
+                    void* stream);
 int fs2_bn_tanh_fwd(const void* x, int dtype, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, void* y, int64_t M, int C, float p, const uint64_t* rng, uint32_t site,
                     void* stream);
@@ -177,9 +179,9 @@ int fs2_bn_tanh_bwd_reduce(const void* dy, const void* x, int dtype, const float
                            const float* gamma, const float* beta, float* red, int64_t M, int C, float p,
                            const uint64_t* rng, uint32_t site, void* stream);
 int fs2_bn_tanh_bwd_apply(const void* dy, const void* x, int dtype, const float* mean, const float* rstd,
-                          const float* gamma, const float* beta, const float* red, float count, void* dx,
-                          float* dgamma, float* dbeta, int64_t M, int C, float p, const uint64_t* rng, uint32_t site,
-                          void* stream);
+                          const float* gamma, const float* beta, const float* red, float count,
+                          const float* count_dev, void* dx, float* dgamma, float* dbeta, int64_t M, int C, float p,
+                          const uint64_t* rng, uint32_t site, void* stream);
 
 /* nn.L1Loss (train_fastspeech2.py:212-259): loss[0] += sum|pred - tgt| / n.  target_mode 1: tgt = log(int64 tgt + 1).
  * backward: dpred = sign(pred - tgt) * (*gscale) / n  (gscale: device scalar, upstream gradient).          */

@@ -90,7 +90,7 @@ def _epi(v, bias, relu, residual, relu_mask, colstats, out, out_dtype, alpha=1.0
         n = r.shape[-1]
         rr = _f(r).reshape(-1, n)
         colstats[:n] += rr.sum(0).float()
-        colstats[n:] += (rr * rr).sum(0).float()
+        colstats[n:2 * n] += (rr * rr).sum(0).float()
     if out is not None:
         out.copy_(r)
         return out
@@ -305,7 +305,7 @@ def softmax_fwd(s, p_drop, key_mask, t, p=0.0, rng=None, site=0):
 
 def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
     B, H, _, tp = dp.shape
-    sc = drop_scale((B, H, t, tp), p, rng, site, base_index=_strided_index(dp))
+    sc = drop_scale((B, H, t, tp), p, rng, site, base_index=_strided_index(p_saved))   # the forward's offsets
     g = torch.zeros((B, H, t, tp), dtype=_COMPUTE)
     g[..., :t] = (_f(dp) * sc)[..., :t]          # pad columns of dP are undefined on input
     pr = torch.zeros_like(g)
@@ -373,15 +373,17 @@ def colstats(x, sums):
     C = x.shape[-1]
     v = _f(x).reshape(-1, C)
     sums[:C] += v.sum(0).float()
-    sums[C:] += (v * v).sum(0).float()
+    sums[C:2 * C] += (v * v).sum(0).float()
 
 
-def bn_finalize(sums, count, eps, momentum, running_mean, running_var, num_batches_tracked):
+def bn_finalize(sums, count, eps, momentum, running_mean, running_var, num_batches_tracked, count_dev=None):
     """nn.BatchNorm1d in training mode (Models/postnets.py:58-59): biased batch variance for the
     normalisation, unbiased for running_var, momentum 0.1."""
-    C = sums.numel() // 2
+    C = running_mean.numel()
+    if count_dev is not None:
+        count = float(count_dev[0])
     mu = _f(sums[:C]) / count
-    var = (_f(sums[C:]) / count - mu * mu).clamp(min=0)
+    var = (_f(sums[C:2 * C]) / count - mu * mu).clamp(min=0)
     if running_mean is not None:
         unb = var * count / (count - 1) if count > 1 else var
         running_mean.copy_(((1 - momentum) * _f(running_mean) + momentum * mu).float())
@@ -407,17 +409,20 @@ def bn_tanh_bwd_reduce(dy, x, mean, rstd, gamma, beta, red, p=0.0, rng=None, sit
     xh, th = _bn_z(x, mean, rstd, gamma, beta)
     dz = _f(dy) * drop_scale(tuple(x.shape), p, rng, site) * (1 - th * th)
     red[:C] += dz.reshape(-1, C).sum(0).float()
-    red[C:] += (dz * xh).reshape(-1, C).sum(0).float()
+    red[C:2 * C] += (dz * xh).reshape(-1, C).sum(0).float()
 
 
-def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta, p=0.0, rng=None, site=0):
+def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta, p=0.0, rng=None, site=0,
+                      count_dev=None):
     C = x.shape[-1]
+    if count_dev is not None:
+        count = float(count_dev[0])
     xh, th = _bn_z(x, mean, rstd, gamma, beta)
     dz = _f(dy) * drop_scale(tuple(x.shape), p, rng, site) * (1 - th * th)
-    r0, r1 = _f(red[:C]) / count, _f(red[C:]) / count
+    r0, r1 = _f(red[:C]) / count, _f(red[C:2 * C]) / count
     if dgamma is not None:
         dbeta += red[:C]
-        dgamma += red[C:]
+        dgamma += red[C:2 * C]
     return (_f(gamma) * _f(rstd) * (dz - r0 - xh * r1)).to(x.dtype)
 
 

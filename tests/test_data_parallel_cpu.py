@@ -1,0 +1,119 @@
+"""Data-parallel path with world_size 2 over gloo on CPU (HIP ops replaced by the oracle primitives).
+
+Two ranks, each with half of a 4-utterance batch padded to common lengths, must end an optimizer step with
+identical parameters, equal to those of ONE process training on the whole batch: SyncBatchNorm statistics make
+the forward identical and the mean of the per-rank mean losses equals the whole-batch mean (DDP semantics,
+reference train_fastspeech2.py:421)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _patch_ops():
+    import inspect
+    from oracle import primitives
+    from transformer_tts_amd import ops
+    for name, fn in inspect.getmembers(primitives, inspect.isfunction):
+        if not name.startswith("_") and hasattr(ops, name):
+            setattr(ops, name, fn)
+    ops.Rng = primitives.Rng
+
+
+def _setup():
+    for p in (os.path.dirname(HERE), HERE, os.path.join(HERE, "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    _patch_ops()
+    import transformer_tts_amd.train_fastspeech2 as T
+    T.DEVICE = torch.device("cpu")
+    return T
+
+
+def _slice(batch, sl):
+    return tuple(b[sl] if torch.is_tensor(b) else b for b in batch)
+
+
+def _step(T, model, opt, batch, hp):
+    loss, _, _ = T.train_step(model, opt, 4000, batch, hp)
+    return loss.item()
+
+
+def _worker(rank, world, port, out_dir):
+    T = _setup()
+    from helpers import CONFIGS, product_model
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.parallel import DataParallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, hp, _ = product_model("small")
+    if rank == 1:                      # DataParallel must broadcast rank 0's parameters and buffers
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.5)
+    opt = FusedAdam(model)
+    opt.dp = DataParallel(model, opt.arena, bucket_bytes=64 << 10)
+    batch = CONFIGS["small"]["batch"]()
+    loss = _step(T, model, opt, _slice(batch, slice(2 * rank, 2 * rank + 2)), hp)
+    torch.save(dict(p=opt.arena.p.clone(), loss=loss, rm=model.postnet.pre_batchnorm.running_mean.clone()),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert torch.equal(r0["p"], r1["p"]), "ranks diverged"
+    assert torch.equal(r0["rm"], r1["rm"]), "SyncBatchNorm running stats diverged"
+    # single process, whole batch
+    T = _setup()
+    from helpers import CONFIGS, product_model
+    from transformer_tts_amd.optim import FusedAdam
+    model, hp, _ = product_model("small")
+    opt = FusedAdam(model)
+    loss = _step(T, model, opt, CONFIGS["small"]["batch"](), hp)
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - loss) <= 1e-5 * abs(loss)
+    # parameters whose gradient is ~0 (tests/helpers.py is_null_gradient_param) take +-noise Adam steps
+    diff = (r0["p"] - opt.arena.p).abs()
+    bad = diff > (2e-5 + 2e-4 * opt.arena.p.abs())
+    assert float(bad.float().mean()) < 1e-4 and float(diff.max()) < 5e-4, (int(bad.sum()), float(diff.max()))
+    torch.testing.assert_close(r0["rm"], model.postnet.pre_batchnorm.running_mean, rtol=1e-5, atol=1e-6)
+
+
+def test_bucket_merging_covers_the_arena_once():
+    """grads_ready() merges adjacent module spans into buckets; finish() reduces every element exactly once."""
+    _setup()
+    from helpers import product_model
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.parallel import DataParallel
+    model, hp, _ = product_model("tiny")
+    opt = FusedAdam(model)
+    dp = DataParallel.__new__(DataParallel)
+    dp.arena, dp.bucket_elems, dp.pending, dp.works, dp.done, dp.world, dp.pg = opt.arena, 20000, None, [], [], 1, None
+    launched = []
+    dp._launch = lambda lo, hi: (launched.append((lo, hi)), dp.done.append((lo, hi)))
+    for mod in (model.postnet, model.decoder, model.variance_adaptor.energy_predictor,
+                model.variance_adaptor.pitch_predictor, model.encoder.layers[1]):
+        dp.grads_ready(mod)
+    dp.finish()
+    cover = np.zeros(opt.arena.numel, np.int32)
+    for lo, hi in launched:
+        cover[lo:hi] += 1
+    assert cover.min() == 1 and cover.max() == 1

@@ -1,0 +1,406 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point (through transformer_tts_amd.ops) against its
+CPU restatement in oracle/primitives.py on the same seeded inputs.
+
+Tolerances: exact-fp32 mode (f32-input MFMA, fp32 everywhere): rtol 2e-5 / atol 2e-5 (+ accumulation
+order); bf16 mode: both sides see identical bf16 inputs, the oracle computes in fp64 and rounds once, the
+kernels accumulate in fp32 and round once -> within 2 bf16 ulps (rtol 1.6e-2) plus a small absolute term
+for sums that cancel.  Integer / index outputs are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import primitives as P
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, k=1):
+    if dtype == torch.float32:
+        return dict(rtol=2e-5, atol=2e-5 * k)
+    return dict(rtol=1.6e-2, atol=1.6e-2 * k)
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = np.random.default_rng(hash((shape, seed)) % (2 ** 32))
+    return (torch.from_numpy(g.standard_normal(shape).astype(np.float32)) * scale).to(dtype)
+
+
+def gpu(t):
+    return None if t is None else t.cuda()
+
+
+def close(a, b, what="", **kw):
+    torch.testing.assert_close(a.detach().cpu().double(), b.detach().cpu().double(), msg=lambda m: f"{what}: {m}", **kw)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from transformer_tts_amd import ops as o
+    o.lib()
+    return o
+
+
+# ------------------------------------------------------------------------------------------------ GEMM family
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,N,K", [(300, 80, 72), (129, 256, 256), (40, 768, 64), (1000, 1024, 8)])
+def test_linear_epilogues(ops, dtype, M, N, K):
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias, res, mask = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, dtype=dtype, seed=5)
+    for kw in (dict(), dict(bias=True), dict(bias=True, relu=True), dict(residual=True, out_f32=True),
+               dict(relu_mask=True), dict(bias=True, colstats=True), dict(alpha=0.25)):
+        def call(o, dev):
+            mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+            cs = torch.zeros(2 * N, dtype=torch.float32, device=dev) if kw.get("colstats") else None
+            out = o.linear(mv(x), mv(w), bias=mv(bias) if kw.get("bias") else None, relu=kw.get("relu", False),
+                           residual=mv(res) if kw.get("residual") else None,
+                           relu_mask=mv(mask) if kw.get("relu_mask") else None, colstats=cs,
+                           out_dtype=torch.float32 if kw.get("out_f32") else None, alpha=kw.get("alpha", 1.0))
+            return out, cs
+        (a, acs), (b, bcs) = call(ops, "cuda"), call(P, "cpu")
+        close(a, b, f"linear {kw}", **tol(a.dtype))
+        if acs is not None:
+            close(acs, bcs, "colstats", rtol=2e-3, atol=2e-2 * M ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,t,C,N,taps,pad", [(3, 37, 32, 128, 3, 1), (2, 50, 80, 256, 5, 4), (3, 37, 64, 64, 9, 4),
+                                               (2, 131, 256, 80, 5, 0), (4, 20, 32, 32, 1, 0)])
+def test_conv_forward_dgrad_geometry(ops, dtype, B, t, C, N, taps, pad):
+    x, w = rnd(B, t, C, dtype=dtype, seed=1), rnd(N, taps * C, dtype=dtype, seed=2, scale=(taps * C) ** -0.5)
+    bias = rnd(N, seed=3)
+    a = ops.conv(x.cuda(), w.cuda(), taps, pad, bias=bias.cuda(), relu=True)
+    b = P.conv(x, w, taps, pad, bias=bias, relu=True)
+    close(a, b, "conv", **tol(dtype))
+    res = rnd(B, t, N, seed=4)
+    a = ops.conv(x.cuda(), w.cuda(), taps, pad, residual=res.cuda(), out_dtype=torch.float32)
+    b = P.conv(x, w, taps, pad, residual=res, out_dtype=torch.float32)
+    close(a, b, "conv+res f32 out", **tol(dtype))
+
+
+def test_conv_matches_torch_conv1d(ops):
+    """the implicit-GEMM geometry against nn.functional.conv1d itself (symmetric and causal padding)"""
+    import torch.nn.functional as F
+    for k, pad, crop in ((9, 4, 0), (3, 1, 0), (5, 4, 4)):
+        x, w, bias = rnd(2, 45, 16, seed=1), rnd(24, 16, k, seed=2, scale=0.2), rnd(24, seed=3)
+        ref = F.conv1d(x.transpose(1, 2), w, bias, padding=pad)
+        ref = (ref[:, :, :-crop] if crop else ref).transpose(1, 2)
+        shadow = torch.empty(24, k * 16).cuda()
+        ops.cast_permute(w.cuda(), shadow, 0)
+        out = ops.conv(x.cuda(), shadow, k, pad, bias=bias.cuda())
+        close(out, ref, f"conv1d k={k}", rtol=2e-5, atol=2e-5)
+        # dgrad: d/dx of sum(out * g)  ==  conv of g with the flipped/transposed shadow, pad' = k-1-pad
+        g = rnd(2, 45, 24, seed=4)
+        xr = x.clone().requires_grad_(True)
+        o2 = F.conv1d(xr.transpose(1, 2), w, bias, padding=pad)
+        o2 = (o2[:, :, :-crop] if crop else o2).transpose(1, 2)
+        (o2 * g).sum().backward()
+        sd = torch.empty(16, k * 24).cuda()
+        ops.cast_permute(w.cuda(), sd, 1)
+        dx = ops.conv(g.cuda(), sd, k, k - 1 - pad)
+        close(dx, xr.grad, f"conv1d dgrad k={k}", rtol=2e-5, atol=2e-5)
+        # wgrad in kernel layout, permuted back into the (O,I,k) gradient
+        wr = w.clone().requires_grad_(True)
+        o3 = F.conv1d(x.transpose(1, 2), wr, bias, padding=pad)
+        o3 = (o3[:, :, :-crop] if crop else o3).transpose(1, 2)
+        (o3 * g).sum().backward()
+        scratch = torch.zeros(24, k * 16).cuda()
+        ops.conv_wgrad(g.cuda(), x.cuda(), k, pad, scratch)
+        gw = torch.zeros(24, 16, k).cuda()
+        ops.permute_add(scratch, gw)
+        close(gw, wr.grad, f"conv1d wgrad k={k}", rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_wgrad_and_colsum(ops, dtype):
+    for M, N, K in ((300, 80, 72), (2000, 256, 1024), (77, 768, 32)):
+        dy, x = rnd(M, N, dtype=dtype, seed=1), rnd(M, K, dtype=dtype, seed=2)
+        out0 = rnd(N, K, seed=3)
+        a = ops.wgrad(dy.cuda(), x.cuda(), out0.cuda())
+        b = P.wgrad(dy, x, out0.clone())
+        close(a, b, "wgrad", rtol=1e-4, atol=1e-4 * M ** 0.5)
+        # strided column slice as A (the q/k/v slices of dqkv) and colsum on it
+        dq = rnd(M, 3 * N, dtype=dtype, seed=4)
+        sl = slice(N, 2 * N)
+        a = ops.wgrad(dq.cuda()[:, sl], x.cuda(), torch.zeros(N, K).cuda())
+        b = P.wgrad(dq[:, sl], x, torch.zeros(N, K))
+        close(a, b, "wgrad slice", rtol=1e-4, atol=1e-4 * M ** 0.5)
+        a = ops.colsum(dq.cuda()[:, sl], torch.zeros(N).cuda())
+        b = P.colsum(dq[:, sl], torch.zeros(N))
+        close(a, b, "colsum", rtol=1e-4, atol=1e-4 * M ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,t,C,N,taps,pad", [(3, 37, 32, 64, 3, 1), (2, 50, 80, 256, 5, 4), (3, 37, 64, 256, 9, 4)])
+def test_conv_wgrad(ops, dtype, B, t, C, N, taps, pad):
+    dy, x = rnd(B, t, N, dtype=dtype, seed=1), rnd(B, t, C, dtype=dtype, seed=2)
+    a = ops.conv_wgrad(dy.cuda(), x.cuda(), taps, pad, torch.zeros(N, taps * C).cuda())
+    b = P.conv_wgrad(dy, x, taps, pad, torch.zeros(N, taps * C))
+    close(a, b, "conv_wgrad", rtol=1e-4, atol=1e-4 * (B * t) ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("t", [37, 128, 200])
+def test_attention_products(ops, dtype, t):
+    """the five batched products of attention forward/backward on the strided q/k/v views and the
+    padded (B,N,H,t,tp) probability buffer"""
+    B, H, dk, NL = 2, 2, 16, 2
+    d = H * dk
+    tp = (t + 7) // 8 * 8
+
+    def views(dev):
+        mv = (lambda x: x.cuda()) if dev == "cuda" else (lambda x: x.clone())
+        qkv = mv(rnd(B, t, 3 * d, dtype=dtype, seed=1))
+        q, k, v = (qkv.view(B, t, 3, H, dk)[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        pbuf = mv(rnd(B, NL, H, t, tp, dtype=dtype, seed=2))
+        pbuf[..., t:] = 0
+        return q, k, v, pbuf
+
+    res = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        q, k, v, pbuf = views(dev)
+        S = torch.full((B, NL, H, t, tp), 7.0, dtype=dtype, device=dev)
+        o.bmm(q, k, S[:, 1][..., :t], trans_b=True, alpha=0.25)
+        Pm = pbuf[:, 1]
+        O = torch.zeros((B, t, H, dk), dtype=dtype, device=dev)
+        o.bmm(Pm, v, O.permute(0, 2, 1, 3), trans_b=False)
+        dqkv = torch.zeros((B, t, 3 * d), dtype=dtype, device=dev)
+        dq, dk_, dv = (dqkv.view(B, t, 3, H, dk)[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        dO4 = O.permute(0, 2, 1, 3)
+        o.bmm(Pm, dO4, dv, trans_a=True, trans_b=False)
+        o.bmm(Pm, k, dq, trans_b=False, alpha=0.5)
+        o.bmm(Pm, q, dk_, trans_a=True, trans_b=False, alpha=0.5)
+        res[dev] = (S[:, 1][..., :t].clone(), O, dqkv, S[:, 0].clone())
+    for a, b, n in zip(res["cuda"], res["cpu"], ("QK^T", "PV", "dqkv", "untouched layer slice")):
+        close(a, b, n, **tol(dtype, k=16))     # sums of up to 200 O(1) terms: fp32 accumulation-order noise
+
+
+# ------------------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("d", [32, 256, 384])
+def test_layernorm_family(ops, dtype, p, d):
+    M = 203
+    x32, xt = rnd(M, d, seed=1), rnd(M, d, dtype=dtype, seed=2)
+    a, h = rnd(M, d, dtype=dtype, seed=3), rnd(M, d, dtype=dtype, seed=4)
+    gm, bt = 1 + 0.1 * rnd(d, seed=5), 0.1 * rnd(d, seed=6)
+    dy, dsd = rnd(M, d, dtype=dtype, seed=7), rnd(M, d, seed=8)
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        rng = o.Rng(99, dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        r = []
+        # plain LN fp32 -> T and T -> T (+dropout), backward with relu mask / accumulate
+        y, mu, rs = o.layernorm_fwd(mv(x32), mv(gm), mv(bt), dtype, 1e-5, p, rng, 5)
+        dg, db = z(d), z(d)
+        dx = o.layernorm_bwd(mv(dy), mv(x32), mv(gm), mu, rs, dg, db, p, rng, 5, dx=mv(dsd))
+        r += [y, mu, rs, dx, dg, db]
+        y, mu, rs = o.layernorm_fwd(mv(xt), mv(gm), mv(bt), dtype, 1e-5, p, rng, 6)
+        dg, db = z(d), z(d)
+        dx = o.layernorm_bwd(mv(dy), mv(xt), mv(gm), mu, rs, dg, db, p, rng, 6, relu_mask=True)
+        r += [y, dx, dg, db]
+        # residual + dropout + LN
+        s, y, mu, rs = o.add_ln_fwd(mv(x32), mv(a), mv(gm), mv(bt), 1e-5, p, rng, 7)
+        dg, db = z(d), z(d)
+        dr, da = o.add_ln_bwd(mv(dsd), mv(dy), s, mv(gm), mu, rs, dg, db, p, rng, 7)
+        dr2, _ = o.add_ln_bwd(None, mv(dy), s, mv(gm), mu, rs, z(d), z(d), p, rng, 7)
+        r += [s, y, dr, da, dg, db, dr2]
+        # FFN tail
+        y, mu, rs = o.ffn_ln_fwd(mv(a), mv(h), mv(gm), mv(bt), 1e-5, p, rng, 8)
+        dg, db = z(d), z(d)
+        g = o.ffn_ln_bwd(mv(dy), mv(a), mv(h), mv(gm), mu, rs, dg, db, p, rng, 8)
+        r += [y, g, dg, db]
+        out[dev] = r
+    for i, (a_, b_) in enumerate(zip(out["cuda"], out["cpu"])):
+        k = 30 if a_.dim() == 1 and a_.numel() == d else 2     # per-channel sums over 203 rows
+        close(a_, b_, f"layernorm family output #{i}", **tol(a_.dtype if a_.dtype != torch.float32 else dtype, k=k))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("t", [37, 128, 300])
+def test_softmax_fwd_bwd(ops, dtype, p, t):
+    B, H, NL = 3, 2, 2
+    tp = (t + 7) // 8 * 8
+    lens = [t, max(1, t // 2), max(1, t - 5)]
+    km = torch.zeros(B, t, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        km[b, :n] = True
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda x: x.cuda()) if dev == "cuda" else (lambda x: x.clone())
+        rng = o.Rng(5, dev)
+        buf = mv(rnd(B, NL, H, t, tp, dtype=dtype, seed=1, scale=3.0))
+        bufd = torch.zeros_like(buf) if p > 0 else buf
+        S, Pd = buf[:, 1], bufd[:, 1]
+        o.softmax_fwd(S, Pd, mv(km), t, p, rng, 11)
+        dP = mv(rnd(B, H, t, tp, dtype=dtype, seed=2))
+        dP[..., t:] = float("nan")          # pad columns are never written by the producer GEMM
+        o.softmax_bwd(dP, S, t, p, rng, 11)
+        out[dev] = (S.clone(), Pd.clone(), dP)
+    for a, b, n in zip(out["cuda"], out["cpu"], ("P", "P_drop", "dS")):
+        close(a, b, n, **tol(dtype))
+    Pc = out["cuda"][0].float().cpu()
+    assert torch.all(Pc[..., t:] == 0), "pad columns must be written as zero"
+    close(Pc[..., :t].sum(-1), torch.ones(B, H, t), "rows sum to one", rtol=1e-2, atol=1e-2)
+    assert float(Pc[1, :, :, lens[1]:t].abs().max()) < 1e-6, "masked keys get ~0 probability (-1e4 fill)"
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_pe_embedding_linear1(ops, dtype):
+    B, t, d, V = 3, 29, 64, 40
+    pe, alpha = rnd(100, d, seed=1), torch.tensor([1.3])
+    a, dout = rnd(B, t, d, dtype=dtype, seed=2), rnd(B, t, d, seed=3)
+    ids = torch.from_numpy(np.random.default_rng(0).integers(0, V, size=(B, t)))
+    table = rnd(V, d, seed=4)
+    w, bb = rnd(d, seed=5), torch.tensor([0.37])
+    mask = torch.from_numpy(np.random.default_rng(1).random((B, t)) > 0.3)
+    dvec = rnd(B, t, seed=6)
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda x: x.cuda()) if dev == "cuda" else (lambda x: x.clone())
+        rng = o.Rng(3, dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        r = []
+        for p in (0.0, 0.25):
+            x = o.pe_add_fwd(mv(a), mv(pe), mv(alpha), p, rng, 21)
+            dal = z(1)
+            da = o.pe_add_bwd(mv(dout), mv(pe), dtype, dal, p, rng, 21)
+            r += [x, da, dal]
+        e = o.embedding_fwd(mv(ids), mv(table), torch.float32)
+        dt_ = z(V, d)
+        o.embedding_bwd(mv(ids), mv(dout), dt_, padding_idx=0)
+        r += [e, dt_]
+        y = o.linear1_fwd(mv(a), mv(w), mv(bb), mv(mask))
+        dw, db = z(d), z(1)
+        dx = o.linear1_bwd(mv(dvec), mv(a), mv(w), mv(mask), dw, db)
+        r += [y, dx, dw, db]
+        out[dev] = r
+    for i, (a_, b_) in enumerate(zip(out["cuda"], out["cpu"])):
+        close(a_, b_, f"pe/embedding/linear1 output #{i}", **tol(dtype, k=20))
+    assert float(out["cuda"][7][0].abs().sum()) == 0.0, "padding_idx row receives no gradient"
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_length_regulator_and_bucket_embed(ops, dtype):
+    B, L, d, T = 4, 13, 32, 40
+    g = np.random.default_rng(3)
+    dur = torch.from_numpy(g.integers(0, 6, size=(B, L)))
+    dur[0] = 0
+    dur[0, 4] = 3                     # mostly zero durations
+    dur[1] = 5                        # sum 65 > T: cropped
+    dur[2, 0] = -2                    # negative duration is clamped
+    x = rnd(B, L, d, dtype=dtype, seed=1)
+    dout = rnd(B, T, d, dtype=dtype, seed=2)
+    f0 = torch.from_numpy(g.uniform(0, 900, size=(B, T)).astype(np.float32))
+    en = torch.from_numpy(g.uniform(-5, 420, size=(B, T)).astype(np.float32))
+    pb = torch.exp(torch.linspace(np.log(71.0), np.log(799.8), 255))
+    eb = torch.linspace(0.0, 403.8, 255)
+    f0[0, :5] = pb[[0, 10, 100, 254, 77]]      # exactly on a boundary
+    f0[0, 5:8] = torch.tensor([0.0, 71.0, 1e6])
+    en[0, :3] = eb[[0, 128, 254]]
+    Ep, Ee = rnd(256, d, seed=3), rnd(256, d, seed=4)
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        y, starts = o.length_regulate_fwd(mv(x), mv(dur), T)
+        dx = o.length_regulate_bwd(mv(dout), starts, L)
+        dx2 = o.length_regulate_bwd(mv(dout), starts, L, dx=mv(x))
+        v, idx = o.bucket_embed_add_fwd(mv(dout), mv(f0), mv(en), mv(pb), mv(eb), mv(Ep), mv(Ee))
+        dEp = torch.zeros(256, d, device=dev)
+        dEe = torch.zeros(256, d, device=dev)
+        o.bucket_embed_bwd(mv(dout), idx, dEp, dEe)
+        out[dev] = (y, starts, dx, dx2, v, idx, dEp, dEe)
+    a, b = out["cuda"], out["cpu"]
+    assert torch.equal(a[0].cpu(), b[0]), "length regulator output is a pure copy: bit-exact"
+    assert torch.equal(a[1].cpu(), b[1]) and torch.equal(a[5].cpu(), b[5]), "scan / bucket indices bit-exact"
+    for i in (2, 3, 4, 6, 7):
+        close(a[i], b[i], f"LR/bucket output #{i}", **tol(dtype, k=4))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_batchnorm_tanh(ops, dtype, p):
+    M, C = 333, 256
+    x, dy = rnd(M, C, dtype=dtype, seed=1, scale=2.0) + 0.3, rnd(M, C, dtype=dtype, seed=2)
+    gm, bt = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        rng = o.Rng(8, dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        sums = z(2 * C)
+        o.colstats(mv(x), sums)
+        rm, rv, nbt = z(C) + 0.1, z(C) + 1.0, torch.zeros((), dtype=torch.int64, device=dev)
+        mean, rstd = o.bn_finalize(sums, M, 1e-5, 0.1, rm, rv, nbt)
+        y = o.bn_tanh_fwd(mv(x), mean, rstd, mv(gm), mv(bt), p, rng, 31)
+        red = z(2 * C)
+        o.bn_tanh_bwd_reduce(mv(dy), mv(x), mean, rstd, mv(gm), mv(bt), red, p, rng, 31)
+        cd = torch.tensor([float(M)], device=dev)
+        dx = o.bn_tanh_bwd_apply(mv(dy), mv(x), mean, rstd, mv(gm), mv(bt), red, 1.0, None, None, p, rng, 31, count_dev=cd)
+        out[dev] = (sums, mean, rstd, rm, rv, nbt.float(), y, red, dx)
+    for i, (a_, b_) in enumerate(zip(out["cuda"], out["cpu"])):
+        close(a_, b_, f"bn output #{i}", rtol=2e-3 if i in (0, 7) else tol(dtype)["rtol"],
+              atol=(5e-2 if i in (0, 7) else tol(dtype, k=2)["atol"]))
+    # against torch's own BatchNorm1d in training mode (fp32)
+    if dtype == torch.float32 and p == 0.0:
+        bn = torch.nn.BatchNorm1d(C)
+        with torch.no_grad():
+            bn.weight.copy_(gm); bn.bias.copy_(bt); bn.running_mean.fill_(0.1); bn.running_var.fill_(1.0)
+        ref = torch.tanh(bn(x.t().unsqueeze(0))).squeeze(0).t()
+        close(out["cuda"][6], ref, "vs nn.BatchNorm1d", rtol=1e-4, atol=1e-5)
+        close(out["cuda"][3], bn.running_mean, "running_mean", rtol=1e-5, atol=1e-6)
+        close(out["cuda"][4], bn.running_var, "running_var", rtol=1e-4, atol=1e-6)
+
+
+def test_l1_cast_permute_optimizer(ops):
+    n = 5003
+    pred, tgt = rnd(n, seed=1), rnd(n, seed=2)
+    pred[:7] = tgt[:7]                                   # sign(0) = 0
+    itgt = torch.from_numpy(np.random.default_rng(0).integers(0, 9, size=n))
+    gs = torch.tensor([0.7])
+    res = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        l1, l2 = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        o.l1_fwd(mv(pred), mv(tgt), l1)
+        o.l1_fwd(mv(pred), mv(itgt), l2, True)
+        d1 = o.l1_bwd(mv(pred), mv(tgt), mv(gs), torch.float32)
+        d2 = o.l1_bwd(mv(pred), mv(itgt), mv(gs), torch.float32, True)
+        w = mv(rnd(24, 16, 5, seed=3))
+        sf, sd = torch.zeros(24, 80, device=dev), torch.zeros(16, 120, device=dev)
+        o.cast_permute(w, sf, 0)
+        o.cast_permute(w, sd, 1)
+        gsq = torch.zeros(1, device=dev)
+        g = mv(rnd(n, seed=4))
+        o.sqnorm(g, gsq)
+        p_, m_, v_ = mv(rnd(n, seed=5)), mv(0.1 * rnd(n, seed=6)), mv(0.01 * rnd(n, seed=7).abs())
+        hyper = torch.tensor([3e-3, 1 - 0.9 ** 3, 1 - 0.98 ** 3, 1.0], device=dev)
+        o.adam_step(p_, g, m_, v_, hyper, gsq, 0.9, 0.98, 1e-9, 1.0)
+        res[dev] = (l1, l2, d1, d2, sf, sd, gsq, p_, m_, v_)
+    for i, (a, b) in enumerate(zip(res["cuda"], res["cpu"])):
+        close(a, b, f"l1/cast/adam output #{i}", rtol=2e-5, atol=1e-6)
+    # the optimizer against torch.optim.Adam + clip_grad_norm_ (3rd step of a state with history)
+    assert float(res["cuda"][2][:7].abs().sum()) == 0.0
+
+
+def test_adam_matches_torch_optimizer(ops):
+    n = 4099
+    p0, g1, g2 = rnd(n, seed=1), 3 * rnd(n, seed=2), 0.01 * rnd(n, seed=3)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    p, m, v = p0.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step, (g, lr) in enumerate(((g1, 2e-3), (g2, 1e-3)), start=1):
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        ref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        gsq = torch.zeros(1).cuda()
+        ops.sqnorm(g.cuda(), gsq)
+        hyper = torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.98 ** step, 1.0]).cuda()
+        ops.adam_step(p, g.cuda(), m, v, hyper, gsq, 0.9, 0.98, 1e-9, 1.0)
+        close(p, ref.data, f"Adam step {step}", rtol=1e-5, atol=1e-7)

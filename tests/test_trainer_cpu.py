@@ -1,0 +1,114 @@
+"""Host logic of the trainer on CPU (HIP ops replaced by the oracle primitives, tests/fake_backend.py):
+BASELINE.json configs[0] plumbing run (16 synthetic utterances, batch 2, 1 epoch, checkpoint + resume),
+the collate contract, the hparams singleton and the template config."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from fake_backend import fake_ops  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SMALL_HP = """
+architecture = 'text-mel'; model = 'Fastspeech2'; comment = ''
+save_dir = {save!r}; train_script = {script!r}; test_script = ''; lengths_file = ''
+mean_file = None; var_file = None; spm_model = None
+vocab_size = 152; mel_dim = 80; amp = False; optimizer = 'Noam'; warmup_step = 4000; warmup_factor = 1.0
+max_seqlen = None; batch_size = 2; max_epoch = 1; save_per_epoch = 1; clip = 1.0
+loaded_epoch = None; loaded_dir = None
+encoder_type = 'transformer'; decoder_type = 'transformer'
+d_model_encoder = 32; n_layer_encoder = 1; n_head_encoder = 2; ff_conv_kernel_size_encoder = 9
+d_model_decoder = 32; n_layer_decoder = 1; n_head_decoder = 2; ff_conv_kernel_size_decoder = 1
+concat_after_encoder = False; concat_after_decoder = False
+postnet_pred = True; reduction_rate = 1; dropout = 0.1
+nbins = 256; f0_min = 71.0; f0_max = 799.8; energy_min = 0.0; energy_max = 403.8
+pitch_pred = True; energy_pred = True; is_multi_speaker = False; different_spk_emb_samespeaker = False
+num_workers = 0; log_every = 4
+"""
+
+
+def test_collate_contract(tmp_path):
+    from transformer_tts_amd.datasets import datasets_fastspeech2 as D
+    script = D.write_synthetic_corpus(str(tmp_path / "corpus"), n_utt=5)
+    hp = SimpleNamespace(mel_dim=80, mean_file=None, var_file=None, spm_model=None, is_multi_speaker=False,
+                         tail_alignment="_alignment")
+    ds = D.TrainDatasets(script, hp)
+    assert len(ds) == 5
+    b = D.collate_fn([ds[i] for i in range(3)])
+    assert len(b) == 16
+    text, mel, pos_text, pos_mel, tl, ml, stop, spk, f0, en, ali = b[:11]
+    B, L, T = 3, int(tl.max()), int(ml.max())
+    assert text.shape == (B, L) and text.dtype == torch.int64 and mel.shape == (B, T, 80) and mel.dtype == torch.float32
+    assert pos_text.dtype == pos_mel.dtype == ali.dtype == torch.int64 and f0.dtype == en.dtype == torch.float32
+    for i in range(B):
+        n, m = int(tl[i]), int(ml[i])
+        assert int(ali[i].sum()) == m                      # sum of durations == mel length
+        assert torch.all(mel[i, m:] == -0.5) and torch.all(stop[i, m:] == 1.0) and torch.all(stop[i, :m] == 0.0)
+        assert torch.all(text[i, n:] == 0) and torch.all(f0[i, m:] == 0) and torch.all(ali[i, n:] == 0)
+        assert pos_text[i, :n].tolist() == list(range(1, n + 1)) and torch.all(pos_mel[i, m:] == 0)
+    assert spk is None and b[11] is None and b[12] is None and b[13] is None and b[15] == [None] * B
+    s = D.NumBatchSampler(ds, 2, shuffle=False)
+    assert list(s) == [[0, 1], [2, 3], [4]]
+    w = D.DistributedSamplerWrapper(s, num_replicas=2, rank=1)
+    assert list(w) == [[2, 3], [0, 1]] and len(w) == 2     # padded by repetition to a multiple of the world size
+
+
+def test_hparams_singleton_and_template(tmp_path):
+    from transformer_tts_amd.utils import HParams
+    from transformer_tts_amd.utils.utils import fill_variables, get_learning_rate
+    h = HParams()
+    with pytest.raises(AttributeError, match="not configured"):
+        h.foo
+    with pytest.raises(FileNotFoundError):
+        h.configure(tmp_path / "missing.py")
+    with pytest.raises(ValueError):
+        (tmp_path / "x.txt").write_text("a=1")
+        h.configure(tmp_path / "x.txt")
+    h.configure(os.path.join(ROOT, "config", "hparams_template.py"))
+    with pytest.raises(RuntimeError, match="reconfigure"):
+        h.configure(os.path.join(ROOT, "config", "hparams_template.py"))
+    with pytest.raises(AttributeError, match="does not have"):
+        h.no_such_key
+    fill_variables(h, verbose=False)
+    assert h.d_model_encoder == 256 and h.n_layer_decoder == 4 and h.mel_dim == 80 and h.spk_emb_architecture == ""
+    assert h.dropout_variance_adaptor == 0.5 and h.fix_mask is None
+    from transformer_tts_amd.train_fastspeech2 import build_model
+    h.d_model_encoder = h.d_model_decoder = 32      # keep the constructor cheap; all template keys are consumed
+    m = build_model(h)
+    assert len(m.state_dict()) == 217                # 205 parameters + 4 x 3 BN buffers
+    # Noam schedule of the reference (utils/utils.py:204-215)
+    assert get_learning_rate(1, 256, 1.0, 4000) == pytest.approx(4000 ** -1.5 * 256 ** -0.5)
+    assert get_learning_rate(8000, 256, 1.0, 4000) == pytest.approx(8000 ** -0.5 * 256 ** -0.5)
+
+
+def test_plumbing_epoch_checkpoint_and_resume(fake_ops, tmp_path, capsys):
+    from transformer_tts_amd.datasets import datasets_fastspeech2 as D
+    from transformer_tts_amd import train_fastspeech2 as T
+    from transformer_tts_amd.utils import HParams
+    from transformer_tts_amd.utils.utils import fill_variables
+    script = D.write_synthetic_corpus(str(tmp_path / "synthetic16"), n_utt=16)
+    hp_file = tmp_path / "hparams.py"
+    save = str(tmp_path / "ckpt")
+    hp_file.write_text(SMALL_HP.format(save=save, script=script))
+    hp = HParams()
+    hp.configure(hp_file)
+    fill_variables(hp, verbose=False)
+    os.makedirs(save, exist_ok=True)
+    args = SimpleNamespace(n_gpus=0)
+    T.run_training(0, args, hp, None)
+    out = capsys.readouterr().out
+    assert "EPOCH 1 end" in out and "loss_total" in out and "step 4 / 8" in out
+    sd = torch.load(os.path.join(save, "network.epoch1"), weights_only=True)
+    assert "encoder.layers.0.ff.f_1.weight" in sd and sd["encoder.layers.0.ff.f_1.weight"].shape == (128, 32, 9)
+    osd = torch.load(os.path.join(save, "network.optimizer.epoch1"), weights_only=True)
+    assert int(osd["state"][0]["step"]) == 8
+    # resume: epoch counter and Adam state come back (reference :428-446)
+    hp.loaded_epoch, hp.loaded_dir, hp.max_epoch = 1, save, 2
+    T.run_training(0, args, hp, None)
+    out = capsys.readouterr().out
+    assert "epoch 1 loaded" in out and "EPOCH 2 end" in out
+    osd2 = torch.load(os.path.join(save, "network.optimizer.epoch2"), weights_only=True)
+    assert int(osd2["state"][0]["step"]) == 16

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Run the GPU-side checks in sequence on the gpurun box; stop at the first step that times out / is killed.
+mkdir -p gpurun_out
+run() {  # name, timeout, command...
+  local name=$1 tmo=$2; shift 2
+  echo "=== $name" | tee -a gpurun_out/ci.log
+  timeout -k 10 "$tmo" "$@" > "gpurun_out/$name.log" 2>&1
+  local rc=$?
+  echo "$name rc=$rc" | tee -a gpurun_out/ci.log
+  tail -3 "gpurun_out/$name.log" | tee -a gpurun_out/ci.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "ABORT after $name (timeout/kill)" | tee -a gpurun_out/ci.log; exit 1; fi
+}
+: > gpurun_out/ci.log
+for step in "$@"; do
+  case $step in
+    kernels) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider ;;
+    model)   run model 900 python -m pytest tests/test_model_gpu.py -q -m gpu --timeout 400 -p no:cacheprovider ;;
+    smoke)   run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench)   run bench 600 python bench.py --steps 8 --warmup 8 ;;
+    benchq)  run benchq 300 python bench.py --steps 8 --warmup 8 --no-cpu-baseline ;;
+    prof)    cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+             run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline ;;
+    *) echo "unknown step $step" ;;
+  esac
+done

@@ -388,15 +388,17 @@ class PostNetFunction(torch.autograd.Function):
         bns = [mod.pre_batchnorm] + list(mod.batch_norm_list)
         inputs, cs, stats = [], [], []
         h = mel_T
-        count = M
         for li, (cv, bn) in enumerate(zip(convs, bns)):
             C = cv.weight.shape[0]
-            sums = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+            sums = torch.zeros(2 * C + 4, dtype=torch.float32, device=x.device)   # [sum | sum^2 | rows,-,-,-]
             c = ops.conv(h, rt.w_fwd(cv.weight), 5, 4, cv.bias.detach(), colstats=sums)          # causal: pad 4, crop 4
-            if rt.dp is not None:
-                count = rt.dp.allreduce_stats(sums, M)
-            mean, rstd = ops.bn_finalize(sums, count, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                                         bn.num_batches_tracked)
+            count = None
+            if rt.dp is not None:       # SyncBatchNorm: one all-reduce of [sums, row count] over the ranks
+                sums[2 * C:].fill_(float(M))
+                rt.dp.allreduce_sum(sums)
+                count = sums[2 * C:2 * C + 1]
+            mean, rstd = ops.bn_finalize(sums, M, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                         bn.num_batches_tracked, count_dev=count)
             inputs.append(h)
             h = ops.bn_tanh_fwd(c, mean, rstd, bn.weight.detach(), bn.bias.detach(), p, rng, mod.sites[li])  # :71-73
             cs.append(c)
@@ -437,8 +439,8 @@ class PostNetFunction(torch.autograd.Function):
                 ops.colsum(red[C:].view(1, C), grad_of(bn.weight))
                 if rt.dp is not None:
                     rt.dp.allreduce_sum(red)
-                dc = ops.bn_tanh_bwd_apply(dh, s["cs"][li], mean, rstd, bn.weight.detach(), bn.bias.detach(), red, count,
-                                           None, None, p, rng, mod.sites[li])
+                dc = ops.bn_tanh_bwd_apply(dh, s["cs"][li], mean, rstd, bn.weight.detach(), bn.bias.detach(), red, M,
+                                           None, None, p, rng, mod.sites[li], count_dev=count)
                 _conv_wgrad(rt, dc, s["inputs"][li], cv, 4)
                 if li > 0:
                     dh = ops.conv(dc, rt.w_dgrad(cv.weight), 5, 0)

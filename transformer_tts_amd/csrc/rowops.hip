@@ -395,17 +395,18 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd_k(T* __restrict__ s, T*
 }
 
 template <typename T, int NG>
-__global__ __launch_bounds__(ROW_BLOCK) void softmax_bwd_k(T* __restrict__ dp, const T* __restrict__ ps, int B, int H,
-        int t, int tp, int64_t batch_stride, float p, const uint64_t* rng, uint32_t site) {
+__global__ __launch_bounds__(ROW_BLOCK) void softmax_bwd_k(T* __restrict__ dp, int64_t dp_stride, const T* __restrict__ ps,
+        int64_t p_stride, int B, int H, int t, int tp, float p, const uint64_t* rng, uint32_t site) {
     const DropCtx dc = drop_ctx(rng, site, p);
     const int64_t rows = (int64_t)B * H * t;
     ROW_LOOP(rows) {
         const int b = (int)(row / ((int64_t)H * t));
         const int64_t inb = row - (int64_t)b * H * t;
-        const int64_t off = b * batch_stride + inb * tp;
+        const int64_t off = b * dp_stride + inb * tp;       // in the dP / dS buffer
+        const int64_t poff = b * p_stride + inb * tp;       // in the saved-probabilities buffer (= the forward's offsets)
         float4 g_[NG], pv[NG];
         row_load<NG, T>(dp + off, tp, lane, g_);
-        row_load<NG, T>(ps + off, tp, lane, pv);
+        row_load<NG, T>(ps + poff, tp, lane, pv);
         float dot = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_bwd_k(T* __restrict__ dp, c
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (GCOL(g) + c >= t) { ge[c] = 0.f; pe_[c] = 0.f; }
-            if (dc.on && GCOL(g) < tp) g_[g] = mul4(g_[g], drop_scale4(dc, (uint64_t)(off + GCOL(g)) >> 2));
+            if (dc.on && GCOL(g) < tp) g_[g] = mul4(g_[g], drop_scale4(dc, (uint64_t)(poff + GCOL(g)) >> 2));
             dot += sum4(mul4(g_[g], pv[g]));
         }
         dot = wave_sum(dot);
@@ -534,10 +535,11 @@ __global__ __launch_bounds__(ROW_BLOCK) void colstats_k(const T* __restrict__ x,
     flush_channel_sums<NG>(a2, sums + C, C, red);
 }
 
-__global__ void bn_finalize_k(const float* __restrict__ sums, float count, float eps, float momentum,
+__global__ void bn_finalize_k(const float* __restrict__ sums, float count, const float* __restrict__ count_dev, float eps, float momentum,
         float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
         float* __restrict__ running_var, int64_t* __restrict__ nbt, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (count_dev != nullptr) count = count_dev[0];
     if (c < C) {
         const double mud = (double)sums[c] / (double)count;
         const float mu = (float)mud;
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_fwd_k(const T* __restrict__
 template <typename T, int NG, int MODE>
 __global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-        const float* __restrict__ beta, float* __restrict__ red_io, float count, T* __restrict__ dx,
+        const float* __restrict__ beta, float* __restrict__ red_io, float count, const float* __restrict__ count_dev, T* __restrict__ dx,
         float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M, int C, float p, const uint64_t* rng,
         uint32_t site) {
     __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_bwd_k(const T* __restrict__
         if (MODE == 1) {
             row_load<NG, float>(red_io, C, lane, r0);
             row_load<NG, float>(red_io + C, C, lane, r1);
-            const float ic = 1.f / count;
+            const float ic = 1.f / (count_dev != nullptr ? count_dev[0] : count);
 #pragma unroll
             for (int g = 0; g < NG; ++g) { r0[g] = scale4(r0[g], ic); r1[g] = scale4(r1[g], ic); }
         }
@@ -788,15 +790,16 @@ extern "C" int fs2_softmax_fwd(void* s, void* pd, int dtype, const uint8_t* key_
     return FS2_OK;
 }
 
-extern "C" int fs2_softmax_bwd(void* dp, const void* ps, int dtype, int B, int H, int t, int tp, int64_t batch_stride,
-                               float p, const uint64_t* rng, uint32_t site, void* stream) {
+extern "C" int fs2_softmax_bwd(void* dp, int64_t dp_batch_stride, const void* ps, int64_t p_batch_stride, int dtype, int B,
+                               int H, int t, int tp, float p, const uint64_t* rng, uint32_t site, void* stream) {
     CHECK_DT("fs2_softmax_bwd", dtype);
     FS2_REQUIRE(t > 0 && tp >= t && tp % 8 == 0 && tp <= 2048, "fs2_softmax_bwd: need 0 < t <= tp <= 2048, tp %% 8 == 0");
+    FS2_REQUIRE(dp_batch_stride % 4 == 0 && p_batch_stride % 4 == 0, "fs2_softmax_bwd: batch strides must be multiples of 4");
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_softmax_bwd: dropout needs rng");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid((int64_t)B * H * t)), block(ROW_BLOCK);
     NG_DISPATCH(tp, NG, { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((softmax_bwd_k<T, NG>), grid, block, 0, st, (T*)dp, (const T*)ps, B, H, t, tp, batch_stride, p, rng, site);
+        hipLaunchKernelGGL((softmax_bwd_k<T, NG>), grid, block, 0, st, (T*)dp, dp_batch_stride, (const T*)ps, p_batch_stride, B, H, t, tp, p, rng, site);
     }); });
     FS2_CHECK_LAUNCH("fs2_softmax_bwd");
     return FS2_OK;
@@ -870,11 +873,11 @@ extern "C" int fs2_colstats(const void* x, int dtype, int64_t M, int C, float* s
     return FS2_OK;
 }
 
-extern "C" int fs2_bn_finalize(const float* sums, float count, float eps, float momentum, float* mean, float* rstd,
-                               float* running_mean, float* running_var, int64_t* num_batches_tracked, int C,
-                               void* stream) {
-    FS2_REQUIRE(C > 0 && count > 0.f, "fs2_bn_finalize: bad C/count");
-    hipLaunchKernelGGL(bn_finalize_k, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, eps,
+extern "C" int fs2_bn_finalize(const float* sums, float count, const float* count_dev, float eps, float momentum,
+                               float* mean, float* rstd, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, int C, void* stream) {
+    FS2_REQUIRE(C > 0 && (count > 0.f || count_dev != nullptr), "fs2_bn_finalize: bad C/count");
+    hipLaunchKernelGGL(bn_finalize_k, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count, count_dev, eps,
                        momentum, mean, rstd, running_mean, running_var, num_batches_tracked, C);
     FS2_CHECK_LAUNCH("fs2_bn_finalize");
     return FS2_OK;
@@ -904,24 +907,24 @@ extern "C" int fs2_bn_tanh_bwd_reduce(const void* dy, const void* x, int dtype, 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid(M)), block(ROW_BLOCK);
     NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 0>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, red, 1.f, (T*)nullptr, (float*)nullptr, (float*)nullptr, M, C, p, rng, site);
+        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 0>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, red, 1.f, (const float*)nullptr, (T*)nullptr, (float*)nullptr, (float*)nullptr, M, C, p, rng, site);
     }); } });
     FS2_CHECK_LAUNCH("fs2_bn_tanh_bwd_reduce");
     return FS2_OK;
 }
 
 extern "C" int fs2_bn_tanh_bwd_apply(const void* dy, const void* x, int dtype, const float* mean, const float* rstd,
-                                     const float* gamma, const float* beta, const float* red, float count, void* dx,
-                                     float* dgamma, float* dbeta, int64_t M, int C, float p, const uint64_t* rng,
-                                     uint32_t site, void* stream) {
+                                     const float* gamma, const float* beta, const float* red, float count,
+                                     const float* count_dev, void* dx, float* dgamma, float* dbeta, int64_t M, int C,
+                                     float p, const uint64_t* rng, uint32_t site, void* stream) {
     CHECK_ROW("fs2_bn_tanh_bwd_apply", C, 1024); CHECK_DT("fs2_bn_tanh_bwd_apply", dtype);
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_bn_tanh_bwd_apply: dropout needs rng");
-    FS2_REQUIRE(count > 0.f, "fs2_bn_tanh_bwd_apply: count must be positive");
+    FS2_REQUIRE(count > 0.f || count_dev != nullptr, "fs2_bn_tanh_bwd_apply: count must be positive");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid(M)), block(ROW_BLOCK);
     NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 1>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, const_cast<float*>(red), count, (T*)dx, dgamma, dbeta, M, C, p, rng, site);
+        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 1>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, const_cast<float*>(red), count, count_dev, (T*)dx, dgamma, dbeta, M, C, p, rng, site);
     }); } });
     FS2_CHECK_LAUNCH("fs2_bn_tanh_bwd_apply");
     return FS2_OK;

@@ -54,7 +54,7 @@ SIGNATURES = {
     "fs2_ffn_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
     "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
-    "fs2_softmax_bwd": [_P, _P, _I, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
+    "fs2_softmax_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_length_regulate_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "fs2_length_regulate_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "fs2_bucket_embed_add_fwd": [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _P],
@@ -62,10 +62,10 @@ SIGNATURES = {
     "fs2_linear1_fwd": [_P, _I, _P, _P, _P, _P, _L, _I, _P],
     "fs2_linear1_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _P],
     "fs2_colstats": [_P, _I, _L, _I, _P, _P],
-    "fs2_bn_finalize": [_P, _F, _F, _F, _P, _P, _P, _P, _P, _I, _P],
+    "fs2_bn_finalize": [_P, _F, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P],
     "fs2_bn_tanh_fwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
     "fs2_bn_tanh_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
-    "fs2_bn_tanh_bwd_apply": [_P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_bn_tanh_bwd_apply": [_P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
     "fs2_l1_fwd": [_P, _I, _P, _I, _L, _P, _P],
     "fs2_l1_bwd": [_P, _I, _P, _I, _L, _P, _P, _I, _P],
     "fs2_sqnorm": [_P, _L, _P, _P],
@@ -417,9 +417,9 @@ def softmax_fwd(s, p_drop, key_mask, t, p=0.0, rng=None, site=0):
 def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
     B, H, _, tp = dp.shape
     assert dp.stride(3) == 1 and dp.stride(2) == tp and dp.stride(1) == t * tp
-    assert p_saved.stride() == dp.stride()
-    _check(lib().fs2_softmax_bwd(_p(dp), _p(p_saved), _dt(dp), B, H, t, tp, dp.stride(0), p, _rng_ptr(rng, p), site,
-                                 _stream()), "fs2_softmax_bwd")
+    assert p_saved.stride()[1:] == dp.stride()[1:] and p_saved.dtype == dp.dtype
+    _check(lib().fs2_softmax_bwd(_p(dp), dp.stride(0), _p(p_saved), p_saved.stride(0), _dt(dp), B, H, t, tp, p,
+                                 _rng_ptr(rng, p), site, _stream()), "fs2_softmax_bwd")
 
 
 # ------------------------------------------------------------------------------------------------ variance adaptor
@@ -484,11 +484,12 @@ def colstats(x, sums):
     _check(lib().fs2_colstats(_p(_c(x)), _dt(x), x.numel() // C, C, _p(sums), _stream()), "fs2_colstats")
 
 
-def bn_finalize(sums, count, eps, momentum, running_mean, running_var, num_batches_tracked):
-    C = sums.numel() // 2
+def bn_finalize(sums, count, eps, momentum, running_mean, running_var, num_batches_tracked, count_dev=None):
+    """sums: [2C] (+ optional trailing slots); count_dev: 1-element device tensor overriding `count`"""
+    C = running_mean.numel()
     mean = torch.empty(C, dtype=torch.float32, device=sums.device)
     rstd = torch.empty(C, dtype=torch.float32, device=sums.device)
-    _check(lib().fs2_bn_finalize(_p(sums), float(count), eps, momentum, _p(mean), _p(rstd), _p(running_mean),
+    _check(lib().fs2_bn_finalize(_p(sums), float(count), _p(count_dev), eps, momentum, _p(mean), _p(rstd), _p(running_mean),
                                  _p(running_var), _p(num_batches_tracked), C, _stream()), "fs2_bn_finalize")
     return mean, rstd
 
@@ -508,11 +509,12 @@ def bn_tanh_bwd_reduce(dy, x, mean, rstd, gamma, beta, red, p=0.0, rng=None, sit
            "fs2_bn_tanh_bwd_reduce")
 
 
-def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta, p=0.0, rng=None, site=0):
+def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta, p=0.0, rng=None, site=0,
+                      count_dev=None):
     C = x.shape[-1]
     dx = torch.empty_like(x)
     _check(lib().fs2_bn_tanh_bwd_apply(_p(_c(dy)), _p(_c(x)), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(red),
-                                       float(count), _p(dx), _p(dgamma), _p(dbeta), x.numel() // C, C, p,
+                                       float(count), _p(count_dev), _p(dx), _p(dgamma), _p(dbeta), x.numel() // C, C, p,
                                        _rng_ptr(rng, p), site, _stream()), "fs2_bn_tanh_bwd_apply")
     return dx
 

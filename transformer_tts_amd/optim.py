@@ -1,0 +1,111 @@
+"""Flat fp32 parameter / gradient / Adam-moment arenas and the fused clip + Adam step.
+
+Replaces ``torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)`` + ``torch.optim.Adam(lr=1e-3,
+betas=(0.9, 0.98), eps=1e-9).step()`` of the reference trainer (train_fastspeech2.py:304-315,411-416)
+by two kernel launches over one contiguous buffer (fs2_sqnorm, fs2_adam_step).  Parameters become
+views of the arena (state_dict keys / shapes unchanged); ``param.grad`` are views of the gradient
+arena that the backward kernels accumulate into directly, so data-parallel all-reduce works on
+arena slices in place.
+"""
+import torch
+
+from . import ops
+
+
+class ParamArena:
+    ALIGN = 4   # elements: keeps every parameter 16-byte aligned for float4 loads
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no parameters"
+        dev = self.params[0].device
+        self.offsets, off = [], 0
+        for p in self.params:
+            assert p.dtype == torch.float32 and p.device == dev
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.numel = off
+        self.p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            view = self.p[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p._fs2_grad = self.g[o:o + p.numel()].view_as(p)
+            p.grad = p._fs2_grad
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+
+    def span(self, params):
+        """[lo, hi) element range of the arena covered by `params` (must be registered here)"""
+        idx = [self._index[id(p)] for p in params if id(p) in self._index]
+        if not idx:
+            return None
+        lo = min(self.offsets[i] for i in idx)
+        hi = max(self.offsets[i] + (self.params[i].numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN for i in idx)
+        return lo, hi
+
+
+class FusedAdam:
+    """Adam with the reference's hyper-parameters, global-norm clipping fused in, over a ParamArena.
+
+    Keeps the pieces of the torch.optim interface the reference trainer touches:
+    ``param_groups[i]['lr']`` (set every step by the Noam schedule), ``zero_grad()``, ``step()``,
+    ``state_dict()`` / ``load_state_dict()`` in torch.optim.Adam's format (``state[0]['step']`` is what
+    the reference reads on resume, train_fastspeech2.py:444)."""
+
+    def __init__(self, model_or_params, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=1.0, runtime=None, dp=None):
+        params = list(model_or_params.parameters()) if hasattr(model_or_params, "parameters") else list(model_or_params)
+        self.arena = ParamArena(params)
+        self.runtime = runtime if runtime is not None else getattr(model_or_params, "rt", None)
+        self.dp = dp
+        self.betas, self.eps, self.max_norm = betas, eps, max_norm
+        dev = self.arena.p.device
+        self.m = torch.zeros_like(self.arena.p)
+        self.v = torch.zeros_like(self.arena.p)
+        self.gsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.t = 0
+        self.param_groups = [dict(params=self.arena.params, lr=lr, betas=betas, eps=eps)]
+        if self.runtime is not None:
+            self.runtime.invalidate()
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.g.zero_()
+        for p in self.arena.params:     # re-attach if a caller dropped the views
+            if p.grad is None:
+                p.grad = p._fs2_grad
+
+    def step(self):
+        self.t += 1
+        world = 1
+        if self.dp is not None:
+            world = self.dp.finish()
+        lr = float(self.param_groups[0]["lr"])
+        b1, b2 = self.betas
+        self.hyper.copy_(torch.tensor([lr, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, 1.0 / world], dtype=torch.float32))
+        self.gsq.zero_()
+        ops.sqnorm(self.arena.g, self.gsq)
+        ops.adam_step(self.arena.p, self.arena.g, self.m, self.v, self.hyper, self.gsq, b1, b2, self.eps,
+                      self.max_norm if self.max_norm is not None else 0.0)
+        if self.runtime is not None:
+            self.runtime.invalidate()
+
+    # ---- torch.optim.Adam-compatible checkpoints
+    def state_dict(self):
+        state = {}
+        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+            n = p.numel()
+            state[i] = dict(step=torch.tensor(float(self.t)), exp_avg=self.m[o:o + n].view_as(p).clone(),
+                            exp_avg_sq=self.v[o:o + n].view_as(p).clone())
+        groups = [dict(lr=self.param_groups[0]["lr"], betas=self.betas, eps=self.eps, weight_decay=0, amsgrad=False,
+                       params=list(range(len(self.arena.params))))]
+        return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
+            st = sd["state"][i]
+            n = p.numel()
+            self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+        self.t = int(sd["state"][0]["step"])
+        self.param_groups[0]["lr"] = sd["param_groups"][0]["lr"]

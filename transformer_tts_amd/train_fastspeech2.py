@@ -1,0 +1,231 @@
+# -*- coding: utf-8 -*-
+"""FastSpeech2 trainer -- the reference's ``train_fastspeech2.py`` surface on the MI355X-native path.
+
+Same CLI (``--hp_file``), same module-level functions and arguments as the reference
+(``create_masks`` :55-82, ``train_loop`` :100-323, ``train_epoch`` :330-350, ``init_distributed`` :352-362,
+``cleanup`` :364-365, ``run_distributed`` :368-374, ``run_training`` :376-454), same checkpoint file names.
+Differences, all on purpose:
+* the model is ``transformer_tts_amd.Models.fastspeech2.FastSpeech2`` (HIP kernels, no CPU path);
+* clip_grad_norm_ + Adam are one fused kernel over flat arenas (``optim.FusedAdam``); ``hp.amp`` selects
+  bf16 MFMA compute (fp32 master weights, no GradScaler needed) instead of fp16 autocast;
+* one process per GPU is started by ``torch.distributed.run`` / ``mp.spawn`` as in the reference, but the
+  gradient exchange is ``parallel.DataParallel`` (bucketed in-place RCCL all-reduce overlapped with
+  backward + SyncBatchNorm statistics), not DistributedDataParallel;
+* losses are printed every ``hp.log_every`` steps (reference: every step, ~10 host syncs per step).
+"""
+import argparse
+import filecmp
+import os
+import random
+import shutil
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch.utils.data import DataLoader
+
+from .Models.fastspeech2 import FastSpeech2
+from .Models.functional import l1_loss
+from .optim import FusedAdam
+from .utils import hparams as hp
+from .utils.utils import fill_variables, get_learning_rate, init_weight, load_model, log_config
+from .datasets import datasets_fastspeech2 as datasets
+
+random.seed(77)
+DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def create_masks(src_pos, trg_pos, task="transformer", src_pad=0, trg_pad=0, debug=False):
+    """(B,t) positions -> (B,1,t) bool key masks.  Only the FastSpeech2 branch of the reference
+    (:69-70) is on this path; the causal mask of the AR Transformer is a later row."""
+    assert not debug and task.lower() in ("fastspeech2", "lightspeech")
+    return (src_pos != src_pad).unsqueeze(-2), (trg_pos != trg_pad).unsqueeze(-2)
+
+
+def compute_losses(hp, outputs, mel, alignment, f0, energy):
+    """The five nn.L1Loss() terms of the reference (:212-259); returns (total, dict of parts)."""
+    outputs_prenet, outputs_postnet, log_d_prediction, p_prediction, e_prediction = outputs[:5]
+    parts = {"frame_before": l1_loss(outputs_prenet, mel)}
+    loss = parts["frame_before"]
+    if hp.postnet_pred:
+        parts["frame_after"] = l1_loss(outputs_postnet, mel)
+        loss = loss + parts["frame_after"]
+    parts["duration"] = l1_loss(log_d_prediction, alignment, True)       # target log(alignment + 1)
+    if hp.pitch_pred:
+        parts["f0"] = l1_loss(p_prediction, f0)
+        loss = loss + parts["f0"]
+    if hp.energy_pred:
+        parts["energy"] = l1_loss(e_prediction, energy)
+        loss = loss + parts["energy"]
+    loss = loss + parts["duration"]
+    return loss, parts
+
+
+def train_step(model, optimizer, step, d, hp):
+    """One iteration of the reference loop body (:117-315) without host synchronisation; returns
+    (loss tensor, parts, batch size)."""
+    if hp.optimizer.lower() != "radam":
+        lr = get_learning_rate(step, hp.d_model_decoder, hp.warmup_factor, hp.warmup_step)
+        for param_group in optimizer.param_groups:
+            param_group["lr"] = lr
+    text, mel, pos_text, pos_mel, text_lengths, mel_lengths, stop_token, spk_emb, f0, energy, alignment = d[:11]
+    mv = lambda x: x.to(DEVICE, non_blocking=True)
+    text, mel, pos_text, pos_mel, f0, energy, alignment = (mv(x) for x in (text, mel, pos_text, pos_mel, f0, energy, alignment))
+    src_mask, trg_mask = create_masks(pos_text, pos_mel, task=hp.model)
+    optimizer.zero_grad()
+    outputs = model(text, src_mask, trg_mask, alignment, f0, energy, None, spkr_emb=None, fix_mask=hp.fix_mask,
+                    temperature=None, hop_size=None)
+    loss, parts = compute_losses(hp, outputs, mel, alignment, f0, energy)
+    loss.backward()
+    if isinstance(optimizer, FusedAdam):
+        optimizer.step()                                    # global-norm clip (1.0) fused into the Adam kernel
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        optimizer.step()
+        model.rt.invalidate()
+    model.rt.get_rng(text.device).advance()
+    return loss, parts, mel.shape[0]
+
+
+def train_loop(model, optimizer, step, epoch, args, hp, rank, dataloader):
+    log_every = max(1, int(getattr(hp, "log_every", 1)))
+    for d in dataloader:
+        loss, parts, batch_size = train_step(model, optimizer, step, d, hp)
+        if step % log_every == 0:
+            print(f"loss_frame_before = {parts['frame_before'].item()}")
+            print(f"loss_duration = {parts['duration'].item()}")
+            if "f0" in parts:
+                print(f"loss_f0 = {parts['f0'].item()}")
+            if "energy" in parts:
+                print(f"loss_energy = {parts['energy'].item()}")
+            if "frame_after" in parts:
+                print(f"loss_frame_after = {parts['frame_after'].item()}")
+            print(f"loss_total = {loss.item()}")
+            print(f"batch size = {batch_size}")
+            print(f"step {step} / {len(dataloader)}")
+            assert not torch.isnan(loss), "loss is nan"
+            sys.stdout.flush()
+        step += 1
+    if rank == 0 and (epoch + 1) >= (hp.max_epoch - 10):
+        torch.save(model.state_dict(), hp.save_dir + "/network.epoch{}".format(epoch + 1))
+    elif rank == 0 and ((epoch + 1) % hp.save_per_epoch >= (hp.save_per_epoch - 10) or ((epoch + 1) % hp.save_per_epoch == 0)):
+        torch.save(model.state_dict(), hp.save_dir + "/network.epoch{}".format(epoch + 1))
+    if rank == 0 and (epoch + 1) % hp.save_per_epoch == 0:
+        torch.save(optimizer.state_dict(), hp.save_dir + "/network.optimizer.epoch{}".format(epoch + 1))
+    return step
+
+
+def train_epoch(model, optimizer, step, start_epoch, args, hp, rank):
+    alignment_pred = hp.model.lower() in ("fastspeech2", "lightspeech")
+    dataset_train = datasets.TrainDatasets(hp.train_script, hp, alignment_pred=alignment_pred, pitch_pred=hp.pitch_pred,
+                                           energy_pred=hp.energy_pred, accent_emb=hp.accent_emb)
+    assert hp.batch_size is not None, "max_seqlen batching (LengthsBatchSampler) is a later row of SURVEY section 8(f)"
+    sampler = datasets.NumBatchSampler(dataset_train, hp.batch_size)
+    train_sampler = datasets.DistributedSamplerWrapper(sampler) if args.n_gpus > 1 else sampler
+    dataloader = DataLoader(dataset_train, batch_sampler=train_sampler, num_workers=int(getattr(hp, "num_workers", 8)),
+                            collate_fn=datasets.collate_fn, pin_memory=True)
+    for epoch in range(start_epoch, hp.max_epoch):
+        start_time = time.time()
+        step = train_loop(model, optimizer, step, epoch, args, hp, rank, dataloader)
+        print("EPOCH {} end".format(epoch + 1))
+        print(f"elapsed time {time.time() - start_time}")
+
+
+def init_distributed(rank, n_gpus, port):
+    assert torch.cuda.is_available(), "Distributed mode requires CUDA."
+    torch.cuda.set_device(rank % n_gpus)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", world_size=n_gpus, rank=rank)   # "nccl" is RCCL on ROCm
+
+
+def cleanup():
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def run_distributed(fn, args, hp):
+    port = "60" + str(int(time.time()))[-4:]
+    print(f"port = {port}")
+    try:
+        mp.spawn(fn, args=(args, hp, port), nprocs=args.n_gpus, join=True)
+    finally:
+        cleanup()
+
+
+def build_model(hp):
+    """Argument wiring of the reference (:381-389), dropout_postnet hard-coded to 0.5 there."""
+    return FastSpeech2(hp=hp, src_vocab=hp.vocab_size, trg_vocab=hp.mel_dim, d_model_encoder=hp.d_model_encoder,
+                       N_e=hp.n_layer_encoder, n_head_encoder=hp.n_head_encoder,
+                       ff_conv_kernel_size_encoder=hp.ff_conv_kernel_size_encoder,
+                       concat_after_encoder=hp.concat_after_encoder, d_model_decoder=hp.d_model_decoder,
+                       N_d=hp.n_layer_decoder, n_head_decoder=hp.n_head_decoder,
+                       ff_conv_kernel_size_decoder=hp.ff_conv_kernel_size_decoder,
+                       concat_after_decoder=hp.concat_after_decoder,
+                       dropout_variance_adaptor=hp.dropout_variance_adaptor, reduction_rate=hp.reduction_rate,
+                       dropout=hp.dropout, dropout_postnet=0.5, n_bins=hp.nbins, f0_min=hp.f0_min, f0_max=hp.f0_max,
+                       energy_min=hp.energy_min, energy_max=hp.energy_max, pitch_pred=hp.pitch_pred,
+                       energy_pred=hp.energy_pred, accent_emb=hp.accent_emb, output_type=hp.output_type,
+                       num_group=hp.num_group, multi_speaker=hp.is_multi_speaker, spk_emb_dim=hp.spk_emb_dim,
+                       spk_emb_architecture=hp.spk_emb_architecture)
+
+
+def run_training(rank, args, hp, port=None):
+    if args.n_gpus > 1:
+        init_distributed(rank, args.n_gpus, port)
+    if hp.model.lower() != "fastspeech2":
+        raise AttributeError(hp.model)
+    model = build_model(hp)
+    model.apply(init_weight)
+    model.train()
+    print(model)
+    device = torch.device("cuda", rank) if torch.cuda.is_available() else torch.device("cpu")
+    model = model.to(device)
+    assert hp.optimizer.lower() != "radam", "the reference's radam branch is unreachable (SURVEY section 2.1 #20)"
+    optimizer = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=1.0)
+    if args.n_gpus > 1:
+        from .parallel import DataParallel
+        optimizer.dp = DataParallel(model, optimizer.arena)
+        dist.barrier()
+    if hp.loaded_epoch is not None:
+        start_epoch = hp.loaded_epoch
+        path = os.path.join(hp.loaded_dir, "network.epoch{}".format(hp.loaded_epoch))
+        print("epoch {} loaded".format(hp.loaded_epoch))
+        state = load_model(path, map_location=device)
+        state = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
+        model.load_state_dict(state)
+        model.rt.invalidate()
+        opt_state = torch.load(os.path.join(hp.loaded_dir, "network.optimizer.epoch{}".format(hp.loaded_epoch)),
+                               map_location=device, weights_only=True)
+        optimizer.load_state_dict(opt_state)
+        step = int(opt_state["state"][0]["step"])
+    else:
+        start_epoch, step = 0, 1
+    print("params = {0:.2f}M".format(sum(p.numel() for p in model.parameters()) / 1000 / 1000))
+    train_epoch(model, optimizer, step, start_epoch, args, hp, rank)
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--hp_file", type=str, default="hparams.py")
+    args = parser.parse_args(argv)
+    hp.configure(args.hp_file)
+    fill_variables(hp)
+    log_config(hp)
+    assert hp.architecture == "text-mel", f"invalid architecture {hp.architecture}"
+    os.makedirs(hp.save_dir, exist_ok=True)
+    dst = f"{hp.save_dir}/hparams.py"
+    if args.hp_file != dst and not (os.path.exists(dst) and filecmp.cmp(args.hp_file, dst)):
+        shutil.copyfile(args.hp_file, dst)
+    args.n_gpus = torch.cuda.device_count()
+    if args.n_gpus > 1:
+        run_distributed(run_training, args, hp)
+    else:
+        run_training(0, args, hp, None)
+
+
+if __name__ == "__main__":
+    main()
