@@ -34,7 +34,7 @@ def oracle_model(name, dtype=torch.float32):
 
 def check_digest(actual, dig, rtol, atol, what):
     """Compare a tensor with a stored digest [sum, sum|x|, l2, n, samples...]."""
-    x = torch.as_tensor(actual).detach().double().reshape(-1)
+    x = torch.as_tensor(actual).detach().double().cpu().reshape(-1)
     n = int(dig[3])
     assert x.numel() == n, f"{what}: numel {x.numel()} != {n}"
     samples = x[torch.from_numpy(sample_index(n))].numpy()

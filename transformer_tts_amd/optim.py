@@ -76,13 +76,23 @@ class FusedAdam:
                 p.grad = p._fs2_grad
 
     def step(self):
+        self.host_update()
+        self.launch()
+
+    def host_update(self):
+        """host half of a step: advance t and refresh the 4-float device buffer {lr, 1-b1^t, 1-b2^t, 1/world}
+        (kept outside a captured hipGraph; the kernels read the buffer)"""
         self.t += 1
-        world = 1
-        if self.dp is not None:
-            world = self.dp.finish()
+        world = self.dp.world if self.dp is not None else 1
         lr = float(self.param_groups[0]["lr"])
         b1, b2 = self.betas
         self.hyper.copy_(torch.tensor([lr, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, 1.0 / world], dtype=torch.float32))
+
+    def launch(self):
+        """device half of a step (graph-capturable): finish the gradient exchange, global norm, clip + Adam"""
+        if self.dp is not None:
+            self.dp.finish()
+        b1, b2 = self.betas
         self.gsq.zero_()
         ops.sqnorm(self.arena.g, self.gsq)
         ops.adam_step(self.arena.p, self.arena.g, self.m, self.v, self.hyper, self.gsq, b1, b2, self.eps,

@@ -63,16 +63,16 @@ def compute_losses(hp, outputs, mel, alignment, f0, energy):
     return loss, parts
 
 
-def train_step(model, optimizer, step, d, hp):
-    """One iteration of the reference loop body (:117-315) without host synchronisation; returns
-    (loss tensor, parts, batch size)."""
+def _set_lr(optimizer, step, hp):
     if hp.optimizer.lower() != "radam":
         lr = get_learning_rate(step, hp.d_model_decoder, hp.warmup_factor, hp.warmup_step)
         for param_group in optimizer.param_groups:
             param_group["lr"] = lr
-    text, mel, pos_text, pos_mel, text_lengths, mel_lengths, stop_token, spk_emb, f0, energy, alignment = d[:11]
-    mv = lambda x: x.to(DEVICE, non_blocking=True)
-    text, mel, pos_text, pos_mel, f0, energy, alignment = (mv(x) for x in (text, mel, pos_text, pos_mel, f0, energy, alignment))
+
+
+def step_body(model, optimizer, hp, text, mel, pos_text, pos_mel, f0, energy, alignment):
+    """Device work of one iteration (reference :153-315): masks, zero_grad, forward, losses, backward,
+    clip + Adam kernels, dropout-stream advance.  No host synchronisation: capturable in a hipGraph."""
     src_mask, trg_mask = create_masks(pos_text, pos_mel, task=hp.model)
     optimizer.zero_grad()
     outputs = model(text, src_mask, trg_mask, alignment, f0, energy, None, spkr_emb=None, fix_mask=hp.fix_mask,
@@ -80,13 +80,64 @@ def train_step(model, optimizer, step, d, hp):
     loss, parts = compute_losses(hp, outputs, mel, alignment, f0, energy)
     loss.backward()
     if isinstance(optimizer, FusedAdam):
-        optimizer.step()                                    # global-norm clip (1.0) fused into the Adam kernel
+        optimizer.launch()                                  # global-norm clip (1.0) fused into the Adam kernel
     else:
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
         optimizer.step()
         model.rt.invalidate()
     model.rt.get_rng(text.device).advance()
+    return loss, parts
+
+
+def train_step(model, optimizer, step, d, hp):
+    """One iteration of the reference loop body (:117-315); returns (loss tensor, parts, batch size)."""
+    _set_lr(optimizer, step, hp)
+    text, mel, pos_text, pos_mel, text_lengths, mel_lengths, stop_token, spk_emb, f0, energy, alignment = d[:11]
+    mv = lambda x: x.to(DEVICE, non_blocking=True)
+    text, mel, pos_text, pos_mel, f0, energy, alignment = (mv(x) for x in (text, mel, pos_text, pos_mel, f0, energy, alignment))
+    if isinstance(optimizer, FusedAdam):
+        optimizer.host_update()
+    loss, parts = step_body(model, optimizer, hp, text, mel, pos_text, pos_mel, f0, energy, alignment)
     return loss, parts, mel.shape[0]
+
+
+class GraphedTrainStep:
+    """train_step with the device work of each batch SHAPE captured once in a hipGraph and replayed:
+    the ~600 kernel launches of a step stop costing host time (the step is launch-bound in Python otherwise).
+    First occurrence of a shape runs eagerly (allocator warm-up), the second is captured, later ones replay.
+    Padding is semantically live in this model (BatchNorm statistics and the L1 losses include padded
+    positions), so batches are never padded to a common shape -- one graph per (B, L_pad, T_pad)."""
+
+    def __init__(self, model, optimizer, hp, max_graphs=32):
+        assert isinstance(optimizer, FusedAdam)
+        self.model, self.optimizer, self.hp = model, optimizer, hp
+        self.max_graphs = max_graphs
+        self.seen, self.graphs = set(), {}
+        self.pool = None
+
+    def __call__(self, step, d):
+        _set_lr(self.optimizer, step, self.hp)
+        tensors = [d[i] for i in (0, 1, 2, 3, 8, 9, 10)]       # text, mel, pos_text, pos_mel, f0, energy, alignment
+        key = (tuple(tensors[0].shape), tuple(tensors[1].shape))
+        entry = self.graphs.get(key)
+        if entry is None and (key not in self.seen or len(self.graphs) >= self.max_graphs):
+            self.seen.add(key)
+            return train_step(self.model, self.optimizer, step, d, self.hp)
+        self.optimizer.host_update()
+        if entry is None:
+            static = [t.to(DEVICE).clone() for t in tensors]
+            g = torch.cuda.CUDAGraph()
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, pool=self.pool):
+                loss, parts = step_body(self.model, self.optimizer, self.hp, *static[:4], *static[4:])
+            entry = self.graphs[key] = (g, static, loss, parts)
+        g, static, loss, parts = entry
+        for dst, src in zip(static, tensors):
+            dst.copy_(src, non_blocking=True)
+        g.replay()
+        return loss, parts, static[1].shape[0]
 
 
 def train_loop(model, optimizer, step, epoch, args, hp, rank, dataloader):
