@@ -64,7 +64,8 @@ class GemmTimer:
             taps = g.taps if g.conv == 1 else 1
             flops = 2.0 * g.M * g.N * g.K * taps * max(1, g.batch1) * max(1, g.batch2)
             key = ("bf16" if g.dtype == 1 else "f32", "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm")
-            self.records.append((key, flops, s, e))
+            shape = (g.M, g.N, g.K, taps if g.conv == 1 else (g.batch2 if g.conv == 2 else 1), g.batch1 * g.batch2, g.split_k)
+            self.records.append((key, flops, s, e, shape))
         ops._gemm_call = timed
 
     def remove(self):
@@ -73,11 +74,22 @@ class GemmTimer:
 
     def summary(self):
         agg = {}
-        for key, flops, s, e in self.records:
+        for key, flops, s, e, shape in self.records:
             ms = s.elapsed_time(e)
             a = agg.setdefault(key, [0.0, 0.0, 0])
             a[0] += flops; a[1] += ms; a[2] += 1
         return agg
+
+    def by_shape(self):
+        agg = {}
+        for key, flops, s, e, shape in self.records:
+            a = agg.setdefault(key + shape, [0.0, 0.0, 0])
+            a[0] += flops; a[1] += s.elapsed_time(e); a[2] += 1
+        lines = ["variant M N K taps batch split | launches total_ms avg_us TFLOP/s"]
+        for k, (fl, ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            lines.append(f"{'/'.join(k[:3])} {k[3]} {k[4]} {k[5]} {k[6]} {k[7]} {k[8]} | {n} {ms:.2f} {ms * 1e3 / n:.1f} "
+                         f"{fl / (ms * 1e-3) / 1e12:.1f}")
+        return "\n".join(lines)
 
 
 def cpu_baseline(hp, batch):
@@ -85,20 +97,29 @@ def cpu_baseline(hp, batch):
     from oracle import train as otrain
     from oracle.model import FastSpeech2 as OracleFS2
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))          # the box's CPU share for one GPU
     torch.set_num_threads(cores)
     m = OracleFS2.from_hp(hp, dropout=hp.dropout, dropout_postnet=0.5, dropout_variance_adaptor=hp.dropout_variance_adaptor)
     m.train()
     opt = otrain.make_optimizer(m)
-    small = tuple(b[:2] if torch.is_tensor(b) else b for b in batch)
-    otrain.train_step(m, opt, 1, small, hp.d_model_decoder)           # untimed warm-up on 2 utterances
+    cut = lambda n: tuple(b[:n] if torch.is_tensor(b) else b for b in batch)
+    print("[cpu_baseline] warm-up step on 2 utterances ...", file=sys.stderr, flush=True)
+    otrain.train_step(m, opt, 1, cut(2), hp.d_model_decoder)
+    n_utt = 12                                # bounded sample: a quarter of the config-2 batch, same padded lengths
+    sample = cut(n_utt)
+    print(f"[cpu_baseline] timing 1 step on {n_utt} utterances with {cores} threads ...", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    otrain.train_step(m, opt, 2, batch, hp.d_model_decoder)
+    otrain.train_step(m, opt, 2, sample, hp.d_model_decoder)
     dt = time.perf_counter() - t0
-    frames = int(batch[5].sum())
-    return dict(value=frames / dt, unit="mel-frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"1 train step (fwd+bwd+clip+Adam, fp32) of the config-2 batch: {batch[0].shape[0]} utterances, "
-                       f"{frames} valid mel frames, {dt:.1f} s")
+    frames = int(sample[5].sum())
+    print(f"[cpu_baseline] {dt:.1f} s", file=sys.stderr, flush=True)
+    return dict(value=round(frames / dt, 1), unit="mel-frames/s", cores=cores, kind="port",
+                sample=f"1 train step (fwd+bwd+clip+Adam, fp32 eager PyTorch oracle, reference dropout rates) on the first "
+                       f"{n_utt} utterances of the config-2 batch (T_pad {sample[1].shape[1]}, {frames} valid mel frames): {dt:.1f} s")
 
 
 def main():
@@ -108,12 +129,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 parity mode instead of bf16 (not the headline)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--gemm-report", type=str, default=None, help="write per-shape GEMM timings to this file")
     args = ap.parse_args()
 
     import torch.distributed as dist
     from transformer_tts_amd import ops, synthetic
     from transformer_tts_amd.optim import FusedAdam
-    from transformer_tts_amd.train_fastspeech2 import build_model, train_step
+    from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep, build_model, train_step
     from transformer_tts_amd.utils.utils import init_weight
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,26 +167,42 @@ def main():
             for i in range(POOL)]
     frames = [int(b[5].sum()) for b in pool]
 
+    # hipGraph replay of the whole step (one graph per batch shape); the GEMM event timer needs eager launches,
+    # so the roofline leg below re-runs a few eager, instrumented steps after the timed region
+    use_graph = not args.no_graph and (world == 1 or os.environ.get('FS2_GRAPH_DP', '0') == '1')
+    graphed = GraphedTrainStep(model, opt, hp) if use_graph else None
+    run = (lambda st, b: graphed(st, b)) if use_graph else (lambda st, b: train_step(model, opt, st, b, hp))
     step = 1
-    for i in range(args.warmup):
-        train_step(model, opt, step, pool[i % POOL], hp)
+    warm = max(args.warmup, 2 * POOL) if use_graph else args.warmup      # each shape: 1 eager + 1 capture before replay
+    for i in range(warm):
+        run(step, pool[i % POOL])
         step += 1
     timer = GemmTimer()
-    timer.install()
+    if not use_graph:
+        timer.install()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     done = 0
     for i in range(args.steps):
-        train_step(model, opt, step, pool[(args.warmup + i) % POOL], hp)
-        done += frames[(args.warmup + i) % POOL]
+        run(step, pool[(warm + i) % POOL])
+        done += frames[(warm + i) % POOL]
         step += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if use_graph:       # roofline leg: the same kernels, launched eagerly with a HIP event pair around every GEMM
+        timer.install()
+        for i in range(min(args.steps, POOL)):
+            train_step(model, opt, step, pool[i % POOL], hp)
+            step += 1
+        torch.cuda.synchronize()
     timer.remove()
+    if args.gemm_report and rank == 0:
+        with open(args.gemm_report, "w") as f:
+            f.write(timer.by_shape() + "\n")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         n = torch.tensor([float(done)], device=dev, dtype=torch.float64)
@@ -184,7 +223,7 @@ def main():
             roof = dict(bound="mfma", kernel=f"gemm_kernel<{key[0]}> A {key[1]} B {key[2]}", achieved=round(achieved, 2),
                         peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
                         traffic=traffic, launches=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
-                        gemm_share_of_step=round(sum(v[1] for v in agg.values()) / (dt * 1e3), 3),
+                        gemm_ms_per_step=round(sum(v[1] for v in agg.values()) / max(1, (min(args.steps, POOL) if use_graph else args.steps)), 3),
                         all_variants={"/".join(k): dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), ms=round(v[1], 2),
                                                          launches=v[2]) for k, v in agg.items()})
         cpu = None
@@ -192,12 +231,13 @@ def main():
             cpu = cpu_baseline(hp, synthetic.benchmark_batch(2024, 48))
         line = {
             "metric": "mel-frames/sec (train step) FastSpeech2 d_model=256", "value": round(done / dt, 1),
-            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: FastSpeech2 d_model=256, 4+4 FFT layers (H=2, k_enc=9, k_dec=1), "
                                    "80-mel, batch 48/GPU (L_pad<=128, T_pad~925), fwd+bwd+clip+Adam, dropout 0.1/0.5/0.5",
-                       "global_batch": 48 * world, "parallelism": f"dp{world}", "padded_frames_per_step": 48 * 925},
+                       "global_batch": 48 * world, "parallelism": f"dp{world}", "padded_frames_per_step": 48 * 925,
+                       "launch": "hipGraph replay per batch shape" if use_graph else "eager"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -76,7 +76,7 @@ typedef struct FS2Gemm {
     int32_t batch1, batch2;
     int32_t conv, taps, pad, seq_len;
     float alpha;
-    int32_t reserved;
+    int32_t colstats_mode; /* 0: sum and sum of squares; 1: column sums only (bias gradient) into colstats[0..N) */
 } FS2Gemm;
 
 int fs2_gemm(const FS2Gemm* g, void* stream);
@@ -88,6 +88,16 @@ int fs2_gemm(const FS2Gemm* g, void* stream);
 int fs2_cast_permute(const float* src, void* dst, int O, int I, int k, int64_t dld, int mode, int dtype, void* stream);
 int fs2_permute_add(const float* scratch, float* grad, int O, int I, int k, void* stream);
 int fs2_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* All weight shadows of a model in ONE launch: `table` is a DEVICE array of n descriptors. */
+typedef struct FS2CastDesc {
+    const float* src;
+    void* dst;
+    int64_t dld;
+    int32_t O, I, k, mode; /* as fs2_cast_permute; mode 2 = plain fp32 copy of O*I*k elements (fused bias vectors) */
+} FS2CastDesc;
+int fs2_cast_permute_batched(const FS2CastDesc* table, int n, int dtype, void* stream);
+/* out[m][idx[m]] = 1, every other entry of the row 0  (one-hot operand of the embedding-gradient GEMM) */
+int fs2_onehot(const int32_t* idx, void* out, int dtype, int64_t M, int nb, void* stream);
 /* out[n] += sum_m x[m][n]   (bias gradients); x is [M][N] with row stride ldx */
 int fs2_colsum(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, void* stream);
 
@@ -100,8 +110,11 @@ int fs2_embedding_bwd(const int64_t* ids, const void* dout, int dout_dtype, floa
 int fs2_pe_add_fwd(const void* a, int a_dtype, const float* pe, const float* alpha, float* out, int B, int t, int d,
                    float p, const uint64_t* rng, uint32_t site, void* stream);
 int fs2_pe_add_bwd(const float* dout, const float* pe, void* da, int da_dtype, float* dalpha, int B, int t, int d,
-                   float p, const uint64_t* rng, uint32_t site, void* stream);
+                   float p, const uint64_t* rng, uint32_t site, float* dcolsum, void* stream);
 
+/* dcolsum (may be NULL) on the backward entry points below: dcolsum[c] += sum over rows of the gradient tensor the
+ * call writes (dx / da / g) -- the bias gradient of the layer that produced the forward input, fused here so the
+ * tensor is not read a second time.                                                                             */
 /* nn.LayerNorm over the last dim (eps 1e-5), optionally followed by dropout (Models/varianceadaptor.py:219,222)
  * and, in backward, by the ReLU mask of its input (x > 0).  dx_accumulate: dx += instead of dx =.        */
 int fs2_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
@@ -109,7 +122,8 @@ int fs2_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const floa
                       uint32_t site, void* stream);
 int fs2_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const float* mean,
                       const float* rstd, void* dx, int dx_dtype, float* dgamma, float* dbeta, int64_t M, int d,
-                      float p, const uint64_t* rng, uint32_t site, int relu_mask, int dx_accumulate, void* stream);
+                      float p, const uint64_t* rng, uint32_t site, int relu_mask, int dx_accumulate, float* dcolsum,
+                      void* stream);
 
 /* Residual + dropout + LayerNorm (Models/layers.py:31-35,40 with the next norm fused):
  *   s = r + dropout_p(a);  y = LN(s)      r,s fp32 [M][d];  a,y dtype `dtype`.
@@ -119,7 +133,7 @@ int fs2_add_ln_fwd(const float* r, const void* a, int dtype, float* s, const flo
                    void* stream);
 int fs2_add_ln_bwd(const float* ds_down, const void* dy, int dtype, const float* s, const float* gamma,
                    const float* mean, const float* rstd, float* dr, void* da, float* dgamma, float* dbeta, int64_t M,
-                   int d, float p, const uint64_t* rng, uint32_t site, void* stream);
+                   int d, float p, const uint64_t* rng, uint32_t site, float* dcolsum, void* stream);
 
 /* FeedForward tail (Models/modules.py:85-87): y = LN(dropout_p(f2 + h)) ;  backward returns g = d(f2) = d(h). */
 int fs2_ffn_ln_fwd(const void* f2, const void* h, int dtype, const float* gamma, const float* beta, void* y,
@@ -127,7 +141,7 @@ int fs2_ffn_ln_fwd(const void* f2, const void* h, int dtype, const float* gamma,
                    void* stream);
 int fs2_ffn_ln_bwd(const void* dy, const void* f2, const void* h, int dtype, const float* gamma, const float* mean,
                    const float* rstd, void* g, float* dgamma, float* dbeta, int64_t M, int d, float p,
-                   const uint64_t* rng, uint32_t site, void* stream);
+                   const uint64_t* rng, uint32_t site, float* dcolsum, void* stream);
 
 /* attention() softmax (Models/modules.py:9-19): in place on S [rows = B*H*t][ld = tp >= t]:
  *   P = softmax(mask_keys(S, -1e4));  P_drop = dropout_p(P) (always on).  S already holds QK^T/sqrt(d_k).
@@ -181,7 +195,7 @@ int fs2_bn_tanh_bwd_reduce(const void* dy, const void* x, int dtype, const float
 int fs2_bn_tanh_bwd_apply(const void* dy, const void* x, int dtype, const float* mean, const float* rstd,
                           const float* gamma, const float* beta, const float* red, float count,
                           const float* count_dev, void* dx, float* dgamma, float* dbeta, int64_t M, int C, float p,
-                          const uint64_t* rng, uint32_t site, void* stream);
+                          const uint64_t* rng, uint32_t site, float* dcolsum, void* stream);
 
 /* nn.L1Loss (train_fastspeech2.py:212-259): loss[0] += sum|pred - tgt| / n.  target_mode 1: tgt = log(int64 tgt + 1).
  * backward: dpred = sign(pred - tgt) * (*gscale) / n  (gscale: device scalar, upstream gradient).          */

@@ -74,7 +74,7 @@ def _out(v, dtype):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM family
-def _epi(v, bias, relu, residual, relu_mask, colstats, out, out_dtype, alpha=1.0):
+def _epi(v, bias, relu, residual, relu_mask, colstats, out, out_dtype, alpha=1.0, colsum=None):
     v = v * alpha
     if bias is not None:
         v = v + _f(bias)
@@ -91,6 +91,8 @@ def _epi(v, bias, relu, residual, relu_mask, colstats, out, out_dtype, alpha=1.0
         rr = _f(r).reshape(-1, n)
         colstats[:n] += rr.sum(0).float()
         colstats[n:2 * n] += (rr * rr).sum(0).float()
+    if colsum is not None:
+        colsum += _f(r).reshape(-1, r.shape[-1]).sum(0).float()
     if out is not None:
         out.copy_(r)
         return out
@@ -98,9 +100,9 @@ def _epi(v, bias, relu, residual, relu_mask, colstats, out, out_dtype, alpha=1.0
 
 
 def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, out_dtype=None,
-           alpha=1.0):
+           alpha=1.0, colsum=None):
     """nn.Linear: Models/modules.py:32-41,49-51,68; Models/encoder.py:57; Models/postnets.py:43,67."""
-    return _epi(_f(x) @ _f(w).t(), bias, relu, residual, relu_mask, colstats, out, out_dtype or x.dtype, alpha)
+    return _epi(_f(x) @ _f(w).t(), bias, relu, residual, relu_mask, colstats, out, out_dtype or x.dtype, alpha, colsum)
 
 
 def _unfold(x, taps, pad):
@@ -118,11 +120,11 @@ def _unfold(x, taps, pad):
 
 
 def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None,
-         out_dtype=None):
+         out_dtype=None, colsum=None):
     """nn.Conv1d over time (Models/modules.py:76-84; varianceadaptor.py:203-209; postnets.py:28-39,71-75)
     in channels-last form; w is the kernel-layout shadow [n][j*C + c] = weight[n][c][j]."""
     return _epi(_unfold(_f(x), taps, pad) @ _f(w).t(), bias, relu, residual, relu_mask, colstats, out,
-                out_dtype or x.dtype)
+                out_dtype or x.dtype, 1.0, colsum)
 
 
 def wgrad(dy, x, out):
@@ -174,6 +176,22 @@ def cast(src, dtype, out=None):
     return out
 
 
+def make_cast_table(entries, device):
+    return list(entries)
+
+
+def cast_permute_batched(table, n, dtype):
+    for src, dst, mode in table:
+        if mode == 2:
+            dst.copy_(src.reshape(dst.shape))
+        else:
+            cast_permute(src, dst, mode)
+
+
+def onehot(idx, nb, dtype):
+    return torch.nn.functional.one_hot(idx.long(), nb).to(dtype)
+
+
 def colsum(x, out):
     out += _f(x).sum(0).float()
     return out
@@ -198,10 +216,12 @@ def pe_add_fwd(a, pe, alpha, p, rng, site):
     return v.float()
 
 
-def pe_add_bwd(dout, pe, da_dtype, dalpha, p, rng, site, need_da=True):
+def pe_add_bwd(dout, pe, da_dtype, dalpha, p, rng, site, need_da=True, dcolsum=None):
     B, t, d = dout.shape
     g = _f(dout) * drop_scale((B, t, d), p, rng, site)
     dalpha += (g * _f(pe[:t])).sum().float()
+    if dcolsum is not None:
+        dcolsum += g.reshape(-1, d).sum(0).float()
     return g.to(da_dtype) if need_da else None
 
 
@@ -230,13 +250,16 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5, p=0.0, rng=None, site=0):
     return y.to(out_dtype), mu.reshape(-1).float(), rstd.reshape(-1).float()
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, relu_mask=False, dx=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, relu_mask=False, dx=None,
+                  dcolsum=None):
     g = _f(dy) * drop_scale(tuple(x.shape), p, rng, site)
     v, dg, db = _ln_bwd(g, _f(x), gamma, mean.reshape(x.shape[:-1]), rstd.reshape(x.shape[:-1]))
     dgamma += dg.float()
     dbeta += db.float()
     if relu_mask:
         v = torch.where(_f(x) > 0, v, torch.zeros_like(v))
+    if dcolsum is not None:
+        dcolsum += v.reshape(-1, v.shape[-1]).sum(0).float()
     if dx is not None:
         dx.copy_((_f(dx) + v).to(dx.dtype))
         return dx
@@ -250,15 +273,17 @@ def add_ln_fwd(r, a, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
     return s, y.to(a.dtype), mu.reshape(-1).float(), rstd.reshape(-1).float()
 
 
-def add_ln_bwd(ds_down, dy, s, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0):
+def add_ln_bwd(ds_down, dy, s, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, dcolsum=None):
     v, dg, db = _ln_bwd(_f(dy), _f(s), gamma, mean.reshape(s.shape[:-1]), rstd.reshape(s.shape[:-1]))
     dgamma += dg.float()
     dbeta += db.float()
     if ds_down is not None:
         v = v + _f(ds_down)
     dr = v.float()
-    da = (_f(dr) * drop_scale(tuple(s.shape), p, rng, site)).to(dy.dtype)
-    return dr, da
+    da64 = _f(dr) * drop_scale(tuple(s.shape), p, rng, site)
+    if dcolsum is not None:
+        dcolsum += da64.reshape(-1, s.shape[-1]).sum(0).float()
+    return dr, da64.to(dy.dtype)
 
 
 def ffn_ln_fwd(f2, h, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
@@ -268,12 +293,14 @@ def ffn_ln_fwd(f2, h, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
     return y.to(h.dtype), mu.reshape(-1).float(), rstd.reshape(-1).float()
 
 
-def ffn_ln_bwd(dy, f2, h, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0):
+def ffn_ln_bwd(dy, f2, h, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, dcolsum=None):
     ds = drop_scale(tuple(h.shape), p, rng, site)
     u = (_f(f2) + _f(h)) * ds
     v, dg, db = _ln_bwd(_f(dy), u, gamma, mean.reshape(h.shape[:-1]), rstd.reshape(h.shape[:-1]))
     dgamma += dg.float()
     dbeta += db.float()
+    if dcolsum is not None:
+        dcolsum += (v * ds).reshape(-1, h.shape[-1]).sum(0).float()
     return (v * ds).to(h.dtype)
 
 
@@ -413,7 +440,7 @@ def bn_tanh_bwd_reduce(dy, x, mean, rstd, gamma, beta, red, p=0.0, rng=None, sit
 
 
 def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta, p=0.0, rng=None, site=0,
-                      count_dev=None):
+                      count_dev=None, dcolsum=None):
     C = x.shape[-1]
     if count_dev is not None:
         count = float(count_dev[0])
@@ -423,7 +450,10 @@ def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta,
     if dgamma is not None:
         dbeta += red[:C]
         dgamma += red[C:2 * C]
-    return (_f(gamma) * _f(rstd) * (dz - r0 - xh * r1)).to(x.dtype)
+    dx = _f(gamma) * _f(rstd) * (dz - r0 - xh * r1)
+    if dcolsum is not None:
+        dcolsum += dx.reshape(-1, C).sum(0).float()
+    return dx.to(x.dtype)
 
 
 # ------------------------------------------------------------------------------------------------ losses / optimizer

@@ -404,3 +404,57 @@ def test_adam_matches_torch_optimizer(ops):
         hyper = torch.tensor([lr, 1 - 0.9 ** step, 1 - 0.98 ** step, 1.0]).cuda()
         ops.adam_step(p, g.cuda(), m, v, hyper, gsq, 0.9, 0.98, 1e-9, 1.0)
         close(p, ref.data, f"Adam step {step}", rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_fused_bias_gradients_onehot_and_batched_shadows(ops, dtype):
+    """dcolsum outputs of the backward row kernels, the sums-only GEMM epilogue, the one-hot embedding-gradient
+    operand and the one-launch weight-shadow refresh"""
+    M, d = 203, 64
+    x32, a, h = rnd(M, d, seed=1), rnd(M, d, dtype=dtype, seed=3), rnd(M, d, dtype=dtype, seed=4)
+    gm, bt = 1 + 0.1 * rnd(d, seed=5), 0.1 * rnd(d, seed=6)
+    dy, dsd = rnd(M, d, dtype=dtype, seed=7), rnd(M, d, seed=8)
+    w = rnd(48, d, dtype=dtype, seed=9, scale=0.2)
+    idx = torch.from_numpy(np.random.default_rng(0).integers(0, 256, size=M).astype(np.int32))
+    idx[:60] = 0
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        rng = o.Rng(99, dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        r = []
+        p = 0.25
+        y, mu, rs = o.layernorm_fwd(mv(a), mv(gm), mv(bt), dtype, 1e-5, p, rng, 5)
+        cs = z(d)
+        dx = o.layernorm_bwd(mv(dy), mv(a), mv(gm), mu, rs, z(d), z(d), p, rng, 5, relu_mask=True, dcolsum=cs)
+        r += [cs, dx]
+        s, y, mu, rs = o.add_ln_fwd(mv(x32), mv(a), mv(gm), mv(bt), 1e-5, p, rng, 7)
+        cs = z(d)
+        dr, da = o.add_ln_bwd(mv(dsd), mv(dy), s, mv(gm), mu, rs, z(d), z(d), p, rng, 7, dcolsum=cs)
+        r += [cs, da]
+        y, mu, rs = o.ffn_ln_fwd(mv(a), mv(h), mv(gm), mv(bt), 1e-5, p, rng, 8)
+        cs = z(d)
+        g = o.ffn_ln_bwd(mv(dy), mv(a), mv(h), mv(gm), mu, rs, z(d), z(d), p, rng, 8, dcolsum=cs)
+        r += [cs, g]
+        cs, dal = z(d), z(1)
+        da0 = o.pe_add_bwd(mv(dsd).view(7, 29, d), mv(rnd(64, d, seed=11)), dtype, dal, p, rng, 9, dcolsum=cs)
+        r += [cs, da0]
+        cs = z(48)
+        yy = o.linear(mv(a), mv(w), relu_mask=mv(rnd(M, 48, dtype=dtype, seed=12)), colsum=cs)
+        r += [cs, yy]
+        oh = o.onehot(mv(idx), 256, dtype)
+        dE = z(256, d)
+        o.wgrad(oh, mv(dy), dE)
+        r += [oh, dE]
+        # batched shadows
+        w3, w2, b1 = mv(rnd(24, 16, 5, seed=13)), mv(rnd(32, 16, seed=14)), mv(rnd(32, seed=15))
+        f3, d3 = torch.zeros(24, 80, dtype=dtype, device=dev), torch.zeros(16, 120, dtype=dtype, device=dev)
+        fused, bias = torch.zeros(64, 16, dtype=dtype, device=dev), torch.zeros(64, device=dev)
+        table = o.make_cast_table([(w3, f3, 0), (w3, d3, 1), (w2, fused[32:64], 0), (b1, bias[32:64], 2)], dev)
+        o.cast_permute_batched(table, 4, dtype)
+        r += [f3, d3, fused, bias]
+        out[dev] = r
+    for i, (a_, b_) in enumerate(zip(out["cuda"], out["cpu"])):
+        k = 30 if a_.dim() == 1 else 2
+        close(a_, b_, f"fused output #{i}", **tol(dtype, k=k))
+    assert torch.equal(out["cuda"][10].cpu(), out["cpu"][10]), "one-hot is exact"

@@ -16,10 +16,12 @@ for step in "$@"; do
     kernels) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider ;;
     model)   run model 900 python -m pytest tests/test_model_gpu.py -q -m gpu --timeout 400 -p no:cacheprovider ;;
     smoke)   run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
-    bench)   run bench 600 python bench.py --steps 8 --warmup 8 ;;
-    benchq)  run benchq 300 python bench.py --steps 8 --warmup 8 --no-cpu-baseline ;;
+    bench)   run bench 600 python bench.py ;;
+    benchq)  run benchq 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report.txt ;;
+    benche)  run benche 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-graph ;;
     prof)    cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
              run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline ;;
+    ncclgraph) run ncclgraph 200 python tools/exp_nccl_graph.py ;;
     *) echo "unknown step $step" ;;
   esac
 done

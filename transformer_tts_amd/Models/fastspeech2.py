@@ -52,6 +52,7 @@ class FastSpeech2(nn.Module):
         assert (self.training and not pitch_perturbation) or (not self.training)
         if fix_mask is not None or d_target is None:
             raise NotImplementedError("fix_mask / inference branch are later rows of SURVEY section 8(f)")
+        self.rt.refresh(self)           # all weight shadows in one launch (no-op if the weights did not change)
         e_outputs, attn_enc = self.encoder(src, src_mask)
         variance_adaptor_output, log_d_prediction, p_prediction, e_prediction, _, _, text_dur_predicted = \
             self.variance_adaptor(e_outputs, src_mask, mel_mask, d_target, p_target, e_target,

@@ -99,6 +99,56 @@ class Runtime:
             return old
         return self._cached((id(attn), "qkv"), ws + bs, build)
 
+    # ---- all shadows of a model in one launch (fs2_cast_permute_batched)
+    def _build_table(self, model):
+        import torch.nn as nn
+        entries, records = [], []       # records: (cache key, params tuple, cached value)
+        qkv_owned = set()
+        for mod in model.modules():
+            if hasattr(mod, "q_linear") and hasattr(mod, "k_linear") and hasattr(mod, "v_linear"):
+                ws = (mod.q_linear.weight, mod.k_linear.weight, mod.v_linear.weight)
+                bs = (mod.q_linear.bias, mod.k_linear.bias, mod.v_linear.bias)
+                d, dev = ws[0].shape[0], ws[0].device
+                wf = torch.empty((3 * d, d), dtype=self.dtype, device=dev)
+                wd = torch.empty((d, 3 * d), dtype=self.dtype, device=dev)
+                bias = torch.empty((3 * d,), dtype=torch.float32, device=dev)
+                for j, (w, b) in enumerate(zip(ws, bs)):
+                    entries += [(w.detach(), wf[j * d:(j + 1) * d], 0), (w.detach(), wd[:, j * d:(j + 1) * d], 1),
+                                (b.detach(), bias[j * d:(j + 1) * d], 2)]
+                    qkv_owned.add(id(w))
+                records.append(((id(mod), "qkv"), ws + bs, (wf, wd, bias)))
+        for mod in model.modules():
+            if isinstance(mod, (nn.Linear, nn.Conv1d)) and id(mod.weight) not in qkv_owned and mod.weight.shape[0] > 1:
+                w = mod.weight
+                O, I = w.shape[0], w.shape[1]
+                k = w.shape[2] if w.dim() == 3 else 1
+                if not (k == 1 and self.dtype == torch.float32):
+                    f = torch.empty((O, k * I), dtype=self.dtype, device=w.device)
+                    entries.append((w.detach(), f, 0))
+                    records.append(((id(w), "f"), (w,), f))
+                dg = torch.empty((I, k * O), dtype=self.dtype, device=w.device)
+                entries.append((w.detach(), dg, 1))
+                records.append(((id(w), "d"), (w,), dg))
+        self._table = ops.make_cast_table(entries, next(model.parameters()).device)
+        self._table_n = len(entries)
+        self._records = records
+        self._table_sig = tuple(p.data_ptr() for _, ps, _ in records for p in ps)   # rebuilt if parameters are re-homed
+        self._table_entries = entries      # keeps the views alive
+
+    def refresh(self, model):
+        """bring every weight shadow up to date with ONE kernel launch (no-op when nothing changed)"""
+        if getattr(self, "_table", None) is None or \
+                self._table_sig != tuple(p.data_ptr() for _, ps, _ in self._records for p in ps):
+            self._build_table(model)
+            self._table_ver = None
+        ver = (self.epoch,) + tuple(p._version for _, ps, _ in self._records for p in ps)
+        if ver == self._table_ver:
+            return
+        ops.cast_permute_batched(self._table, self._table_n, self.dtype)
+        for key, ps, val in self._records:
+            self.shadows[key] = (tuple(p._version for p in ps) + (self.epoch,), val)
+        self._table_ver = ver
+
     def zeros(self, key, shape, dtype, device):
         """persistent zero-filled scratch (re-zeroed on every request)"""
         buf = self.scratch.get(key)
@@ -122,8 +172,9 @@ def grad_of(p):
     return p.grad
 
 
-def _conv_wgrad(rt, dy, x, conv, pad):
-    """accumulate weight and bias gradients of an nn.Conv1d (weight (O,I,k)) from dy (B,t,O), x (B,t,I)"""
+def _conv_wgrad(rt, dy, x, conv, pad, bias_done=False):
+    """accumulate weight (and, unless the producer of dy already did, bias) gradients of an nn.Conv1d
+    (weight (O,I,k)) from dy (B,t,O), x (B,t,I)"""
     w = conv.weight
     O, I, k = w.shape
     gw = grad_of(w)
@@ -133,12 +184,14 @@ def _conv_wgrad(rt, dy, x, conv, pad):
         scratch = rt.zeros(("wg", O, I, k), (O, k * I), torch.float32, w.device)
         ops.conv_wgrad(dy, x, k, pad, scratch)
         ops.permute_add(scratch, gw)
-    ops.colsum(dy.view(-1, O), grad_of(conv.bias))
+    if not bias_done:
+        ops.colsum(dy.view(-1, O), grad_of(conv.bias))
 
 
-def _linear_wgrad(dy2, x2, lin):
+def _linear_wgrad(dy2, x2, lin, bias_done=False):
     ops.wgrad(dy2, x2, grad_of(lin.weight))
-    ops.colsum(dy2, grad_of(lin.bias))
+    if not bias_done:
+        ops.colsum(dy2, grad_of(lin.bias))
 
 
 def _tp(t):
@@ -241,19 +294,19 @@ class EncoderStackFunction(torch.autograd.Function):
             ff = layer.ff
             lnf = ff.layer_norm
             g = ops.ffn_ln_bwd(dyff, L["f2"], L["h2"], lnf.weight.detach(), L["mf"], L["rf"], grad_of(lnf.weight),
-                               grad_of(lnf.bias), p, rng, layer.site_ffn)
+                               grad_of(lnf.bias), p, rng, layer.site_ffn, dcolsum=grad_of(ff.f_2.bias))
             kk = ff.f_1.weight.shape[2]
             pad = kk // 2
-            _conv_wgrad(rt, g, L["f1"], ff.f_2, pad)
-            dz1 = ops.conv(g, rt.w_dgrad(ff.f_2.weight), kk, kk - 1 - pad, relu_mask=L["f1"])
-            _conv_wgrad(rt, dz1, L["h2"], ff.f_1, pad)
+            _conv_wgrad(rt, g, L["f1"], ff.f_2, pad, bias_done=True)
+            dz1 = ops.conv(g, rt.w_dgrad(ff.f_2.weight), kk, kk - 1 - pad, relu_mask=L["f1"], colsum=grad_of(ff.f_1.bias))
+            _conv_wgrad(rt, dz1, L["h2"], ff.f_1, pad, bias_done=True)
             dh2 = ops.conv(dz1, rt.w_dgrad(ff.f_1.weight), kk, kk - 1 - pad, residual=g)
             n2 = layer.norm_2
-            dx, da = ops.add_ln_bwd(dx1, dh2, L["x1"], n2.weight.detach(), L["m2"], L["r2"], grad_of(n2.weight),
-                                    grad_of(n2.bias), p, rng, layer.site_res1)
             at = layer.attn
+            dx, da = ops.add_ln_bwd(dx1, dh2, L["x1"], n2.weight.detach(), L["m2"], L["r2"], grad_of(n2.weight),
+                                    grad_of(n2.bias), p, rng, layer.site_res1, dcolsum=grad_of(at.out.bias))
             da2 = da.view(M, d)
-            _linear_wgrad(da2, L["O"].view(M, d), at.out)
+            _linear_wgrad(da2, L["O"].view(M, d), at.out, bias_done=True)
             dO = ops.linear(da2, rt.w_dgrad(at.out.weight))
             dO4 = dO.view(B, t, H, dk).permute(0, 2, 1, 3)
             qkv = L["qkv"]
@@ -283,8 +336,8 @@ class EncoderStackFunction(torch.autograd.Function):
             ops.embedding_bwd(src, da0, grad_of(enc.embed.weight), padding_idx=0)
             dsrc = None
         else:
-            da0 = ops.pe_add_bwd(dx0, pe, T, grad_of(enc.pe.alpha), p, rng, enc.pe.site)
-            _linear_wgrad(da0.view(M, d), src.reshape(M, -1), enc.embed)
+            da0 = ops.pe_add_bwd(dx0, pe, T, grad_of(enc.pe.alpha), p, rng, enc.pe.site, dcolsum=grad_of(enc.embed.bias))
+            _linear_wgrad(da0.view(M, d), src.reshape(M, -1), enc.embed, bias_done=True)
             dsrc = ops.linear(da0.view(M, d), rt.w_dgrad(enc.embed.weight)).view(src.shape)
         if rt.dp is not None:
             rt.dp.grads_ready(enc)
@@ -323,12 +376,12 @@ class VariancePredictorFunction(torch.autograd.Function):
         dn2 = ops.linear1_bwd(dout.contiguous(), s["n2"], lin.weight.detach().view(-1), s["km"],
                               grad_of(lin.weight).view(-1), grad_of(lin.bias))
         dz2 = ops.layernorm_bwd(dn2, s["c2"], l2.weight.detach(), s["m2"], s["r2"], grad_of(l2.weight),
-                                grad_of(l2.bias), p, rng, mod.site2, relu_mask=True)
-        _conv_wgrad(rt, dz2, s["n1"], mod.conv2, 1)
+                                grad_of(l2.bias), p, rng, mod.site2, relu_mask=True, dcolsum=grad_of(mod.conv2.bias))
+        _conv_wgrad(rt, dz2, s["n1"], mod.conv2, 1, bias_done=True)
         dn1 = ops.conv(dz2, rt.w_dgrad(mod.conv2.weight), 3, 1)
         dz1 = ops.layernorm_bwd(dn1, s["c1"], l1.weight.detach(), s["m1"], s["r1"], grad_of(l1.weight),
-                                grad_of(l1.bias), p, rng, mod.site1, relu_mask=True)
-        _conv_wgrad(rt, dz1, s["x"], mod.conv1, 1)
+                                grad_of(l1.bias), p, rng, mod.site1, relu_mask=True, dcolsum=grad_of(mod.conv1.bias))
+        _conv_wgrad(rt, dz1, s["x"], mod.conv1, 1, bias_done=True)
         dx = ops.conv(dz1, rt.w_dgrad(mod.conv1.weight), 3, 1)
         return (None, dx, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
@@ -364,7 +417,12 @@ class BucketEmbedAddFunction(torch.autograd.Function):
     def backward(ctx, dout):
         va = ctx.va
         dout = dout.contiguous()
-        ops.bucket_embed_bwd(dout, ctx.idx, grad_of(va.pitch_embedding.weight), grad_of(va.energy_embedding.weight))
+        # dE[bucket] = sum of the rows that selected it = onehot(idx)^T @ dout: an MFMA weight-gradient GEMM instead of
+        # 2 x M x d float atomics that pile up on a few rows (padded frames all select bucket 0)
+        d2 = dout.view(-1, dout.shape[-1])
+        for j, emb in enumerate((va.pitch_embedding, va.energy_embedding)):
+            oh = ops.onehot(ctx.idx[j], emb.weight.shape[0], dout.dtype)
+            ops.wgrad(oh, d2, grad_of(emb.weight))
         return (None, dout, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
@@ -440,8 +498,8 @@ class PostNetFunction(torch.autograd.Function):
                 if rt.dp is not None:
                     rt.dp.allreduce_sum(red)
                 dc = ops.bn_tanh_bwd_apply(dh, s["cs"][li], mean, rstd, bn.weight.detach(), bn.bias.detach(), red, M,
-                                           None, None, p, rng, mod.sites[li], count_dev=count)
-                _conv_wgrad(rt, dc, s["inputs"][li], cv, 4)
+                                           None, None, p, rng, mod.sites[li], count_dev=count, dcolsum=grad_of(cv.bias))
+                _conv_wgrad(rt, dc, s["inputs"][li], cv, 4, bias_done=True)
                 if li > 0:
                     dh = ops.conv(dc, rt.w_dgrad(cv.weight), 5, 0)
                 else:   # gradient w.r.t. mel_pred through conv1, plus the residual path of `post`

@@ -215,6 +215,34 @@ __global__ __launch_bounds__(TPB) void cast_permute_k(const float* __restrict__ 
         }
     }
 }
+template <typename T>
+__global__ __launch_bounds__(TPB) void cast_permute_batched_k(const FS2CastDesc* __restrict__ table) {
+    const FS2CastDesc d = table[blockIdx.y];
+    const int O = d.O, I = d.I, k = d.k;
+    const int64_t n = (int64_t)O * I * k;
+    const float* __restrict__ src = d.src;
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+        if (d.mode == 0) {
+            const int i = (int)(e % I); const int j = (int)((e / I) % k); const int o = (int)(e / ((int64_t)I * k));
+            reinterpret_cast<T*>(d.dst)[(int64_t)o * d.dld + (int64_t)j * I + i] = from_f32<T>(src[((int64_t)o * I + i) * k + j]);
+        } else if (d.mode == 1) {
+            const int o = (int)(e % O); const int j = (int)((e / O) % k); const int i = (int)(e / ((int64_t)O * k));
+            reinterpret_cast<T*>(d.dst)[(int64_t)i * d.dld + (int64_t)j * O + o] = from_f32<T>(src[((int64_t)o * I + i) * k + (k - 1 - j)]);
+        } else {
+            reinterpret_cast<float*>(d.dst)[e] = src[e];
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(TPB) void onehot_k(const int32_t* __restrict__ idx, T* __restrict__ out, int64_t M, int nb) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < M; r += (int64_t)gridDim.x * 4) {
+        const int hot = idx[r];
+        for (int c = lane * 4; c < nb; c += 256)
+            store4<T>(out + r * nb + c, make_float4(c == hot ? 1.f : 0.f, c + 1 == hot ? 1.f : 0.f, c + 2 == hot ? 1.f : 0.f,
+                                                     c + 3 == hot ? 1.f : 0.f));
+    }
+}
 __global__ __launch_bounds__(TPB) void permute_add_k(const float* __restrict__ scratch, float* __restrict__ grad, int O,
         int I, int k) {
     const int64_t n = (int64_t)O * I * k;
@@ -397,6 +425,22 @@ extern "C" int fs2_cast_permute(const float* src, void* dst, int O, int I, int k
     const int64_t n = (int64_t)O * I * k;
     T_DISPATCH(dtype, T, { hipLaunchKernelGGL((cast_permute_k<T>), dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, src, (T*)dst, O, I, k, dld, mode); });
     FS2_CHECK_LAUNCH("fs2_cast_permute");
+    return FS2_OK;
+}
+extern "C" int fs2_cast_permute_batched(const FS2CastDesc* table, int n, int dtype, void* stream) {
+    CHECK_DT("fs2_cast_permute_batched", dtype);
+    FS2_REQUIRE(table != nullptr && n > 0 && n <= 65535, "fs2_cast_permute_batched: bad table");
+    dim3 grid(64, (unsigned)n);
+    T_DISPATCH(dtype, T, { hipLaunchKernelGGL((cast_permute_batched_k<T>), grid, dim3(TPB), 0, (hipStream_t)stream, table); });
+    FS2_CHECK_LAUNCH("fs2_cast_permute_batched");
+    return FS2_OK;
+}
+extern "C" int fs2_onehot(const int32_t* idx, void* out, int dtype, int64_t M, int nb, void* stream) {
+    CHECK_DT("fs2_onehot", dtype);
+    FS2_REQUIRE(nb > 0 && nb % 4 == 0, "fs2_onehot: nb must be a multiple of 4");
+    if (M <= 0) return FS2_OK;
+    T_DISPATCH(dtype, T, { hipLaunchKernelGGL((onehot_k<T>), dim3(wave_rows_grid(M)), dim3(TPB), 0, (hipStream_t)stream, idx, (T*)out, M, nb); });
+    FS2_CHECK_LAUNCH("fs2_onehot");
     return FS2_OK;
 }
 extern "C" int fs2_permute_add(const float* scratch, float* grad, int O, int I, int k, void* stream) {

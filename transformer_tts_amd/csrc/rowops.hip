@@ -108,15 +108,15 @@ template <typename TDY, typename TX, typename TDX, int NG>
 __global__ __launch_bounds__(ROW_BLOCK) void layernorm_bwd_k(const TDY* __restrict__ dy, const TX* __restrict__ x,
         const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
         TDX* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M, int d, float p,
-        const uint64_t* rng, uint32_t site, int relu_mask, int dx_accumulate) {
+        const uint64_t* rng, uint32_t site, int relu_mask, int dx_accumulate, float* __restrict__ dcolsum) {
     __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
-    float4 gm[NG], ag[NG], ab[NG];
+    float4 gm[NG], ag[NG], ab[NG], ac[NG];
     {
         const int lane = threadIdx.x & 63;
         row_load<NG, float>(gamma, d, lane, gm);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float invd = 1.f / (float)d;
     ROW_LOOP(M) {
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void layernorm_bwd_k(const TDY* __restri
                 o[g].x = (pos[g] & 1u) ? o[g].x : 0.f; o[g].y = (pos[g] & 2u) ? o[g].y : 0.f;
                 o[g].z = (pos[g] & 4u) ? o[g].z : 0.f; o[g].w = (pos[g] & 8u) ? o[g].w : 0.f;
             }
+            ac[g] = add4(ac[g], o[g]);
         }
         if (dx_accumulate) {
             float4 old[NG];
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void layernorm_bwd_k(const TDY* __restri
     }
     flush_channel_sums<NG>(ag, dgamma, d, red);
     flush_channel_sums<NG>(ab, dbeta, d, red);
+    if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
 }
 
 // ================================================================ s = r + dropout(a); y = LN(s)
@@ -206,15 +208,16 @@ template <typename T, int NG>
 __global__ __launch_bounds__(ROW_BLOCK) void add_ln_bwd_k(const float* __restrict__ ds_down, const T* __restrict__ dy,
         const float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ mean,
         const float* __restrict__ rstd, float* __restrict__ dr, T* __restrict__ da, float* __restrict__ dgamma,
-        float* __restrict__ dbeta, int64_t M, int d, float p, const uint64_t* rng, uint32_t site) {
+        float* __restrict__ dbeta, int64_t M, int d, float p, const uint64_t* rng, uint32_t site,
+        float* __restrict__ dcolsum) {
     __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
-    float4 gm[NG], ag[NG], ab[NG];
+    float4 gm[NG], ag[NG], ab[NG], ac[NG];
     {
         const int lane = threadIdx.x & 63;
         row_load<NG, float>(gamma, d, lane, gm);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float invd = 1.f / (float)d;
     ROW_LOOP(M) {
@@ -249,11 +252,15 @@ __global__ __launch_bounds__(ROW_BLOCK) void add_ln_bwd_k(const float* __restric
         row_store<NG, float>(dr + row * d, d, lane, o);
 #pragma unroll
         for (int g = 0; g < NG; ++g)
+        {
             if (dc.on && GCOL(g) < d) o[g] = mul4(o[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+            ac[g] = add4(ac[g], o[g]);
+        }
         row_store<NG, T>(da + row * d, d, lane, o);
     }
     flush_channel_sums<NG>(ag, dgamma, d, red);
     flush_channel_sums<NG>(ab, dbeta, d, red);
+    if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
 }
 
 // ================================================================ y = LN(dropout(f2 + h))
@@ -293,15 +300,15 @@ template <typename T, int NG>
 __global__ __launch_bounds__(ROW_BLOCK) void ffn_ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ f2,
         const T* __restrict__ h, const float* __restrict__ gamma, const float* __restrict__ mean,
         const float* __restrict__ rstd, T* __restrict__ gout, float* __restrict__ dgamma, float* __restrict__ dbeta,
-        int64_t M, int d, float p, const uint64_t* rng, uint32_t site) {
+        int64_t M, int d, float p, const uint64_t* rng, uint32_t site, float* __restrict__ dcolsum) {
     __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
-    float4 gm[NG], ag[NG], ab[NG];
+    float4 gm[NG], ag[NG], ab[NG], ac[NG];
     {
         const int lane = threadIdx.x & 63;
         row_load<NG, float>(gamma, d, lane, gm);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float invd = 1.f / (float)d;
     ROW_LOOP(M) {
@@ -334,11 +341,13 @@ __global__ __launch_bounds__(ROW_BLOCK) void ffn_ln_bwd_k(const T* __restrict__ 
         for (int g = 0; g < NG; ++g) {
             o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2) * ds[g].x; o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2) * ds[g].y;
             o[g].z = rs * (g_[g].z - c1 - xv[g].z * c2) * ds[g].z; o[g].w = rs * (g_[g].w - c1 - xv[g].w * c2) * ds[g].w;
+            ac[g] = add4(ac[g], o[g]);
         }
         row_store<NG, T>(gout + row * d, d, lane, o);
     }
     flush_channel_sums<NG>(ag, dgamma, d, red);
     flush_channel_sums<NG>(ab, dbeta, d, red);
+    if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
 }
 
 // ================================================================ attention softmax (in place) + dropout
@@ -452,9 +461,13 @@ __global__ __launch_bounds__(ROW_BLOCK) void pe_add_fwd_k(const T* __restrict__ 
 template <typename T, int NG>
 __global__ __launch_bounds__(ROW_BLOCK) void pe_add_bwd_k(const float* __restrict__ dout, const float* __restrict__ pe,
         T* __restrict__ da, float* __restrict__ dalpha, int64_t M, int t, int d, float p, const uint64_t* rng,
-        uint32_t site) {
+        uint32_t site, float* __restrict__ dcolsum) {
+    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
     float acc = 0.f;
+    float4 ac[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     ROW_LOOP(M) {
         const int pos = (int)(row % t);
         float4 v[NG], pv[NG];
@@ -464,11 +477,13 @@ __global__ __launch_bounds__(ROW_BLOCK) void pe_add_bwd_k(const float* __restric
         for (int g = 0; g < NG; ++g) {
             if (dc.on && GCOL(g) < d) v[g] = mul4(v[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
             acc += sum4(mul4(v[g], pv[g]));
+            ac[g] = add4(ac[g], v[g]);
         }
         if (da != nullptr) row_store<NG, T>(da + row * d, d, lane, v);
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) atomicAdd(dalpha, acc);
+    if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
 }
 
 // ================================================================ Linear(d -> 1) + masked_fill(0)
@@ -593,7 +608,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_bwd_k(const T* __restrict__
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
         const float* __restrict__ beta, float* __restrict__ red_io, float count, const float* __restrict__ count_dev, T* __restrict__ dx,
         float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M, int C, float p, const uint64_t* rng,
-        uint32_t site) {
+        uint32_t site, float* __restrict__ dcolsum) {
     __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
     float4 mu[NG], rs[NG], gm[NG], bt[NG], a1[NG], a2[NG], r0[NG], r1[NG];
@@ -632,6 +647,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_bwd_k(const T* __restrict__
                 g_[g].y = gm[g].y * rs[g].y * (dz.y - r0[g].y - xh.y * r1[g].y);
                 g_[g].z = gm[g].z * rs[g].z * (dz.z - r0[g].z - xh.z * r1[g].z);
                 g_[g].w = gm[g].w * rs[g].w * (dz.w - r0[g].w - xh.w * r1[g].w);
+                if (GCOL(g) < C) a1[g] = add4(a1[g], g_[g]);      // column sums of dx (bias gradient of the producing conv)
             }
         }
         if (MODE == 1) row_store<NG, T>(dx + row * C, C, lane, g_);
@@ -639,11 +655,14 @@ __global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_bwd_k(const T* __restrict__
     if (MODE == 0) {
         flush_channel_sums<NG>(a1, red_io, C, red);
         flush_channel_sums<NG>(a2, red_io + C, C, red);
-    } else if (blockIdx.x == 0 && dgamma != nullptr) {
-        // dbeta += sum dz, dgamma += sum dz*xhat (already reduced over rows -- and over ranks -- in red_io)
-        for (int c = threadIdx.x; c < C; c += ROW_BLOCK) {
-            atomicAdd(dbeta + c, red_io[c]);
-            atomicAdd(dgamma + c, red_io[C + c]);
+    } else {
+        if (dcolsum != nullptr) flush_channel_sums<NG>(a1, dcolsum, C, red);
+        if (blockIdx.x == 0 && dgamma != nullptr) {
+            // dbeta += sum dz, dgamma += sum dz*xhat (already reduced over rows -- and over ranks -- in red_io)
+            for (int c = threadIdx.x; c < C; c += ROW_BLOCK) {
+                atomicAdd(dbeta + c, red_io[c]);
+                atomicAdd(dgamma + c, red_io[C + c]);
+            }
         }
     }
 }
@@ -687,7 +706,7 @@ extern "C" int fs2_layernorm_fwd(const void* x, int x_dtype, const float* gamma,
 extern "C" int fs2_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma,
                                  const float* mean, const float* rstd, void* dx, int dx_dtype, float* dgamma,
                                  float* dbeta, int64_t M, int d, float p, const uint64_t* rng, uint32_t site,
-                                 int relu_mask, int dx_accumulate, void* stream) {
+                                 int relu_mask, int dx_accumulate, float* dcolsum, void* stream) {
     CHECK_ROW("fs2_layernorm_bwd", d, 1024);
     FS2_REQUIRE(x_dtype == dx_dtype, "fs2_layernorm_bwd: dx dtype must equal x dtype");
     FS2_REQUIRE(!(dy_dtype == FS2_F32 && x_dtype == FS2_BF16), "fs2_layernorm_bwd: f32 dy with bf16 x is not provided");
@@ -698,11 +717,11 @@ extern "C" int fs2_layernorm_bwd(const void* dy, int dy_dtype, const void* x, in
     NG_DISPATCH(d, NG, {
         if constexpr (NG <= 4) {
             if (dy_dtype == FS2_F32)
-                hipLaunchKernelGGL((layernorm_bwd_k<float, float, float, NG>), grid, block, 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, d, p, rng, site, relu_mask, dx_accumulate);
+                hipLaunchKernelGGL((layernorm_bwd_k<float, float, float, NG>), grid, block, 0, st, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, d, p, rng, site, relu_mask, dx_accumulate, dcolsum);
             else if (x_dtype == FS2_F32)
-                hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, float, float, NG>), grid, block, 0, st, (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, d, p, rng, site, relu_mask, dx_accumulate);
+                hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, float, float, NG>), grid, block, 0, st, (const bf16_t*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, M, d, p, rng, site, relu_mask, dx_accumulate, dcolsum);
             else
-                hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, bf16_t, bf16_t, NG>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, d, p, rng, site, relu_mask, dx_accumulate);
+                hipLaunchKernelGGL((layernorm_bwd_k<bf16_t, bf16_t, bf16_t, NG>), grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, M, d, p, rng, site, relu_mask, dx_accumulate, dcolsum);
         }
     });
     FS2_CHECK_LAUNCH("fs2_layernorm_bwd");
@@ -732,14 +751,14 @@ extern "C" int fs2_add_ln_fwd(const float* r, const void* a, int dtype, float* s
 
 extern "C" int fs2_add_ln_bwd(const float* ds_down, const void* dy, int dtype, const float* s, const float* gamma,
                               const float* mean, const float* rstd, float* dr, void* da, float* dgamma, float* dbeta,
-                              int64_t M, int d, float p, const uint64_t* rng, uint32_t site, void* stream) {
+                              int64_t M, int d, float p, const uint64_t* rng, uint32_t site, float* dcolsum, void* stream) {
     CHECK_ROW("fs2_add_ln_bwd", d, 1024); CHECK_DT("fs2_add_ln_bwd", dtype);
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_add_ln_bwd: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid(M)), block(ROW_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((add_ln_bwd_k<T, NG>), grid, block, 0, st, ds_down, (const T*)dy, s, gamma, mean, rstd, dr, (T*)da, dgamma, dbeta, M, d, p, rng, site);
+        hipLaunchKernelGGL((add_ln_bwd_k<T, NG>), grid, block, 0, st, ds_down, (const T*)dy, s, gamma, mean, rstd, dr, (T*)da, dgamma, dbeta, M, d, p, rng, site, dcolsum);
     }); } });
     FS2_CHECK_LAUNCH("fs2_add_ln_bwd");
     return FS2_OK;
@@ -762,14 +781,14 @@ extern "C" int fs2_ffn_ln_fwd(const void* f2, const void* h, int dtype, const fl
 
 extern "C" int fs2_ffn_ln_bwd(const void* dy, const void* f2, const void* h, int dtype, const float* gamma,
                               const float* mean, const float* rstd, void* g, float* dgamma, float* dbeta, int64_t M,
-                              int d, float p, const uint64_t* rng, uint32_t site, void* stream) {
+                              int d, float p, const uint64_t* rng, uint32_t site, float* dcolsum, void* stream) {
     CHECK_ROW("fs2_ffn_ln_bwd", d, 1024); CHECK_DT("fs2_ffn_ln_bwd", dtype);
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ffn_ln_bwd: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid(M)), block(ROW_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((ffn_ln_bwd_k<T, NG>), grid, block, 0, st, (const T*)dy, (const T*)f2, (const T*)h, gamma, mean, rstd, (T*)g, dgamma, dbeta, M, d, p, rng, site);
+        hipLaunchKernelGGL((ffn_ln_bwd_k<T, NG>), grid, block, 0, st, (const T*)dy, (const T*)f2, (const T*)h, gamma, mean, rstd, (T*)g, dgamma, dbeta, M, d, p, rng, site, dcolsum);
     }); } });
     FS2_CHECK_LAUNCH("fs2_ffn_ln_bwd");
     return FS2_OK;
@@ -821,7 +840,7 @@ extern "C" int fs2_pe_add_fwd(const void* a, int a_dtype, const float* pe, const
 }
 
 extern "C" int fs2_pe_add_bwd(const float* dout, const float* pe, void* da, int da_dtype, float* dalpha, int B, int t,
-                              int d, float p, const uint64_t* rng, uint32_t site, void* stream) {
+                              int d, float p, const uint64_t* rng, uint32_t site, float* dcolsum, void* stream) {
     CHECK_ROW("fs2_pe_add_bwd", d, 1024); CHECK_DT("fs2_pe_add_bwd", da_dtype);
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_pe_add_bwd: dropout needs rng");
     const int64_t M = (int64_t)B * t;
@@ -829,7 +848,7 @@ extern "C" int fs2_pe_add_bwd(const float* dout, const float* pe, void* da, int 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid(M)), block(ROW_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(da_dtype, T, {
-        hipLaunchKernelGGL((pe_add_bwd_k<T, NG>), grid, block, 0, st, dout, pe, (T*)da, dalpha, M, t, d, p, rng, site);
+        hipLaunchKernelGGL((pe_add_bwd_k<T, NG>), grid, block, 0, st, dout, pe, (T*)da, dalpha, M, t, d, p, rng, site, dcolsum);
     }); } });
     FS2_CHECK_LAUNCH("fs2_pe_add_bwd");
     return FS2_OK;
@@ -907,7 +926,7 @@ extern "C" int fs2_bn_tanh_bwd_reduce(const void* dy, const void* x, int dtype, 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid(M)), block(ROW_BLOCK);
     NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 0>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, red, 1.f, (const float*)nullptr, (T*)nullptr, (float*)nullptr, (float*)nullptr, M, C, p, rng, site);
+        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 0>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, red, 1.f, (const float*)nullptr, (T*)nullptr, (float*)nullptr, (float*)nullptr, M, C, p, rng, site, (float*)nullptr);
     }); } });
     FS2_CHECK_LAUNCH("fs2_bn_tanh_bwd_reduce");
     return FS2_OK;
@@ -916,7 +935,7 @@ extern "C" int fs2_bn_tanh_bwd_reduce(const void* dy, const void* x, int dtype, 
 extern "C" int fs2_bn_tanh_bwd_apply(const void* dy, const void* x, int dtype, const float* mean, const float* rstd,
                                      const float* gamma, const float* beta, const float* red, float count,
                                      const float* count_dev, void* dx, float* dgamma, float* dbeta, int64_t M, int C,
-                                     float p, const uint64_t* rng, uint32_t site, void* stream) {
+                                     float p, const uint64_t* rng, uint32_t site, float* dcolsum, void* stream) {
     CHECK_ROW("fs2_bn_tanh_bwd_apply", C, 1024); CHECK_DT("fs2_bn_tanh_bwd_apply", dtype);
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_bn_tanh_bwd_apply: dropout needs rng");
     FS2_REQUIRE(count > 0.f || count_dev != nullptr, "fs2_bn_tanh_bwd_apply: count must be positive");
@@ -924,7 +943,7 @@ extern "C" int fs2_bn_tanh_bwd_apply(const void* dy, const void* x, int dtype, c
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid(M)), block(ROW_BLOCK);
     NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 1>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, const_cast<float*>(red), count, count_dev, (T*)dx, dgamma, dbeta, M, C, p, rng, site);
+        hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 1>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, const_cast<float*>(red), count, count_dev, (T*)dx, dgamma, dbeta, M, C, p, rng, site, dcolsum);
     }); } });
     FS2_CHECK_LAUNCH("fs2_bn_tanh_bwd_apply");
     return FS2_OK;

@@ -18,6 +18,11 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 _lib = None
 
 
+class FS2CastDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dld", ctypes.c_int64), ("O", ctypes.c_int32),
+                ("I", ctypes.c_int32), ("k", ctypes.c_int32), ("mode", ctypes.c_int32)]
+
+
 class FS2Gemm(ctypes.Structure):
     _fields_ = [
         ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -31,7 +36,7 @@ class FS2Gemm(ctypes.Structure):
         ("c_dtype", ctypes.c_int32), ("res_dtype", ctypes.c_int32), ("relu", ctypes.c_int32),
         ("accumulate", ctypes.c_int32), ("split_k", ctypes.c_int32), ("batch1", ctypes.c_int32),
         ("batch2", ctypes.c_int32), ("conv", ctypes.c_int32), ("taps", ctypes.c_int32), ("pad", ctypes.c_int32),
-        ("seq_len", ctypes.c_int32), ("alpha", ctypes.c_float), ("reserved", ctypes.c_int32),
+        ("seq_len", ctypes.c_int32), ("alpha", ctypes.c_float), ("colstats_mode", ctypes.c_int32),
     ]
 
 
@@ -42,17 +47,19 @@ SIGNATURES = {
     "fs2_cast_permute": [_P, _P, _I, _I, _I, _L, _I, _I, _P],
     "fs2_permute_add": [_P, _P, _I, _I, _I, _P],
     "fs2_cast": [_P, _I, _P, _I, _L, _P],
+    "fs2_cast_permute_batched": [_P, _I, _I, _P],
+    "fs2_onehot": [_P, _P, _I, _L, _I, _P],
     "fs2_colsum": [_P, _I, _L, _I, _L, _P, _P],
     "fs2_embedding_fwd": [_P, _P, _P, _I, _L, _I, _P],
     "fs2_embedding_bwd": [_P, _P, _I, _P, _L, _I, _L, _P],
     "fs2_pe_add_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _U32, _P],
-    "fs2_pe_add_bwd": [_P, _P, _P, _I, _P, _I, _I, _I, _F, _P, _U32, _P],
+    "fs2_pe_add_bwd": [_P, _P, _P, _I, _P, _I, _I, _I, _F, _P, _U32, _P, _P],
     "fs2_layernorm_fwd": [_P, _I, _P, _P, _P, _I, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
-    "fs2_layernorm_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _L, _I, _F, _P, _U32, _I, _I, _P],
+    "fs2_layernorm_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _L, _I, _F, _P, _U32, _I, _I, _P, _P],
     "fs2_add_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
-    "fs2_add_ln_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_add_ln_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_ffn_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
-    "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
     "fs2_softmax_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_length_regulate_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -65,7 +72,7 @@ SIGNATURES = {
     "fs2_bn_finalize": [_P, _F, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P],
     "fs2_bn_tanh_fwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
     "fs2_bn_tanh_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
-    "fs2_bn_tanh_bwd_apply": [_P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_bn_tanh_bwd_apply": [_P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_l1_fwd": [_P, _I, _P, _I, _L, _P, _P],
     "fs2_l1_bwd": [_P, _I, _P, _I, _L, _P, _P, _I, _P],
     "fs2_sqnorm": [_P, _L, _P, _P],
@@ -150,7 +157,7 @@ def _gemm_call(g):
     _check(lib().fs2_gemm(ctypes.byref(g), _stream()), "fs2_gemm")
 
 
-def _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha):
+def _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha, colsum=None):
     g.C, g.ldc, g.c_dtype = _p(out), _ld(out), _dt(out)
     g.bias = _p(bias)
     g.relu = int(relu)
@@ -161,10 +168,12 @@ def _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha):
         g.relu_mask, g.ldm = _p(relu_mask), _ld(relu_mask)
     if colstats is not None:
         g.colstats = _p(colstats)
+    elif colsum is not None:        # column sums only (bias gradient of the layer that produced this GEMM's input)
+        g.colstats, g.colstats_mode = _p(colsum), 1
 
 
 def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, out_dtype=None,
-           alpha=1.0):
+           alpha=1.0, colsum=None):
     """out[M,N] = alpha * x[M,K] @ w[N,K]^T (+bias)(ReLU)(*mask>0)(+residual).  x, w: same dtype (f32 | bf16)."""
     M, K = x.shape
     N = w.shape[0]
@@ -174,13 +183,13 @@ def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=
     g.A, g.B, g.lda, g.ldb = _p(x), _p(w), _ld(x), _ld(w)
     g.M, g.N, g.K, g.dtype = M, N, K, _dt(x)
     g.split_k = g.batch1 = g.batch2 = 1
-    _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha)
+    _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha, colsum)
     _gemm_call(g)
     return out
 
 
 def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None,
-         out_dtype=None):
+         out_dtype=None, colsum=None):
     """Conv1d over time as implicit GEMM: x (B,t,C) channels-last, w (N, taps*C) [n][j*C + c];
     out[b,t,n] = sum_{j,c} x[b, t+j-pad, c] * w[n, j*C+c]  (zero outside the sequence)."""
     B, t, C = x.shape
@@ -196,7 +205,7 @@ def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, 
     g.conv, g.taps, g.pad, g.seq_len = 1, taps, pad, t
     r2 = residual.view(B * t, N) if residual is not None else None
     m2 = relu_mask.view(B * t, N) if relu_mask is not None else None
-    _epilogue(g, o2, bias, relu, r2, m2, colstats, 1.0)
+    _epilogue(g, o2, bias, relu, r2, m2, colstats, 1.0, colsum)
     _gemm_call(g)
     return out
 
@@ -298,6 +307,34 @@ def cast(src, dtype, out=None):
     return out
 
 
+def cast_permute_batched(table_dev, n, dtype):
+    """table_dev: uint8 device tensor holding n FS2CastDesc records"""
+    _check(lib().fs2_cast_permute_batched(_p(table_dev), n, _DT[dtype], _stream()), "fs2_cast_permute_batched")
+
+
+def make_cast_table(entries, device):
+    """entries: list of (src fp32 tensor, dst 2-D view or 1-D fp32 tensor, mode) -> device table for cast_permute_batched"""
+    arr = (FS2CastDesc * len(entries))()
+    for d, (src, dst, mode) in zip(arr, entries):
+        d.src, d.dst, d.mode = src.data_ptr(), dst.data_ptr(), mode
+        if mode == 2:
+            d.O, d.I, d.k, d.dld = src.numel(), 1, 1, 0
+        else:
+            d.O, d.I = src.shape[0], src.shape[1]
+            d.k = src.shape[2] if src.dim() == 3 else 1
+            d.dld = _ld(dst)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+    return raw.to(device)
+
+
+def onehot(idx, nb, dtype):
+    """idx int32 (M,) -> (M, nb) one-hot matrix in `dtype`"""
+    M = idx.numel()
+    out = torch.empty((M, nb), dtype=dtype, device=idx.device)
+    _check(lib().fs2_onehot(_p(_c(idx)), _p(out), _dt(out), M, nb, _stream()), "fs2_onehot")
+    return out
+
+
 def colsum(x, out):
     """out[N] (fp32) += sum over rows of x[M,N] (row stride may exceed N)."""
     M, N = x.shape
@@ -326,11 +363,11 @@ def pe_add_fwd(a, pe, alpha, p, rng, site):
     return out
 
 
-def pe_add_bwd(dout, pe, da_dtype, dalpha, p, rng, site, need_da=True):
+def pe_add_bwd(dout, pe, da_dtype, dalpha, p, rng, site, need_da=True, dcolsum=None):
     B, t, d = dout.shape
     da = torch.empty((B, t, d), dtype=da_dtype, device=dout.device) if need_da else None
     _check(lib().fs2_pe_add_bwd(_p(_c(dout)), _p(pe), _p(da), _DT[da_dtype], _p(dalpha), B, t, d, p,
-                                _rng_ptr(rng, p), site, _stream()), "fs2_pe_add_bwd")
+                                _rng_ptr(rng, p), site, _p(dcolsum), _stream()), "fs2_pe_add_bwd")
     return da
 
 
@@ -346,7 +383,8 @@ def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5, p=0.0, rng=None, site=0):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, relu_mask=False, dx=None):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, relu_mask=False, dx=None,
+                  dcolsum=None):
     """dx (dtype of x) = LNbwd(dropout'(dy)) (* (x > 0) when relu_mask); with dx given: dx += ..."""
     d = x.shape[-1]
     M = x.numel() // d
@@ -355,7 +393,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site
         dx = torch.empty_like(x)
     _check(lib().fs2_layernorm_bwd(_p(_c(dy)), _dt(dy), _p(_c(x)), _dt(x), _p(gamma), _p(mean), _p(rstd), _p(_c(dx)),
                                    _dt(dx), _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, int(relu_mask),
-                                   int(acc), _stream()), "fs2_layernorm_bwd")
+                                   int(acc), _p(dcolsum), _stream()), "fs2_layernorm_bwd")
     return dx
 
 
@@ -372,14 +410,14 @@ def add_ln_fwd(r, a, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
     return s, y, mean, rstd
 
 
-def add_ln_bwd(ds_down, dy, s, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0):
+def add_ln_bwd(ds_down, dy, s, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, dcolsum=None):
     """returns dr (fp32, = ds_down + LNbwd(dy)) and da (dtype of dy, = dropout'(dr))"""
     d = s.shape[-1]
     M = s.numel() // d
     dr = torch.empty_like(s)
     da = torch.empty_like(dy)
     _check(lib().fs2_add_ln_bwd(_p(ds_down), _p(_c(dy)), _dt(dy), _p(_c(s)), _p(gamma), _p(mean), _p(rstd), _p(dr),
-                                _p(da), _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, _stream()),
+                                _p(da), _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, _p(dcolsum), _stream()),
            "fs2_add_ln_bwd")
     return dr, da
 
@@ -395,12 +433,13 @@ def ffn_ln_fwd(f2, h, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
     return y, mean, rstd
 
 
-def ffn_ln_bwd(dy, f2, h, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0):
+def ffn_ln_bwd(dy, f2, h, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, site=0, dcolsum=None):
     d = h.shape[-1]
     M = h.numel() // d
     g = torch.empty_like(h)
     _check(lib().fs2_ffn_ln_bwd(_p(_c(dy)), _p(_c(f2)), _p(_c(h)), _dt(h), _p(gamma), _p(mean), _p(rstd), _p(g),
-                                _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, _stream()), "fs2_ffn_ln_bwd")
+                                _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, _p(dcolsum), _stream()),
+           "fs2_ffn_ln_bwd")
     return g
 
 
@@ -510,12 +549,12 @@ def bn_tanh_bwd_reduce(dy, x, mean, rstd, gamma, beta, red, p=0.0, rng=None, sit
 
 
 def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta, p=0.0, rng=None, site=0,
-                      count_dev=None):
+                      count_dev=None, dcolsum=None):
     C = x.shape[-1]
     dx = torch.empty_like(x)
     _check(lib().fs2_bn_tanh_bwd_apply(_p(_c(dy)), _p(_c(x)), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(red),
                                        float(count), _p(count_dev), _p(dx), _p(dgamma), _p(dbeta), x.numel() // C, C, p,
-                                       _rng_ptr(rng, p), site, _stream()), "fs2_bn_tanh_bwd_apply")
+                                       _rng_ptr(rng, p), site, _p(dcolsum), _stream()), "fs2_bn_tanh_bwd_apply")
     return dx
 
 
