@@ -169,7 +169,7 @@ def main():
 
     # hipGraph replay of the whole step (one graph per batch shape); the GEMM event timer needs eager launches,
     # so the roofline leg below re-runs a few eager, instrumented steps after the timed region
-    use_graph = not args.no_graph and (world == 1 or os.environ.get('FS2_GRAPH_DP', '0') == '1')
+    use_graph = not args.no_graph and (world == 1 or os.environ.get('FS2_GRAPH_DP', '1') == '1')
     graphed = GraphedTrainStep(model, opt, hp) if use_graph else None
     run = (lambda st, b: graphed(st, b)) if use_graph else (lambda st, b: train_step(model, opt, st, b, hp))
     step = 1

@@ -1,0 +1,65 @@
+"""GEMM microbenchmark over the product shapes of BASELINE.json configs[1] (for rocprofv3 / tuning)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from transformer_tts_amd import ops  # noqa: E402
+
+dev = "cuda"
+T = torch.bfloat16
+
+
+def bench(name, fn, flops, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / iters
+    print(f"{name:34s} {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+def main():
+    which = sys.argv[1:] or ["all"]
+    g = torch.Generator(device=dev).manual_seed(0)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g).to(T)
+    M = 44400
+    cases = {}
+    x, w = r(M, 256), r(1024, 256)
+    cases["dec_ffn1 44400x1024x256"] = (lambda: ops.linear(x, w), 2.0 * M * 1024 * 256)
+    x2, w2 = r(M, 1024), r(256, 1024)
+    cases["dec_ffn2 44400x256x1024"] = (lambda: ops.linear(x2, w2), 2.0 * M * 256 * 1024)
+    xe, we = r(48, 128, 256), r(1024, 9 * 256)
+    cases["enc_conv1 6144x1024x(9x256)"] = (lambda: ops.conv(xe, we, 9, 4), 2.0 * 6144 * 1024 * 2304)
+    xe2, we2 = r(48, 128, 1024), r(256, 9 * 1024)
+    cases["enc_conv2 6144x256x(9x1024)"] = (lambda: ops.conv(xe2, we2, 9, 4), 2.0 * 6144 * 256 * 9216)
+    xp, wp = r(48, 925, 256), r(256, 5 * 256)
+    cases["post_conv 44400x256x(5x256)"] = (lambda: ops.conv(xp, wp, 5, 4), 2.0 * M * 256 * 1280)
+    big_a, big_b = r(8192, 4096), r(4096, 4096)
+    cases["square 8192x4096x4096"] = (lambda: ops.linear(big_a, big_b), 2.0 * 8192 * 4096 * 4096)
+    t, tp = 925, 928
+    qkv = r(48, t, 768)
+    q, k, v = (qkv.view(48, t, 3, 2, 128)[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+    S = torch.zeros(48, 2, t, tp, device=dev, dtype=T)
+    cases["attn_qk 96x(925x925x128)"] = (lambda: ops.bmm(q, k, S[..., :t], trans_b=True), 2.0 * 96 * t * t * 128)
+    O = torch.empty(48, t, 2, 128, device=dev, dtype=T)
+    cases["attn_pv 96x(925x128x928)"] = (lambda: ops.bmm(S, v, O.permute(0, 2, 1, 3), trans_b=False), 2.0 * 96 * t * 128 * tp)
+    dy, xx = r(M, 1024), r(M, 256)
+    gw = torch.zeros(1024, 256, device=dev)
+    cases["wgrad 1024x256 red 44400"] = (lambda: ops.wgrad(dy, xx, gw), 2.0 * M * 1024 * 256)
+    dye, xxe = r(48, 128, 1024), r(48, 128, 256)
+    gwe = torch.zeros(1024, 9 * 256, device=dev)
+    cases["conv_wgrad 1024x(9x256) red 6144"] = (lambda: ops.conv_wgrad(dye, xxe, 9, 4, gwe), 2.0 * 6144 * 1024 * 2304)
+    for name, (fn, fl) in cases.items():
+        if "all" in which or any(wn in name for wn in which):
+            bench(name, fn, fl)
+
+
+if __name__ == "__main__":
+    main()

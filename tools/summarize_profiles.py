@@ -1,0 +1,64 @@
+"""Condense the rocprofv3 outputs under gpurun_out/ into the tracked summaries under profiles/ (run locally
+after a gpurun call):  python tools/summarize_profiles.py <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(n):
+    return n.replace("(anonymous namespace)::", "").replace("void ", "")[:150]
+
+
+stats = sorted(glob.glob("gpurun_out/prof/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
+if stats:
+    rows = list(csv.DictReader(open(stats[-1])))
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+    print("wrote", f"profiles/{tag}_kernel_stats.csv", "total kernel ms", sum(float(r["TotalDurationNs"]) for r in rows) / 1e6)
+
+
+def pmc(dirname, counter):
+    f = sorted(glob.glob(f"gpurun_out/{dirname}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    if not f:
+        return agg
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == counter:
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+    return agg
+
+
+fetch, write = pmc("pmcb1", "FETCH_SIZE"), pmc("pmcb2", "WRITE_SIZE")
+if fetch and write:
+    out = {}
+    for k in fetch:
+        if "gemm_kernel" not in k or k not in write:
+            continue
+        n = fetch[k][1]
+        # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
+        # reads (MI355X_MICROARCH.md, HBM section) -> doubled
+        rd = 2.0 * fetch[k][0] * 1024 / n
+        wr = write[k][0] * 1024 / write[k][1]
+        out[k] = dict(launches=n, hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
+    dom = max(out.items(), key=lambda kv: kv[1]["launches"] * kv[1]["hbm_bytes_per_launch"]) if out else None
+    res = dict(per_kernel=out, note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); "
+               "separate --pmc passes; bench.py --no-graph --steps 4 --warmup 8")
+    # the bench's dominant variant is the row-major/row-major bf16 kernel with the 128 tile
+    for k, v in out.items():
+        if "Lb0ELb0ELi128" in k or "false, false, 128" in k:
+            if "DF16bDF16b" in k or "__hip_bfloat16" in k or "bf16" in k.lower():
+                res["hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
+                res["kernel"] = k
+    json.dump(res, open("profiles/gemm_traffic.json", "w"), indent=1)
+    print("wrote profiles/gemm_traffic.json", res.get("kernel"), res.get("hbm_bytes_per_launch"))

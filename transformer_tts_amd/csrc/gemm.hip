@@ -1,46 +1,43 @@
 // MFMA GEMM family for gfx950: linear / implicit-GEMM Conv1d / batched attention products, forward,
 // dgrad and wgrad, in bf16 (v_mfma_f32_16x16x32_bf16) or exact fp32 (v_mfma_f32_16x16x4_f32).
 //
-// Block = 256 threads = 4 waves (2x2), block tile 128x128, wave tile 64x64 = 4x4 MFMA tiles of 16x16.
-// K is consumed in stages of 128 BYTES per row (64 bf16 / 32 f32): both dtypes share one LDS geometry,
-// one 16-byte fragment read per lane per 64-byte k-step; only the MFMA issue differs
-// (1 x 16x16x32 bf16, or 4 x 16x16x4 f32 whose k-slots are the 4 floats of the same 16 bytes).
+// Block = 256 threads = 4 waves (2x2).  Block tile TM x TM (128, or 64 for problems with few tiles),
+// wave tile TM/2 x TM/2 = (TM/32)^2 MFMA tiles of 16x16.  K is consumed in stages of 128 BYTES per row
+// (64 bf16 / 32 f32): both dtypes share one LDS geometry and one 16-byte fragment read per lane per
+// 64-byte k-step; only the MFMA issue differs (1 x 16x16x32 bf16, or 4 x 16x16x4 f32 whose k-slots are
+// the 4 floats of the same 16 bytes).
 //
-// LDS images (16 KiB per operand per stage, double buffered -> 64 KiB; epilogue reuses them):
-//   row-major operand  [128 rows][128 B], 16-B chunk c of row r stored at c ^ ((r>>1)&7)
+// PERSISTENT blocks: the grid is min(work items, 2 x 256 CUs); a block walks work items (output tile x
+// batch x k-split) with stride gridDim.x and issues the global loads of the NEXT item's first stage before
+// the epilogue of the current one, so neither the load latency at the head of a tile nor the store tail is
+// exposed -- most products of this model have only 2-16 k-stages per tile.
+//
+// LDS images (128*TM bytes per operand per stage, double buffered; the epilogue reuses them):
+//   row-major operand  [TM rows][128 B], 16-B chunk c of row r stored at c ^ ((r>>1)&7)
 //                      -> the 16 rows of a ds_read_b128 lane group fall on 16 distinct 16-B slots;
 //   k-major bf16       [64 k][256 B], chunk c of row r at c ^ (((r&3)<<2)|((r>>2)&3)) and read with
 //                      ds_read_b64_tr_b16 (hardware transpose; image (b) of the CDNA4 guide, T10);
-//   k-major f32        [32 k][512 B], plain, read with ds_read_b32.
-// Staging is global -> registers -> LDS with the next stage's loads issued before the MFMAs of the
-// current one (one barrier per stage).  Out-of-range rows / conv halo rows are zero-filled by predicate.
+//   k-major f32        [32 k][512 B], plain, read with ds_read_b32.          (k-major: TM = 128 only)
+// Staging is global -> registers -> LDS through a ring of D register sets (D = 2 for the 128 tile, 4 for the
+// 64 tile): the block walks ONE flattened stream of stages over all its work items, the loads of stage s+D are
+// issued before the MFMAs of stage s (also across tile boundaries), and hipcc counts vmcnt for the set that is
+// moved to LDS.  Loads are raw buffer loads: rows outside the matrix / conv halo rows get an out-of-range
+// offset and read as zeros (no branches around loads -- a predicated `if (ok) v = *p` serialises them).
 #include "common.cuh"
+#include <stdlib.h>
 
 namespace {
-
-constexpr int BM = 128, BN = 128;
-constexpr int STAGE_BYTES = 16384;                 // one operand, one stage
-constexpr int EPI_LD = 68;                         // floats per epilogue row (64 + 4 pad: conflict-free)
-constexpr int EPI_BYTES = 4 * 64 * EPI_LD * 4;     // 4 waves x 64 rows
-constexpr int SMEM_BYTES = (4 * STAGE_BYTES > EPI_BYTES) ? 4 * STAGE_BYTES : EPI_BYTES;
 
 template <typename T, bool KM> struct Tile {
     static constexpr int EPC = 16 / (int)sizeof(T);                 // elements per 16-B chunk
     static constexpr int BK = 128 / (int)sizeof(T);                 // k elements per stage
     static constexpr int CPR = KM ? (128 * (int)sizeof(T)) / 16 : 8;  // chunks per LDS row
-    static constexpr int ROWB = CPR * 16;                           // bytes per LDS row
     __device__ static __forceinline__ int lds_off(int row, int ch) {
         if constexpr (!KM) return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
         else if constexpr (sizeof(T) == 2) return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4);
         else return row * 512 + (ch << 4);
     }
 };
-
-// bijective XCD-aware remap: blocks that share an XCD (id % 8) get a contiguous range of tiles
-__device__ __forceinline__ int xcd_remap(int id, int n) {
-    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
@@ -84,208 +81,377 @@ __device__ __forceinline__ void mma(f32x4& acc, const typename Frag<T>::type& a,
     }
 }
 
-template <typename T, typename TC, bool AKM, bool BKM>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p) {
+template <int TM> struct Geo {
+    static constexpr int WT = TM / 2;                         // wave tile
+    static constexpr int NI = WT / 16;                        // MFMA tiles per wave per dim
+    static constexpr int STAGE = 128 * TM;                    // bytes per operand per stage
+    static constexpr int NCH = STAGE / 16 / 256;              // 16-B chunks per thread per operand per stage
+    static constexpr int EPI_LD = WT + 4;                     // floats per epilogue row (+4 pad: conflict-free)
+    static constexpr int EPI_BYTES = 4 * WT * EPI_LD * 4;
+    static constexpr int SMEM = (4 * STAGE > EPI_BYTES) ? 4 * STAGE : EPI_BYTES;
+};
+
+// one work item: output tile (m0,n0) of batch (b1,b2), k-stages [it0,it1)
+struct Work {
+    int m0, n0, split, b2, it0, it1;
+    int64_t aoff, boff, coff;
+};
+
+template <int N> struct IC { static constexpr int value = N; };
+
+template <typename T, typename TC, bool AKM, bool BKM, int TM, bool DIRECT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int total_work) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef Tile<T, AKM> TA;
     typedef Tile<T, BKM> TB;
-    constexpr int EPC = TA::EPC, BK = TA::BK;
+    typedef Geo<TM> G;
+    constexpr int EPC = TA::EPC, BK = TA::BK, NI = G::NI, NCH = G::NCH, WT = G::WT, EPI_LD = G::EPI_LD;
+    constexpr int D = (TM == 128) ? 2 : 4;     // stages in flight in registers (prefetch depth)
+    static_assert(TM == 128 || (!AKM && !BKM), "k-major operands use the 128 tile only");
+    static_assert(!DIRECT, "a register-direct epilogue was tried (partial-line stores, accumulators in scratch) and dropped");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
-    const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
-    const int lin = xcd_remap(blockIdx.x, tilesM * tilesN);
-    const int m0 = (lin / tilesN) * BM, n0 = (lin % tilesN) * BN;
-    int z = blockIdx.y;
-    const int split = z % p.split_k; z /= p.split_k;
-    const int b2 = z % p.batch2, b1 = z / p.batch2;
-
-    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
-    const T* __restrict__ B = reinterpret_cast<const T*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
-    const int64_t coff = b1 * p.sC1 + b2 * p.sC2;
-
+    const int tilesN = (p.N + TM - 1) / TM, tilesM = (p.M + TM - 1) / TM;
+    const int tiles = tilesM * tilesN;
     const int Kb = p.Kb > 0 ? p.Kb : p.K;
     const int nkt = (p.K + BK - 1) / BK;                       // k tiles per tap
     const int ntot = (p.conv == 1 ? p.taps : 1) * nkt;         // stages in the whole reduction
-    const int per = (ntot + p.split_k - 1) / p.split_k;
-    const int it0 = split * per, it1 = min(ntot, it0 + per);
+    const int per = (ntot + p.split_k - 1) / p.split_k;        // the host guarantees no empty split
     const int seq = p.seq_len;
-    const int shiftB = (p.conv == 2) ? (b2 - p.pad) : 0;
 
-    // ---- per-thread staging coordinates (4 chunks of 16 B per operand per stage)
-    int a_row[4], a_ch[4], a_t[4], b_row[4], b_ch[4];
+    auto make_work = [&](int w) {
+        Work k;
+        const int lin = w % tiles;
+        int z = w / tiles;
+        k.split = z % p.split_k; z /= p.split_k;
+        k.b2 = z % p.batch2;
+        const int b1 = z / p.batch2;
+        k.m0 = (lin / tilesN) * TM; k.n0 = (lin % tilesN) * TM;
+        k.aoff = b1 * p.sA1 + k.b2 * p.sA2; k.boff = b1 * p.sB1 + k.b2 * p.sB2; k.coff = b1 * p.sC1 + k.b2 * p.sC2;
+        k.it0 = k.split * per; k.it1 = min(ntot, k.it0 + per);
+        return k;
+    };
+
+    // ---- per-thread, tile-independent staging coordinates and LDS addresses (hoisted out of every loop)
+    int a_row[NCH], a_ch[NCH], b_row[NCH], b_ch[NCH], wrA[NCH], wrB[NCH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int c = tid + 256 * i;
         a_row[i] = c / TA::CPR; a_ch[i] = c % TA::CPR;
         b_row[i] = c / TB::CPR; b_ch[i] = c % TB::CPR;
-        a_t[i] = 0;
-        if constexpr (!AKM) { if (p.conv == 1) a_t[i] = (m0 + a_row[i]) % seq; }
+        wrA[i] = TA::lds_off(a_row[i], a_ch[i]);
+        int brow = b_row[i];
+        wrB[i] = TB::lds_off(brow, b_ch[i]);
     }
-
-    uint4 ra[4], rb[4];
-    auto load_stage = [&](int it) {
-        const int tap = (p.conv == 1) ? it / nkt : 0;
-        const int kb = (it - tap * nkt) * BK;
-        const int shiftA = (p.conv == 1) ? tap - p.pad : 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if constexpr (!AKM) {
-                const int m = m0 + a_row[i], k = kb + a_ch[i] * EPC;
-                bool ok = (m < p.M) && (k < p.K);
-                if (p.conv == 1) { const int tt = a_t[i] + shiftA; ok = ok && (tt >= 0) && (tt < seq); }
-                if (ok) v = *reinterpret_cast<const uint4*>(A + (int64_t)(m + shiftA) * p.lda + k);
-            } else {
-                const int k = kb + a_row[i], m = m0 + a_ch[i] * EPC;
-                if ((k < p.K) && (m < p.M)) v = *reinterpret_cast<const uint4*>(A + (int64_t)k * p.lda + m);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if constexpr (!BKM) {
-                const int n = n0 + b_row[i], k = kb + b_ch[i] * EPC;
-                if ((n < p.N) && (k < p.K)) v = *reinterpret_cast<const uint4*>(B + (int64_t)n * p.ldb + (int64_t)tap * p.K + k);
-            } else {
-                const int k = kb + b_row[i], n = n0 + b_ch[i] * EPC;
-                bool ok = (k < Kb) && (n < p.N);
-                if (p.conv == 2) { const int tt = (k % seq) + shiftB; ok = ok && (tt >= 0) && (tt < seq); }
-                if (ok) v = *reinterpret_cast<const uint4*>(B + (int64_t)(k + shiftB) * p.ldb + n);
-            }
-            rb[i] = v;
-        }
-    };
-    auto store_stage = [&](int buf) {
-        unsigned char* la = smem + buf * 2 * STAGE_BYTES;
-        unsigned char* lb = la + STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(la + TA::lds_off(a_row[i], a_ch[i])) = ra[i];
-            *reinterpret_cast<uint4*>(lb + TB::lds_off(b_row[i], b_ch[i])) = rb[i];
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (it0 < it1) {
-        load_stage(it0);
-        store_stage(0);
-        __syncthreads();
-        for (int it = it0; it < it1; ++it) {
-            const int buf = (it - it0) & 1;
-            if (it + 1 < it1) load_stage(it + 1);
-            const unsigned char* la = smem + buf * 2 * STAGE_BYTES;
-            const unsigned char* lb = la + STAGE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                typename Frag<T>::type fa[4], fb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = read_frag<T, AKM>(la, wr * 64 + i * 16, ks, lane);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = read_frag<T, BKM>(lb, wc * 64 + j * 16, ks, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
-            }
-            if (it + 1 < it1) store_stage(buf ^ 1);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: accumulators -> wave-private LDS rows -> coalesced 4-column groups
-    __syncthreads();
-    float* ew = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
+    int rdA[2], rdB[2];     // fragment read addresses of row-major operands: one lane offset per k-step, tile i adds i*2048
     {
         const int g = lane >> 4, i16 = lane & 15;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ew[(i * 16 + g * 4 + r) * EPI_LD + j * 16 + i16] = acc[i][j][r];
+        for (int ks = 0; ks < 2; ++ks) {
+            rdA[ks] = AKM ? 0 : TA::lds_off(wr * WT + i16, ks * 4 + g);
+            rdB[ks] = BKM ? 0 : TB::lds_off(wc * WT + i16, ks * 4 + g);
+        }
     }
-    __syncthreads();
-    TC* __restrict__ C = reinterpret_cast<TC*>(p.C) + coff;
-    const int cg = lane & 15;                      // column group: 4 columns
-    const int ncol = n0 + wc * 64 + cg * 4;
-    const bool col_ok = ncol < p.N;                // N is a multiple of 4 (checked on the host)
-    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias != nullptr && col_ok && split == 0) bias4 = *reinterpret_cast<const float4*>(p.bias + ncol);
-    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int pass = 0; pass < 16; ++pass) {
-        const int rl = pass * 4 + (lane >> 4);
-        const int m = m0 + wr * 64 + rl;
-        float4 v = *reinterpret_cast<const float4*>(ew + rl * EPI_LD + cg * 4);
-        if (!(col_ok && m < p.M)) continue;
-        v.x = v.x * p.alpha + bias4.x; v.y = v.y * p.alpha + bias4.y;
-        v.z = v.z * p.alpha + bias4.z; v.w = v.w * p.alpha + bias4.w;
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (p.relu_mask != nullptr) {
-            const float4 mk = load4<T>(reinterpret_cast<const T*>(p.relu_mask) + coff + (int64_t)m * p.ldm + ncol);
-            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-            v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-        }
-        if (p.residual != nullptr) {
-            float4 rr;
-            if (p.res_dtype == FS2_F32) rr = load4<float>(reinterpret_cast<const float*>(p.residual) + coff + (int64_t)m * p.ldr + ncol);
-            else rr = load4<bf16_t>(reinterpret_cast<const bf16_t*>(p.residual) + coff + (int64_t)m * p.ldr + ncol);
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        TC* dst = C + (int64_t)m * p.ldc + ncol;
-        if constexpr (sizeof(TC) == 4) {
-            if (p.accumulate) {
-                atomicAdd(reinterpret_cast<float*>(dst) + 0, v.x); atomicAdd(reinterpret_cast<float*>(dst) + 1, v.y);
-                atomicAdd(reinterpret_cast<float*>(dst) + 2, v.z); atomicAdd(reinterpret_cast<float*>(dst) + 3, v.w);
+
+    // Staging: branch-free raw buffer loads through a (base, 2 GiB) descriptor; a lane whose chunk lies outside the
+    // matrix / the sequence (conv halo) uses the out-of-range voffset 0x80000000 and the hardware returns zeros.
+    // D stages are kept in flight in D register sets; the compiler counts vmcnt for the set being stored to LDS.
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int ES = (int)sizeof(T);
+    const int lda = (int)p.lda, ldb = (int)p.ldb;
+    u32x4 ra[D][NCH], rb[D][NCH];
+
+    // ---- LOAD cursor: the next stage to fetch, possibly several stages / one work item ahead of the compute cursor
+    int lw = blockIdx.x;
+    Work lk = make_work(lw < total_work ? lw : 0);
+    int lit = lk.it0;
+    unsigned offA[NCH], offB[NCH];     // voffset of the chunk at k = 0, tap shift 0 of work lk (OOB if the row is outside)
+    int tA[NCH];                       // conv: position of the row inside its sequence
+    auto prep_work = [&](const Work& k) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if constexpr (!AKM) {
+                const int m = k.m0 + a_row[i];
+                offA[i] = (m < p.M) ? (unsigned)((m * lda + a_ch[i] * EPC) * ES) : OOB;
+                tA[i] = (p.conv == 1) ? (m % seq) : 0;
             } else {
-                store4<TC>(dst, v);
+                const int m = k.m0 + a_ch[i] * EPC;
+                offA[i] = (m < p.M) ? (unsigned)((a_row[i] * lda + m) * ES) : OOB;
+                tA[i] = 0;
             }
-        } else {
-            store4<TC>(dst, v);
-            // statistics are taken on the values as stored (rounded to TC)
-            v.x = (float)(TC)v.x; v.y = (float)(TC)v.y; v.z = (float)(TC)v.z; v.w = (float)(TC)v.w;
+            if constexpr (!BKM) {
+                const int n = k.n0 + b_row[i];
+                offB[i] = (n < p.N) ? (unsigned)((n * ldb + b_ch[i] * EPC) * ES) : OOB;
+            } else {
+                const int n = k.n0 + b_ch[i] * EPC;
+                offB[i] = (n < p.N) ? (unsigned)((b_row[i] * ldb + n) * ES) : OOB;
+            }
         }
-        if (p.colstats != nullptr) {
-            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-            cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+    };
+    auto issue_load = [&](auto slot_c) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        if (lw >= total_work) return;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(reinterpret_cast<const T*>(p.A) + lk.aoff), 0, 0x7FFFFFF0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(reinterpret_cast<const T*>(p.B) + lk.boff), 0, 0x7FFFFFF0, 0x00020000);
+        const int it = lit;
+        const int tap = (p.conv == 1) ? it / nkt : 0;
+        const int kb = (it - tap * nkt) * BK;
+        const int shiftA = (p.conv == 1) ? tap - p.pad : 0;
+        const int shiftB = (p.conv == 2) ? (lk.b2 - p.pad) : 0;
+        // wave-uniform byte advance of this stage (may be negative for conv taps left of the centre: added per lane)
+        const int sA = AKM ? kb * lda * ES : (shiftA * lda + kb) * ES;
+        const int sB = BKM ? (kb + shiftB) * ldb * ES : (tap * p.K + kb) * ES;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            bool ok = offA[i] != OOB;
+            if constexpr (!AKM) {
+                ok = ok && (kb + a_ch[i] * EPC < p.K);
+                if (p.conv == 1) { const int tt = tA[i] + shiftA; ok = ok && (tt >= 0) && (tt < seq); }
+            } else {
+                ok = ok && (kb + a_row[i] < p.K);
+            }
+            ra[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? offA[i] + (unsigned)sA : OOB, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            bool ok = offB[i] != OOB;
+            if constexpr (!BKM) {
+                ok = ok && (kb + b_ch[i] * EPC < p.K);
+            } else {
+                const int kk = kb + b_row[i];
+                ok = ok && (kk < Kb);
+                if (p.conv == 2) { const int tt = (kk % seq) + shiftB; ok = ok && (tt >= 0) && (tt < seq); }
+            }
+            rb[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? offB[i] + (unsigned)sB : OOB, 0, 0);
+        }
+        // advance the load cursor
+        if (++lit == lk.it1) {
+            lw += gridDim.x;
+            if (lw < total_work) { lk = make_work(lw); prep_work(lk); lit = lk.it0; }
+        }
+    };
+    auto store_stage = [&](auto slot_c, int buf) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        unsigned char* la = smem + buf * 2 * G::STAGE;
+        unsigned char* lb = la + G::STAGE;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            *reinterpret_cast<u32x4*>(la + wrA[i]) = ra[SLOT][i];
+            *reinterpret_cast<u32x4*>(lb + wrB[i]) = rb[SLOT][i];
+        }
+    };
+
+    if (lw >= total_work) return;
+    // number of stages this block will run through (all its work items)
+    int nst = 0;
+    for (int w = blockIdx.x; w < total_work; w += gridDim.x) {
+        const int sp = (w / tiles) % p.split_k;
+        nst += min(ntot, sp * per + per) - sp * per;
     }
-    if (p.colstats != nullptr) {
-        // reduce over the 4 row groups (lane>>4), then one atomic per column per wave
-        float* f[2] = {&cs.x, &cq.x};
+    prep_work(lk);
+
+    // ---- COMPUTE cursor
+    int cw = blockIdx.x;
+    Work ck = lk;
+    int cit = ck.it0;
+    f32x4 acc[NI][NI];
 #pragma unroll
-        for (int w = 0; w < 2; ++w)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float s = f[w][e];
-                s += __shfl_xor(s, 16, 64);
-                s += __shfl_xor(s, 32, 64);
-                f[w][e] = s;
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto epilogue = [&]() {
+        const Work& cur = ck;
+        TC* __restrict__ C = reinterpret_cast<TC*>(p.C) + cur.coff;
+        {
+            // ---- staged epilogue (k-major B, or fp32 atomic accumulate): accumulators -> wave-private LDS rows.
+            // The stage that follows is still in registers, so the LDS image is free between the two barriers.
+            float* ew = reinterpret_cast<float*>(smem) + wave * WT * EPI_LD;
+            __syncthreads();            // every wave has finished reading the stage buffers
+            {
+                const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ew[(i * 16 + g * 4 + r) * EPI_LD + j * 16 + i16] = acc[i][j][r];
             }
-        if ((lane >> 4) == 0 && col_ok) {
-            atomicAdd(p.colstats + ncol + 0, cs.x); atomicAdd(p.colstats + ncol + 1, cs.y);
-            atomicAdd(p.colstats + ncol + 2, cs.z); atomicAdd(p.colstats + ncol + 3, cs.w);
-            atomicAdd(p.colstats + p.N + ncol + 0, cq.x); atomicAdd(p.colstats + p.N + ncol + 1, cq.y);
-            atomicAdd(p.colstats + p.N + ncol + 2, cq.z); atomicAdd(p.colstats + p.N + ncol + 3, cq.w);
+            __syncthreads();
+            bool stored = false;
+            if constexpr (sizeof(TC) == 4) {
+                if (p.accumulate) {
+                    // one output row per wave-instruction, consecutive lanes on consecutive floats: every atomic
+                    // instruction covers contiguous bytes (the full-rate shape)
+                    for (int c0 = 0; c0 < WT; c0 += 64) {
+                        const int cl = c0 + lane;
+                        const int n = cur.n0 + wc * WT + cl;
+                        if (cl < WT && n < p.N) {
+                            float bias1 = 0.f;
+                            if (p.bias != nullptr && cur.split == 0) bias1 = p.bias[n];
+                            for (int rl = 0; rl < WT; ++rl) {
+                                const int m = cur.m0 + wr * WT + rl;
+                                if (m >= p.M) break;
+                                atomicAdd(reinterpret_cast<float*>(C) + (int64_t)m * p.ldc + n, ew[rl * EPI_LD + cl] * p.alpha + bias1);
+                            }
+                        }
+                    }
+                    stored = true;
+                }
+            }
+            if (!stored) {
+                constexpr int CG = WT / 4;                      // 4-column groups per wave-tile row
+                constexpr int RPP = 64 / CG;                    // rows per pass
+                const int cg = lane % CG;
+                const int ncol = cur.n0 + wc * WT + cg * 4;
+                const bool col_ok = ncol < p.N;
+                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias != nullptr && col_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + ncol);
+                float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+                for (int pass = 0; pass < WT / RPP; ++pass) {
+                    const int rl = pass * RPP + lane / CG;
+                    const int m = cur.m0 + wr * WT + rl;
+                    float4 v = *reinterpret_cast<const float4*>(ew + rl * EPI_LD + cg * 4);
+                    if (!(col_ok && m < p.M)) continue;
+                    v.x = v.x * p.alpha + bias4.x; v.y = v.y * p.alpha + bias4.y;
+                    v.z = v.z * p.alpha + bias4.z; v.w = v.w * p.alpha + bias4.w;
+                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (p.relu_mask != nullptr) {
+                        const float4 mk = load4<T>(reinterpret_cast<const T*>(p.relu_mask) + cur.coff + (int64_t)m * p.ldm + ncol);
+                        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                    }
+                    if (p.residual != nullptr) {
+                        float4 rr;
+                        if (p.res_dtype == FS2_F32) rr = load4<float>(reinterpret_cast<const float*>(p.residual) + cur.coff + (int64_t)m * p.ldr + ncol);
+                        else rr = load4<bf16_t>(reinterpret_cast<const bf16_t*>(p.residual) + cur.coff + (int64_t)m * p.ldr + ncol);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    }
+                    store4<TC>(C + (int64_t)m * p.ldc + ncol, v);
+                    if (p.colstats != nullptr) {
+                        if constexpr (sizeof(TC) != 4) {   // statistics of the values as stored
+                            v.x = (float)(TC)v.x; v.y = (float)(TC)v.y; v.z = (float)(TC)v.z; v.w = (float)(TC)v.w;
+                        }
+                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                        cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+                    }
+                }
+                if (p.colstats != nullptr) {
+                    float* f[2] = {&cs.x, &cq.x};
+#pragma unroll
+                    for (int wq = 0; wq < 2; ++wq)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float sv = f[wq][e];
+#pragma unroll
+                            for (int o = CG; o < 64; o <<= 1) sv += __shfl_xor(sv, o, 64);
+                            f[wq][e] = sv;
+                        }
+                    if (lane < CG && col_ok) {
+                        atomicAdd(p.colstats + ncol + 0, cs.x); atomicAdd(p.colstats + ncol + 1, cs.y);
+                        atomicAdd(p.colstats + ncol + 2, cs.z); atomicAdd(p.colstats + ncol + 3, cs.w);
+                        if (p.colstats_mode == 0) {
+                            atomicAdd(p.colstats + p.N + ncol + 0, cq.x); atomicAdd(p.colstats + p.N + ncol + 1, cq.y);
+                            atomicAdd(p.colstats + p.N + ncol + 2, cq.z); atomicAdd(p.colstats + p.N + ncol + 3, cq.w);
+                        }
+                    }
+                }
+            }
+            __syncthreads();            // the epilogue image is free again before the next stage is stored
         }
+    };
+
+    // one step of the flattened stage stream: fetch stage s+D, compute stage s, finish the tile if it was its last
+    // stage, move stage s+1 from registers to LDS
+    auto step = [&](auto slot_c, auto next_c, int s) {
+        constexpr int SLOT = decltype(slot_c)::value;   // = s % D: the register set that held stage s (free now)
+        const int buf = s & 1;
+        if (s + D < nst) issue_load(slot_c);
+        const unsigned char* la = smem + buf * 2 * G::STAGE;
+        const unsigned char* lb = la + G::STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            typename Frag<T>::type fa[NI], fb[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if constexpr (!AKM) fa[i] = *reinterpret_cast<const typename Frag<T>::type*>(la + rdA[ks] + i * 2048);
+                else fa[i] = read_frag<T, AKM>(la, wr * WT + i * 16, ks, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if constexpr (!BKM) fb[j] = *reinterpret_cast<const typename Frag<T>::type*>(lb + rdB[ks] + j * 2048);
+                else fb[j] = read_frag<T, BKM>(lb, wc * WT + j * 16, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    mma<T>(acc[i][j], fa[i], fb[j]);
+                }
+        }
+        if (++cit == ck.it1) {          // last stage of this work item
+            epilogue();
+            cw += gridDim.x;
+            if (cw < total_work) { ck = make_work(cw); cit = ck.it0; }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (s + 1 < nst) store_stage(next_c, buf ^ 1);
+        __syncthreads();
+    };
+
+    // prologue: D stages in flight, stage 0 to LDS
+    issue_load(IC<0>{});
+    if constexpr (D > 1) { if (1 < nst) issue_load(IC<1>{}); }
+    if constexpr (D > 2) { if (2 < nst) issue_load(IC<2>{}); if (3 < nst) issue_load(IC<3>{}); }
+    store_stage(IC<0>{}, 0);
+    __syncthreads();
+
+    int s = 0;
+    if constexpr (D == 2) {
+        for (; s + 2 <= nst; s += 2) { step(IC<0>{}, IC<1>{}, s); step(IC<1>{}, IC<0>{}, s + 1); }
+        if (s < nst) step(IC<0>{}, IC<1>{}, s);
+    } else {
+        for (; s + 4 <= nst; s += 4) {
+            step(IC<0>{}, IC<1>{}, s); step(IC<1>{}, IC<2>{}, s + 1); step(IC<2>{}, IC<3>{}, s + 2); step(IC<3>{}, IC<0>{}, s + 3);
+        }
+        if (s < nst) { step(IC<0>{}, IC<1>{}, s); ++s; }
+        if (s < nst) { step(IC<1>{}, IC<2>{}, s); ++s; }
+        if (s < nst) { step(IC<2>{}, IC<3>{}, s); ++s; }
     }
 }
 
-template <typename T, typename TC>
-int launch(const FS2Gemm& g, dim3 grid, hipStream_t st) {
-    if (!g.a_kmajor && !g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<T, TC, false, false>), grid, dim3(256), SMEM_BYTES, st, g);
-    else if (!g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<T, TC, false, true>), grid, dim3(256), SMEM_BYTES, st, g);
-    else if (g.a_kmajor && g.b_kmajor) hipLaunchKernelGGL((gemm_kernel<T, TC, true, true>), grid, dim3(256), SMEM_BYTES, st, g);
-    else { fs2_set_error("fs2_gemm: a_kmajor=1 with b_kmajor=0 is not provided"); return FS2_EINVAL; }
+template <typename T, typename TC, bool AKM, bool BKM, int TM, bool DIRECT>
+int launch1(const FS2Gemm& g, int total, hipStream_t st) {
+    const int slots = (TM == 128) ? 512 : 768;      // resident blocks: 2 (128-tile) / 3 (64-tile) per CU x 256 CUs
+    const int grid = total < slots ? total : slots;
+    hipLaunchKernelGGL((gemm_kernel<T, TC, AKM, BKM, TM, DIRECT>), dim3(grid), dim3(256), Geo<TM>::SMEM, st, g, total);
     FS2_CHECK_LAUNCH("fs2_gemm");
     return FS2_OK;
+}
+
+template <typename T, typename TC>
+int launch(const FS2Gemm& g, hipStream_t st) {
+    const long zdim = (long)g.batch1 * g.batch2 * g.split_k;
+    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * zdim;
+    if (!g.a_kmajor && !g.b_kmajor) {
+        if (t128 < 384) {       // too few 128-tiles to fill 256 CUs: quarter-size tiles
+            const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * zdim;
+            return launch1<T, TC, false, false, 64, false>(g, (int)t64, st);
+        }
+        return launch1<T, TC, false, false, 128, false>(g, (int)t128, st);
+    }
+    if (!g.a_kmajor && g.b_kmajor) return launch1<T, TC, false, true, 128, false>(g, (int)t128, st);
+    if (g.a_kmajor && g.b_kmajor) return launch1<T, TC, true, true, 128, false>(g, (int)t128, st);
+    fs2_set_error("fs2_gemm: a_kmajor=1 with b_kmajor=0 is not provided");
+    return FS2_EINVAL;
 }
 
 }  // namespace
@@ -307,8 +473,8 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
                 "fs2_gemm: batch strides of A/B must be multiples of %d elements", epc);
     FS2_REQUIRE(g.N % 4 == 0 || g.ldc >= ((g.N + 3) / 4) * 4, "fs2_gemm: N=%d needs ldc >= N rounded up to 4", g.N);
     FS2_REQUIRE(g.ldc % 4 == 0 && g.sC1 % 4 == 0 && g.sC2 % 4 == 0, "fs2_gemm: ldc and C batch strides must be multiples of 4");
+    if (g.c_dtype == FS2_BF16) FS2_REQUIRE(g.ldc % 8 == 0 && g.sC1 % 8 == 0 && g.sC2 % 8 == 0, "fs2_gemm: bf16 C needs ldc and batch strides in multiples of 8 (16-byte stores)");
     if (!g.a_kmajor) FS2_REQUIRE(g.K % epc == 0, "fs2_gemm: K=%d must be a multiple of %d for a row-major A", g.K, epc);
-    if (!g.a_kmajor && !g.b_kmajor) FS2_REQUIRE(g.K % epc == 0, "fs2_gemm: K must be a multiple of %d", epc);
     if (g.a_kmajor) FS2_REQUIRE(((g.M + epc - 1) / epc) * epc <= g.lda, "fs2_gemm: k-major A needs lda >= M rounded up to %d", epc);
     if (g.b_kmajor) FS2_REQUIRE(((g.N + epc - 1) / epc) * epc <= g.ldb, "fs2_gemm: k-major B needs ldb >= N rounded up to %d", epc);
     FS2_REQUIRE(g.conv >= 0 && g.conv <= 2, "fs2_gemm: bad conv mode");
@@ -326,15 +492,26 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
     if (g.N % 4 != 0)
         FS2_REQUIRE(!g.b_kmajor && !g.bias && !g.residual && !g.relu_mask && !g.colstats && !g.accumulate,
                     "fs2_gemm: N=%d not a multiple of 4 only for plain row-major-B products", g.N);
-
-    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    const long zdim = (long)g.batch1 * g.batch2 * g.split_k;
-    FS2_REQUIRE(zdim <= 65535, "fs2_gemm: batch1*batch2*split_k = %ld exceeds 65535", zdim);
-    dim3 grid((unsigned)tiles, (unsigned)zdim, 1);
+    {   // staging uses 32-bit byte offsets from the (batch-adjusted) operand base
+        const long es = g.dtype == FS2_BF16 ? 2 : 4;
+        const long ra = g.a_kmajor ? g.K : g.M, rb = g.b_kmajor ? (g.Kb > 0 ? g.Kb : g.K) : g.N;
+        FS2_REQUIRE((ra + 16) * g.lda * es < 0x7FFFFFF0L && (rb + 16) * g.ldb * es < 0x7FFFFFF0L,
+                    "fs2_gemm: an operand slice exceeds 2 GiB");
+    }
+    // no empty k-split: shrink split_k so that every split owns at least one stage
+    {
+        const int bk = g.dtype == FS2_BF16 ? 64 : 32;
+        const int ntot = (g.conv == 1 ? g.taps : 1) * ((g.K + bk - 1) / bk);
+        if (g.split_k > ntot) g.split_k = ntot;
+        const int per = (ntot + g.split_k - 1) / g.split_k;
+        g.split_k = (ntot + per - 1) / per;
+    }
+    const long total = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch1 * g.batch2 * g.split_k;
+    FS2_REQUIRE(total < (1L << 30), "fs2_gemm: too many work items");
     hipStream_t st = (hipStream_t)stream;
     if (g.dtype == FS2_BF16) {
-        if (g.c_dtype == FS2_F32) return launch<bf16_t, float>(g, grid, st);
-        return launch<bf16_t, bf16_t>(g, grid, st);
+        if (g.c_dtype == FS2_F32) return launch<bf16_t, float>(g, st);
+        return launch<bf16_t, bf16_t>(g, st);
     }
-    return launch<float, float>(g, grid, st);
+    return launch<float, float>(g, st);
 }

@@ -11,16 +11,28 @@ namespace {
 
 constexpr int ROW_BLOCK = 256;  // 4 waves
 constexpr int ROW_WAVES = 4;
+constexpr int RED_BLOCK = 1024; // 16 waves (row-reducing kernels)
+constexpr int RED_WAVES = 16;
+static inline int red_grid(int64_t rows) {
+    int64_t b = (rows + RED_WAVES - 1) / RED_WAVES;
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
 
 static inline int row_grid(int64_t rows) {
     int64_t b = (rows + ROW_WAVES - 1) / ROW_WAVES;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
-#define ROW_LOOP(M)                                                                          \
+#define ROW_LOOP_W(M, W)                                                                     \
     const int lane = threadIdx.x & 63;                                                       \
     const int wave = threadIdx.x >> 6;                                                       \
-    for (int64_t row = (int64_t)blockIdx.x * ROW_WAVES + wave; row < (M); row += (int64_t)gridDim.x * ROW_WAVES)
+    for (int64_t row = (int64_t)blockIdx.x * (W) + wave; row < (M); row += (int64_t)gridDim.x * (W))
+#define ROW_LOOP(M) ROW_LOOP_W(M, ROW_WAVES)
+// Kernels that reduce over rows (dgamma, dbeta, bias gradients, BatchNorm sums) run 16-wave blocks: every block
+// ends with one float atomic per channel onto the SAME few hundred addresses, and contended atomics serialise
+// (MI355X_MICROARCH.md, "Global float atomics": ~14x slower when every workgroup adds into one row) -- so the
+// number of blocks, not the bytes, sets that tail: <= 512 blocks instead of 2048.
+#define RED_LOOP(M) ROW_LOOP_W(M, RED_WAVES)
 
 // column of group g for this lane, and whether it is inside the row
 #define GCOL(g) (4 * (lane + 64 * (g)))
@@ -60,15 +72,17 @@ __device__ __forceinline__ void row_stats(const float4 (&v)[NG], int d, int lane
 
 // flush per-lane per-channel partial sums: LDS across the 4 waves, then one atomic per channel
 template <int NG>
-__device__ __forceinline__ void flush_channel_sums(const float4 (&acc)[NG], float* out, int d, float* lds /* [4][NG*256] */) {
+__device__ __forceinline__ void flush_channel_sums(const float4 (&acc)[NG], float* out, int d, float* lds /* [waves][NG*256] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = blockDim.x >> 6;
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < NG; ++g) *reinterpret_cast<float4*>(lds + wave * NG * 256 + GCOL(g)) = acc[g];
     __syncthreads();
-    for (int c = threadIdx.x; c < NG * 256; c += ROW_BLOCK) {
+    for (int c = threadIdx.x; c < NG * 256; c += blockDim.x) {
         if (c < d) {
-            float s = lds[c] + lds[NG * 256 + c] + lds[2 * NG * 256 + c] + lds[3 * NG * 256 + c];
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += lds[w * NG * 256 + c];
             atomicAdd(out + c, s);
         }
     }
@@ -105,11 +119,11 @@ __global__ __launch_bounds__(ROW_BLOCK) void layernorm_fwd_k(const TX* __restric
 }
 
 template <typename TDY, typename TX, typename TDX, int NG>
-__global__ __launch_bounds__(ROW_BLOCK) void layernorm_bwd_k(const TDY* __restrict__ dy, const TX* __restrict__ x,
+__global__ __launch_bounds__(RED_BLOCK) void layernorm_bwd_k(const TDY* __restrict__ dy, const TX* __restrict__ x,
         const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
         TDX* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M, int d, float p,
         const uint64_t* rng, uint32_t site, int relu_mask, int dx_accumulate, float* __restrict__ dcolsum) {
-    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
     float4 gm[NG], ag[NG], ab[NG], ac[NG];
     {
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void layernorm_bwd_k(const TDY* __restri
         for (int g = 0; g < NG; ++g) ag[g] = ab[g] = ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float invd = 1.f / (float)d;
-    ROW_LOOP(M) {
+    RED_LOOP(M) {
         float4 g_[NG], xv[NG];
         row_load<NG, TDY>(dy + row * d, d, lane, g_);
         row_load<NG, TX>(x + row * d, d, lane, xv);
@@ -205,12 +219,12 @@ __global__ __launch_bounds__(ROW_BLOCK) void add_ln_fwd_k(const float* __restric
 }
 
 template <typename T, int NG>
-__global__ __launch_bounds__(ROW_BLOCK) void add_ln_bwd_k(const float* __restrict__ ds_down, const T* __restrict__ dy,
+__global__ __launch_bounds__(RED_BLOCK) void add_ln_bwd_k(const float* __restrict__ ds_down, const T* __restrict__ dy,
         const float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ mean,
         const float* __restrict__ rstd, float* __restrict__ dr, T* __restrict__ da, float* __restrict__ dgamma,
         float* __restrict__ dbeta, int64_t M, int d, float p, const uint64_t* rng, uint32_t site,
         float* __restrict__ dcolsum) {
-    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
     float4 gm[NG], ag[NG], ab[NG], ac[NG];
     {
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void add_ln_bwd_k(const float* __restric
         for (int g = 0; g < NG; ++g) ag[g] = ab[g] = ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float invd = 1.f / (float)d;
-    ROW_LOOP(M) {
+    RED_LOOP(M) {
         float4 g_[NG], xv[NG];
         row_load<NG, T>(dy + row * d, d, lane, g_);
         row_load<NG, float>(s + row * d, d, lane, xv);
@@ -297,11 +311,11 @@ __global__ __launch_bounds__(ROW_BLOCK) void ffn_ln_fwd_k(const T* __restrict__ 
 }
 
 template <typename T, int NG>
-__global__ __launch_bounds__(ROW_BLOCK) void ffn_ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ f2,
+__global__ __launch_bounds__(RED_BLOCK) void ffn_ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ f2,
         const T* __restrict__ h, const float* __restrict__ gamma, const float* __restrict__ mean,
         const float* __restrict__ rstd, T* __restrict__ gout, float* __restrict__ dgamma, float* __restrict__ dbeta,
         int64_t M, int d, float p, const uint64_t* rng, uint32_t site, float* __restrict__ dcolsum) {
-    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
     float4 gm[NG], ag[NG], ab[NG], ac[NG];
     {
@@ -311,7 +325,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void ffn_ln_bwd_k(const T* __restrict__ 
         for (int g = 0; g < NG; ++g) ag[g] = ab[g] = ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float invd = 1.f / (float)d;
-    ROW_LOOP(M) {
+    RED_LOOP(M) {
         float4 g_[NG], xv[NG], hv[NG], ds[NG];
         row_load<NG, T>(dy + row * d, d, lane, g_);
         row_load<NG, T>(f2 + row * d, d, lane, xv);
@@ -459,16 +473,16 @@ __global__ __launch_bounds__(ROW_BLOCK) void pe_add_fwd_k(const T* __restrict__ 
 }
 
 template <typename T, int NG>
-__global__ __launch_bounds__(ROW_BLOCK) void pe_add_bwd_k(const float* __restrict__ dout, const float* __restrict__ pe,
+__global__ __launch_bounds__(RED_BLOCK) void pe_add_bwd_k(const float* __restrict__ dout, const float* __restrict__ pe,
         T* __restrict__ da, float* __restrict__ dalpha, int64_t M, int t, int d, float p, const uint64_t* rng,
         uint32_t site, float* __restrict__ dcolsum) {
-    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
     float acc = 0.f;
     float4 ac[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ROW_LOOP(M) {
+    RED_LOOP(M) {
         const int pos = (int)(row % t);
         float4 v[NG], pv[NG];
         row_load<NG, float>(dout + row * d, d, lane, v);
@@ -505,10 +519,10 @@ __global__ __launch_bounds__(ROW_BLOCK) void linear1_fwd_k(const T* __restrict__
 }
 
 template <typename T, int NG>
-__global__ __launch_bounds__(ROW_BLOCK) void linear1_bwd_k(const float* __restrict__ dout, const T* __restrict__ x,
+__global__ __launch_bounds__(RED_BLOCK) void linear1_bwd_k(const float* __restrict__ dout, const T* __restrict__ x,
         const float* __restrict__ w, const uint8_t* __restrict__ mask, T* __restrict__ dx, float* __restrict__ dw,
         float* __restrict__ db, int64_t M, int d) {
-    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
     float4 wv[NG], aw[NG];
     {
         const int lane = threadIdx.x & 63;
@@ -517,7 +531,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void linear1_bwd_k(const float* __restri
         for (int g = 0; g < NG; ++g) aw[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float ab = 0.f;
-    ROW_LOOP(M) {
+    RED_LOOP(M) {
         const float go = mask[row] ? dout[row] : 0.f;
         float4 v[NG], o[NG];
         row_load<NG, T>(x + row * d, d, lane, v);
@@ -535,12 +549,12 @@ __global__ __launch_bounds__(ROW_BLOCK) void linear1_bwd_k(const float* __restri
 
 // ================================================================ BatchNorm(batch stats) + tanh + dropout
 template <typename T, int NG>
-__global__ __launch_bounds__(ROW_BLOCK) void colstats_k(const T* __restrict__ x, int64_t M, int C, float* __restrict__ sums) {
-    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+__global__ __launch_bounds__(RED_BLOCK) void colstats_k(const T* __restrict__ x, int64_t M, int C, float* __restrict__ sums) {
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
     float4 a1[NG], a2[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) a1[g] = a2[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ROW_LOOP(M) {
+    RED_LOOP(M) {
         float4 v[NG];
         row_load<NG, T>(x + row * C, C, lane, v);
 #pragma unroll
@@ -604,12 +618,12 @@ __global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_fwd_k(const T* __restrict__
 
 // MODE 0: accumulate red[0..C) += sum dz, red[C..2C) += sum dz*xhat.   MODE 1: write dx.
 template <typename T, int NG, int MODE>
-__global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(RED_BLOCK) void bn_tanh_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
         const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
         const float* __restrict__ beta, float* __restrict__ red_io, float count, const float* __restrict__ count_dev, T* __restrict__ dx,
         float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t M, int C, float p, const uint64_t* rng,
         uint32_t site, float* __restrict__ dcolsum) {
-    __shared__ __attribute__((aligned(16))) float red[ROW_WAVES * NG * 256];
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
     float4 mu[NG], rs[NG], gm[NG], bt[NG], a1[NG], a2[NG], r0[NG], r1[NG];
     {
@@ -626,7 +640,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_bwd_k(const T* __restrict__
             for (int g = 0; g < NG; ++g) { r0[g] = scale4(r0[g], ic); r1[g] = scale4(r1[g], ic); }
         }
     }
-    ROW_LOOP(M) {
+    RED_LOOP(M) {
         float4 g_[NG], xv[NG];
         row_load<NG, T>(dy + row * C, C, lane, g_);
         row_load<NG, T>(x + row * C, C, lane, xv);
@@ -713,7 +727,7 @@ extern "C" int fs2_layernorm_bwd(const void* dy, int dy_dtype, const void* x, in
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_layernorm_bwd: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(d, NG, {
         if constexpr (NG <= 4) {
             if (dy_dtype == FS2_F32)
@@ -756,7 +770,7 @@ extern "C" int fs2_add_ln_bwd(const float* ds_down, const void* dy, int dtype, c
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_add_ln_bwd: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((add_ln_bwd_k<T, NG>), grid, block, 0, st, ds_down, (const T*)dy, s, gamma, mean, rstd, dr, (T*)da, dgamma, dbeta, M, d, p, rng, site, dcolsum);
     }); } });
@@ -786,7 +800,7 @@ extern "C" int fs2_ffn_ln_bwd(const void* dy, const void* f2, const void* h, int
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ffn_ln_bwd: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((ffn_ln_bwd_k<T, NG>), grid, block, 0, st, (const T*)dy, (const T*)f2, (const T*)h, gamma, mean, rstd, (T*)g, dgamma, dbeta, M, d, p, rng, site, dcolsum);
     }); } });
@@ -846,7 +860,7 @@ extern "C" int fs2_pe_add_bwd(const float* dout, const float* pe, void* da, int 
     const int64_t M = (int64_t)B * t;
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(da_dtype, T, {
         hipLaunchKernelGGL((pe_add_bwd_k<T, NG>), grid, block, 0, st, dout, pe, (T*)da, dalpha, M, t, d, p, rng, site, dcolsum);
     }); } });
@@ -872,7 +886,7 @@ extern "C" int fs2_linear1_bwd(const float* dout, const void* x, int dtype, cons
     CHECK_ROW("fs2_linear1_bwd", d, 1024); CHECK_DT("fs2_linear1_bwd", dtype);
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((linear1_bwd_k<T, NG>), grid, block, 0, st, dout, (const T*)x, w, mask, (T*)dx, dw, db, M, d);
     }); } });
@@ -884,7 +898,7 @@ extern "C" int fs2_colstats(const void* x, int dtype, int64_t M, int C, float* s
     CHECK_ROW("fs2_colstats", C, 1024); CHECK_DT("fs2_colstats", dtype);
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((colstats_k<T, NG>), grid, block, 0, st, (const T*)x, M, C, sums);
     }); } });
@@ -924,7 +938,7 @@ extern "C" int fs2_bn_tanh_bwd_reduce(const void* dy, const void* x, int dtype, 
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_bn_tanh_bwd_reduce: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 0>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, red, 1.f, (const float*)nullptr, (T*)nullptr, (float*)nullptr, (float*)nullptr, M, C, p, rng, site, (float*)nullptr);
     }); } });
@@ -941,7 +955,7 @@ extern "C" int fs2_bn_tanh_bwd_apply(const void* dy, const void* x, int dtype, c
     FS2_REQUIRE(count > 0.f || count_dev != nullptr, "fs2_bn_tanh_bwd_apply: count must be positive");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((bn_tanh_bwd_k<T, NG, 1>), grid, block, 0, st, (const T*)dy, (const T*)x, mean, rstd, gamma, beta, const_cast<float*>(red), count, count_dev, (T*)dx, dgamma, dbeta, M, C, p, rng, site, dcolsum);
     }); } });
