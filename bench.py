@@ -15,7 +15,7 @@ Extra objects on the JSON line:
                   their summed duration measured with HIP events on the launch stream inside the timed
                   region; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md); traffic from profiles/ if collected.
   cpu_baseline -- the oracle (CPU restatement of the reference step, kind "port") timed on this host's cores
-                  on one full config-2 batch; a reported baseline, not the target.
+                  on one config-2 batch (~10 s); a reported baseline, not the target.
 """
 import argparse
 import json
@@ -109,7 +109,7 @@ def cpu_baseline(hp, batch):
     cut = lambda n: tuple(b[:n] if torch.is_tensor(b) else b for b in batch)
     print("[cpu_baseline] warm-up step on 2 utterances ...", file=sys.stderr, flush=True)
     otrain.train_step(m, opt, 1, cut(2), hp.d_model_decoder)
-    n_utt = 12                                # bounded sample: a quarter of the config-2 batch, same padded lengths
+    n_utt = 48                                # the whole config-2 batch: ~10 s on the box's 16 cores
     sample = cut(n_utt)
     print(f"[cpu_baseline] timing 1 step on {n_utt} utterances with {cores} threads ...", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
@@ -169,7 +169,7 @@ def main():
 
     # hipGraph replay of the whole step (one graph per batch shape); the GEMM event timer needs eager launches,
     # so the roofline leg below re-runs a few eager, instrumented steps after the timed region
-    use_graph = not args.no_graph and (world == 1 or os.environ.get('FS2_GRAPH_DP', '1') == '1')
+    use_graph = not args.no_graph and (world == 1 or os.environ.get('FS2_GRAPH_DP', '0') == '1')
     graphed = GraphedTrainStep(model, opt, hp) if use_graph else None
     run = (lambda st, b: graphed(st, b)) if use_graph else (lambda st, b: train_step(model, opt, st, b, hp))
     step = 1

@@ -86,7 +86,7 @@ int fs2_gemm(const FS2Gemm* g, void* stream);
  *  mode 1 (dgrad):    dst[i*dld + j*O + o]       = src[o][i][k-1-j]
  * and the inverse for weight gradients: grad[o][i][j] += scratch[o*(k*I) + j*I + i].          */
 int fs2_cast_permute(const float* src, void* dst, int O, int I, int k, int64_t dld, int mode, int dtype, void* stream);
-int fs2_permute_add(const float* scratch, float* grad, int O, int I, int k, void* stream);
+int fs2_permute_add(float* scratch, float* grad, int O, int I, int k, int rezero_scratch, void* stream);
 int fs2_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
 /* All weight shadows of a model in ONE launch: `table` is a DEVICE array of n descriptors. */
 typedef struct FS2CastDesc {

@@ -163,10 +163,12 @@ def cast_permute(src, dst, mode):
     return dst
 
 
-def permute_add(scratch, grad):
+def permute_add(scratch, grad, rezero=False):
     g = grad if grad.dim() == 3 else grad.unsqueeze(-1)
     O, I, k = g.shape
     g += scratch.reshape(O, k, I).permute(0, 2, 1)
+    if rezero:
+        scratch.zero_()
 
 
 def cast(src, dtype, out=None):

@@ -149,13 +149,14 @@ class Runtime:
             self.shadows[key] = (tuple(p._version for p in ps) + (self.epoch,), val)
         self._table_ver = ver
 
-    def zeros(self, key, shape, dtype, device):
-        """persistent zero-filled scratch (re-zeroed on every request)"""
+    def zeros(self, key, shape, dtype, device, self_cleaning=False):
+        """persistent zero-filled scratch; re-zeroed on every request unless its consumer leaves it clean
+        (fs2_permute_add with rezero_scratch=1)"""
         buf = self.scratch.get(key)
         if buf is None or buf.shape != torch.Size(shape) or buf.dtype != dtype or buf.device != device:
             buf = torch.zeros(shape, dtype=dtype, device=device)
             self.scratch[key] = buf
-        else:
+        elif not self_cleaning:
             buf.zero_()
         return buf
 
@@ -181,9 +182,9 @@ def _conv_wgrad(rt, dy, x, conv, pad, bias_done=False):
     if k == 1:
         ops.conv_wgrad(dy, x, 1, 0, gw.view(O, I))
     else:
-        scratch = rt.zeros(("wg", O, I, k), (O, k * I), torch.float32, w.device)
+        scratch = rt.zeros(("wg", O, I, k), (O, k * I), torch.float32, w.device, self_cleaning=True)
         ops.conv_wgrad(dy, x, k, pad, scratch)
-        ops.permute_add(scratch, gw)
+        ops.permute_add(scratch, gw, rezero=True)
     if not bias_done:
         ops.colsum(dy.view(-1, O), grad_of(conv.bias))
 

@@ -215,21 +215,56 @@ __global__ __launch_bounds__(TPB) void cast_permute_k(const float* __restrict__ 
         }
     }
 }
+// One block iteration = a tile of 32 o x 32 i x k source elements staged in LDS: the source is read in contiguous
+// runs of 32*k floats per o, the shadows are written in runs of 32 contiguous elements ([o][j*I + i] or [i][j*O + o]).
 template <typename T>
 __global__ __launch_bounds__(TPB) void cast_permute_batched_k(const FS2CastDesc* __restrict__ table) {
+    __shared__ float tile[32 * (32 * 9 + 1)];
     const FS2CastDesc d = table[blockIdx.y];
     const int O = d.O, I = d.I, k = d.k;
-    const int64_t n = (int64_t)O * I * k;
     const float* __restrict__ src = d.src;
-    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
-        if (d.mode == 0) {
-            const int i = (int)(e % I); const int j = (int)((e / I) % k); const int o = (int)(e / ((int64_t)I * k));
-            reinterpret_cast<T*>(d.dst)[(int64_t)o * d.dld + (int64_t)j * I + i] = from_f32<T>(src[((int64_t)o * I + i) * k + j]);
-        } else if (d.mode == 1) {
-            const int o = (int)(e % O); const int j = (int)((e / O) % k); const int i = (int)(e / ((int64_t)O * k));
-            reinterpret_cast<T*>(d.dst)[(int64_t)i * d.dld + (int64_t)j * O + o] = from_f32<T>(src[((int64_t)o * I + i) * k + (k - 1 - j)]);
-        } else {
+    if (d.mode == 2) {
+        const int64_t n = (int64_t)O * I * k;
+        for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB)
             reinterpret_cast<float*>(d.dst)[e] = src[e];
+        return;
+    }
+    if (k > 9) {    // generic fallback (no conv of this model has more than 9 taps)
+        const int64_t n = (int64_t)O * I * k;
+        for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
+            if (d.mode == 0) {
+                const int i = (int)(e % I); const int j = (int)((e / I) % k); const int o = (int)(e / ((int64_t)I * k));
+                reinterpret_cast<T*>(d.dst)[(int64_t)o * d.dld + (int64_t)j * I + i] = from_f32<T>(src[((int64_t)o * I + i) * k + j]);
+            } else {
+                const int o = (int)(e % O); const int j = (int)((e / O) % k); const int i = (int)(e / ((int64_t)O * k));
+                reinterpret_cast<T*>(d.dst)[(int64_t)i * d.dld + (int64_t)j * O + o] = from_f32<T>(src[((int64_t)o * I + i) * k + (k - 1 - j)]);
+            }
+        }
+        return;
+    }
+    const int to = (O + 31) / 32, ti = (I + 31) / 32;
+    const int run = 32 * k, ldt = run + 1;                 // +1: the transposed reads below hit distinct banks
+    for (int t = blockIdx.x; t < to * ti; t += gridDim.x) {
+        const int o0 = (t / ti) * 32, i0 = (t % ti) * 32;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * run; e += TPB) {
+            const int oo = e / run, r = e % run;           // r = ii*k + j
+            const int o = o0 + oo, i = i0 + r / k;
+            tile[oo * ldt + r] = (o < O && i < I) ? src[((int64_t)o * I + i0) * k + r] : 0.f;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * run; e += TPB) {
+            if (d.mode == 0) {          // dst[o][j*I + i]: 32 consecutive i per (o, j)
+                const int ii = e % 32, j = (e / 32) % k, oo = e / (32 * k);
+                const int o = o0 + oo, i = i0 + ii;
+                if (o < O && i < I)
+                    reinterpret_cast<T*>(d.dst)[(int64_t)o * d.dld + (int64_t)j * I + i] = from_f32<T>(tile[oo * ldt + ii * k + j]);
+            } else {                    // dst[i][j*O + o]: 32 consecutive o per (i, j), taps flipped
+                const int oo = e % 32, j = (e / 32) % k, ii = e / (32 * k);
+                const int o = o0 + oo, i = i0 + ii;
+                if (o < O && i < I)
+                    reinterpret_cast<T*>(d.dst)[(int64_t)i * d.dld + (int64_t)j * O + o] = from_f32<T>(tile[oo * ldt + ii * k + (k - 1 - j)]);
+            }
         }
     }
 }
@@ -243,12 +278,14 @@ __global__ __launch_bounds__(TPB) void onehot_k(const int32_t* __restrict__ idx,
                                                      c + 3 == hot ? 1.f : 0.f));
     }
 }
-__global__ __launch_bounds__(TPB) void permute_add_k(const float* __restrict__ scratch, float* __restrict__ grad, int O,
-        int I, int k) {
+__global__ __launch_bounds__(TPB) void permute_add_k(float* __restrict__ scratch, float* __restrict__ grad, int O,
+        int I, int k, int rezero) {
     const int64_t n = (int64_t)O * I * k;
     for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < n; e += (int64_t)gridDim.x * TPB) {
         const int j = (int)(e % k); const int i = (int)((e / k) % I); const int o = (int)(e / ((int64_t)I * k));
-        grad[e] += scratch[((int64_t)o * k + j) * I + i];
+        const int64_t si = ((int64_t)o * k + j) * I + i;
+        grad[e] += scratch[si];
+        if (rezero) scratch[si] = 0.f;     // each scratch element is read exactly once: leave it zeroed for the next user
     }
 }
 
@@ -260,11 +297,20 @@ __global__ __launch_bounds__(TPB) void colsum_k(const T* __restrict__ x, int64_t
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 256 + lane * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (col < N)
-        for (int64_t r = (int64_t)blockIdx.y * 4 + wave; r < M; r += (int64_t)gridDim.y * 4) {
+    if (col < N) {
+        const int64_t stride = (int64_t)gridDim.y * 4;
+        int64_t r = (int64_t)blockIdx.y * 4 + wave;
+        for (; r + 3 * stride < M; r += 4 * stride) {       // 4 independent row loads in flight
+            const float4 v0 = load4<T>(x + r * ldx + col), v1 = load4<T>(x + (r + stride) * ldx + col);
+            const float4 v2 = load4<T>(x + (r + 2 * stride) * ldx + col), v3 = load4<T>(x + (r + 3 * stride) * ldx + col);
+            acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+            acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; r < M; r += stride) {
             const float4 v = load4<T>(x + r * ldx + col);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+    }
     *reinterpret_cast<float4*>(red + wave * 256 + lane * 4) = acc;
     __syncthreads();
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -430,7 +476,7 @@ extern "C" int fs2_cast_permute(const float* src, void* dst, int O, int I, int k
 extern "C" int fs2_cast_permute_batched(const FS2CastDesc* table, int n, int dtype, void* stream) {
     CHECK_DT("fs2_cast_permute_batched", dtype);
     FS2_REQUIRE(table != nullptr && n > 0 && n <= 65535, "fs2_cast_permute_batched: bad table");
-    dim3 grid(64, (unsigned)n);
+    dim3 grid(96, (unsigned)n);
     T_DISPATCH(dtype, T, { hipLaunchKernelGGL((cast_permute_batched_k<T>), grid, dim3(TPB), 0, (hipStream_t)stream, table); });
     FS2_CHECK_LAUNCH("fs2_cast_permute_batched");
     return FS2_OK;
@@ -443,10 +489,10 @@ extern "C" int fs2_onehot(const int32_t* idx, void* out, int dtype, int64_t M, i
     FS2_CHECK_LAUNCH("fs2_onehot");
     return FS2_OK;
 }
-extern "C" int fs2_permute_add(const float* scratch, float* grad, int O, int I, int k, void* stream) {
+extern "C" int fs2_permute_add(float* scratch, float* grad, int O, int I, int k, int rezero, void* stream) {
     FS2_REQUIRE(O > 0 && I > 0 && k > 0, "fs2_permute_add: bad shape");
     const int64_t n = (int64_t)O * I * k;
-    hipLaunchKernelGGL(permute_add_k, dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, scratch, grad, O, I, k);
+    hipLaunchKernelGGL(permute_add_k, dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, scratch, grad, O, I, k, rezero);
     FS2_CHECK_LAUNCH("fs2_permute_add");
     return FS2_OK;
 }

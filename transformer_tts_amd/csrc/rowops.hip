@@ -383,11 +383,15 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd_k(T* __restrict__ s, T*
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             float* e = &v[g].x;
+            unsigned mk4 = 0x01010101u;               // 4 key-mask bytes in one load when the group is fully inside
+            const bool whole = GCOL(g) + 4 <= t && ((reinterpret_cast<uintptr_t>(km) + GCOL(g)) & 3) == 0;
+            if (whole) mk4 = *reinterpret_cast<const unsigned*>(km + GCOL(g));
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int j = GCOL(g) + c;
                 if (j < t) {
-                    if (km[j] == 0) e[c] = -1e4f;     // masked_fill(mask == 0, -1e4) on keys
+                    const bool keep = whole ? ((mk4 >> (8 * c)) & 0xFFu) != 0 : km[j] != 0;
+                    if (!keep) e[c] = -1e4f;          // masked_fill(mask == 0, -1e4) on keys
                     mx = fmaxf(mx, e[c]);
                 } else e[c] = -3.0e38f;
             }
@@ -495,8 +499,16 @@ __global__ __launch_bounds__(RED_BLOCK) void pe_add_bwd_k(const float* __restric
         }
         if (da != nullptr) row_store<NG, T>(da + row * d, d, lane, v);
     }
+    // one atomic per BLOCK on the single dalpha word (8192 per-wave atomics on one address serialise: ~100 us)
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(dalpha, acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        atomicAdd(dalpha, t);
+    }
     if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
 }
 
@@ -544,7 +556,14 @@ __global__ __launch_bounds__(RED_BLOCK) void linear1_bwd_k(const float* __restri
         if (lane == 0) ab += go;
     }
     flush_channel_sums<NG>(aw, dw, d, red);
-    if ((threadIdx.x & 63) == 0 && ab != 0.f) atomicAdd(db, ab);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ab;      // one atomic per block on the single db word
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+        atomicAdd(db, t);
+    }
 }
 
 // ================================================================ BatchNorm(batch stats) + tanh + dropout

@@ -45,7 +45,7 @@ _P, _I, _L, _F, _U32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_f
 SIGNATURES = {
     "fs2_gemm": [ctypes.POINTER(FS2Gemm), _P],
     "fs2_cast_permute": [_P, _P, _I, _I, _I, _L, _I, _I, _P],
-    "fs2_permute_add": [_P, _P, _I, _I, _I, _P],
+    "fs2_permute_add": [_P, _P, _I, _I, _I, _I, _P],
     "fs2_cast": [_P, _I, _P, _I, _L, _P],
     "fs2_cast_permute_batched": [_P, _I, _I, _P],
     "fs2_onehot": [_P, _P, _I, _L, _I, _P],
@@ -293,11 +293,11 @@ def cast_permute(src, dst, mode):
     return dst
 
 
-def permute_add(scratch, grad):
-    """grad (O,I,k) fp32 += scratch (O, k*I) laid out [o][j*I+i]"""
+def permute_add(scratch, grad, rezero=False):
+    """grad (O,I,k) fp32 += scratch (O, k*I) laid out [o][j*I+i]; rezero: leave the scratch zero-filled"""
     O, I = grad.shape[0], grad.shape[1]
     k = grad.shape[2] if grad.dim() == 3 else 1
-    _check(lib().fs2_permute_add(_p(_c(scratch)), _p(_c(grad)), O, I, k, _stream()), "fs2_permute_add")
+    _check(lib().fs2_permute_add(_p(_c(scratch)), _p(_c(grad)), O, I, k, int(rezero), _stream()), "fs2_permute_add")
 
 
 def cast(src, dtype, out=None):
