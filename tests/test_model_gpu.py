@@ -163,3 +163,32 @@ def test_dropout_statistics_and_replay():
     assert not torch.equal(out2[8], out[8])
     out3, _, _ = fwd_bwd(model, hp, batch)
     assert torch.equal(out3[8], out2[8]), "same rng offset -> same masks (deterministic replay)"
+
+
+def test_hipgraph_replay_equals_eager_training():
+    """GraphedTrainStep (one captured hipGraph per batch shape, weight gradients on a second stream) must follow the
+    eager trainer exactly: same Philox dropout streams, same kernels -> same losses and parameters (up to the
+    order of float atomics in the weight-gradient / reduction kernels)."""
+    from transformer_tts_amd import synthetic
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep, train_step
+    batches = [synthetic.make_batch(100 + (i % 2), 4, l_range=(9, 20), dur_range=(1, 9), vocab=60) for i in range(6)]
+    results = []
+    from transformer_tts_amd.Models import functional
+    for use_graph in (False, True):
+        functional._site_counter[0] = 1000      # same dropout call-site ids (= Philox streams) for both models
+        model, hp, _ = product_model("small", amp=False, dropout=0.1, device="cuda")
+        opt = FusedAdam(model)
+        stepper = GraphedTrainStep(model, opt, hp) if use_graph else None
+        losses = []
+        for i, b in enumerate(batches):
+            b = batch_to(b, "cuda")
+            out = stepper(4000 + i, b) if use_graph else train_step(model, opt, 4000 + i, b, hp)
+            losses.append(out[0].item())
+        if use_graph:
+            assert len(stepper.graphs) == 2, "two batch shapes -> two captured graphs"
+        results.append((losses, opt.arena.p.clone()))
+    np.testing.assert_allclose(results[0][0], results[1][0], rtol=1e-5)
+    diff = (results[0][1] - results[1][1]).abs()
+    bad = diff > (2e-5 + 2e-4 * results[0][1].abs())
+    assert float(bad.float().mean()) < 1e-3 and float(diff.max()) < 5e-3, (int(bad.sum()), float(diff.max()))

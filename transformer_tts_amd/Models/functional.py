@@ -10,6 +10,7 @@ optimizer is ``FusedAdam``), so the Functions return None for their parameter in
 Layout: activations are channels-last (B, t, C); `T` below is the compute dtype (torch.bfloat16 in
 bf16 mode, torch.float32 in the exact-fp32 parity mode); the residual stream is always fp32.
 """
+import contextlib
 import math
 
 import torch
@@ -38,6 +39,12 @@ class Runtime:
         self.scratch = {}
         self.dp = None           # parallel.DataParallel or None
         self.return_attn = True
+        # weight-gradient GEMMs (and their scratch handling) run on a second HIP stream, concurrently with the
+        # data-gradient chain of the same backward: they only feed the optimizer
+        self.overlap_wgrad = True
+        self._side = None
+        self._side_dirty = False
+        self._keep = []
 
     def get_rng(self, device):
         if self.rng is None:
@@ -46,6 +53,26 @@ class Runtime:
 
     def invalidate(self):
         self.epoch += 1
+
+    # ---- second stream for weight gradients
+    def side(self, *reads):
+        """context manager: work launched inside runs on the side stream, after everything already enqueued on the
+        current stream (so `reads` are complete); `reads` are kept alive until side_join()"""
+        if not self.overlap_wgrad or not reads or not reads[0].is_cuda:
+            return contextlib.nullcontext()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=reads[0].device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        self._keep.extend(reads)
+        self._side_dirty = True
+        return torch.cuda.stream(self._side)
+
+    def side_join(self):
+        """the current stream waits for all side-stream work (call before the gradients are consumed)"""
+        if self._side_dirty:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_dirty = False
+            self._keep.clear()
 
     # ---- weight shadows: fp32 master (reference layout) -> compute dtype, kernel layout
     def _cached(self, key, params, build):
@@ -179,20 +206,22 @@ def _conv_wgrad(rt, dy, x, conv, pad, bias_done=False):
     w = conv.weight
     O, I, k = w.shape
     gw = grad_of(w)
-    if k == 1:
-        ops.conv_wgrad(dy, x, 1, 0, gw.view(O, I))
-    else:
-        scratch = rt.zeros(("wg", O, I, k), (O, k * I), torch.float32, w.device, self_cleaning=True)
-        ops.conv_wgrad(dy, x, k, pad, scratch)
-        ops.permute_add(scratch, gw, rezero=True)
-    if not bias_done:
-        ops.colsum(dy.view(-1, O), grad_of(conv.bias))
+    with rt.side(dy, x):
+        if k == 1:
+            ops.conv_wgrad(dy, x, 1, 0, gw.view(O, I))
+        else:
+            scratch = rt.zeros(("wg", O, I, k), (O, k * I), torch.float32, w.device, self_cleaning=True)
+            ops.conv_wgrad(dy, x, k, pad, scratch)
+            ops.permute_add(scratch, gw, rezero=True)
+        if not bias_done:
+            ops.colsum(dy.view(-1, O), grad_of(conv.bias))
 
 
-def _linear_wgrad(dy2, x2, lin, bias_done=False):
-    ops.wgrad(dy2, x2, grad_of(lin.weight))
-    if not bias_done:
-        ops.colsum(dy2, grad_of(lin.bias))
+def _linear_wgrad(rt, dy2, x2, lin, bias_done=False):
+    with rt.side(dy2, x2):
+        ops.wgrad(dy2, x2, grad_of(lin.weight))
+        if not bias_done:
+            ops.colsum(dy2, grad_of(lin.bias))
 
 
 def _tp(t):
@@ -307,7 +336,7 @@ class EncoderStackFunction(torch.autograd.Function):
             dx, da = ops.add_ln_bwd(dx1, dh2, L["x1"], n2.weight.detach(), L["m2"], L["r2"], grad_of(n2.weight),
                                     grad_of(n2.bias), p, rng, layer.site_res1, dcolsum=grad_of(at.out.bias))
             da2 = da.view(M, d)
-            _linear_wgrad(da2, L["O"].view(M, d), at.out, bias_done=True)
+            _linear_wgrad(rt, da2, L["O"].view(M, d), at.out, bias_done=True)
             dO = ops.linear(da2, rt.w_dgrad(at.out.weight))
             dO4 = dO.view(B, t, H, dk).permute(0, 2, 1, 3)
             qkv = L["qkv"]
@@ -323,8 +352,14 @@ class EncoderStackFunction(torch.autograd.Function):
             ops.bmm(dP, k, dq, trans_b=False, alpha=scale)                    # dQ = dS K / sqrt(dk)
             ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale)     # dK = dS^T Q / sqrt(dk)
             dqkv2, h2d = dqkv.view(M, 3 * d), L["h"].view(M, d)
+            # bias gradients of q/k/v: ONE pass over dqkv into a 3d-vector, then three d-sized adds
+            with rt.side(dqkv2):
+                bsum = rt.zeros(("qkvb", d), (3 * d,), torch.float32, dev)
+                ops.colsum(dqkv2, bsum)
+                for j, lin in enumerate((at.q_linear, at.k_linear, at.v_linear)):
+                    ops.colsum(bsum[j * d:(j + 1) * d].view(1, d), grad_of(lin.bias))
             for j, lin in enumerate((at.q_linear, at.k_linear, at.v_linear)):
-                _linear_wgrad(dqkv2[:, j * d:(j + 1) * d], h2d, lin)
+                _linear_wgrad(rt, dqkv2[:, j * d:(j + 1) * d], h2d, lin, bias_done=True)
             _, wd, _ = rt.qkv(at)
             dh = ops.linear(dqkv2, wd).view(B, t, d)
 
@@ -338,8 +373,9 @@ class EncoderStackFunction(torch.autograd.Function):
             dsrc = None
         else:
             da0 = ops.pe_add_bwd(dx0, pe, T, grad_of(enc.pe.alpha), p, rng, enc.pe.site, dcolsum=grad_of(enc.embed.bias))
-            _linear_wgrad(da0.view(M, d), src.reshape(M, -1), enc.embed, bias_done=True)
+            _linear_wgrad(rt, da0.view(M, d), src.reshape(M, -1), enc.embed, bias_done=True)
             dsrc = ops.linear(da0.view(M, d), rt.w_dgrad(enc.embed.weight)).view(src.shape)
+        rt.side_join()
         if rt.dp is not None:
             rt.dp.grads_ready(enc)
         return (None, dsrc, None) + (None,) * (len(ctx.needs_input_grad) - 3)
@@ -384,6 +420,7 @@ class VariancePredictorFunction(torch.autograd.Function):
                                 grad_of(l1.bias), p, rng, mod.site1, relu_mask=True, dcolsum=grad_of(mod.conv1.bias))
         _conv_wgrad(rt, dz1, s["x"], mod.conv1, 1, bias_done=True)
         dx = ops.conv(dz1, rt.w_dgrad(mod.conv1.weight), 3, 1)
+        rt.side_join()
         return (None, dx, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
@@ -421,9 +458,13 @@ class BucketEmbedAddFunction(torch.autograd.Function):
         # dE[bucket] = sum of the rows that selected it = onehot(idx)^T @ dout: an MFMA weight-gradient GEMM instead of
         # 2 x M x d float atomics that pile up on a few rows (padded frames all select bucket 0)
         d2 = dout.view(-1, dout.shape[-1])
-        for j, emb in enumerate((va.pitch_embedding, va.energy_embedding)):
-            oh = ops.onehot(ctx.idx[j], emb.weight.shape[0], dout.dtype)
-            ops.wgrad(oh, d2, grad_of(emb.weight))
+        rt = va.rt
+        with rt.side(d2, ctx.idx):
+            for j, emb in enumerate((va.pitch_embedding, va.energy_embedding)):
+                oh = ops.onehot(ctx.idx[j], emb.weight.shape[0], dout.dtype)
+                rt._keep.append(oh)
+                ops.wgrad(oh, d2, grad_of(emb.weight))
+        rt.side_join()
         return (None, dout, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
@@ -513,8 +554,9 @@ class PostNetFunction(torch.autograd.Function):
                 continue
             term = term.contiguous()
             term_T = (term if T == torch.float32 else ops.cast(term, T)).view(M, -1)
-            _linear_wgrad(term_T, x2, mod.out)
+            _linear_wgrad(rt, term_T, x2, mod.out)
             dx = ops.linear(term_T, rt.w_dgrad(mod.out.weight), residual=dx)
+        rt.side_join()
         if rt.dp is not None:
             rt.dp.grads_ready(mod)
         return (None, None if dx is None else dx.view(B, t, d)) + (None,) * (len(ctx.needs_input_grad) - 2)
