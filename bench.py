@@ -193,8 +193,9 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if use_graph:       # roofline leg: the same kernels, launched eagerly with a HIP event pair around every GEMM
-        timer.install()
+    if use_graph:       # roofline leg: the same kernels, launched eagerly with a HIP event pair around every GEMM;
+        timer.install() # one stream only, so that a kernel's event pair times that kernel alone
+        model.rt.overlap_wgrad = False
         for i in range(min(args.steps, POOL)):
             train_step(model, opt, step, pool[i % POOL], hp)
             step += 1

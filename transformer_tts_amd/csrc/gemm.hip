@@ -93,7 +93,7 @@ template <int TM> struct Geo {
 
 // one work item: output tile (m0,n0) of batch (b1,b2), k-stages [it0,it1)
 struct Work {
-    int m0, n0, split, b2, it0, it1;
+    int m0, n0, split, b1, b2, it0, it1;
     int64_t aoff, boff, coff;
 };
 
@@ -120,17 +120,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
     const int per = (ntot + p.split_k - 1) / p.split_k;        // the host guarantees no empty split
     const int seq = p.seq_len;
 
-    auto make_work = [&](int w) {
+    // Work items are numbered tile-fastest (n, then m), then k-split, then batch; a block owns the CONTIGUOUS range
+    // [wbeg, wend): neighbouring tiles share operand panels in L2, and stepping to the next item is a few scalar
+    // increments instead of six integer divisions.
+    const int wbeg = (int)((int64_t)blockIdx.x * total_work / gridDim.x);
+    const int wend = (int)((int64_t)(blockIdx.x + 1) * total_work / gridDim.x);
+    auto set_batch = [&](Work& k) {
+        k.aoff = k.b1 * p.sA1 + k.b2 * p.sA2; k.boff = k.b1 * p.sB1 + k.b2 * p.sB2; k.coff = k.b1 * p.sC1 + k.b2 * p.sC2;
+        k.it0 = k.split * per; k.it1 = min(ntot, k.it0 + per);
+    };
+    auto first_work = [&](int w) {
         Work k;
         const int lin = w % tiles;
         int z = w / tiles;
         k.split = z % p.split_k; z /= p.split_k;
         k.b2 = z % p.batch2;
-        const int b1 = z / p.batch2;
+        k.b1 = z / p.batch2;
         k.m0 = (lin / tilesN) * TM; k.n0 = (lin % tilesN) * TM;
-        k.aoff = b1 * p.sA1 + k.b2 * p.sA2; k.boff = b1 * p.sB1 + k.b2 * p.sB2; k.coff = b1 * p.sC1 + k.b2 * p.sC2;
-        k.it0 = k.split * per; k.it1 = min(ntot, k.it0 + per);
+        set_batch(k);
         return k;
+    };
+    auto next_work = [&](Work& k) {
+        k.n0 += TM;
+        if (k.n0 >= p.N) {
+            k.n0 = 0; k.m0 += TM;
+            if (k.m0 >= p.M) {
+                k.m0 = 0;
+                if (++k.split == p.split_k) { k.split = 0; if (++k.b2 == p.batch2) { k.b2 = 0; ++k.b1; } }
+                set_batch(k);
+            }
+        }
     };
 
     // ---- per-thread, tile-independent staging coordinates and LDS addresses (hoisted out of every loop)
@@ -164,12 +183,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
     u32x4 ra[D][NCH], rb[D][NCH];
 
     // ---- LOAD cursor: the next stage to fetch, possibly several stages / one work item ahead of the compute cursor
-    int lw = blockIdx.x;
-    Work lk = make_work(lw < total_work ? lw : 0);
+    int lw = wbeg;
+    if (lw >= wend) return;
+    Work lk = first_work(lw);
     int lit = lk.it0;
+    int ltap, lkb;                     // tap and k offset of the next stage to load (advanced incrementally)
     unsigned offA[NCH], offB[NCH];     // voffset of the chunk at k = 0, tap shift 0 of work lk (OOB if the row is outside)
     int tA[NCH];                       // conv: position of the row inside its sequence
+    __amdgpu_buffer_rsrc_t rsA, rsB;   // buffer descriptors of work lk (rebuilt only when the batch changes)
+    const bool plain = (p.conv == 0) && (p.K % BK == 0) && (Kb == p.K);   // no per-stage validity: zero VALU per load
     auto prep_work = [&](const Work& k) {
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.A) + k.aoff), 0, 0x7FFFFFF0, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const T*>(p.B) + k.boff), 0, 0x7FFFFFF0, 0x00020000);
+        ltap = (p.conv == 1) ? k.it0 / nkt : 0;
+        lkb = (k.it0 - ltap * nkt) * BK;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             if constexpr (!AKM) {
@@ -192,51 +219,58 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
     };
     auto issue_load = [&](auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        if (lw >= total_work) return;
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(reinterpret_cast<const T*>(p.A) + lk.aoff), 0, 0x7FFFFFF0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(reinterpret_cast<const T*>(p.B) + lk.boff), 0, 0x7FFFFFF0, 0x00020000);
-        const int it = lit;
-        const int tap = (p.conv == 1) ? it / nkt : 0;
-        const int kb = (it - tap * nkt) * BK;
-        const int shiftA = (p.conv == 1) ? tap - p.pad : 0;
-        const int shiftB = (p.conv == 2) ? (lk.b2 - p.pad) : 0;
-        // wave-uniform byte advance of this stage (may be negative for conv taps left of the centre: added per lane)
-        const int sA = AKM ? kb * lda * ES : (shiftA * lda + kb) * ES;
-        const int sB = BKM ? (kb + shiftB) * ldb * ES : (tap * p.K + kb) * ES;
+        if (lw >= wend) return;
+        const int kb = lkb, tap = ltap;
+        if (plain) {
+            // wave-uniform, non-negative byte advance of this stage -> the scalar offset operand; the per-lane offsets
+            // (row validity already folded in as OOB) are untouched: no VALU at all
+            const int sA = AKM ? kb * lda * ES : kb * ES;
+            const int sB = BKM ? kb * ldb * ES : kb * ES;
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            bool ok = offA[i] != OOB;
-            if constexpr (!AKM) {
-                ok = ok && (kb + a_ch[i] * EPC < p.K);
-                if (p.conv == 1) { const int tt = tA[i] + shiftA; ok = ok && (tt >= 0) && (tt < seq); }
-            } else {
-                ok = ok && (kb + a_row[i] < p.K);
-            }
-            ra[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? offA[i] + (unsigned)sA : OOB, 0, 0);
-        }
+            for (int i = 0; i < NCH; ++i) ra[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, offA[i], sA, 0);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            bool ok = offB[i] != OOB;
-            if constexpr (!BKM) {
-                ok = ok && (kb + b_ch[i] * EPC < p.K);
-            } else {
-                const int kk = kb + b_row[i];
-                ok = ok && (kk < Kb);
-                if (p.conv == 2) { const int tt = (kk % seq) + shiftB; ok = ok && (tt >= 0) && (tt < seq); }
+            for (int i = 0; i < NCH; ++i) rb[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, offB[i], sB, 0);
+        } else {
+            const int shiftA = (p.conv == 1) ? tap - p.pad : 0;
+            const int shiftB = (p.conv == 2) ? (lk.b2 - p.pad) : 0;
+            // byte advance of this stage; may be negative for conv taps left of the centre -> added per lane
+            const int sA = AKM ? kb * lda * ES : (shiftA * lda + kb) * ES;
+            const int sB = BKM ? (kb + shiftB) * ldb * ES : (tap * p.K + kb) * ES;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                bool ok = offA[i] != OOB;
+                if constexpr (!AKM) {
+                    ok = ok && (kb + a_ch[i] * EPC < p.K);
+                    if (p.conv == 1) { const int tt = tA[i] + shiftA; ok = ok && (tt >= 0) && (tt < seq); }
+                } else {
+                    ok = ok && (kb + a_row[i] < p.K);
+                }
+                ra[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? offA[i] + (unsigned)sA : OOB, 0, 0);
             }
-            rb[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? offB[i] + (unsigned)sB : OOB, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                bool ok = offB[i] != OOB;
+                if constexpr (!BKM) {
+                    ok = ok && (kb + b_ch[i] * EPC < p.K);
+                } else {
+                    const int kk = kb + b_row[i];
+                    ok = ok && (kk < Kb);
+                    if (p.conv == 2) { const int tt = (kk % seq) + shiftB; ok = ok && (tt >= 0) && (tt < seq); }
+                }
+                rb[SLOT][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, ok ? offB[i] + (unsigned)sB : OOB, 0, 0);
+            }
         }
-        // advance the load cursor
+        // advance the load cursor (no divisions)
+        lkb += BK;
+        if (lkb >= p.K) { lkb = 0; ++ltap; }
         if (++lit == lk.it1) {
-            lw += gridDim.x;
-            if (lw < total_work) { lk = make_work(lw); prep_work(lk); lit = lk.it0; }
+            if (++lw < wend) { next_work(lk); prep_work(lk); lit = lk.it0; }
         }
     };
-    auto store_stage = [&](auto slot_c, int buf) {
+    auto store_stage = [&](auto slot_c, auto buf_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        unsigned char* la = smem + buf * 2 * G::STAGE;
+        constexpr int BUF = decltype(buf_c)::value;      // compile-time: the LDS addresses are lane offset + immediate
+        unsigned char* la = smem + BUF * 2 * G::STAGE;
         unsigned char* lb = la + G::STAGE;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -245,17 +279,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
         }
     };
 
-    if (lw >= total_work) return;
     // number of stages this block will run through (all its work items)
     int nst = 0;
-    for (int w = blockIdx.x; w < total_work; w += gridDim.x) {
-        const int sp = (w / tiles) % p.split_k;
-        nst += min(ntot, sp * per + per) - sp * per;
+    {
+        int sp = (wbeg / tiles) % p.split_k, lin = wbeg % tiles;
+        for (int w = wbeg; w < wend; ++w) {
+            nst += min(ntot, sp * per + per) - sp * per;
+            if (++lin == tiles) { lin = 0; if (++sp == p.split_k) sp = 0; }
+        }
     }
     prep_work(lk);
 
     // ---- COMPUTE cursor
-    int cw = blockIdx.x;
+    int cw = wbeg;
     Work ck = lk;
     int cit = ck.it0;
     f32x4 acc[NI][NI];
@@ -370,9 +406,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
     // stage, move stage s+1 from registers to LDS
     auto step = [&](auto slot_c, auto next_c, int s) {
         constexpr int SLOT = decltype(slot_c)::value;   // = s % D: the register set that held stage s (free now)
-        const int buf = s & 1;
+        constexpr int BUF = SLOT & 1;                   // = s % 2 (D is even): compile-time LDS buffer
         if (s + D < nst) issue_load(slot_c);
-        const unsigned char* la = smem + buf * 2 * G::STAGE;
+        const unsigned char* la = smem + BUF * 2 * G::STAGE;
         const unsigned char* lb = la + G::STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -396,14 +432,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
         }
         if (++cit == ck.it1) {          // last stage of this work item
             epilogue();
-            cw += gridDim.x;
-            if (cw < total_work) { ck = make_work(cw); cit = ck.it0; }
+            if (++cw < wend) { next_work(ck); cit = ck.it0; }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (s + 1 < nst) store_stage(next_c, buf ^ 1);
+        if (s + 1 < nst) store_stage(next_c, IC<(BUF ^ 1)>{});
         __syncthreads();
     };
 
@@ -411,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
     issue_load(IC<0>{});
     if constexpr (D > 1) { if (1 < nst) issue_load(IC<1>{}); }
     if constexpr (D > 2) { if (2 < nst) issue_load(IC<2>{}); if (3 < nst) issue_load(IC<3>{}); }
-    store_stage(IC<0>{}, 0);
+    store_stage(IC<0>{}, IC<0>{});
     __syncthreads();
 
     int s = 0;
