@@ -146,9 +146,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the product has no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dp = os.environ.get("FS2_FORCE_DP", "0") == "1"      # exercise the RCCL path with a 1-rank group (testing)
+    if world > 1 or force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     ops.lib()
 
     hp = bench_hp(amp=not args.fp32)
@@ -158,7 +161,7 @@ def main():
     model.train()
     model = model.to(dev)
     opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=1.0)
-    if world > 1:
+    if world > 1 or force_dp:
         from transformer_tts_amd.parallel import DataParallel
         opt.dp = DataParallel(model, opt.arena)
 
@@ -169,7 +172,7 @@ def main():
 
     # hipGraph replay of the whole step (one graph per batch shape); the GEMM event timer needs eager launches,
     # so the roofline leg below re-runs a few eager, instrumented steps after the timed region
-    use_graph = not args.no_graph and (world == 1 or os.environ.get('FS2_GRAPH_DP', '0') == '1')
+    use_graph = not args.no_graph and ((world == 1 and not force_dp) or os.environ.get('FS2_GRAPH_DP', '0') == '1')
     graphed = GraphedTrainStep(model, opt, hp) if use_graph else None
     run = (lambda st, b: graphed(st, b)) if use_graph else (lambda st, b: train_step(model, opt, st, b, hp))
     step = 1
@@ -242,7 +245,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

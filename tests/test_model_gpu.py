@@ -192,3 +192,41 @@ def test_hipgraph_replay_equals_eager_training():
     diff = (results[0][1] - results[1][1]).abs()
     bad = diff > (2e-5 + 2e-4 * results[0][1].abs())
     assert float(bad.float().mean()) < 1e-3 and float(diff.max()) < 5e-3, (int(bad.sum()), float(diff.max()))
+
+
+def test_long_sequences_and_wide_model_vs_oracle():
+    """t > 1024 (8-group softmax rows, many key tiles), L_pad > 128, d_model 128 with 4 heads of 32: the oracle and
+    the HIP path on a batch no fixture covers (exact-fp32 mode)."""
+    from types import SimpleNamespace
+    from golden_configs import _BASE
+    from oracle import train as otrain
+    from oracle.model import FastSpeech2 as OracleFS2
+    from transformer_tts_amd import synthetic
+    from transformer_tts_amd.train_fastspeech2 import build_model
+    from transformer_tts_amd.utils.utils import fill_variables
+    d = dict(_BASE)
+    d.update(vocab_size=50, batch_size=2, d_model_encoder=128, n_layer_encoder=1, n_head_encoder=4,
+             ff_conv_kernel_size_encoder=5, d_model_decoder=128, n_layer_decoder=1, n_head_decoder=4,
+             ff_conv_kernel_size_decoder=3, dropout=0.0, dropout_variance_adaptor=0.0)
+    hp = SimpleNamespace(**d)
+    fill_variables(hp, verbose=False)
+    torch.manual_seed(3)
+    omodel = OracleFS2.from_hp(hp, dropout=0.0, dropout_postnet=0.0, dropout_variance_adaptor=0.0)
+    omodel.train()
+    model = build_model(hp)
+    model.postnet.dropout = 0.0
+    model.load_state_dict(omodel.state_dict())
+    model = model.cuda().train()
+    batch = synthetic.make_batch(77, 2, l_range=(150, 171), dur_range=(5, 11), vocab=50)
+    assert batch[1].shape[1] > 1024 and batch[0].shape[1] > 128
+    out, total, parts = fwd_bwd(model, hp, batch_to(batch, "cuda"))
+    ototal, _, oout = otrain.forward_backward(omodel, batch)
+    for n, a, b in zip(OUT_NAMES[:7], out[:7], oout[:7]):
+        torch.testing.assert_close(a.detach().float().cpu(), b.detach(), rtol=2e-3, atol=5e-4, msg=lambda m: f"{n}: {m}")
+    for n, a, b in zip(OUT_NAMES[7:9], out[7:9], oout[7:9]):
+        torch.testing.assert_close(a.detach().float().cpu(), b.detach(), rtol=2e-3, atol=2e-5, msg=lambda m: f"{n}: {m}")
+    assert abs(total.item() - ototal.item()) <= 5e-5 * abs(ototal.item())
+    og = dict(omodel.named_parameters())
+    for k, p in model.named_parameters():
+        g = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
+        torch.testing.assert_close(p.grad.cpu(), g, rtol=1e-2, atol=2e-4, msg=lambda m: f"grad {k}: {m}")

@@ -28,6 +28,9 @@ for step in "$@"; do
     pmcbench) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
              run pmcb1 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcb1 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph
              run pmcb2 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcb2 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph ;;
+    benchdp) FS2_FORCE_DP=1 run benchdp 400 python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-graph
+             FS2_FORCE_DP=1 FS2_GRAPH_DP=1 run benchdpg 400 python bench.py --steps 8 --warmup 4 --no-cpu-baseline
+             run benchtr 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline ;;
     *) echo "unknown step $step" ;;
   esac
 done
