@@ -407,38 +407,60 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
     auto step = [&](auto slot_c, auto next_c, int s) {
         constexpr int SLOT = decltype(slot_c)::value;   // = s % D: the register set that held stage s (free now)
         constexpr int BUF = SLOT & 1;                   // = s % 2 (D is even): compile-time LDS buffer
+        const bool tile_end = (cit + 1 == ck.it1);
+        // Stage s+1 goes from registers to the other LDS buffer FIRST (its loads were issued a whole step ago), so the
+        // LDS writes run under this step's MFMAs instead of sitting between them and the barrier.  Exception: a step
+        // that ends a tile needs the whole LDS image for its epilogue and stores afterwards.
+        if (!tile_end && s + 1 < nst) store_stage(next_c, IC<(BUF ^ 1)>{});
         if (s + D < nst) issue_load(slot_c);
         const unsigned char* la = smem + BUF * 2 * G::STAGE;
         const unsigned char* lb = la + G::STAGE;
+        if constexpr (!AKM && !BKM) {
+            // all fragment reads of the stage in flight before the first MFMA: LDS latency is exposed once, not twice
+            typename Frag<T>::type fa[2][NI], fb[2][NI];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            typename Frag<T>::type fa[NI], fb[NI];
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                if constexpr (!AKM) fa[i] = *reinterpret_cast<const typename Frag<T>::type*>(la + rdA[ks] + i * 2048);
-                else fa[i] = read_frag<T, AKM>(la, wr * WT + i * 16, ks, lane);
+                for (int i = 0; i < NI; ++i) fa[ks][i] = *reinterpret_cast<const typename Frag<T>::type*>(la + rdA[ks] + i * 2048);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) fb[ks][j] = *reinterpret_cast<const typename Frag<T>::type*>(lb + rdB[ks] + j * 2048);
             }
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                if constexpr (!BKM) fb[j] = *reinterpret_cast<const typename Frag<T>::type*>(lb + rdB[ks] + j * 2048);
-                else fb[j] = read_frag<T, BKM>(lb, wc * WT + j * 16, ks, lane);
-            }
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) mma<T>(acc[i][j], fa[ks][i], fb[ks][j]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                typename Frag<T>::type fa[NI], fb[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    if constexpr (!AKM) fa[i] = *reinterpret_cast<const typename Frag<T>::type*>(la + rdA[ks] + i * 2048);
+                    else fa[i] = read_frag<T, AKM>(la, wr * WT + i * 16, ks, lane);
+                }
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
-                    mma<T>(acc[i][j], fa[i], fb[j]);
+                    if constexpr (!BKM) fb[j] = *reinterpret_cast<const typename Frag<T>::type*>(lb + rdB[ks] + j * 2048);
+                    else fb[j] = read_frag<T, BKM>(lb, wc * WT + j * 16, ks, lane);
                 }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) mma<T>(acc[i][j], fa[i], fb[j]);
+            }
         }
-        if (++cit == ck.it1) {          // last stage of this work item
+        ++cit;
+        if (tile_end) {                 // last stage of this work item
             epilogue();
             if (++cw < wend) { next_work(ck); cit = ck.it0; }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (s + 1 < nst) store_stage(next_c, IC<(BUF ^ 1)>{});
         }
-        if (s + 1 < nst) store_stage(next_c, IC<(BUF ^ 1)>{});
         __syncthreads();
     };
 
