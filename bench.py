@@ -11,9 +11,12 @@ always on).  `value` = valid (un-padded) mel frames of all ranks / wall time of 
 barrier + synchronize, MAX over ranks.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel family (the MFMA GEMM), achieved = algorithmic FLOPs of its launches /
-                  their summed duration measured with HIP events on the launch stream inside the timed
-                  region; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md); traffic from profiles/ if collected.
+  roofline     -- the dominant kernel (the MFMA GEMM variant with the largest summed time): algorithmic FLOPs
+                  and algorithmic bytes (every operand element once) of its launches / their summed duration,
+                  measured with a HIP event pair on the launch stream around every launch of instrumented eager
+                  steps that follow the timed region (graph replays cannot be bracketed per kernel).  `bound` is
+                  the roof that binds those launches on average (FLOP/byte against 2.5 PFLOP/s : 8 TB/s); both
+                  fractions are given.  `traffic` = HBM bytes per launch from the PMC pass in profiles/.
   cpu_baseline -- the oracle (CPU restatement of the reference step, kind "port") timed on this host's cores
                   on one config-2 batch (~10 s); a reported baseline, not the target.
 """
@@ -31,6 +34,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0       # dense bf16 MFMA, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0           # HBM3E spec peak (6.3 TB/s achievable), same table
 POOL = 8                        # pre-built batches cycled
 
 
@@ -51,21 +55,32 @@ class GemmTimer:
 
     def __init__(self):
         self.records = []      # (key, flops, start, end)
+        self._pool = []        # events created ahead of the instrumented steps (creation is host time)
+
+    def reserve(self, n):
+        self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
 
     def install(self):
         from transformer_tts_amd import ops
         self._orig = ops._gemm_call
 
         def timed(g):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
+            e = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
             s.record()
             self._orig(g)
             e.record()
             taps = g.taps if g.conv == 1 else 1
-            flops = 2.0 * g.M * g.N * g.K * taps * max(1, g.batch1) * max(1, g.batch2)
-            key = ("bf16" if g.dtype == 1 else "f32", "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm")
+            nb = max(1, g.batch1) * max(1, g.batch2)
+            flops = 2.0 * g.M * g.N * g.K * taps * nb
+            es, cs = (2 if g.dtype == 1 else 4), (2 if g.c_dtype == 1 else 4)
+            # algorithmic bytes: every operand element once (conv: the A rows once, not once per tap)
+            abytes = (es * (g.M * g.K + g.N * g.K * taps) + cs * g.M * g.N) * float(nb)
+            t128 = ((g.M + 127) // 128) * ((g.N + 127) // 128) * nb * max(1, g.split_k)
+            tile = 64 if (not g.a_kmajor and not g.b_kmajor and t128 < 384) else 128      # as fs2_gemm's launcher picks it
+            key = ("bf16" if g.dtype == 1 else "f32", "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm", tile)
             shape = (g.M, g.N, g.K, taps if g.conv == 1 else (g.batch2 if g.conv == 2 else 1), g.batch1 * g.batch2, g.split_k)
-            self.records.append((key, flops, s, e, shape))
+            self.records.append((key, flops, s, e, shape, abytes))
         ops._gemm_call = timed
 
     def remove(self):
@@ -74,16 +89,16 @@ class GemmTimer:
 
     def summary(self):
         agg = {}
-        for key, flops, s, e, shape in self.records:
+        for key, flops, s, e, shape, abytes in self.records:
             ms = s.elapsed_time(e)
-            a = agg.setdefault(key, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += ms; a[2] += 1
+            a = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
+            a[0] += flops; a[1] += ms; a[2] += 1; a[3] += abytes
         return agg
 
     def by_shape(self):
         agg = {}
-        for key, flops, s, e, shape in self.records:
-            a = agg.setdefault(key + shape, [0.0, 0.0, 0])
+        for key, flops, s, e, shape, abytes in self.records:
+            a = agg.setdefault(key[:3] + shape, [0.0, 0.0, 0])
             a[0] += flops; a[1] += s.elapsed_time(e); a[2] += 1
         lines = ["variant M N K taps batch split | launches total_ms avg_us TFLOP/s"]
         for k, (fl, ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -131,6 +146,7 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 parity mode instead of bf16 (not the headline)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--gemm-report", type=str, default=None, help="write per-shape GEMM timings to this file")
+    ap.add_argument("--no-overlap", action="store_true", help="keep the weight-gradient GEMMs on the main stream (profiling)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -161,6 +177,8 @@ def main():
     model.train()
     model = model.to(dev)
     opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=1.0)
+    if args.no_overlap:
+        model.rt.overlap_wgrad = False
     if world > 1 or force_dp:
         from transformer_tts_amd.parallel import DataParallel
         opt.dp = DataParallel(model, opt.arena)
@@ -199,7 +217,21 @@ def main():
     if use_graph:       # roofline leg: the same kernels, launched eagerly with a HIP event pair around every GEMM;
         timer.install() # one stream only, so that a kernel's event pair times that kernel alone
         model.rt.overlap_wgrad = False
-        for i in range(min(args.steps, POOL)):
+        # An event pair also counts any time the stream sits idle between the start event and the kernel, i.e. whenever
+        # the Python launcher falls behind the GPU. Each instrumented step therefore starts with a spin kernel long
+        # enough for the host to enqueue the whole step ahead of the GPU, so every pair brackets back-to-back work.
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record(); torch.cuda._sleep(20_000_000); c1.record(); torch.cuda.synchronize()
+        cycles_per_ms = 20_000_000 / max(c0.elapsed_time(c1), 1e-3)
+        t_e = time.perf_counter()
+        train_step(model, opt, step, pool[0], hp); step += 1          # also measures the host time of one eager step
+        host_ms = (time.perf_counter() - t_e) * 1e3
+        torch.cuda.synchronize()
+        timer.records.clear()
+        n_inst = min(args.steps, POOL)
+        timer.reserve(2 * 400 * n_inst)
+        for i in range(n_inst):
+            torch.cuda._sleep(int(cycles_per_ms * min(60.0, 1.5 * host_ms + 5.0)))
             train_step(model, opt, step, pool[i % POOL], hp)
             step += 1
         torch.cuda.synchronize()
@@ -218,18 +250,28 @@ def main():
         agg = timer.summary()
         roof = None
         if agg:
-            key, (fl, ms, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
-            achieved = fl / (ms * 1e-3) / 1e12
+            key, (fl, ms, cnt, by) = max(agg.items(), key=lambda kv: kv[1][1])
+            tflops = fl / (ms * 1e-3) / 1e12
+            gbs = by / (ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            roof = dict(bound="mfma", kernel=f"gemm_kernel<{key[0]}> A {key[1]} B {key[2]}", achieved=round(achieved, 2),
-                        peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
-                        traffic=traffic, launches=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
+            # the roof that binds the dominant kernel's launches on average: algorithmic FLOP per algorithmic byte
+            # against the machine balance 2.5 PFLOP/s / 8 TB/s
+            hbm_bound = (fl / by) < (PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
+            roof = dict(bound="hbm" if hbm_bound else "mfma",
+                        kernel=f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}",
+                        achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                        unit="GB/s" if hbm_bound else "TFLOP/s",
+                        frac=round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_BF16_TFLOPS), 4), traffic=traffic,
+                        launches=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
+                        algorithmic_bytes_per_launch=round(by / cnt), algorithmic_flops_per_launch=round(fl / cnt),
+                        achieved_tflops=round(tflops, 1), mfma_frac=round(tflops / PEAK_BF16_TFLOPS, 4),
+                        achieved_gbs=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
                         gemm_ms_per_step=round(sum(v[1] for v in agg.values()) / max(1, (min(args.steps, POOL) if use_graph else args.steps)), 3),
-                        all_variants={"/".join(k): dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), ms=round(v[1], 2),
-                                                         launches=v[2]) for k, v in agg.items()})
+                        all_variants={"/".join(str(x) for x in k): dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), gbs=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                                                         ms=round(v[1], 2), launches=v[2]) for k, v in agg.items()})
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(hp, synthetic.benchmark_batch(2024, 48))

@@ -20,14 +20,14 @@ for step in "$@"; do
     benchq)  run benchq 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report.txt ;;
     benche)  run benche 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-graph ;;
     prof)    cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-             run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph ;;
+             run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap ;;
     ncclgraph) run ncclgraph 200 python tools/exp_nccl_graph.py ;;
     gemmbench) run gemmbench 300 python tools/gemm_bench.py ;;
     benchs)  FS2_GEMM_DIRECT=0 run benchs 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report_staged.txt ;;
     kernelss) FS2_GEMM_DIRECT=0 run kernelss 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider ;;
     pmcbench) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-             run pmcb1 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcb1 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph
-             run pmcb2 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcb2 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph ;;
+             run pmcb1 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcb1 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap
+             run pmcb2 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcb2 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap ;;
     benchdp) FS2_FORCE_DP=1 run benchdp 400 python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-graph
              FS2_FORCE_DP=1 FS2_GRAPH_DP=1 run benchdpg 400 python bench.py --steps 8 --warmup 4 --no-cpu-baseline
              run benchtr 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline ;;
