@@ -14,7 +14,7 @@
  *  - stateless and re-entrant; return 0, or a negative FS2_E* code with text in fs2_last_error();
  *  - activations are channels-last [rows = (batch, time)][channels], row-major;
  *  - dtype codes: FS2_F32 = 0 (exact-fp32 mode: f32-input MFMA), FS2_BF16 = 1 (bf16 MFMA, fp32 accumulate);
- *  - dropout: Philox4x32-10 keyed by the device-resident {seed, offset} pair `rng` and a per call
+ *  - dropout: Philox4x32-7 keyed by the device-resident {seed, offset} pair `rng` and a per call
  *    site id `site`; the backward entry point regenerates the mask from the same triple.
  */
 #ifndef FS2_HIP_H

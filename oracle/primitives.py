@@ -7,7 +7,7 @@ backend that tests monkeypatch over ``transformer_tts_amd.ops`` so the host-side
 composition in transformer_tts_amd/Models can be checked on a machine without a GPU.
 
 Each op cites the reference arithmetic it stands for (file:line of syoamakase/Transformer_TTS).
-Dropout masks reproduce the kernels' Philox4x32-10 stream bit for bit (``drop_scale``), so
+Dropout masks reproduce the kernels' Philox4x32-7 stream bit for bit (``drop_scale``), so
 dropout-on comparisons are exact rather than statistical.
 """
 import numpy as np
@@ -31,12 +31,15 @@ class Rng:
 
 
 # ------------------------------------------------------------------------------------------------ Philox dropout
-def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+PHILOX_ROUNDS = 7          # common.cuh PHILOX_ROUNDS
+
+
+def _philox4x32(c0, c1, c2, c3, k0, k1):
     M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
     mask = np.uint64(0xFFFFFFFF)
     c0, c1, c2, c3 = (np.asarray(x, np.uint64) for x in (c0, c1, c2, c3))
     k0, k1 = np.uint64(k0), np.uint64(k1)
-    for _ in range(10):
+    for _ in range(PHILOX_ROUNDS):
         p0, p1 = M0 * c0, M1 * c2
         hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
         c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
@@ -55,12 +58,11 @@ def drop_scale(shape, p, rng, site, base_index=None):
     q = idx >> np.uint64(2)
     k0 = seed & 0xFFFFFFFF
     k1 = ((seed >> 32) ^ (off >> 32)) & 0xFFFFFFFF
-    r = _philox4x32_10(q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.full(n, site, np.uint64),
+    r = _philox4x32(q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.full(n, site, np.uint64),
                        np.full(n, off & 0xFFFFFFFF, np.uint64), k0, k1)
     lane = (idx & np.uint64(3)).astype(np.int64)
     bits = np.stack(r, axis=1)[np.arange(n), lane].astype(np.uint32)
-    u = bits.astype(np.float32) * np.float32(2.3283064365386963e-10)
-    keep = u >= np.float32(p)
+    keep = bits >= np.uint32(int(float(np.float32(p)) * 4294967296.0))      # DropCtx.thr
     scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
     return torch.from_numpy(np.where(keep, scale, np.float32(0)).astype(np.float64).reshape(shape))
 

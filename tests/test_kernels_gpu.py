@@ -221,7 +221,7 @@ def test_layernorm_family(ops, dtype, p, d):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("p", [0.0, 0.2])
-@pytest.mark.parametrize("t", [37, 128, 300])
+@pytest.mark.parametrize("t", [37, 128, 300, 925, 1100])      # bf16: 1, 2 and 3 sixteen-byte groups per lane
 def test_softmax_fwd_bwd(ops, dtype, p, t):
     B, H, NL = 3, 2, 2
     tp = (t + 7) // 8 * 8

@@ -167,31 +167,41 @@ def test_dropout_statistics_and_replay():
 
 def test_hipgraph_replay_equals_eager_training():
     """GraphedTrainStep (one captured hipGraph per batch shape, weight gradients on a second stream) must follow the
-    eager trainer exactly: same Philox dropout streams, same kernels -> same losses and parameters (up to the
-    order of float atomics in the weight-gradient / reduction kernels)."""
+    eager trainer: same Philox dropout streams, same kernels -> same losses and the same parameter update at every
+    step, up to the order of the float atomics in the weight-gradient / reduction kernels.  That order changes a
+    gradient by ~1e-7 relative, which the training dynamics amplify (an L1 loss has sign() gradients, Adam turns a
+    near-zero gradient into a +-lr step), so the two trainers run in lockstep and the graphed one is re-synchronised to
+    the eager one after every step: each comparison then covers exactly one update from identical state."""
     from transformer_tts_amd import synthetic
     from transformer_tts_amd.optim import FusedAdam
     from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep, train_step
-    batches = [synthetic.make_batch(100 + (i % 2), 4, l_range=(9, 20), dur_range=(1, 9), vocab=60) for i in range(6)]
-    results = []
     from transformer_tts_amd.Models import functional
-    for use_graph in (False, True):
+    batches = [batch_to(synthetic.make_batch(100 + (i % 2), 4, l_range=(9, 20), dur_range=(1, 9), vocab=60), "cuda")
+               for i in range(6)]
+    pair = []
+    for _ in range(2):
         functional._site_counter[0] = 1000      # same dropout call-site ids (= Philox streams) for both models
         model, hp, _ = product_model("small", amp=False, dropout=0.1, device="cuda")
-        opt = FusedAdam(model)
-        stepper = GraphedTrainStep(model, opt, hp) if use_graph else None
-        losses = []
-        for i, b in enumerate(batches):
-            b = batch_to(b, "cuda")
-            out = stepper(4000 + i, b) if use_graph else train_step(model, opt, 4000 + i, b, hp)
-            losses.append(out[0].item())
-        if use_graph:
-            assert len(stepper.graphs) == 2, "two batch shapes -> two captured graphs"
-        results.append((losses, opt.arena.p.clone()))
-    np.testing.assert_allclose(results[0][0], results[1][0], rtol=1e-5)
-    diff = (results[0][1] - results[1][1]).abs()
-    bad = diff > (2e-5 + 2e-4 * results[0][1].abs())
-    assert float(bad.float().mean()) < 1e-3 and float(diff.max()) < 5e-3, (int(bad.sum()), float(diff.max()))
+        pair.append((model, hp, FusedAdam(model)))
+    (m_e, hp_e, opt_e), (m_g, hp_g, opt_g) = pair
+    stepper = GraphedTrainStep(m_g, opt_g, hp_g)
+    for i, b in enumerate(batches):
+        before = opt_e.arena.p.clone()
+        out_e = train_step(m_e, opt_e, 4000 + i, b, hp_e)
+        out_g = stepper(4000 + i, b)
+        np.testing.assert_allclose(out_g[0].item(), out_e[0].item(), rtol=2e-6, err_msg=f"loss at step {i}")
+        update = float((opt_e.arena.p - before).abs().max())            # the largest Adam step of this update
+        diff = (opt_e.arena.p - opt_g.arena.p).abs()
+        loose = diff > 1e-7 + 1e-6 * opt_e.arena.p.abs()
+        assert float(diff.max()) <= 2.05 * update, (i, float(diff.max()), update)          # at worst one flipped step
+        assert float(loose.float().mean()) < 0.02, (i, int(loose.sum()))                    # near-zero gradients only
+        gerr = float((opt_e.arena.g - opt_g.arena.g).norm() / opt_e.arena.g.norm())
+        assert gerr < 1e-4, (i, gerr)       # a flipped sign(pred - target) in an L1 term moves the gradient by ~1/N
+        for dst, src in ((opt_g.arena.p, opt_e.arena.p), (opt_g.m, opt_e.m), (opt_g.v, opt_e.v)):
+            dst.copy_(src)
+        for bg, be in zip(m_g.buffers(), m_e.buffers()):
+            bg.copy_(be)
+    assert len(stepper.graphs) == 2, "two batch shapes -> two captured graphs"
 
 
 def test_long_sequences_and_wide_model_vs_oracle():

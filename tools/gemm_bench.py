@@ -56,6 +56,25 @@ def main():
     dye, xxe = r(48, 128, 1024), r(48, 128, 256)
     gwe = torch.zeros(1024, 9 * 256, device=dev)
     cases["conv_wgrad 1024x(9x256) red 6144"] = (lambda: ops.conv_wgrad(dye, xxe, 9, 4, gwe), 2.0 * 6144 * 1024 * 2304)
+    for (n_, k_, m_) in ((256, 256, 6144), (256, 256, 44400), (768, 256, 44400), (256, 1024, 44400), (80, 256, 44400)):
+        dyw, xw = r(m_, n_), r(m_, k_)
+        gww = torch.zeros(n_, k_, device=dev)
+        for sp in (4, 8, 16, 32, 64):
+            cases[f"wsplit {n_}x{k_} red {m_} split {sp}"] = (lambda a=dyw, b=xw, c=gww, sp=sp: ops.wgrad(a, b, c, split=sp), 2.0 * m_ * n_ * k_)
+    # calibration only: the vendor library (hipBLASLt through torch.matmul) on the same plain-GEMM shapes
+    cases["  lib dec_ffn1"] = (lambda: torch.nn.functional.linear(x, w), 2.0 * M * 1024 * 256)
+    cases["  lib dec_ffn2"] = (lambda: torch.nn.functional.linear(x2, w2), 2.0 * M * 256 * 1024)
+    cases["  lib square"] = (lambda: torch.nn.functional.linear(big_a, big_b), 2.0 * 8192 * 4096 * 4096)
+    qc, kc, vc = q.contiguous(), k.contiguous(), v.contiguous()
+    cases["  lib attn_qk"] = (lambda: torch.matmul(qc, kc.transpose(-1, -2)), 2.0 * 96 * t * t * 128)
+    Sc = S[..., :t].contiguous()
+    cases["  lib attn_pv"] = (lambda: torch.matmul(Sc, vc), 2.0 * 96 * t * 128 * t)
+    xim = r(6144, 2304)
+    cases["  lib enc_conv1 as plain 6144x1024x2304"] = (lambda: torch.nn.functional.linear(xim, we), 2.0 * 6144 * 1024 * 2304)
+    xim2 = r(6144, 9216)
+    cases["  lib enc_conv2 as plain 6144x256x9216"] = (lambda: torch.nn.functional.linear(xim2, we2), 2.0 * 6144 * 256 * 9216)
+    dyt = dy.t().contiguous()
+    cases["  lib wgrad 1024x256 red 44400"] = (lambda: torch.matmul(dyt, xx), 2.0 * M * 1024 * 256)
     for name, (fn, fl) in cases.items():
         if "all" in which or any(wn in name for wn in which):
             bench(name, fn, fl)

@@ -23,6 +23,7 @@ for step in "$@"; do
              run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap ;;
     ncclgraph) run ncclgraph 200 python tools/exp_nccl_graph.py ;;
     gemmbench) run gemmbench 300 python tools/gemm_bench.py ;;
+    wsplit)  run wsplit 300 python tools/gemm_bench.py wsplit ;;
     benchs)  FS2_GEMM_DIRECT=0 run benchs 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report_staged.txt ;;
     kernelss) FS2_GEMM_DIRECT=0 run kernelss 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider ;;
     pmcbench) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null

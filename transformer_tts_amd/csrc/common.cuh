@@ -70,15 +70,19 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// ---------------------------------------------------------------- Philox4x32-10 dropout stream
+// ---------------------------------------------------------------- Philox4x32-7 dropout stream
+// Seven rounds is the Crush-resistant minimum of Salmon et al. (SC'11); the 32x32->64 products compile to one
+// quarter-rate v_mad_u64_u32 each, so a call costs 14 of them (the 10-round mul_hi/mul_lo form cost 40 multiplies
+// and made the attention softmax ALU-bound).
+constexpr int PHILOX_ROUNDS = 7;
 struct Philox4 { uint32_t x, y, z, w; };
-__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ Philox4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    for (int r = 0; r < PHILOX_ROUNDS; ++r) {
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += W0; k1 += W1;
     }
@@ -89,6 +93,7 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 // Returns 1/(1-p) for kept elements and 0 for dropped ones.  p == 0 -> all ones without touching rng.
 struct DropCtx {
     uint32_t k0, k1, off, site;
+    uint32_t thr;       // an element is kept iff its 32 random bits are >= thr = floor(p * 2^32)
     float p, scale;
     bool on;
 };
@@ -97,6 +102,7 @@ __device__ __forceinline__ DropCtx drop_ctx(const uint64_t* rng, uint32_t site, 
     c.on = p > 0.f;
     c.p = p;
     c.scale = c.on ? 1.f / (1.f - p) : 1.f;
+    c.thr = (uint32_t)((double)p * 4294967296.0);
     c.site = site;
     if (c.on) {
         uint64_t seed = rng[0], off = rng[1];
@@ -110,12 +116,11 @@ __device__ __forceinline__ DropCtx drop_ctx(const uint64_t* rng, uint32_t site, 
 }
 __device__ __forceinline__ float4 drop_scale4(const DropCtx& c, uint64_t q) {
     if (!c.on) return make_float4(1.f, 1.f, 1.f, 1.f);
-    Philox4 r = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), c.site, c.off, c.k0, c.k1);
-    const float inv = 2.3283064365386963e-10f;  // 2^-32
+    Philox4 r = philox4x32((uint32_t)q, (uint32_t)(q >> 32), c.site, c.off, c.k0, c.k1);
     float4 o;
-    o.x = (r.x * inv >= c.p) ? c.scale : 0.f;
-    o.y = (r.y * inv >= c.p) ? c.scale : 0.f;
-    o.z = (r.z * inv >= c.p) ? c.scale : 0.f;
-    o.w = (r.w * inv >= c.p) ? c.scale : 0.f;
+    o.x = (r.x >= c.thr) ? c.scale : 0.f;
+    o.y = (r.y >= c.thr) ? c.scale : 0.f;
+    o.z = (r.z >= c.thr) ? c.scale : 0.f;
+    o.w = (r.w >= c.thr) ? c.scale : 0.f;
     return o;
 }

@@ -455,6 +455,175 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_bwd_k(T* __restrict__ dp, i
     }
 }
 
+// ---------------------------------------------------------------- bf16 fast path: 16-byte accesses, R rows per wave
+// The t ~ 925 probability tensors are the largest streams of the step (165 MB per decoder layer); with 8-byte lane
+// accesses and one row in flight per wave the kernels above reached ~2 TB/s.  Here a lane owns 8 consecutive keys per
+// group (GCOL8), a wave issues the loads of R rows before it reduces the first one, and the key mask comes from
+// aligned 32-bit words.  Same arithmetic, same Philox counters (element offset >> 2) as the generic kernels.
+#define GCOL8(g) (8 * (lane + 64 * (g)))
+
+__device__ __forceinline__ void unpack8(const bf16x8& v, float (&e)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) e[c] = (float)v[c];
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&e)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (bf16_t)e[c];
+    return o;
+}
+// bytes km[0..8) as a 64-bit word (byte c in bits 8c..8c+7); reads the aligned words that cover them
+__device__ __forceinline__ uint64_t load_mask8(const uint8_t* km) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(km);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+    const unsigned sh = (unsigned)(a & 3) * 8;
+    const uint32_t w0 = w[0], w1 = w[1];
+    if (sh == 0) return ((uint64_t)w1 << 32) | w0;
+    const uint32_t w2 = w[2];
+    const uint32_t lo = (w0 >> sh) | (w1 << (32 - sh));
+    const uint32_t hi = (w1 >> sh) | (w2 << (32 - sh));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int NG8, int R>
+__global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd8_k(bf16_t* __restrict__ s, bf16_t* __restrict__ pd,
+        const uint8_t* __restrict__ key_mask, int B, int H, int t, int tp, int64_t batch_stride, float p,
+        const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    const int64_t rows = (int64_t)B * H * t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t row0 = ((int64_t)blockIdx.x * ROW_WAVES + wave) * R; row0 < rows; row0 += (int64_t)gridDim.x * ROW_WAVES * R) {
+        bf16x8 raw[R][NG8];
+        uint64_t mk[R][NG8];
+        int64_t off[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + r < rows ? row0 + r : rows - 1;      // a clamped duplicate; not stored
+            const int b = (int)(row / ((int64_t)H * t));
+            off[r] = b * batch_stride + (row - (int64_t)b * H * t) * tp;
+            const uint8_t* km = key_mask + (int64_t)b * t;
+#pragma unroll
+            for (int g = 0; g < NG8; ++g) {
+                const int col = GCOL8(g);
+                if (col < tp) raw[r][g] = *reinterpret_cast<const bf16x8*>(s + off[r] + col);
+                mk[r][g] = 0;
+                if (col + 8 <= t) mk[r][g] = load_mask8(km + col);
+                else
+                    for (int c = 0; c < 8; ++c)
+                        if (col + c < t && km[col + c] != 0) mk[r][g] |= (uint64_t)0xFF << (8 * c);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float e[NG8][8];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int g = 0; g < NG8; ++g) {
+                const int col = GCOL8(g);
+                if (col < tp) unpack8(raw[r][g], e[g]);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (col + c < t) {
+                        if (((mk[r][g] >> (8 * c)) & 0xFFu) == 0) e[g][c] = -1e4f;     // masked_fill(mask == 0, -1e4) on keys
+                        mx = fmaxf(mx, e[g][c]);
+                    } else e[g][c] = -3.0e38f;
+                }
+            }
+            mx = wave_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG8; ++g)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    e[g][c] = (GCOL8(g) + c < t) ? __expf(e[g][c] - mx) : 0.f;
+                    sum += e[g][c];
+                }
+            const float inv = 1.f / wave_sum(sum);
+            if (row0 + r < rows) {
+#pragma unroll
+                for (int g = 0; g < NG8; ++g) {
+                    const int col = GCOL8(g);
+                    if (col >= tp) continue;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) e[g][c] *= inv;
+                    *reinterpret_cast<bf16x8*>(s + off[r] + col) = pack8(e[g]);
+                    if (pd != s) {
+                        if (dc.on) {
+                            const float4 m0 = drop_scale4(dc, (uint64_t)(off[r] + col) >> 2);
+                            const float4 m1 = drop_scale4(dc, ((uint64_t)(off[r] + col) >> 2) + 1);
+                            e[g][0] *= m0.x; e[g][1] *= m0.y; e[g][2] *= m0.z; e[g][3] *= m0.w;
+                            e[g][4] *= m1.x; e[g][5] *= m1.y; e[g][6] *= m1.z; e[g][7] *= m1.w;
+                        }
+                        *reinterpret_cast<bf16x8*>(pd + off[r] + col) = pack8(e[g]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NG8, int R>
+__global__ __launch_bounds__(ROW_BLOCK) void softmax_bwd8_k(bf16_t* __restrict__ dp, int64_t dp_stride,
+        const bf16_t* __restrict__ ps, int64_t p_stride, int B, int H, int t, int tp, float p, const uint64_t* rng,
+        uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    const int64_t rows = (int64_t)B * H * t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t row0 = ((int64_t)blockIdx.x * ROW_WAVES + wave) * R; row0 < rows; row0 += (int64_t)gridDim.x * ROW_WAVES * R) {
+        bf16x8 rg[R][NG8], rp[R][NG8];
+        int64_t off[R], poff[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+            const int b = (int)(row / ((int64_t)H * t));
+            const int64_t inb = row - (int64_t)b * H * t;
+            off[r] = b * dp_stride + inb * tp;
+            poff[r] = b * p_stride + inb * tp;
+#pragma unroll
+            for (int g = 0; g < NG8; ++g) {
+                const int col = GCOL8(g);
+                if (col < tp) {
+                    rg[r][g] = *reinterpret_cast<const bf16x8*>(dp + off[r] + col);
+                    rp[r][g] = *reinterpret_cast<const bf16x8*>(ps + poff[r] + col);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float ge[NG8][8], pe_[NG8][8];
+            float dot = 0.f;
+#pragma unroll
+            for (int g = 0; g < NG8; ++g) {
+                const int col = GCOL8(g);
+                if (col < tp) { unpack8(rg[r][g], ge[g]); unpack8(rp[r][g], pe_[g]); }
+                // pad columns [t,tp) of dP were never written by the GEMM: force them (and P's) to 0
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (col + c >= t) { ge[g][c] = 0.f; pe_[g][c] = 0.f; }
+                if (dc.on && col < tp) {
+                    const float4 m0 = drop_scale4(dc, (uint64_t)(poff[r] + col) >> 2);
+                    const float4 m1 = drop_scale4(dc, ((uint64_t)(poff[r] + col) >> 2) + 1);
+                    ge[g][0] *= m0.x; ge[g][1] *= m0.y; ge[g][2] *= m0.z; ge[g][3] *= m0.w;
+                    ge[g][4] *= m1.x; ge[g][5] *= m1.y; ge[g][6] *= m1.z; ge[g][7] *= m1.w;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) dot += ge[g][c] * pe_[g][c];
+            }
+            dot = wave_sum(dot);
+            if (row0 + r < rows) {
+#pragma unroll
+                for (int g = 0; g < NG8; ++g) {
+                    const int col = GCOL8(g);
+                    if (col >= tp) continue;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) ge[g][c] = pe_[g][c] * (ge[g][c] - dot);
+                    *reinterpret_cast<bf16x8*>(dp + off[r] + col) = pack8(ge[g]);
+                }
+            }
+        }
+    }
+}
+
 // ================================================================ positional encoding add
 template <typename T, int NG>
 __global__ __launch_bounds__(ROW_BLOCK) void pe_add_fwd_k(const T* __restrict__ a, const float* __restrict__ pe,
@@ -835,6 +1004,16 @@ extern "C" int fs2_softmax_fwd(void* s, void* pd, int dtype, const uint8_t* key_
     FS2_REQUIRE(p == 0.f || (rng != nullptr && pd != s), "fs2_softmax_fwd: dropout needs rng and a separate p_drop buffer");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid((int64_t)B * H * t)), block(ROW_BLOCK);
+    if (dtype == FS2_BF16 && batch_stride % 8 == 0 && fs2_aligned16(s) && fs2_aligned16(pd) &&
+        (reinterpret_cast<uintptr_t>(key_mask) & 3) == 0) {
+        constexpr int R = 2;
+        dim3 grid8(row_grid(((int64_t)B * H * t + R - 1) / R));
+#define SM8(NG8) hipLaunchKernelGGL((softmax_fwd8_k<NG8, R>), grid8, block, 0, st, (bf16_t*)s, (bf16_t*)pd, key_mask, B, H, t, tp, batch_stride, p, rng, site)
+        if (tp <= 512) SM8(1); else if (tp <= 1024) SM8(2); else if (tp <= 1536) SM8(3); else SM8(4);
+#undef SM8
+        FS2_CHECK_LAUNCH("fs2_softmax_fwd");
+        return FS2_OK;
+    }
     NG_DISPATCH(tp, NG, { T_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((softmax_fwd_k<T, NG>), grid, block, 0, st, (T*)s, (T*)pd, key_mask, B, H, t, tp, batch_stride, p, rng, site);
     }); });
@@ -850,6 +1029,15 @@ extern "C" int fs2_softmax_bwd(void* dp, int64_t dp_batch_stride, const void* ps
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_softmax_bwd: dropout needs rng");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid((int64_t)B * H * t)), block(ROW_BLOCK);
+    if (dtype == FS2_BF16 && dp_batch_stride % 8 == 0 && p_batch_stride % 8 == 0 && fs2_aligned16(dp) && fs2_aligned16(ps)) {
+        constexpr int R = 2;
+        dim3 grid8(row_grid(((int64_t)B * H * t + R - 1) / R));
+#define SM8(NG8) hipLaunchKernelGGL((softmax_bwd8_k<NG8, R>), grid8, block, 0, st, (bf16_t*)dp, dp_batch_stride, (const bf16_t*)ps, p_batch_stride, B, H, t, tp, p, rng, site)
+        if (tp <= 512) SM8(1); else if (tp <= 1024) SM8(2); else if (tp <= 1536) SM8(3); else SM8(4);
+#undef SM8
+        FS2_CHECK_LAUNCH("fs2_softmax_bwd");
+        return FS2_OK;
+    }
     NG_DISPATCH(tp, NG, { T_DISPATCH(dtype, T, {
         hipLaunchKernelGGL((softmax_bwd_k<T, NG>), grid, block, 0, st, (T*)dp, dp_batch_stride, (const T*)ps, p_batch_stride, B, H, t, tp, p, rng, site);
     }); });

@@ -217,7 +217,7 @@ def _pick_split(M_out, N_out, K_red, batch):
     return int(max(1, min(want, ktiles, 64)))
 
 
-def wgrad(dy, x, out):
+def wgrad(dy, x, out, split=None):
     """out[N,K] (fp32) += dy[M,N]^T @ x[M,K]  (k-major operands, split-K with fp32 atomics)."""
     M, N = dy.shape
     K = x.shape[1]
@@ -227,7 +227,7 @@ def wgrad(dy, x, out):
     g.a_kmajor = g.b_kmajor = 1
     g.M, g.N, g.K, g.dtype = N, K, M, _dt(x)
     g.batch1 = g.batch2 = 1
-    g.split_k = _pick_split(N, K, M, 1)
+    g.split_k = split or _pick_split(N, K, M, 1)
     g.accumulate = 1
     _epilogue(g, out, None, False, None, None, None, 1.0)
     _gemm_call(g)
