@@ -79,7 +79,9 @@ class GemmTimer:
             t128 = ((g.M + 127) // 128) * ((g.N + 127) // 128) * nb * max(1, g.split_k)
             tile = 64 if (not g.a_kmajor and not g.b_kmajor and t128 < 384) else 128      # as fs2_gemm's launcher picks it
             key = ("bf16" if g.dtype == 1 else "f32", "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm", tile)
-            shape = (g.M, g.N, g.K, taps if g.conv == 1 else (g.batch2 if g.conv == 2 else 1), g.batch1 * g.batch2, g.split_k)
+            flags = ("b" if g.bias else "") + ("r" if g.relu else "") + ("m" if g.relu_mask else "") + ("+" if g.residual else "") + \
+                    (f"s{g.colstats_mode}" if g.colstats else "") + ("a" if g.accumulate else "") + ("f" if g.c_dtype == 0 and g.dtype == 1 else "")
+            shape = (g.M, g.N, g.K, taps if g.conv == 1 else (g.batch2 if g.conv == 2 else 1), g.batch1 * g.batch2, g.split_k, flags or "-")
             self.records.append((key, flops, s, e, shape, abytes))
         ops._gemm_call = timed
 
@@ -100,9 +102,9 @@ class GemmTimer:
         for key, flops, s, e, shape, abytes in self.records:
             a = agg.setdefault(key[:3] + shape, [0.0, 0.0, 0])
             a[0] += flops; a[1] += s.elapsed_time(e); a[2] += 1
-        lines = ["variant M N K taps batch split | launches total_ms avg_us TFLOP/s"]
+        lines = ["variant M N K taps batch split epilogue(b=bias r=relu m=relu_mask +=residual sN=colstats a=accumulate f=fp32 out) | launches total_ms avg_us TFLOP/s"]
         for k, (fl, ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            lines.append(f"{'/'.join(k[:3])} {k[3]} {k[4]} {k[5]} {k[6]} {k[7]} {k[8]} | {n} {ms:.2f} {ms * 1e3 / n:.1f} "
+            lines.append(f"{'/'.join(k[:3])} {k[3]} {k[4]} {k[5]} {k[6]} {k[7]} {k[8]} {k[9]} | {n} {ms:.2f} {ms * 1e3 / n:.1f} "
                          f"{fl / (ms * 1e-3) / 1e12:.1f}")
         return "\n".join(lines)
 

@@ -129,9 +129,16 @@ def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, 
                 out_dtype or x.dtype, 1.0, colsum)
 
 
-def wgrad(dy, x, out):
+def wgrad(dy, x, out, split=None):
     out += (_f(dy).t() @ _f(x)).float()
     return out
+
+
+def wgrad_batched(dy, x, outs):
+    N = dy.shape[1] // len(outs)
+    for j, o in enumerate(outs):
+        wgrad(dy[:, j * N:(j + 1) * N], x, o)
+    return outs
 
 
 def conv_wgrad(dy, x, taps, pad, out):

@@ -130,6 +130,17 @@ def test_wgrad_and_colsum(ops, dtype):
         a = ops.colsum(dq.cuda()[:, sl], torch.zeros(N).cuda())
         b = P.colsum(dq[:, sl], torch.zeros(N))
         close(a, b, "colsum", rtol=1e-4, atol=1e-4 * M ** 0.5)
+        # the three column blocks of dqkv in one batched launch: outputs at a constant stride inside one arena
+        # (weights interleaved with their biases, as the parameter arena lays q/v/k out), and the irregular fallback
+        arena = rnd(3 * (N * K + N), seed=5)
+        for regular in (True, False):
+            ga, gb = arena.clone().cuda(), arena.clone()
+            offs = [j * (N * K + N) for j in range(3)] if regular else [0, 2 * (N * K + N), N * K + N]
+            outs_a = [ga[o:o + N * K].view(N, K) for o in offs]
+            outs_b = [gb[o:o + N * K].view(N, K) for o in offs]
+            ops.wgrad_batched(dq.cuda(), x.cuda(), outs_a)
+            P.wgrad_batched(dq, x, outs_b)
+            close(ga, gb, f"wgrad_batched regular={regular}", rtol=1e-4, atol=1e-4 * M ** 0.5)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -25,14 +25,47 @@ def bench(name, fn, flops, iters=20):
     print(f"{name:34s} {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s", flush=True)
 
 
+_flush = None
+
+
+def bench_cold(name, fn, flops, iters=8):
+    """every launch preceded by a 1 GiB fill, so that no operand is left in L2 / Infinity Cache (in-model condition)"""
+    global _flush
+    if _flush is None:
+        _flush = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+    fn()
+    tot = 0.0
+    for i in range(iters):
+        _flush.fill_(float(i))
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        tot += s.elapsed_time(e)
+    us = tot * 1e3 / iters
+    print(f"{name:34s} {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s   (cold)", flush=True)
+
+
 def main():
     which = sys.argv[1:] or ["all"]
+    cold = "cold" in which
+    which = [w for w in which if w != "cold"] or ["all"]
     g = torch.Generator(device=dev).manual_seed(0)
     r = lambda *s: torch.randn(*s, device=dev, generator=g).to(T)
     M = 44400
     cases = {}
     x, w = r(M, 256), r(1024, 256)
     cases["dec_ffn1 44400x1024x256"] = (lambda: ops.linear(x, w), 2.0 * M * 1024 * 256)
+    bias_, mask_, cs_ = torch.randn(1024, device=dev), r(M, 1024), torch.zeros(2 * 1024 + 4, device=dev)
+    outb = torch.empty(M, 1024, device=dev, dtype=T)
+    cases["epi ffn1 plain"] = (lambda: ops.linear(x, w, out=outb), 2.0 * M * 1024 * 256)
+    cases["epi ffn1 bias+relu"] = (lambda: ops.linear(x, w, bias_, relu=True, out=outb), 2.0 * M * 1024 * 256)
+    cases["epi ffn1 relu_mask"] = (lambda: ops.linear(x, w, relu_mask=mask_, out=outb), 2.0 * M * 1024 * 256)
+    cases["epi ffn1 colsum"] = (lambda: ops.linear(x, w, colsum=cs_, out=outb), 2.0 * M * 1024 * 256)
+    cases["epi ffn1 relu_mask+colsum"] = (lambda: ops.linear(x, w, relu_mask=mask_, colsum=cs_, out=outb), 2.0 * M * 1024 * 256)
+    cases["epi ffn1 colstats(sum+sumsq)"] = (lambda: ops.linear(x, w, colstats=cs_, out=outb), 2.0 * M * 1024 * 256)
+    cases["epi colsum kernel alone (M,1024)"] = (lambda: ops.colsum(outb, cs_[:1024]), 2.0 * M * 1024)
     x2, w2 = r(M, 1024), r(256, 1024)
     cases["dec_ffn2 44400x256x1024"] = (lambda: ops.linear(x2, w2), 2.0 * M * 256 * 1024)
     xe, we = r(48, 128, 256), r(1024, 9 * 256)
@@ -77,7 +110,7 @@ def main():
     cases["  lib wgrad 1024x256 red 44400"] = (lambda: torch.matmul(dyt, xx), 2.0 * M * 1024 * 256)
     for name, (fn, fl) in cases.items():
         if "all" in which or any(wn in name for wn in which):
-            bench(name, fn, fl)
+            (bench_cold if cold else bench)(name, fn, fl)
 
 
 if __name__ == "__main__":

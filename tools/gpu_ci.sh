@@ -24,6 +24,8 @@ for step in "$@"; do
     ncclgraph) run ncclgraph 200 python tools/exp_nccl_graph.py ;;
     gemmbench) run gemmbench 300 python tools/gemm_bench.py ;;
     wsplit)  run wsplit 300 python tools/gemm_bench.py wsplit ;;
+    gemmcold) run gemmcold 300 python tools/gemm_bench.py cold dec_ffn enc_conv post_conv attn square "wgrad 1024" ;;
+    gemmepi) run gemmepi 300 python tools/gemm_bench.py cold epi ;;
     benchs)  FS2_GEMM_DIRECT=0 run benchs 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report_staged.txt ;;
     kernelss) FS2_GEMM_DIRECT=0 run kernelss 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider ;;
     pmcbench) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null

@@ -107,9 +107,10 @@ class Runtime:
         return self._cached((id(weight), "d"), (weight,), build)
 
     def qkv(self, attn):
-        """fused [q;k;v] projection: forward shadow (3d,d), dgrad shadow (d,3d), bias (3d)"""
-        ws = (attn.q_linear.weight, attn.k_linear.weight, attn.v_linear.weight)
-        bs = (attn.q_linear.bias, attn.k_linear.bias, attn.v_linear.bias)
+        """fused [q;v;k] projection (the registration order of Models/modules.py:48-50, so that the three weight
+        gradients sit at a constant stride in the parameter arena): forward shadow (3d,d), dgrad shadow (d,3d), bias (3d)"""
+        ws = (attn.q_linear.weight, attn.v_linear.weight, attn.k_linear.weight)
+        bs = (attn.q_linear.bias, attn.v_linear.bias, attn.k_linear.bias)
         d = ws[0].shape[0]
 
         def build(old):
@@ -133,8 +134,8 @@ class Runtime:
         qkv_owned = set()
         for mod in model.modules():
             if hasattr(mod, "q_linear") and hasattr(mod, "k_linear") and hasattr(mod, "v_linear"):
-                ws = (mod.q_linear.weight, mod.k_linear.weight, mod.v_linear.weight)
-                bs = (mod.q_linear.bias, mod.k_linear.bias, mod.v_linear.bias)
+                ws = (mod.q_linear.weight, mod.v_linear.weight, mod.k_linear.weight)       # the order of qkv()
+                bs = (mod.q_linear.bias, mod.v_linear.bias, mod.k_linear.bias)
                 d, dev = ws[0].shape[0], ws[0].device
                 wf = torch.empty((3 * d, d), dtype=self.dtype, device=dev)
                 wd = torch.empty((d, 3 * d), dtype=self.dtype, device=dev)
@@ -267,7 +268,7 @@ class EncoderStackFunction(torch.autograd.Function):
             wf, _, bqkv = rt.qkv(layer.attn)
             qkv = ops.linear(h.view(M, d), wf, bqkv)                                             # modules.py:49-51
             q5 = qkv.view(B, t, 3, H, dk)
-            q, k, v = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))                        # (B,H,t,dk) views
+            q, v, k = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))                        # (B,H,t,dk) views
             S, Pd = attn[:, i], attn_drop[:, i]
             ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)                                 # modules.py:8-9
             ops.softmax_fwd(S, Pd, km, t, p, rng, layer.site_attn)                               # modules.py:11-19
@@ -341,10 +342,10 @@ class EncoderStackFunction(torch.autograd.Function):
             dO4 = dO.view(B, t, H, dk).permute(0, 2, 1, 3)
             qkv = L["qkv"]
             q5 = qkv.view(B, t, 3, H, dk)
-            q, k, v = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+            q, v, k = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
             dqkv = torch.empty((B, t, 3 * d), dtype=T, device=dev)
             d5 = dqkv.view(B, t, 3, H, dk)
-            dq, dk_, dv = (d5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+            dq, dv, dk_ = (d5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
             P, Pd = ctx.attn[:, i], ctx.attn_drop[:, i]
             ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)                 # dV = Pd^T dO
             ops.bmm(dO4, v, dP[..., :t], trans_b=True)                        # dP = dO V^T
@@ -356,10 +357,10 @@ class EncoderStackFunction(torch.autograd.Function):
             with rt.side(dqkv2):
                 bsum = rt.zeros(("qkvb", d), (3 * d,), torch.float32, dev)
                 ops.colsum(dqkv2, bsum)
-                for j, lin in enumerate((at.q_linear, at.k_linear, at.v_linear)):
+                for j, lin in enumerate((at.q_linear, at.v_linear, at.k_linear)):
                     ops.colsum(bsum[j * d:(j + 1) * d].view(1, d), grad_of(lin.bias))
-            for j, lin in enumerate((at.q_linear, at.k_linear, at.v_linear)):
-                _linear_wgrad(rt, dqkv2[:, j * d:(j + 1) * d], h2d, lin, bias_done=True)
+                # the three weight gradients in ONE batched split-K GEMM when they sit at a constant stride (arena)
+                ops.wgrad_batched(dqkv2, h2d, [grad_of(lin.weight) for lin in (at.q_linear, at.v_linear, at.k_linear)])
             _, wd, _ = rt.qkv(at)
             dh = ops.linear(dqkv2, wd).view(B, t, d)
 

@@ -23,6 +23,7 @@
 // issued before the MFMAs of stage s (also across tile boundaries), and hipcc counts vmcnt for the set that is
 // moved to LDS.  Loads are raw buffer loads: rows outside the matrix / conv halo rows get an out-of-range
 // offset and read as zeros (no branches around loads -- a predicated `if (ok) v = *p` serialises them).
+#include <type_traits>
 #include "common.cuh"
 #include <stdlib.h>
 
@@ -81,6 +82,8 @@ __device__ __forceinline__ void mma(f32x4& acc, const typename Frag<T>::type& a,
     }
 }
 
+constexpr int COLSTAT_LDS_N = 1024;     // columns whose statistics a block accumulates in LDS (2 floats each)
+
 template <int TM> struct Geo {
     static constexpr int WT = TM / 2;                         // wave tile
     static constexpr int NI = WT / 16;                        // MFMA tiles per wave per dim
@@ -111,6 +114,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
     static_assert(!DIRECT, "a register-direct epilogue was tried (partial-line stores, accumulators in scratch) and dropped");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
+    // Column statistics (BatchNorm sums / bias gradients) are accumulated per block in LDS and flushed with one
+    // global atomic per touched column when the block retires: a global float atomic issued from the epilogue sits
+    // on the in-order vmcnt queue in front of the next stages' loads, and ~700 wave-tiles add into each column.
+    float* cacc = reinterpret_cast<float*>(smem + G::SMEM);
+    const bool lds_stats = p.colstats != nullptr && p.N <= COLSTAT_LDS_N;
+    if (lds_stats) {
+        for (int n = tid; n < 2 * COLSTAT_LDS_N; n += 256) cacc[n] = 0.f;     // visible after the prologue's barrier
+    }
 
     const int tilesN = (p.N + TM - 1) / TM, tilesM = (p.M + TM - 1) / TM;
     const int tiles = tilesM * tilesN;
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto epilogue = [&]() {
+    auto epilogue = [&]() __attribute__((always_inline)) {
         const Work& cur = ck;
         TC* __restrict__ C = reinterpret_cast<TC*>(p.C) + cur.coff;
         {
@@ -342,39 +353,78 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
             if (!stored) {
                 constexpr int CG = WT / 4;                      // 4-column groups per wave-tile row
                 constexpr int RPP = 64 / CG;                    // rows per pass
+                constexpr int NP = WT / RPP;                    // passes
+                constexpr int PC = (AKM || BKM || NP < 8) ? 4 : 8;   // passes per chunk: their mask / residual loads fly together
                 const int cg = lane % CG;
                 const int ncol = cur.n0 + wc * WT + cg * 4;
                 const bool col_ok = ncol < p.N;
                 float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.bias != nullptr && col_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + ncol);
                 float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-                for (int pass = 0; pass < WT / RPP; ++pass) {
-                    const int rl = pass * RPP + lane / CG;
-                    const int m = cur.m0 + wr * WT + rl;
-                    float4 v = *reinterpret_cast<const float4*>(ew + rl * EPI_LD + cg * 4);
-                    if (!(col_ok && m < p.M)) continue;
-                    v.x = v.x * p.alpha + bias4.x; v.y = v.y * p.alpha + bias4.y;
-                    v.z = v.z * p.alpha + bias4.z; v.w = v.w * p.alpha + bias4.w;
-                    if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (p.relu_mask != nullptr) {
-                        const float4 mk = load4<T>(reinterpret_cast<const T*>(p.relu_mask) + cur.coff + (int64_t)m * p.ldm + ncol);
-                        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-                        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-                    }
-                    if (p.residual != nullptr) {
-                        float4 rr;
-                        if (p.res_dtype == FS2_F32) rr = load4<float>(reinterpret_cast<const float*>(p.residual) + cur.coff + (int64_t)m * p.ldr + ncol);
-                        else rr = load4<bf16_t>(reinterpret_cast<const bf16_t*>(p.residual) + cur.coff + (int64_t)m * p.ldr + ncol);
-                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-                    }
-                    store4<TC>(C + (int64_t)m * p.ldc + ncol, v);
-                    if (p.colstats != nullptr) {
-                        if constexpr (sizeof(TC) != 4) {   // statistics of the values as stored
-                            v.x = (float)(TC)v.x; v.y = (float)(TC)v.y; v.z = (float)(TC)v.z; v.w = (float)(TC)v.w;
+                const bool has_mask = p.relu_mask != nullptr, has_res = p.residual != nullptr;
+                const bool res_f32 = p.res_dtype == FS2_F32;
+#pragma unroll
+                for (int pc = 0; pc < NP; pc += PC) {
+                    // The relu-mask and residual rows come from HBM: issue the loads of PC passes back to back (loaded
+                    // inside the pass loop each one waited out its own latency: +90 us on the 44400x1024 dgrad).
+                    typedef typename std::conditional<sizeof(T) == 2, uint2, uint4>::type MaskRaw;
+                    MaskRaw mraw[PC];
+                    uint4 rraw[PC];
+#pragma unroll
+                    for (int q = 0; q < PC; ++q) {
+                        const int rl = (pc + q) * RPP + lane / CG;
+                        const int m = cur.m0 + wr * WT + rl;
+                        const bool ok = col_ok && m < p.M;
+                        mraw[q] = MaskRaw{};
+                        rraw[q] = uint4{0u, 0u, 0u, 0u};
+                        if (has_mask && ok)
+                            mraw[q] = *reinterpret_cast<const MaskRaw*>(reinterpret_cast<const T*>(p.relu_mask) + cur.coff + (int64_t)m * p.ldm + ncol);
+                        if (has_res && ok) {
+                            if (res_f32) rraw[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(p.residual) + cur.coff + (int64_t)m * p.ldr + ncol);
+                            else {
+                                const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.residual) + cur.coff + (int64_t)m * p.ldr + ncol);
+                                rraw[q].x = h.x; rraw[q].y = h.y;
+                            }
                         }
-                        cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-                        cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+                    }
+#pragma unroll
+                    for (int q = 0; q < PC; ++q) {
+                        const int rl = (pc + q) * RPP + lane / CG;
+                        const int m = cur.m0 + wr * WT + rl;
+                        float4 v = *reinterpret_cast<const float4*>(ew + rl * EPI_LD + cg * 4);
+                        if (!(col_ok && m < p.M)) continue;
+                        v.x = v.x * p.alpha + bias4.x; v.y = v.y * p.alpha + bias4.y;
+                        v.z = v.z * p.alpha + bias4.z; v.w = v.w * p.alpha + bias4.w;
+                        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        if (has_mask) {
+                            float4 mk;
+                            if constexpr (sizeof(T) == 2) {
+                                mk.x = __uint_as_float(mraw[q].x << 16); mk.y = __uint_as_float(mraw[q].x & 0xFFFF0000u);
+                                mk.z = __uint_as_float(mraw[q].y << 16); mk.w = __uint_as_float(mraw[q].y & 0xFFFF0000u);
+                            } else {
+                                mk.x = __uint_as_float(mraw[q].x); mk.y = __uint_as_float(mraw[q].y);
+                                mk.z = __uint_as_float(mraw[q].z); mk.w = __uint_as_float(mraw[q].w);
+                            }
+                            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                            v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                        }
+                        if (has_res) {
+                            if (res_f32) {
+                                v.x += __uint_as_float(rraw[q].x); v.y += __uint_as_float(rraw[q].y);
+                                v.z += __uint_as_float(rraw[q].z); v.w += __uint_as_float(rraw[q].w);
+                            } else {
+                                v.x += __uint_as_float(rraw[q].x << 16); v.y += __uint_as_float(rraw[q].x & 0xFFFF0000u);
+                                v.z += __uint_as_float(rraw[q].y << 16); v.w += __uint_as_float(rraw[q].y & 0xFFFF0000u);
+                            }
+                        }
+                        store4<TC>(C + (int64_t)m * p.ldc + ncol, v);
+                        if (p.colstats != nullptr) {
+                            if constexpr (sizeof(TC) != 4) {   // statistics of the values as stored
+                                v.x = (float)(TC)v.x; v.y = (float)(TC)v.y; v.z = (float)(TC)v.z; v.w = (float)(TC)v.w;
+                            }
+                            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                            cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+                        }
                     }
                 }
                 if (p.colstats != nullptr) {
@@ -389,11 +439,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
                             f[wq][e] = sv;
                         }
                     if (lane < CG && col_ok) {
-                        atomicAdd(p.colstats + ncol + 0, cs.x); atomicAdd(p.colstats + ncol + 1, cs.y);
-                        atomicAdd(p.colstats + ncol + 2, cs.z); atomicAdd(p.colstats + ncol + 3, cs.w);
-                        if (p.colstats_mode == 0) {
-                            atomicAdd(p.colstats + p.N + ncol + 0, cq.x); atomicAdd(p.colstats + p.N + ncol + 1, cq.y);
-                            atomicAdd(p.colstats + p.N + ncol + 2, cq.z); atomicAdd(p.colstats + p.N + ncol + 3, cq.w);
+                        if (lds_stats) {        // (two explicit branches: a select of an LDS and a global pointer is a flat pointer)
+                            atomicAdd(cacc + ncol + 0, cs.x); atomicAdd(cacc + ncol + 1, cs.y);
+                            atomicAdd(cacc + ncol + 2, cs.z); atomicAdd(cacc + ncol + 3, cs.w);
+                            if (p.colstats_mode == 0) {
+                                atomicAdd(cacc + COLSTAT_LDS_N + ncol + 0, cq.x); atomicAdd(cacc + COLSTAT_LDS_N + ncol + 1, cq.y);
+                                atomicAdd(cacc + COLSTAT_LDS_N + ncol + 2, cq.z); atomicAdd(cacc + COLSTAT_LDS_N + ncol + 3, cq.w);
+                            }
+                        } else {
+                            atomicAdd(p.colstats + ncol + 0, cs.x); atomicAdd(p.colstats + ncol + 1, cs.y);
+                            atomicAdd(p.colstats + ncol + 2, cs.z); atomicAdd(p.colstats + ncol + 3, cs.w);
+                            if (p.colstats_mode == 0) {
+                                atomicAdd(p.colstats + p.N + ncol + 0, cq.x); atomicAdd(p.colstats + p.N + ncol + 1, cq.y);
+                                atomicAdd(p.colstats + p.N + ncol + 2, cq.z); atomicAdd(p.colstats + p.N + ncol + 3, cq.w);
+                            }
                         }
                     }
                 }
@@ -404,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
 
     // one step of the flattened stage stream: fetch stage s+D, compute stage s, finish the tile if it was its last
     // stage, move stage s+1 from registers to LDS
-    auto step = [&](auto slot_c, auto next_c, int s) {
+    auto step = [&](auto slot_c, auto next_c, int s) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;   // = s % D: the register set that held stage s (free now)
         constexpr int BUF = SLOT & 1;                   // = s % 2 (D is even): compile-time LDS buffer
         const bool tile_end = (cit + 1 == ck.it1);
@@ -483,13 +542,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
         if (s < nst) { step(IC<1>{}, IC<2>{}, s); ++s; }
         if (s < nst) { step(IC<2>{}, IC<3>{}, s); ++s; }
     }
+    if (lds_stats) {        // the last step ended with a barrier: every wave's LDS adds are done
+        for (int n = tid; n < p.N; n += 256) {
+            const float a = cacc[n];
+            if (a != 0.f) atomicAdd(p.colstats + n, a);
+            if (p.colstats_mode == 0) {
+                const float q = cacc[COLSTAT_LDS_N + n];
+                if (q != 0.f) atomicAdd(p.colstats + p.N + n, q);
+            }
+        }
+    }
 }
 
 template <typename T, typename TC, bool AKM, bool BKM, int TM, bool DIRECT>
 int launch1(const FS2Gemm& g, int total, hipStream_t st) {
     const int slots = (TM == 128) ? 512 : 768;      // resident blocks: 2 (128-tile) / 3 (64-tile) per CU x 256 CUs
     const int grid = total < slots ? total : slots;
-    hipLaunchKernelGGL((gemm_kernel<T, TC, AKM, BKM, TM, DIRECT>), dim3(grid), dim3(256), Geo<TM>::SMEM, st, g, total);
+    const int lds = Geo<TM>::SMEM + (g.colstats != nullptr && g.N <= COLSTAT_LDS_N ? 2 * COLSTAT_LDS_N * 4 : 0);
+    hipLaunchKernelGGL((gemm_kernel<T, TC, AKM, BKM, TM, DIRECT>), dim3(grid), dim3(256), lds, st, g, total);
     FS2_CHECK_LAUNCH("fs2_gemm");
     return FS2_OK;
 }

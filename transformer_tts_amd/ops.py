@@ -211,10 +211,12 @@ def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, 
 
 
 def _pick_split(M_out, N_out, K_red, batch):
+    """split-K factor of a weight-gradient GEMM: ~384 blocks in all (1-2 per CU; measured optimum 256-384 on the
+    config-2 shapes, tools/gemm_bench.py wsplit), at least 6 K-stages of 64 per split, at most 64 splits"""
     tiles = ((M_out + 127) // 128) * ((N_out + 127) // 128) * batch
     ktiles = max(1, (K_red + 63) // 64)
-    want = max(1, 512 // max(tiles, 1))
-    return int(max(1, min(want, ktiles, 64)))
+    want = max(1, int(round(384 / max(tiles, 1))))
+    return int(max(1, min(want, max(1, ktiles // 6), 64)))
 
 
 def wgrad(dy, x, out, split=None):
@@ -232,6 +234,33 @@ def wgrad(dy, x, out, split=None):
     _epilogue(g, out, None, False, None, None, None, 1.0)
     _gemm_call(g)
     return out
+
+
+def wgrad_batched(dy, x, outs):
+    """outs[j][N,K] (fp32) += dy[:, j*N:(j+1)*N]^T @ x   for the column blocks of one dy (M, len(outs)*N): one launch
+    with the blocks as the batch when the outputs sit at a constant address stride, else one launch per block."""
+    nb = len(outs)
+    M, N = dy.shape[0], dy.shape[1] // nb
+    K = x.shape[1]
+    ptrs = [o.data_ptr() for o in outs]
+    step = ptrs[1] - ptrs[0] if nb > 1 else 0
+    regular = nb > 1 and step > 0 and step % 4 == 0 and all(ptrs[j + 1] - ptrs[j] == step for j in range(nb - 1)) \
+        and all(o.dtype == torch.float32 and o.shape == (N, K) and o.is_contiguous() for o in outs)
+    if not regular:
+        for j, o in enumerate(outs):
+            wgrad(dy[:, j * N:(j + 1) * N], x, o)
+        return outs
+    g = FS2Gemm()
+    g.A, g.B, g.lda, g.ldb = _p(dy), _p(x), _ld(dy), _ld(x)
+    g.a_kmajor = g.b_kmajor = 1
+    g.M, g.N, g.K, g.dtype = N, K, M, _dt(x)
+    g.batch1, g.batch2 = nb, 1
+    g.sA1, g.sB1, g.sC1 = N, 0, step // 4
+    g.split_k = _pick_split(N, K, M, nb)
+    g.accumulate = 1
+    _epilogue(g, outs[0], None, False, None, None, None, 1.0)
+    _gemm_call(g)
+    return outs
 
 
 def conv_wgrad(dy, x, taps, pad, out):
