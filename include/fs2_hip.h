@@ -152,6 +152,18 @@ int fs2_softmax_fwd(void* s_inout_p, void* p_drop, int dtype, const uint8_t* key
 int fs2_softmax_bwd(void* dp_inout_ds, int64_t dp_batch_stride, const void* p_saved, int64_t p_batch_stride, int dtype,
                     int B, int H, int t, int tp, float p, const uint64_t* rng, uint32_t site, void* stream);
 
+/* attention() scores + softmax + dropout in one kernel (Models/modules.py:8-19), bf16 only: a workgroup keeps the
+ * 64 x tp score strip of its query rows in LDS, so QK^T/sqrt(d_k) never reaches HBM.
+ *   q, k: rows of one head = dk contiguous bf16 at  base + b*batch_stride + i*row_stride + h*head_stride  (elements)
+ *   p_out / p_drop: (B,[..],H,t,tp) as fs2_softmax_fwd writes them (same values, same Philox counters, pad columns 0),
+ *   so fs2_softmax_bwd and the PV / backward GEMMs are unchanged.  alpha = 1/sqrt(d_k).
+ * fs2_attn_probs_lds_bytes(t, dk): dynamic LDS the kernel needs, or -1 when (t, dk) is not supported (dk not in
+ * {32,64,128} or the strip does not fit 160 KiB: t > ~1016) -- then use fs2_gemm + fs2_softmax_fwd.              */
+int fs2_attn_probs_lds_bytes(int t, int dk);
+int fs2_attn_probs_fwd(const void* q, const void* k, int64_t row_stride, int64_t batch_stride, int head_stride, int dk,
+                       const uint8_t* key_mask, void* p_out, void* p_drop, int64_t p_batch_stride, int B, int H, int t,
+                       int tp, float alpha, float p, const uint64_t* rng, uint32_t site, void* stream);
+
 /* LengthRegulator (Models/varianceadaptor.py:141-184,233-249): out[b][f] = x[b][i] for the phoneme i whose
  * duration interval contains frame f, 0 beyond sum(dur) or max_len.  starts is a [B][L+1] int32 workspace
  * (exclusive prefix sums) produced by forward and consumed by backward (segmented sum).               */

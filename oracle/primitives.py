@@ -48,22 +48,26 @@ def _philox4x32(c0, c1, c2, c3, k0, k1):
 
 
 def drop_scale(shape, p, rng, site, base_index=None):
-    """Per-element factors (0 or 1/(1-p)) of the kernels' dropout stream for a tensor whose element
-    index (row-major, or ``base_index`` if given as an int64 array of that shape) is the Philox counter."""
+    """Per-element factors (0 or 65536/(65536 - thr16)) of the kernels' dropout stream (common.cuh drop_scale8/4) for
+    a tensor whose element index (row-major, or ``base_index`` if given as an int64 array of that shape) selects
+    the Philox call (index >> 3) and the 16-bit half of its output (word (index & 7) >> 1, half index & 1)."""
     if p <= 0.0:
         return torch.ones(shape, dtype=_COMPUTE)
     seed, off = int(rng.state[0]) & (2 ** 64 - 1), int(rng.state[1]) & (2 ** 64 - 1)
     n = int(np.prod(shape))
     idx = np.arange(n, dtype=np.uint64) if base_index is None else np.asarray(base_index, np.uint64).reshape(-1)
-    q = idx >> np.uint64(2)
+    q = idx >> np.uint64(3)
     k0 = seed & 0xFFFFFFFF
     k1 = ((seed >> 32) ^ (off >> 32)) & 0xFFFFFFFF
     r = _philox4x32(q & np.uint64(0xFFFFFFFF), q >> np.uint64(32), np.full(n, site, np.uint64),
-                       np.full(n, off & 0xFFFFFFFF, np.uint64), k0, k1)
-    lane = (idx & np.uint64(3)).astype(np.int64)
-    bits = np.stack(r, axis=1)[np.arange(n), lane].astype(np.uint32)
-    keep = bits >= np.uint32(int(float(np.float32(p)) * 4294967296.0))      # DropCtx.thr
-    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+                    np.full(n, off & 0xFFFFFFFF, np.uint64), k0, k1)
+    word = ((idx & np.uint64(7)) >> np.uint64(1)).astype(np.int64)
+    half = (idx & np.uint64(1)).astype(np.uint64)
+    bits = np.stack(r, axis=1)[np.arange(n), word].astype(np.uint64)
+    bits16 = (bits >> (np.uint64(16) * half)) & np.uint64(0xFFFF)
+    thr16 = int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+    keep = bits16 >= np.uint64(thr16)
+    scale = np.float32(65536.0) / (np.float32(65536.0) - np.float32(thr16))
     return torch.from_numpy(np.where(keep, scale, np.float32(0)).astype(np.float64).reshape(shape))
 
 
@@ -339,6 +343,20 @@ def softmax_fwd(s, p_drop, key_mask, t, p=0.0, rng=None, site=0):
     if p_drop.data_ptr() != s.data_ptr() or p > 0:
         sc = drop_scale((B, H, t, tp), p, rng, site, base_index=_strided_index(s))
         p_drop.copy_((_f(s) * sc).to(s.dtype))
+
+
+def attn_probs_supported(t, dk, dtype):
+    """the (t, dk) envelope of fs2_attn_probs_fwd (attention.hip: strip_ld, fs2_attn_probs_lds_bytes)"""
+    tp = (t + 7) // 8 * 8
+    sld = tp + 8 if (tp // 8) % 2 == 0 else tp
+    return dtype == torch.bfloat16 and dk in (32, 64, 128) and 0 < t <= 1024 and \
+        64 * sld * 2 + 2 * 64 * dk * 2 + 1024 <= 160 * 1024
+
+
+def attn_probs_fwd(q, k, key_mask, p_out, p_drop, t, alpha, p=0.0, rng=None, site=0):
+    """Models/modules.py:8-19 in one call: scores (stored in the tensors' dtype), key mask, softmax, dropout."""
+    bmm(q, k, p_out[..., :t], trans_b=True, alpha=alpha)
+    softmax_fwd(p_out, p_drop, key_mask, t, p, rng, site)
 
 
 def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):

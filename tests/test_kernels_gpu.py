@@ -260,6 +260,43 @@ def test_softmax_fwd_bwd(ops, dtype, p, t):
     assert float(Pc[1, :, :, lens[1]:t].abs().max()) < 1e-6, "masked keys get ~0 probability (-1e4 fill)"
 
 
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("t,H,dk", [(37, 2, 32), (64, 1, 64), (130, 2, 128), (925, 2, 128), (1013, 1, 64)])
+def test_attn_probs_fused_vs_gemm_softmax(ops, p, t, H, dk):
+    """fs2_attn_probs_fwd (scores kept in LDS) against the oracle's bmm + softmax_fwd on the same fused-qkv layout,
+    key masks of different lengths, the same Philox counters (so the dropout masks must coincide)."""
+    dtype = torch.bfloat16
+    B, NL = 3, 2
+    tp = (t + 7) // 8 * 8
+    assert P.attn_probs_supported(t, dk, dtype) and ops.attn_probs_supported(t, dk, dtype)
+    lens = [t, max(1, t // 2), max(1, t - 5)]
+    km = torch.zeros(B, t, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        km[b, :n] = True
+    qkv = rnd(B, t, 3, H, dk, dtype=dtype, seed=1, scale=1.5)
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda x: x.cuda()) if dev == "cuda" else (lambda x: x.clone())
+        rng = o.Rng(5, dev)
+        x = mv(qkv)
+        q, k = (x[:, :, j].permute(0, 2, 1, 3) for j in (0, 2))
+        buf = mv(torch.full((B, NL, H, t, tp), float("nan"), dtype=dtype))
+        bufd = mv(torch.full((B, NL, H, t, tp), float("nan"), dtype=dtype)) if p > 0 else buf
+        o.attn_probs_fwd(q, k, mv(km), buf[:, 1], bufd[:, 1], t, 1.0 / dk ** 0.5, p, rng, 11)
+        out[dev] = (buf[:, 1].clone(), bufd[:, 1].clone())
+    # scores are rounded to bf16 before the softmax on both sides; a 1-ulp difference there moves a probability by ~1 %
+    for a, b, n in zip(out["cuda"], out["cpu"], ("P", "P_drop")):
+        close(a, b, n, rtol=4e-2, atol=2e-3)
+    Pc, Pdc = (x.float().cpu() for x in out["cuda"])
+    assert torch.all(Pc[..., t:] == 0) and torch.all(Pdc[..., t:] == 0), "pad columns must be written as zero"
+    close(Pc[..., :t].sum(-1), torch.ones(B, H, t), "rows sum to one", rtol=1e-2, atol=1e-2)
+    assert float(Pc[1, :, :, lens[1]:t].abs().max()) < 1e-6, "masked keys get ~0 probability"
+    if p > 0:      # identical dropout pattern: zeros of P_drop where P is not tiny must coincide with the oracle's
+        big = out["cpu"][0].float() > 1e-3
+        assert torch.equal((Pdc == 0) & big, (out["cpu"][1].float() == 0) & big)
+    assert not ops.attn_probs_supported(1100, 128, dtype) and not ops.attn_probs_supported(100, 48, dtype)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_pe_embedding_linear1(ops, dtype):
     B, t, d, V = 3, 29, 64, 40

@@ -270,8 +270,11 @@ class EncoderStackFunction(torch.autograd.Function):
             q5 = qkv.view(B, t, 3, H, dk)
             q, v, k = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))                        # (B,H,t,dk) views
             S, Pd = attn[:, i], attn_drop[:, i]
-            ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)                                 # modules.py:8-9
-            ops.softmax_fwd(S, Pd, km, t, p, rng, layer.site_attn)                               # modules.py:11-19
+            if ops.attn_probs_supported(t, dk, T):      # scores stay in LDS (one kernel)
+                ops.attn_probs_fwd(q, k, km, S, Pd, t, scale, p, rng, layer.site_attn)           # modules.py:8-19
+            else:
+                ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)                             # modules.py:8-9
+                ops.softmax_fwd(S, Pd, km, t, p, rng, layer.site_attn)                           # modules.py:11-19
             O = torch.empty((B, t, H, dk), dtype=T, device=dev)
             ops.bmm(Pd, v, O.permute(0, 2, 1, 3), trans_b=False)                                 # modules.py:20
             a = ops.linear(O.view(M, d), rt.w_fwd(layer.attn.out.weight), layer.attn.out.bias.detach())  # :68

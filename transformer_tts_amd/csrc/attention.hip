@@ -1,0 +1,260 @@
+// Fused attention-probability kernel for gfx950 (bf16): P = dropout(softmax(mask(Q K^T / sqrt(dk)))) without the
+// score tensor ever reaching HBM.
+//
+// Reference: Models/modules.py:7-21 (attention()): scores = q k^T / sqrt(d_k); masked_fill(mask == 0, -1e4) on keys;
+// softmax over keys; dropout.  The unfused path (fs2_gemm + fs2_softmax_fwd) writes the (B,H,t,tp) scores (165 MB
+// per decoder layer at t ~ 925), reads them back, and writes P and dropout(P).  Here a workgroup owns 64 query rows of
+// one (batch, head): it keeps their whole score strip (64 x tp, bf16 -- the precision the unfused path stores) in
+// LDS, streams the key rows through a double-buffered 64-key tile, and writes only P and dropout(P).
+//
+// Layouts: q/k rows of one head are `dk` contiguous bf16 at q + b*batch_stride + i*row_stride + h*head_stride (the
+// fused qkv projection output); P/Pd are (B,[layers],H,t,tp) with tp = roundup8(t), pad columns written as 0.
+// MFMA: S^T tile = K_tile (16 keys x dk) * Q^T, so that a lane's 4 accumulator values are 4 consecutive keys of one
+// query row (one 8-byte LDS store into the strip).  Dropout uses the same Philox counters (element offset in P >> 3)
+// as fs2_softmax_fwd, so fs2_softmax_bwd regenerates the masks unchanged.
+#include "common.cuh"
+
+namespace {
+
+constexpr int QB = 64;                 // query rows per workgroup
+constexpr int KB = 64;                 // keys per tile
+constexpr int LDS_MAX = 160 * 1024;
+constexpr int MASK_BYTES = 1024;       // key mask of one batch element (t <= 1024 whenever the strip fits)
+
+template <int DK> struct KTile {
+    static constexpr int CPR = DK / 8;             // 16-B chunks per key row
+    static constexpr int RPL = 16 / CPR;           // key rows per 256-B LDS line
+    static constexpr int BYTES = KB * DK * 2;
+    static constexpr int KS = DK / 32;             // MFMA k-steps
+    // byte offset of chunk `ch` of key row `row`: 16 rows read at one chunk index land on 16 different 16-B slots
+    __device__ static __forceinline__ int off(int row, int ch) {
+        const int line = row / RPL;
+        return line * 256 + (((row % RPL) * CPR + (ch ^ (line % CPR))) << 4);
+    }
+};
+
+// strip row length in elements: tp (+8 so that consecutive rows shift by an odd number of 16-B slots)
+static inline int strip_ld(int tp) { return ((tp / 8) % 2 == 0) ? tp + 8 : tp; }
+
+// 512 threads = 8 waves in two groups of four.  Phase 1: group gq takes key tiles gq, gq+2, ... (its own LDS tile
+// buffer, a 2-deep register ring in front of it), wave w4 of a group the 16 keys w4*16.. of the tile against all 64
+// query rows.  Phase 2: wave w owns query rows 8w .. 8w+7, two at a time.
+template <int DK>
+__global__ __launch_bounds__(512, 1) void attn_probs_fwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+        int64_t row_stride, int64_t batch_stride, int head_stride, const uint8_t* __restrict__ key_mask,
+        bf16_t* __restrict__ P, bf16_t* __restrict__ Pd, int64_t p_batch_stride, int H, int t, int tp, int sld,
+        float alpha, float pdrop, const uint64_t* rng, uint32_t site) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef KTile<DK> KT;
+    constexpr int KS = KT::KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gq = wave >> 2, w4 = wave & 3, gtid = tid & 255;
+    const int g = lane >> 4, i16 = lane & 15;
+    const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
+    unsigned char* strip = smem;
+    unsigned char* ktile = smem + QB * sld * 2 + gq * KT::BYTES;      // this group's key tile
+    unsigned char* lmask = smem + QB * sld * 2 + 2 * KT::BYTES;
+    const bf16_t* qb = q + (int64_t)b * batch_stride + (int64_t)h * head_stride;
+    const bf16_t* kb = k + (int64_t)b * batch_stride + (int64_t)h * head_stride;
+
+    constexpr int CPT = KB * KT::CPR / 256;        // 16-B chunks per thread per tile
+    const int nkt = (t + KB - 1) / KB;
+    auto load_tile = [&](uint4 (&r)[CPT], int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = gtid + j * 256;
+            const int row = kt * KB + c / KT::CPR, ch = c % KT::CPR;
+            r[j] = uint4{0u, 0u, 0u, 0u};
+            if (kt < nkt && row < t) r[j] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * row_stride + ch * 8);
+        }
+    };
+    auto store_tile = [&](const uint4 (&r)[CPT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = gtid + j * 256;
+            *reinterpret_cast<uint4*>(ktile + KT::off(c / KT::CPR, c % KT::CPR)) = r[j];
+        }
+    };
+    // every independent global load of the prologue is issued before the first wait
+    uint4 ra[CPT], rb[CPT];
+    load_tile(ra, gq);
+    load_tile(rb, gq + 2);
+    bf16x8 qf[4][KS];                              // Q fragments of all 64 query rows (B operand: column = query row)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int row = q0 + rt * 16 + i16;
+            bf16x8 z = {};
+            qf[rt][ks] = (row < t) ? *reinterpret_cast<const bf16x8*>(qb + (int64_t)row * row_stride + ks * 32 + g * 8) : z;
+        }
+    for (int j = tid; j < MASK_BYTES; j += 512) lmask[j] = (j < t) ? key_mask[(int64_t)b * t + j] : 0;   // 0 beyond t
+
+    // ---- phase 1: score strip
+    auto compute_tile = [&](int kt) __attribute__((always_inline)) {
+        if (kt >= nkt) return;
+        f32x4 acc[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(ktile + KT::off(w4 * 16 + i16, ks * 4 + g));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[rt][ks], acc[rt], 0, 0, 0);
+        // acc[rt][r] = S[query rt*16 + i16][key kt*64 + w4*16 + g*4 + r]
+        const int kcol = kt * KB + w4 * 16 + g * 4;
+        if (kcol < tp) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[rt][r] * alpha);
+                *reinterpret_cast<bf16x4*>(strip + ((rt * 16 + i16) * sld + kcol) * 2) = o;
+            }
+        }
+    };
+    store_tile(ra);
+    __syncthreads();
+    const int nit = (nkt + 1) / 2;                 // iterations: this group's tile of iteration it is 2*it + gq
+    for (int it = 0; it < nit; it += 2) {
+        // even iteration: tile 2*it+gq is in LDS, tile 2*(it+1)+gq in rb; ra is free
+        load_tile(ra, 2 * (it + 2) + gq);
+        compute_tile(2 * it + gq);
+        __syncthreads();
+        store_tile(rb);
+        __syncthreads();
+        if (it + 1 >= nit) break;
+        // odd iteration: tile 2*(it+1)+gq is in LDS, tile 2*(it+2)+gq in ra; rb is free
+        load_tile(rb, 2 * (it + 3) + gq);
+        compute_tile(2 * (it + 1) + gq);
+        __syncthreads();
+        store_tile(ra);
+        __syncthreads();
+    }
+
+    // ---- phase 2: row softmax + dropout straight from the strip; wave w owns query rows 8w .. 8w+7, two at a time
+    const DropCtx dc = drop_ctx(rng, site, pdrop);
+    const int ng = (tp + 511) / 512;               // 16-byte groups per lane (<= 2)
+    constexpr int R = 2;
+    for (int rr = 0; rr < 8; rr += R) {
+        const int ql0 = wave * 8 + rr;
+        if (q0 + ql0 >= t) break;                  // wave-uniform
+        float e[R][2][8];
+        float mx[R], sum[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int ql = ql0 + r;
+            mx[r] = -3.0e38f;
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int col = 8 * (lane + 64 * gi);
+                bf16x8 raw = {};
+                uint2 mk = make_uint2(0u, 0u);
+                if (gi < ng && col < tp) {
+                    raw = *reinterpret_cast<const bf16x8*>(strip + (ql * sld + col) * 2);
+                    mk = *reinterpret_cast<const uint2*>(lmask + col);
+                }
+                // branch-free: invalid columns (>= t) become -3e38 (exp -> 0), masked keys -1e4 (masked_fill(mask == 0, -1e4))
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t mb = ((c < 4 ? mk.x : mk.y) >> (8 * (c & 3))) & 0xFFu;
+                    float x = (float)raw[c];
+                    x = mb != 0 ? x : -1e4f;
+                    x = (col + c < t) ? x : -3.0e38f;
+                    e[r][gi][c] = x;
+                    mx[r] = fmaxf(mx[r], x);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) mx[r] = wave_max(mx[r]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            sum[r] = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    e[r][gi][c] = __expf(e[r][gi][c] - mx[r]);       // invalid columns: exp(-3e38 - mx) = 0
+                    sum[r] += e[r][gi][c];
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) sum[r] = wave_sum(sum[r]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int qrow = q0 + ql0 + r;
+            if (qrow >= t) continue;               // wave-uniform
+            const float inv = 1.f / sum[r];
+            const int64_t off = (int64_t)b * p_batch_stride + ((int64_t)h * t + qrow) * tp;
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int col = 8 * (lane + 64 * gi);
+                if (!(gi < ng && col < tp)) continue;
+                bf16x8 o;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { e[r][gi][c] *= inv; o[c] = (bf16_t)e[r][gi][c]; }
+                *reinterpret_cast<bf16x8*>(P + off + col) = o;
+                if (Pd != P) {
+                    if (dc.on) {
+                        float ds[8];
+                        drop_scale8(dc, (uint64_t)(off + col) >> 3, ds);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) e[r][gi][c] *= ds[c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o[c] = (bf16_t)e[r][gi][c];
+                    *reinterpret_cast<bf16x8*>(Pd + off + col) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int DK>
+int launch_probs(const void* q, const void* k, int64_t row_stride, int64_t batch_stride, int head_stride,
+                 const uint8_t* key_mask, void* P, void* Pd, int64_t p_batch_stride, int B, int H, int t, int tp,
+                 float alpha, float pdrop, const uint64_t* rng, uint32_t site, hipStream_t st) {
+    const int sld = strip_ld(tp);
+    const int lds = QB * sld * 2 + 2 * KTile<DK>::BYTES + MASK_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_probs_fwd_k<DK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        attr_set = true;
+    }
+    dim3 grid((t + QB - 1) / QB, H, B);
+    hipLaunchKernelGGL((attn_probs_fwd_k<DK>), grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, row_stride,
+                       batch_stride, head_stride, key_mask, (bf16_t*)P, (bf16_t*)Pd, p_batch_stride, H, t, tp, sld, alpha,
+                       pdrop, rng, site);
+    FS2_CHECK_LAUNCH("fs2_attn_probs_fwd");
+    return FS2_OK;
+}
+
+}  // namespace
+
+extern "C" int fs2_attn_probs_lds_bytes(int t, int dk) {
+    if (t <= 0 || t > MASK_BYTES || (dk != 32 && dk != 64 && dk != 128)) return -1;
+    const int tp = (t + 7) / 8 * 8;
+    const int lds = QB * strip_ld(tp) * 2 + 2 * KB * dk * 2 + MASK_BYTES;
+    return lds <= LDS_MAX ? lds : -1;
+}
+
+extern "C" int fs2_attn_probs_fwd(const void* q, const void* k, int64_t row_stride, int64_t batch_stride, int head_stride,
+                                  int dk, const uint8_t* key_mask, void* p_out, void* pd_out, int64_t p_batch_stride,
+                                  int B, int H, int t, int tp, float alpha, float p, const uint64_t* rng, uint32_t site,
+                                  void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FS2_REQUIRE(fs2_attn_probs_lds_bytes(t, dk) > 0, "fs2_attn_probs_fwd: t=%d dk=%d does not fit the LDS strip (use fs2_gemm + fs2_softmax_fwd)", t, dk);
+    FS2_REQUIRE(tp == (t + 7) / 8 * 8 && tp <= 1024, "fs2_attn_probs_fwd: tp must be roundup8(t) <= 1024 (t=%d tp=%d)", t, tp);
+    FS2_REQUIRE(B > 0 && H > 0 && B <= 65535 && H <= 65535, "fs2_attn_probs_fwd: bad B/H");
+    FS2_REQUIRE(row_stride % 8 == 0 && batch_stride % 8 == 0 && head_stride % 8 == 0 && p_batch_stride % 8 == 0,
+                "fs2_attn_probs_fwd: strides must be multiples of 8 elements (16-byte accesses)");
+    FS2_REQUIRE(fs2_aligned16(q) && fs2_aligned16(k) && fs2_aligned16(p_out) && fs2_aligned16(pd_out), "fs2_attn_probs_fwd: pointers must be 16-byte aligned");
+    FS2_REQUIRE(p == 0.f || (rng != nullptr && pd_out != p_out), "fs2_attn_probs_fwd: dropout needs rng and a separate p_drop buffer");
+    FS2_REQUIRE(p >= 0.f && p < 1.f, "fs2_attn_probs_fwd: p out of range");
+    if (dk == 128) return launch_probs<128>(q, k, row_stride, batch_stride, head_stride, key_mask, p_out, pd_out, p_batch_stride, B, H, t, tp, alpha, p, rng, site, st);
+    if (dk == 64) return launch_probs<64>(q, k, row_stride, batch_stride, head_stride, key_mask, p_out, pd_out, p_batch_stride, B, H, t, tp, alpha, p, rng, site, st);
+    return launch_probs<32>(q, k, row_stride, batch_stride, head_stride, key_mask, p_out, pd_out, p_batch_stride, B, H, t, tp, alpha, p, rng, site, st);
+}

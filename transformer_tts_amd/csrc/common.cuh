@@ -58,16 +58,29 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) 
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
-// ---------------------------------------------------------------- wave / block reductions (wave = 64 lanes)
+// ---------------------------------------------------------------- wave reductions (wave = 64 lanes)
+// Four DPP steps (quad xor 1, quad xor 2, row rotate 4 and 8) leave the total of each 16-lane row in all of its
+// lanes; the four row totals are then combined through v_readlane.  No LDS crossbar (ds_bpermute, what __shfl_xor
+// compiles to) and no dependent ~100-cycle round trips: the row kernels do 2-3 of these reductions per row.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);     // row_ror:4
+    v += dpp_mov<0x128>(v);     // row_ror:8
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // ---------------------------------------------------------------- Philox4x32-7 dropout stream
@@ -89,11 +102,13 @@ __device__ __forceinline__ Philox4 philox4x32(uint32_t c0, uint32_t c1, uint32_t
     return Philox4{c0, c1, c2, c3};
 }
 
-// Keep-mask scaling factors for the 4 consecutive elements [4*q, 4*q+4) of a tensor at call site `site`.
-// Returns 1/(1-p) for kept elements and 0 for dropped ones.  p == 0 -> all ones without touching rng.
+// Keep-mask scaling factors.  One Philox call serves EIGHT consecutive elements of a tensor at call site `site`
+// (counter = element index >> 3); element e uses the 16-bit half (e & 1) of output word (e & 7) >> 1 and is kept iff
+// that half is >= thr16 = round(p * 65536).  The factor of a kept element is 65536 / (65536 - thr16) (= 1/(1-p) up to
+// the 2^-16 quantisation of p, so the mask stays exactly unbiased); p == 0 -> all ones without touching rng.
 struct DropCtx {
     uint32_t k0, k1, off, site;
-    uint32_t thr;       // an element is kept iff its 32 random bits are >= thr = floor(p * 2^32)
+    uint32_t thr16;
     float p, scale;
     bool on;
 };
@@ -101,8 +116,8 @@ __device__ __forceinline__ DropCtx drop_ctx(const uint64_t* rng, uint32_t site, 
     DropCtx c;
     c.on = p > 0.f;
     c.p = p;
-    c.scale = c.on ? 1.f / (1.f - p) : 1.f;
-    c.thr = (uint32_t)((double)p * 4294967296.0);
+    c.thr16 = (uint32_t)(p * 65536.f + 0.5f);
+    c.scale = c.on ? 65536.f / (65536.f - (float)c.thr16) : 1.f;
     c.site = site;
     if (c.on) {
         uint64_t seed = rng[0], off = rng[1];
@@ -114,13 +129,32 @@ __device__ __forceinline__ DropCtx drop_ctx(const uint64_t* rng, uint32_t site, 
     }
     return c;
 }
-__device__ __forceinline__ float4 drop_scale4(const DropCtx& c, uint64_t q) {
+// factors of elements [8*q8, 8*q8 + 8)
+__device__ __forceinline__ void drop_scale8(const DropCtx& c, uint64_t q8, float (&o)[8]) {
+    if (!c.on) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 1.f;
+        return;
+    }
+    const Philox4 r = philox4x32((uint32_t)q8, (uint32_t)(q8 >> 32), c.site, c.off, c.k0, c.k1);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        o[2 * i] = ((w[i] & 0xFFFFu) >= c.thr16) ? c.scale : 0.f;
+        o[2 * i + 1] = ((w[i] >> 16) >= c.thr16) ? c.scale : 0.f;
+    }
+}
+// factors of elements [4*q4, 4*q4 + 4): the lower or upper half of the call of q4 >> 1
+__device__ __forceinline__ float4 drop_scale4(const DropCtx& c, uint64_t q4) {
     if (!c.on) return make_float4(1.f, 1.f, 1.f, 1.f);
-    Philox4 r = philox4x32((uint32_t)q, (uint32_t)(q >> 32), c.site, c.off, c.k0, c.k1);
+    const uint64_t q8 = q4 >> 1;
+    const Philox4 r = philox4x32((uint32_t)q8, (uint32_t)(q8 >> 32), c.site, c.off, c.k0, c.k1);
+    const bool hi = (q4 & 1) != 0;
+    const uint32_t w0 = hi ? r.z : r.x, w1 = hi ? r.w : r.y;
     float4 o;
-    o.x = (r.x >= c.thr) ? c.scale : 0.f;
-    o.y = (r.y >= c.thr) ? c.scale : 0.f;
-    o.z = (r.z >= c.thr) ? c.scale : 0.f;
-    o.w = (r.w >= c.thr) ? c.scale : 0.f;
+    o.x = ((w0 & 0xFFFFu) >= c.thr16) ? c.scale : 0.f;
+    o.y = ((w0 >> 16) >= c.thr16) ? c.scale : 0.f;
+    o.z = ((w1 & 0xFFFFu) >= c.thr16) ? c.scale : 0.f;
+    o.w = ((w1 >> 16) >= c.thr16) ? c.scale : 0.f;
     return o;
 }

@@ -520,13 +520,17 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd8_k(bf16_t* __restrict__
 #pragma unroll
             for (int g = 0; g < NG8; ++g) {
                 const int col = GCOL8(g);
-                if (col < tp) unpack8(raw[r][g], e[g]);
+                bf16x8 rw = {};
+                if (col < tp) rw = raw[r][g];
+                // branch-free: invalid columns (>= t) become -3e38 (exp -> 0), masked keys -1e4
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    if (col + c < t) {
-                        if (((mk[r][g] >> (8 * c)) & 0xFFu) == 0) e[g][c] = -1e4f;     // masked_fill(mask == 0, -1e4) on keys
-                        mx = fmaxf(mx, e[g][c]);
-                    } else e[g][c] = -3.0e38f;
+                    const uint32_t mb = (uint32_t)(mk[r][g] >> (8 * c)) & 0xFFu;
+                    float x = (float)rw[c];
+                    x = mb != 0 ? x : -1e4f;              // masked_fill(mask == 0, -1e4) on keys
+                    x = (col + c < t) ? x : -3.0e38f;
+                    e[g][c] = x;
+                    mx = fmaxf(mx, x);
                 }
             }
             mx = wave_max(mx);
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd8_k(bf16_t* __restrict__
             for (int g = 0; g < NG8; ++g)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    e[g][c] = (GCOL8(g) + c < t) ? __expf(e[g][c] - mx) : 0.f;
+                    e[g][c] = __expf(e[g][c] - mx);
                     sum += e[g][c];
                 }
             const float inv = 1.f / wave_sum(sum);
@@ -549,10 +553,10 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd8_k(bf16_t* __restrict__
                     *reinterpret_cast<bf16x8*>(s + off[r] + col) = pack8(e[g]);
                     if (pd != s) {
                         if (dc.on) {
-                            const float4 m0 = drop_scale4(dc, (uint64_t)(off[r] + col) >> 2);
-                            const float4 m1 = drop_scale4(dc, ((uint64_t)(off[r] + col) >> 2) + 1);
-                            e[g][0] *= m0.x; e[g][1] *= m0.y; e[g][2] *= m0.z; e[g][3] *= m0.w;
-                            e[g][4] *= m1.x; e[g][5] *= m1.y; e[g][6] *= m1.z; e[g][7] *= m1.w;
+                            float ds[8];
+                            drop_scale8(dc, (uint64_t)(off[r] + col) >> 3, ds);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) e[g][c] *= ds[c];
                         }
                         *reinterpret_cast<bf16x8*>(pd + off[r] + col) = pack8(e[g]);
                     }
@@ -595,16 +599,19 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_bwd8_k(bf16_t* __restrict__
 #pragma unroll
             for (int g = 0; g < NG8; ++g) {
                 const int col = GCOL8(g);
-                if (col < tp) { unpack8(rg[r][g], ge[g]); unpack8(rp[r][g], pe_[g]); }
-                // pad columns [t,tp) of dP were never written by the GEMM: force them (and P's) to 0
+                bf16x8 ag = {}, ap = {};
+                if (col < tp) { ag = rg[r][g]; ap = rp[r][g]; }
+                // pad columns [t,tp) of dP were never written by the GEMM: force them (and P's) to 0 (selects, no branches)
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    if (col + c >= t) { ge[g][c] = 0.f; pe_[g][c] = 0.f; }
+                for (int c = 0; c < 8; ++c) {
+                    ge[g][c] = (col + c < t) ? (float)ag[c] : 0.f;
+                    pe_[g][c] = (col + c < t) ? (float)ap[c] : 0.f;
+                }
                 if (dc.on && col < tp) {
-                    const float4 m0 = drop_scale4(dc, (uint64_t)(poff[r] + col) >> 2);
-                    const float4 m1 = drop_scale4(dc, ((uint64_t)(poff[r] + col) >> 2) + 1);
-                    ge[g][0] *= m0.x; ge[g][1] *= m0.y; ge[g][2] *= m0.z; ge[g][3] *= m0.w;
-                    ge[g][4] *= m1.x; ge[g][5] *= m1.y; ge[g][6] *= m1.z; ge[g][7] *= m1.w;
+                    float ds[8];
+                    drop_scale8(dc, (uint64_t)(poff[r] + col) >> 3, ds);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) ge[g][c] *= ds[c];
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) dot += ge[g][c] * pe_[g][c];

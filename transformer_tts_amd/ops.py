@@ -61,6 +61,8 @@ SIGNATURES = {
     "fs2_ffn_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
     "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
+    "fs2_attn_probs_lds_bytes": [_I, _I],
+    "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
     "fs2_softmax_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_length_regulate_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "fs2_length_regulate_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -480,6 +482,23 @@ def softmax_fwd(s, p_drop, key_mask, t, p=0.0, rng=None, site=0):
     assert p_drop.stride() == s.stride()
     _check(lib().fs2_softmax_fwd(_p(s), _p(p_drop), _dt(s), _p(_c(key_mask)), B, H, t, tp, s.stride(0), p,
                                  _rng_ptr(rng, p), site, _stream()), "fs2_softmax_fwd")
+
+
+def attn_probs_supported(t, dk, dtype):
+    """whether fs2_attn_probs_fwd takes (t, dk): bf16, dk in {32,64,128}, 64 x tp score strip within 160 KiB of LDS"""
+    return dtype == torch.bfloat16 and lib().fs2_attn_probs_lds_bytes(int(t), int(dk)) > 0
+
+
+def attn_probs_fwd(q, k, key_mask, p_out, p_drop, t, alpha, p=0.0, rng=None, site=0):
+    """p_out = softmax(mask_keys(alpha * q k^T)), p_drop = dropout_p(p_out) in one kernel.  q, k: (B,H,t,dk) views of
+    the fused projection (dk contiguous, common strides); p_out, p_drop: (B,H,t,tp) views as softmax_fwd takes them."""
+    B, H, _, dk = q.shape
+    tp = p_out.shape[3]
+    assert q.stride() == k.stride() and q.stride(3) == 1 and q.dtype == k.dtype == torch.bfloat16
+    assert p_out.stride(3) == 1 and p_out.stride(2) == tp and p_out.stride(1) == t * tp and p_drop.stride() == p_out.stride()
+    _check(lib().fs2_attn_probs_fwd(_p(q), _p(k), q.stride(2), q.stride(0), q.stride(1), dk, _p(_c(key_mask)), _p(p_out),
+                                    _p(p_drop), p_out.stride(0), B, H, t, tp, float(alpha), p, _rng_ptr(rng, p), site,
+                                    _stream()), "fs2_attn_probs_fwd")
 
 
 def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
