@@ -157,12 +157,21 @@ int fs2_softmax_bwd(void* dp_inout_ds, int64_t dp_batch_stride, const void* p_sa
  *   q, k: rows of one head = dk contiguous bf16 at  base + b*batch_stride + i*row_stride + h*head_stride  (elements)
  *   p_out / p_drop: (B,[..],H,t,tp) as fs2_softmax_fwd writes them (same values, same Philox counters, pad columns 0),
  *   so fs2_softmax_bwd and the PV / backward GEMMs are unchanged.  alpha = 1/sqrt(d_k).
+ *
  * fs2_attn_probs_lds_bytes(t, dk): dynamic LDS the kernel needs, or -1 when (t, dk) is not supported (dk not in
- * {32,64,128} or the strip does not fit 160 KiB: t > ~1016) -- then use fs2_gemm + fs2_softmax_fwd.              */
+ * {32,64,128} or the strip does not fit 160 KiB: t > ~1016) -- then use fs2_gemm + fs2_softmax_fwd.
+ *
+ * fs2_attn_ds_bwd is the backward counterpart (dP = dO V^T kept in LDS, then the fs2_softmax_bwd arithmetic against the
+ * saved probabilities): ds_out = P * (dP' - sum_j dP'_j P_j), dP' = dropout'(dO V^T); pad columns 0.  d_out rows are
+ * dk contiguous bf16 at  base + b*do_batch_stride + i*do_row_stride + h*head_stride, v likewise with its strides. */
 int fs2_attn_probs_lds_bytes(int t, int dk);
 int fs2_attn_probs_fwd(const void* q, const void* k, int64_t row_stride, int64_t batch_stride, int head_stride, int dk,
                        const uint8_t* key_mask, void* p_out, void* p_drop, int64_t p_batch_stride, int B, int H, int t,
                        int tp, float alpha, float p, const uint64_t* rng, uint32_t site, void* stream);
+int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const void* v, int64_t v_row_stride,
+                    int64_t v_batch_stride, int head_stride, int dk, const void* p_saved, int64_t p_batch_stride,
+                    void* ds_out, int64_t ds_batch_stride, int B, int H, int t, int tp, float p, const uint64_t* rng,
+                    uint32_t site, void* stream);
 
 /* LengthRegulator (Models/varianceadaptor.py:141-184,233-249): out[b][f] = x[b][i] for the phoneme i whose
  * duration interval contains frame f, 0 beyond sum(dur) or max_len.  starts is a [B][L+1] int32 workspace

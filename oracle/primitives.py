@@ -359,6 +359,12 @@ def attn_probs_fwd(q, k, key_mask, p_out, p_drop, t, alpha, p=0.0, rng=None, sit
     softmax_fwd(p_out, p_drop, key_mask, t, p, rng, site)
 
 
+def attn_ds_bwd(d_out, v, p_saved, ds, t, p=0.0, rng=None, site=0):
+    """backward of attn_probs_fwd's softmax/dropout: dP = d_out v^T (stored in the tensors' dtype), then softmax_bwd."""
+    bmm(d_out, v, ds[..., :t], trans_b=True)
+    softmax_bwd(ds, p_saved, t, p, rng, site)
+
+
 def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
     B, H, _, tp = dp.shape
     sc = drop_scale((B, H, t, tp), p, rng, site, base_index=_strided_index(p_saved))   # the forward's offsets

@@ -297,6 +297,42 @@ def test_attn_probs_fused_vs_gemm_softmax(ops, p, t, H, dk):
     assert not ops.attn_probs_supported(1100, 128, dtype) and not ops.attn_probs_supported(100, 48, dtype)
 
 
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("t,H,dk", [(37, 2, 32), (64, 1, 64), (130, 2, 128), (925, 2, 128), (1013, 1, 64)])
+def test_attn_ds_fused_vs_gemm_softmax_bwd(ops, p, t, H, dk):
+    """fs2_attn_ds_bwd (dP = dO V^T kept in LDS) against the oracle's bmm + softmax_bwd: dO in the (B,t,H,dk) layout
+    of the output projection's data gradient, V inside the fused qkv tensor, P from a real forward."""
+    dtype = torch.bfloat16
+    B, NL = 3, 2
+    tp = (t + 7) // 8 * 8
+    lens = [t, max(1, t // 2), max(1, t - 5)]
+    km = torch.zeros(B, t, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        km[b, :n] = True
+    qkv = rnd(B, t, 3, H, dk, dtype=dtype, seed=1, scale=1.5)
+    dO = rnd(B, t, H, dk, dtype=dtype, seed=2)
+    # saved probabilities: the oracle's forward (shared by both sides, so only the backward is compared)
+    rng0 = P.Rng(5, "cpu")
+    Pbuf = torch.zeros(B, NL, H, t, tp, dtype=dtype)
+    Pdbuf = torch.zeros(B, NL, H, t, tp, dtype=dtype)
+    q, v, k = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+    P.attn_probs_fwd(q, k, km, Pbuf[:, 1], Pdbuf[:, 1], t, 1.0 / dk ** 0.5, p, rng0, 11)
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda x: x.cuda()) if dev == "cuda" else (lambda x: x.clone())
+        rng = o.Rng(5, dev)
+        x, g, pb = mv(qkv), mv(dO), mv(Pbuf)
+        vv = x[:, :, 1].permute(0, 2, 1, 3)
+        dS = mv(torch.full((B, H, t, tp), float("nan"), dtype=dtype))
+        o.attn_ds_bwd(g.permute(0, 2, 1, 3), vv, pb[:, 1], dS, t, p, rng, 11)
+        out[dev] = dS
+    a, b_ = out["cuda"].float().cpu(), out["cpu"].float()
+    assert torch.all(a[..., t:] == 0), "pad columns must be written as zero"
+    # dP is rounded to bf16 on both sides before the softmax backward; compare against the scale of each row
+    scale = b_.abs().amax(-1, keepdim=True).clamp_min(1e-6)
+    assert float(((a - b_).abs() / scale).max()) < 4e-2, float(((a - b_).abs() / scale).max())
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_pe_embedding_linear1(ops, dtype):
     B, t, d, V = 3, 29, 64, 40

@@ -26,6 +26,10 @@ for step in "$@"; do
     wsplit)  run wsplit 300 python tools/gemm_bench.py wsplit ;;
     gemmcold) run gemmcold 300 python tools/gemm_bench.py cold dec_ffn enc_conv post_conv attn square "wgrad 1024" ;;
     gemmepi) run gemmepi 300 python tools/gemm_bench.py cold epi ;;
+    ab)      FS2_FUSED_ATTN=0 run ab0 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
+             FS2_FUSED_ATTN=1 run ab1 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
+             FS2_FUSED_ATTN=0 run ab0b 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
+             FS2_FUSED_ATTN=1 run ab1b 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline ;;
     benchs)  FS2_GEMM_DIRECT=0 run benchs 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report_staged.txt ;;
     kernelss) FS2_GEMM_DIRECT=0 run kernelss 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider ;;
     pmcbench) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null

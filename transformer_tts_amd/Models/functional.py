@@ -351,8 +351,11 @@ class EncoderStackFunction(torch.autograd.Function):
             dq, dv, dk_ = (d5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
             P, Pd = ctx.attn[:, i], ctx.attn_drop[:, i]
             ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)                 # dV = Pd^T dO
-            ops.bmm(dO4, v, dP[..., :t], trans_b=True)                        # dP = dO V^T
-            ops.softmax_bwd(dP, P, t, p, rng, layer.site_attn)                # -> dS (pad columns 0)
+            if ops.attn_probs_supported(t, dk, T):      # dP stays in LDS (one kernel)
+                ops.attn_ds_bwd(dO4, v, P, dP, t, p, rng, layer.site_attn)    # dS = softmax'(dropout'(dO V^T))
+            else:
+                ops.bmm(dO4, v, dP[..., :t], trans_b=True)                    # dP = dO V^T
+                ops.softmax_bwd(dP, P, t, p, rng, layer.site_attn)            # -> dS (pad columns 0)
             ops.bmm(dP, k, dq, trans_b=False, alpha=scale)                    # dQ = dS K / sqrt(dk)
             ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale)     # dK = dS^T Q / sqrt(dk)
             dqkv2, h2d = dqkv.view(M, 3 * d), L["h"].view(M, d)

@@ -36,14 +36,29 @@ template <int DK> struct KTile {
 // strip row length in elements: tp (+8 so that consecutive rows shift by an odd number of 16-B slots)
 static inline int strip_ld(int tp) { return ((tp / 8) % 2 == 0) ? tp + 8 : tp; }
 
+struct AttnArgs {
+    const bf16_t* qa;          // query-side rows (MODE 0: Q, MODE 1: dO)
+    const bf16_t* kb;          // key-side rows   (MODE 0: K, MODE 1: V)
+    int64_t q_row, q_batch, k_row, k_batch;     // element strides of the two operands
+    int head_stride;
+    const uint8_t* key_mask;   // MODE 0
+    bf16_t* P;                 // MODE 0: probabilities out; MODE 1: saved probabilities in
+    bf16_t* D;                 // MODE 0: dropout(P) out;    MODE 1: dS out
+    int64_t p_batch, d_batch;  // batch strides of P and D
+    int H, t, tp, sld;
+    float alpha, pdrop;
+    const uint64_t* rng;
+    uint32_t site;
+};
+
 // 512 threads = 8 waves in two groups of four.  Phase 1: group gq takes key tiles gq, gq+2, ... (its own LDS tile
 // buffer, a 2-deep register ring in front of it), wave w4 of a group the 16 keys w4*16.. of the tile against all 64
-// query rows.  Phase 2: wave w owns query rows 8w .. 8w+7, two at a time.
-template <int DK>
-__global__ __launch_bounds__(512, 1) void attn_probs_fwd_k(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-        int64_t row_stride, int64_t batch_stride, int head_stride, const uint8_t* __restrict__ key_mask,
-        bf16_t* __restrict__ P, bf16_t* __restrict__ Pd, int64_t p_batch_stride, int H, int t, int tp, int sld,
-        float alpha, float pdrop, const uint64_t* rng, uint32_t site) {
+// query rows; the 64 x tp product strip (bf16, what the unfused GEMM would have stored) stays in LDS.
+// Phase 2: wave w owns query rows 8w .. 8w+7, two at a time.
+//   MODE 0 (forward):  strip = alpha * Q K^T;  P = softmax(mask_keys(strip));  D = dropout(P)
+//   MODE 1 (backward): strip = dO V^T = dP;    D = dS = P * (dP' - sum_j dP'_j P_j), dP' = dropout'(dP)
+template <int DK, int MODE>
+__global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef KTile<DK> KT;
     constexpr int KS = KT::KS;
@@ -51,11 +66,12 @@ __global__ __launch_bounds__(512, 1) void attn_probs_fwd_k(const bf16_t* __restr
     const int gq = wave >> 2, w4 = wave & 3, gtid = tid & 255;
     const int g = lane >> 4, i16 = lane & 15;
     const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
+    const int t = a.t, tp = a.tp, sld = a.sld;
     unsigned char* strip = smem;
     unsigned char* ktile = smem + QB * sld * 2 + gq * KT::BYTES;      // this group's key tile
     unsigned char* lmask = smem + QB * sld * 2 + 2 * KT::BYTES;
-    const bf16_t* qb = q + (int64_t)b * batch_stride + (int64_t)h * head_stride;
-    const bf16_t* kb = k + (int64_t)b * batch_stride + (int64_t)h * head_stride;
+    const bf16_t* qb = a.qa + (int64_t)b * a.q_batch + (int64_t)h * a.head_stride;
+    const bf16_t* kb = a.kb + (int64_t)b * a.k_batch + (int64_t)h * a.head_stride;
 
     constexpr int CPT = KB * KT::CPR / 256;        // 16-B chunks per thread per tile
     const int nkt = (t + KB - 1) / KB;
@@ -65,7 +81,7 @@ __global__ __launch_bounds__(512, 1) void attn_probs_fwd_k(const bf16_t* __restr
             const int c = gtid + j * 256;
             const int row = kt * KB + c / KT::CPR, ch = c % KT::CPR;
             r[j] = uint4{0u, 0u, 0u, 0u};
-            if (kt < nkt && row < t) r[j] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * row_stride + ch * 8);
+            if (kt < nkt && row < t) r[j] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * a.k_row + ch * 8);
         }
     };
     auto store_tile = [&](const uint4 (&r)[CPT]) __attribute__((always_inline)) {
@@ -79,18 +95,19 @@ __global__ __launch_bounds__(512, 1) void attn_probs_fwd_k(const bf16_t* __restr
     uint4 ra[CPT], rb[CPT];
     load_tile(ra, gq);
     load_tile(rb, gq + 2);
-    bf16x8 qf[4][KS];                              // Q fragments of all 64 query rows (B operand: column = query row)
+    bf16x8 qf[4][KS];                              // query-side fragments of all 64 rows (B operand: column = query row)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int row = q0 + rt * 16 + i16;
             bf16x8 z = {};
-            qf[rt][ks] = (row < t) ? *reinterpret_cast<const bf16x8*>(qb + (int64_t)row * row_stride + ks * 32 + g * 8) : z;
+            qf[rt][ks] = (row < t) ? *reinterpret_cast<const bf16x8*>(qb + (int64_t)row * a.q_row + ks * 32 + g * 8) : z;
         }
-    for (int j = tid; j < MASK_BYTES; j += 512) lmask[j] = (j < t) ? key_mask[(int64_t)b * t + j] : 0;   // 0 beyond t
+    if constexpr (MODE == 0)
+        for (int j = tid; j < MASK_BYTES; j += 512) lmask[j] = (j < t) ? a.key_mask[(int64_t)b * t + j] : 0;   // 0 beyond t
 
-    // ---- phase 1: score strip
+    // ---- phase 1: product strip
     auto compute_tile = [&](int kt) __attribute__((always_inline)) {
         if (kt >= nkt) return;
         f32x4 acc[4];
@@ -103,14 +120,14 @@ __global__ __launch_bounds__(512, 1) void attn_probs_fwd_k(const bf16_t* __restr
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[rt][ks], acc[rt], 0, 0, 0);
-        // acc[rt][r] = S[query rt*16 + i16][key kt*64 + w4*16 + g*4 + r]
+        // acc[rt][r] = strip[query rt*16 + i16][key kt*64 + w4*16 + g*4 + r]
         const int kcol = kt * KB + w4 * 16 + g * 4;
         if (kcol < tp) {
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
                 bf16x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[rt][r] * alpha);
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[rt][r] * a.alpha);
                 *reinterpret_cast<bf16x4*>(strip + ((rt * 16 + i16) * sld + kcol) * 2) = o;
             }
         }
@@ -134,102 +151,161 @@ __global__ __launch_bounds__(512, 1) void attn_probs_fwd_k(const bf16_t* __restr
         __syncthreads();
     }
 
-    // ---- phase 2: row softmax + dropout straight from the strip; wave w owns query rows 8w .. 8w+7, two at a time
-    const DropCtx dc = drop_ctx(rng, site, pdrop);
+    // ---- phase 2: rows straight from the strip; wave w owns query rows 8w .. 8w+7, two at a time
+    const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
     const int ng = (tp + 511) / 512;               // 16-byte groups per lane (<= 2)
     constexpr int R = 2;
     for (int rr = 0; rr < 8; rr += R) {
         const int ql0 = wave * 8 + rr;
         if (q0 + ql0 >= t) break;                  // wave-uniform
-        float e[R][2][8];
-        float mx[R], sum[R];
+        if constexpr (MODE == 0) {
+            float e[R][2][8];
+            float mx[R], sum[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int ql = ql0 + r;
-            mx[r] = -3.0e38f;
+            for (int r = 0; r < R; ++r) {
+                const int ql = ql0 + r;
+                mx[r] = -3.0e38f;
 #pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                const int col = 8 * (lane + 64 * gi);
-                bf16x8 raw = {};
-                uint2 mk = make_uint2(0u, 0u);
-                if (gi < ng && col < tp) {
-                    raw = *reinterpret_cast<const bf16x8*>(strip + (ql * sld + col) * 2);
-                    mk = *reinterpret_cast<const uint2*>(lmask + col);
-                }
-                // branch-free: invalid columns (>= t) become -3e38 (exp -> 0), masked keys -1e4 (masked_fill(mask == 0, -1e4))
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int col = 8 * (lane + 64 * gi);
+                    bf16x8 raw = {};
+                    uint2 mk = make_uint2(0u, 0u);
+                    if (gi < ng && col < tp) {
+                        raw = *reinterpret_cast<const bf16x8*>(strip + (ql * sld + col) * 2);
+                        mk = *reinterpret_cast<const uint2*>(lmask + col);
+                    }
+                    // branch-free: invalid columns (>= t) become -3e38 (exp -> 0), masked keys -1e4 (masked_fill(mask == 0, -1e4))
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const uint32_t mb = ((c < 4 ? mk.x : mk.y) >> (8 * (c & 3))) & 0xFFu;
-                    float x = (float)raw[c];
-                    x = mb != 0 ? x : -1e4f;
-                    x = (col + c < t) ? x : -3.0e38f;
-                    e[r][gi][c] = x;
-                    mx[r] = fmaxf(mx[r], x);
+                    for (int c = 0; c < 8; ++c) {
+                        const uint32_t mb = ((c < 4 ? mk.x : mk.y) >> (8 * (c & 3))) & 0xFFu;
+                        float x = (float)raw[c];
+                        x = mb != 0 ? x : -1e4f;
+                        x = (col + c < t) ? x : -3.0e38f;
+                        e[r][gi][c] = x;
+                        mx[r] = fmaxf(mx[r], x);
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < R; ++r) mx[r] = wave_max(mx[r]);
+            for (int r = 0; r < R; ++r) mx[r] = wave_max(mx[r]);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            sum[r] = 0.f;
+            for (int r = 0; r < R; ++r) {
+                sum[r] = 0.f;
 #pragma unroll
-            for (int gi = 0; gi < 2; ++gi)
+                for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    e[r][gi][c] = __expf(e[r][gi][c] - mx[r]);       // invalid columns: exp(-3e38 - mx) = 0
-                    sum[r] += e[r][gi][c];
-                }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) sum[r] = wave_sum(sum[r]);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int qrow = q0 + ql0 + r;
-            if (qrow >= t) continue;               // wave-uniform
-            const float inv = 1.f / sum[r];
-            const int64_t off = (int64_t)b * p_batch_stride + ((int64_t)h * t + qrow) * tp;
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                const int col = 8 * (lane + 64 * gi);
-                if (!(gi < ng && col < tp)) continue;
-                bf16x8 o;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { e[r][gi][c] *= inv; o[c] = (bf16_t)e[r][gi][c]; }
-                *reinterpret_cast<bf16x8*>(P + off + col) = o;
-                if (Pd != P) {
-                    if (dc.on) {
-                        float ds[8];
-                        drop_scale8(dc, (uint64_t)(off + col) >> 3, ds);
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) e[r][gi][c] *= ds[c];
+                    for (int c = 0; c < 8; ++c) {
+                        e[r][gi][c] = __expf(e[r][gi][c] - mx[r]);       // invalid columns: exp(-3e38 - mx) = 0
+                        sum[r] += e[r][gi][c];
                     }
+            }
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) o[c] = (bf16_t)e[r][gi][c];
-                    *reinterpret_cast<bf16x8*>(Pd + off + col) = o;
+            for (int r = 0; r < R; ++r) sum[r] = wave_sum(sum[r]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int qrow = q0 + ql0 + r;
+                if (qrow >= t) continue;               // wave-uniform
+                const float inv = 1.f / sum[r];
+                const int64_t off = (int64_t)b * a.p_batch + ((int64_t)h * t + qrow) * tp;
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int col = 8 * (lane + 64 * gi);
+                    if (!(gi < ng && col < tp)) continue;
+                    bf16x8 o;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { e[r][gi][c] *= inv; o[c] = (bf16_t)e[r][gi][c]; }
+                    *reinterpret_cast<bf16x8*>(a.P + off + col) = o;
+                    if (a.D != a.P) {
+                        if (dc.on) {
+                            float ds[8];
+                            drop_scale8(dc, (uint64_t)(off + col) >> 3, ds);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) e[r][gi][c] *= ds[c];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) o[c] = (bf16_t)e[r][gi][c];
+                        *reinterpret_cast<bf16x8*>(a.D + off + col) = o;
+                    }
+                }
+            }
+        } else {
+            float ge[R][2][8], pe[R][2][8];
+            float dot[R];
+            int64_t poff[R], doff[R];
+            bf16x8 praw[R][2];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {          // the saved probabilities come from HBM: issue all loads first
+                const int qrow = (q0 + ql0 + r < t) ? q0 + ql0 + r : t - 1;       // clamped duplicate, not stored
+                poff[r] = (int64_t)b * a.p_batch + ((int64_t)h * t + qrow) * tp;
+                doff[r] = (int64_t)b * a.d_batch + ((int64_t)h * t + qrow) * tp;
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int col = 8 * (lane + 64 * gi);
+                    praw[r][gi] = bf16x8{};
+                    if (gi < ng && col < tp) praw[r][gi] = *reinterpret_cast<const bf16x8*>(a.P + poff[r] + col);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int ql = (q0 + ql0 + r < t) ? ql0 + r : ql0;
+                dot[r] = 0.f;
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int col = 8 * (lane + 64 * gi);
+                    bf16x8 raw = {};
+                    if (gi < ng && col < tp) raw = *reinterpret_cast<const bf16x8*>(strip + (ql * sld + col) * 2);
+                    float ds[8];
+                    drop_scale8(dc, (uint64_t)(poff[r] + col) >> 3, ds);      // the forward's offsets
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {                              // pad columns [t,tp): dP' = P = 0
+                        ge[r][gi][c] = (col + c < t) ? (float)raw[c] * ds[c] : 0.f;
+                        pe[r][gi][c] = (col + c < t) ? (float)praw[r][gi][c] : 0.f;
+                        dot[r] += ge[r][gi][c] * pe[r][gi][c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) dot[r] = wave_sum(dot[r]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (q0 + ql0 + r >= t) continue;       // wave-uniform
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int col = 8 * (lane + 64 * gi);
+                    if (!(gi < ng && col < tp)) continue;
+                    bf16x8 o;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) o[c] = (bf16_t)(pe[r][gi][c] * (ge[r][gi][c] - dot[r]));
+                    *reinterpret_cast<bf16x8*>(a.D + doff[r] + col) = o;
                 }
             }
         }
     }
 }
 
-template <int DK>
-int launch_probs(const void* q, const void* k, int64_t row_stride, int64_t batch_stride, int head_stride,
-                 const uint8_t* key_mask, void* P, void* Pd, int64_t p_batch_stride, int B, int H, int t, int tp,
-                 float alpha, float pdrop, const uint64_t* rng, uint32_t site, hipStream_t st) {
-    const int sld = strip_ld(tp);
-    const int lds = QB * sld * 2 + 2 * KTile<DK>::BYTES + MASK_BYTES;
+template <int DK, int MODE>
+int launch_strip(const AttnArgs& a, int B, hipStream_t st, const char* name) {
+    const int lds = QB * a.sld * 2 + 2 * KTile<DK>::BYTES + MASK_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_probs_fwd_k<DK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_strip_k<DK, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         attr_set = true;
     }
-    dim3 grid((t + QB - 1) / QB, H, B);
-    hipLaunchKernelGGL((attn_probs_fwd_k<DK>), grid, dim3(512), lds, st, (const bf16_t*)q, (const bf16_t*)k, row_stride,
-                       batch_stride, head_stride, key_mask, (bf16_t*)P, (bf16_t*)Pd, p_batch_stride, H, t, tp, sld, alpha,
-                       pdrop, rng, site);
-    FS2_CHECK_LAUNCH("fs2_attn_probs_fwd");
+    dim3 grid((a.t + QB - 1) / QB, a.H, B);
+    hipLaunchKernelGGL((attn_strip_k<DK, MODE>), grid, dim3(512), lds, st, a);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) {
+        fs2_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));
+        return FS2_ELAUNCH;
+    }
     return FS2_OK;
+}
+
+template <int MODE>
+int dispatch_strip(const AttnArgs& a, int dk, int B, hipStream_t st, const char* name) {
+    if (dk == 128) return launch_strip<128, MODE>(a, B, st, name);
+    if (dk == 64) return launch_strip<64, MODE>(a, B, st, name);
+    return launch_strip<32, MODE>(a, B, st, name);
 }
 
 }  // namespace
@@ -254,7 +330,33 @@ extern "C" int fs2_attn_probs_fwd(const void* q, const void* k, int64_t row_stri
     FS2_REQUIRE(fs2_aligned16(q) && fs2_aligned16(k) && fs2_aligned16(p_out) && fs2_aligned16(pd_out), "fs2_attn_probs_fwd: pointers must be 16-byte aligned");
     FS2_REQUIRE(p == 0.f || (rng != nullptr && pd_out != p_out), "fs2_attn_probs_fwd: dropout needs rng and a separate p_drop buffer");
     FS2_REQUIRE(p >= 0.f && p < 1.f, "fs2_attn_probs_fwd: p out of range");
-    if (dk == 128) return launch_probs<128>(q, k, row_stride, batch_stride, head_stride, key_mask, p_out, pd_out, p_batch_stride, B, H, t, tp, alpha, p, rng, site, st);
-    if (dk == 64) return launch_probs<64>(q, k, row_stride, batch_stride, head_stride, key_mask, p_out, pd_out, p_batch_stride, B, H, t, tp, alpha, p, rng, site, st);
-    return launch_probs<32>(q, k, row_stride, batch_stride, head_stride, key_mask, p_out, pd_out, p_batch_stride, B, H, t, tp, alpha, p, rng, site, st);
+    AttnArgs a;
+    a.qa = (const bf16_t*)q; a.kb = (const bf16_t*)k;
+    a.q_row = a.k_row = row_stride; a.q_batch = a.k_batch = batch_stride; a.head_stride = head_stride;
+    a.key_mask = key_mask; a.P = (bf16_t*)p_out; a.D = (bf16_t*)pd_out; a.p_batch = a.d_batch = p_batch_stride;
+    a.H = H; a.t = t; a.tp = tp; a.sld = strip_ld(tp); a.alpha = alpha; a.pdrop = p; a.rng = rng; a.site = site;
+    return dispatch_strip<0>(a, dk, B, st, "fs2_attn_probs_fwd");
+}
+
+extern "C" int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const void* v,
+                               int64_t v_row_stride, int64_t v_batch_stride, int head_stride, int dk, const void* p_saved,
+                               int64_t p_batch_stride, void* ds_out, int64_t ds_batch_stride, int B, int H, int t, int tp,
+                               float p, const uint64_t* rng, uint32_t site, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FS2_REQUIRE(fs2_attn_probs_lds_bytes(t, dk) > 0, "fs2_attn_ds_bwd: t=%d dk=%d does not fit the LDS strip (use fs2_gemm + fs2_softmax_bwd)", t, dk);
+    FS2_REQUIRE(tp == (t + 7) / 8 * 8 && tp <= 1024, "fs2_attn_ds_bwd: tp must be roundup8(t) <= 1024 (t=%d tp=%d)", t, tp);
+    FS2_REQUIRE(B > 0 && H > 0 && B <= 65535 && H <= 65535, "fs2_attn_ds_bwd: bad B/H");
+    FS2_REQUIRE(do_row_stride % 8 == 0 && do_batch_stride % 8 == 0 && v_row_stride % 8 == 0 && v_batch_stride % 8 == 0 &&
+                head_stride % 8 == 0 && p_batch_stride % 8 == 0 && ds_batch_stride % 8 == 0,
+                "fs2_attn_ds_bwd: strides must be multiples of 8 elements (16-byte accesses)");
+    FS2_REQUIRE(fs2_aligned16(d_out) && fs2_aligned16(v) && fs2_aligned16(p_saved) && fs2_aligned16(ds_out), "fs2_attn_ds_bwd: pointers must be 16-byte aligned");
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_attn_ds_bwd: dropout needs rng");
+    FS2_REQUIRE(p >= 0.f && p < 1.f, "fs2_attn_ds_bwd: p out of range");
+    AttnArgs a;
+    a.qa = (const bf16_t*)d_out; a.kb = (const bf16_t*)v;
+    a.q_row = do_row_stride; a.q_batch = do_batch_stride; a.k_row = v_row_stride; a.k_batch = v_batch_stride;
+    a.head_stride = head_stride; a.key_mask = nullptr;
+    a.P = (bf16_t*)const_cast<void*>(p_saved); a.D = (bf16_t*)ds_out; a.p_batch = p_batch_stride; a.d_batch = ds_batch_stride;
+    a.H = H; a.t = t; a.tp = tp; a.sld = strip_ld(tp); a.alpha = 1.f; a.pdrop = p; a.rng = rng; a.site = site;
+    return dispatch_strip<1>(a, dk, B, st, "fs2_attn_ds_bwd");
 }

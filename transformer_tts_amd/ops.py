@@ -63,6 +63,7 @@ SIGNATURES = {
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
     "fs2_attn_probs_lds_bytes": [_I, _I],
     "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
+    "fs2_attn_ds_bwd": [_P, _L, _L, _P, _L, _L, _I, _I, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_softmax_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_length_regulate_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "fs2_length_regulate_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -486,6 +487,8 @@ def softmax_fwd(s, p_drop, key_mask, t, p=0.0, rng=None, site=0):
 
 def attn_probs_supported(t, dk, dtype):
     """whether fs2_attn_probs_fwd takes (t, dk): bf16, dk in {32,64,128}, 64 x tp score strip within 160 KiB of LDS"""
+    if os.environ.get("FS2_FUSED_ATTN", "1") == "0":       # A/B switch for measurements (tools/gpu_ci.sh ab)
+        return False
     return dtype == torch.bfloat16 and lib().fs2_attn_probs_lds_bytes(int(t), int(dk)) > 0
 
 
@@ -499,6 +502,18 @@ def attn_probs_fwd(q, k, key_mask, p_out, p_drop, t, alpha, p=0.0, rng=None, sit
     _check(lib().fs2_attn_probs_fwd(_p(q), _p(k), q.stride(2), q.stride(0), q.stride(1), dk, _p(_c(key_mask)), _p(p_out),
                                     _p(p_drop), p_out.stride(0), B, H, t, tp, float(alpha), p, _rng_ptr(rng, p), site,
                                     _stream()), "fs2_attn_probs_fwd")
+
+
+def attn_ds_bwd(d_out, v, p_saved, ds, t, p=0.0, rng=None, site=0):
+    """ds = softmax/dropout backward of dP = d_out v^T in one kernel (dP stays in LDS).  d_out, v: (B,H,t,dk) views
+    (dk contiguous, same head stride); p_saved, ds: (B,H,t,tp) views as softmax_bwd takes them."""
+    B, H, _, dk = v.shape
+    tp = ds.shape[3]
+    assert d_out.stride(3) == 1 and v.stride(3) == 1 and d_out.stride(1) == v.stride(1) and d_out.dtype == v.dtype == torch.bfloat16
+    assert ds.stride(3) == 1 and ds.stride(2) == tp and ds.stride(1) == t * tp and p_saved.stride()[1:] == ds.stride()[1:]
+    _check(lib().fs2_attn_ds_bwd(_p(d_out), d_out.stride(2), d_out.stride(0), _p(v), v.stride(2), v.stride(0), v.stride(1),
+                                 dk, _p(p_saved), p_saved.stride(0), _p(ds), ds.stride(0), B, H, t, tp, p,
+                                 _rng_ptr(rng, p), site, _stream()), "fs2_attn_ds_bwd")
 
 
 def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
