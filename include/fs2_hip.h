@@ -163,15 +163,22 @@ int fs2_softmax_bwd(void* dp_inout_ds, int64_t dp_batch_stride, const void* p_sa
  *
  * fs2_attn_ds_bwd is the backward counterpart (dP = dO V^T kept in LDS, then the fs2_softmax_bwd arithmetic against the
  * saved probabilities): ds_out = P * (dP' - sum_j dP'_j P_j), dP' = dropout'(dO V^T); pad columns 0.  d_out rows are
- * dk contiguous bf16 at  base + b*do_batch_stride + i*do_row_stride + h*head_stride, v likewise with its strides. */
+ * dk contiguous bf16 at  base + b*do_batch_stride + i*do_row_stride + h*head_stride, v likewise with its strides.
+ *
+ * Optional second product from the same LDS strip (dk == 128 only; pass o_out / dq_out = NULL to skip):
+ *   forward:  o_out[b][i][h][:]  = dropout(P)[i][:] V         (Models/modules.py:20; v has q's strides)
+ *   backward: dq_out[b][i][h][:] = dq_alpha * dS[i][:] K      (k has v's strides)
+ * output rows are dk contiguous bf16 at  base + b*batch_stride + i*row_stride + h*head_stride.                    */
 int fs2_attn_probs_lds_bytes(int t, int dk);
 int fs2_attn_probs_fwd(const void* q, const void* k, int64_t row_stride, int64_t batch_stride, int head_stride, int dk,
                        const uint8_t* key_mask, void* p_out, void* p_drop, int64_t p_batch_stride, int B, int H, int t,
-                       int tp, float alpha, float p, const uint64_t* rng, uint32_t site, void* stream);
+                       int tp, float alpha, float p, const uint64_t* rng, uint32_t site, const void* v, void* o_out,
+                       int64_t o_row_stride, int64_t o_batch_stride, void* stream);
 int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const void* v, int64_t v_row_stride,
                     int64_t v_batch_stride, int head_stride, int dk, const void* p_saved, int64_t p_batch_stride,
                     void* ds_out, int64_t ds_batch_stride, int B, int H, int t, int tp, float p, const uint64_t* rng,
-                    uint32_t site, void* stream);
+                    uint32_t site, const void* k, void* dq_out, int64_t dq_row_stride, int64_t dq_batch_stride,
+                    float dq_alpha, void* stream);
 
 /* LengthRegulator (Models/varianceadaptor.py:141-184,233-249): out[b][f] = x[b][i] for the phoneme i whose
  * duration interval contains frame f, 0 beyond sum(dur) or max_len.  starts is a [B][L+1] int32 workspace

@@ -353,16 +353,26 @@ def attn_probs_supported(t, dk, dtype):
         64 * sld * 2 + 2 * 64 * dk * 2 + 1024 <= 160 * 1024
 
 
-def attn_probs_fwd(q, k, key_mask, p_out, p_drop, t, alpha, p=0.0, rng=None, site=0):
-    """Models/modules.py:8-19 in one call: scores (stored in the tensors' dtype), key mask, softmax, dropout."""
+def attn_second_product_supported(dk):
+    return dk == 128
+
+
+def attn_probs_fwd(q, k, key_mask, p_out, p_drop, t, alpha, p=0.0, rng=None, site=0, v=None, out=None):
+    """Models/modules.py:8-20 in one call: scores (stored in the tensors' dtype), key mask, softmax, dropout
+    (and, with v/out, the product with the values)."""
     bmm(q, k, p_out[..., :t], trans_b=True, alpha=alpha)
     softmax_fwd(p_out, p_drop, key_mask, t, p, rng, site)
+    if out is not None:
+        bmm(p_drop, v, out, trans_b=False)
 
 
-def attn_ds_bwd(d_out, v, p_saved, ds, t, p=0.0, rng=None, site=0):
-    """backward of attn_probs_fwd's softmax/dropout: dP = d_out v^T (stored in the tensors' dtype), then softmax_bwd."""
+def attn_ds_bwd(d_out, v, p_saved, ds, t, p=0.0, rng=None, site=0, k=None, dq=None, alpha=1.0):
+    """backward of attn_probs_fwd's softmax/dropout: dP = d_out v^T (stored in the tensors' dtype), then softmax_bwd
+    (and, with k/dq, dQ = alpha dS K)."""
     bmm(d_out, v, ds[..., :t], trans_b=True)
     softmax_bwd(ds, p_saved, t, p, rng, site)
+    if dq is not None:
+        bmm(ds, k, dq, trans_b=False, alpha=alpha)
 
 
 def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):

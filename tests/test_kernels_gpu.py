@@ -282,12 +282,17 @@ def test_attn_probs_fused_vs_gemm_softmax(ops, p, t, H, dk):
         q, k = (x[:, :, j].permute(0, 2, 1, 3) for j in (0, 2))
         buf = mv(torch.full((B, NL, H, t, tp), float("nan"), dtype=dtype))
         bufd = mv(torch.full((B, NL, H, t, tp), float("nan"), dtype=dtype)) if p > 0 else buf
-        o.attn_probs_fwd(q, k, mv(km), buf[:, 1], bufd[:, 1], t, 1.0 / dk ** 0.5, p, rng, 11)
-        out[dev] = (buf[:, 1].clone(), bufd[:, 1].clone())
+        second = o.attn_second_product_supported(dk)
+        O = mv(torch.full((B, t, H, dk), float("nan"), dtype=dtype))
+        o.attn_probs_fwd(q, k, mv(km), buf[:, 1], bufd[:, 1], t, 1.0 / dk ** 0.5, p, rng, 11,
+                         v=x[:, :, 1].permute(0, 2, 1, 3) if second else None, out=O.permute(0, 2, 1, 3) if second else None)
+        out[dev] = (buf[:, 1].clone(), bufd[:, 1].clone(), O if second else None)
     # scores are rounded to bf16 before the softmax on both sides; a 1-ulp difference there moves a probability by ~1 %
-    for a, b, n in zip(out["cuda"], out["cpu"], ("P", "P_drop")):
+    for a, b, n in zip(out["cuda"][:2], out["cpu"][:2], ("P", "P_drop")):
         close(a, b, n, rtol=4e-2, atol=2e-3)
-    Pc, Pdc = (x.float().cpu() for x in out["cuda"])
+    if out["cuda"][2] is not None:        # dropout(P) V from the same LDS strip
+        close(out["cuda"][2], out["cpu"][2], "P_drop @ V", rtol=3e-2, atol=3e-2)
+    Pc, Pdc = (x.float().cpu() for x in out["cuda"][:2])
     assert torch.all(Pc[..., t:] == 0) and torch.all(Pdc[..., t:] == 0), "pad columns must be written as zero"
     close(Pc[..., :t].sum(-1), torch.ones(B, H, t), "rows sum to one", rtol=1e-2, atol=1e-2)
     assert float(Pc[1, :, :, lens[1]:t].abs().max()) < 1e-6, "masked keys get ~0 probability"
@@ -324,8 +329,17 @@ def test_attn_ds_fused_vs_gemm_softmax_bwd(ops, p, t, H, dk):
         x, g, pb = mv(qkv), mv(dO), mv(Pbuf)
         vv = x[:, :, 1].permute(0, 2, 1, 3)
         dS = mv(torch.full((B, H, t, tp), float("nan"), dtype=dtype))
-        o.attn_ds_bwd(g.permute(0, 2, 1, 3), vv, pb[:, 1], dS, t, p, rng, 11)
+        second = o.attn_second_product_supported(dk)
+        dqkv = mv(torch.full((B, t, 3, H, dk), float("nan"), dtype=dtype))
+        o.attn_ds_bwd(g.permute(0, 2, 1, 3), vv, pb[:, 1], dS, t, p, rng, 11,
+                      k=x[:, :, 2].permute(0, 2, 1, 3) if second else None,
+                      dq=dqkv[:, :, 0].permute(0, 2, 1, 3) if second else None, alpha=1.0 / dk ** 0.5)
         out[dev] = dS
+        out[dev + "_dq"] = dqkv[:, :, 0].float().cpu() if second else None
+    if out["cuda_dq"] is not None:        # dQ = dS K / sqrt(dk) from the same LDS strip
+        ref = out["cpu_dq"]
+        err = (out["cuda_dq"] - ref).abs().max() / ref.abs().max().clamp_min(1e-6)
+        assert float(err) < 3e-2, float(err)
     a, b_ = out["cuda"].float().cpu(), out["cpu"].float()
     assert torch.all(a[..., t:] == 0), "pad columns must be written as zero"
     # dP is rounded to bf16 on both sides before the softmax backward; compare against the scale of each row

@@ -270,13 +270,18 @@ class EncoderStackFunction(torch.autograd.Function):
             q5 = qkv.view(B, t, 3, H, dk)
             q, v, k = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))                        # (B,H,t,dk) views
             S, Pd = attn[:, i], attn_drop[:, i]
+            O = torch.empty((B, t, H, dk), dtype=T, device=dev)
+            O4 = O.permute(0, 2, 1, 3)
             if ops.attn_probs_supported(t, dk, T):      # scores stay in LDS (one kernel)
-                ops.attn_probs_fwd(q, k, km, S, Pd, t, scale, p, rng, layer.site_attn)           # modules.py:8-19
+                pv = ops.attn_second_product_supported(dk)
+                ops.attn_probs_fwd(q, k, km, S, Pd, t, scale, p, rng, layer.site_attn,           # modules.py:8-20
+                                   v=v if pv else None, out=O4 if pv else None)
+                if not pv:
+                    ops.bmm(Pd, v, O4, trans_b=False)                                            # modules.py:20
             else:
                 ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)                             # modules.py:8-9
                 ops.softmax_fwd(S, Pd, km, t, p, rng, layer.site_attn)                           # modules.py:11-19
-            O = torch.empty((B, t, H, dk), dtype=T, device=dev)
-            ops.bmm(Pd, v, O.permute(0, 2, 1, 3), trans_b=False)                                 # modules.py:20
+                ops.bmm(Pd, v, O4, trans_b=False)                                                # modules.py:20
             a = ops.linear(O.view(M, d), rt.w_fwd(layer.attn.out.weight), layer.attn.out.bias.detach())  # :68
             n2 = layer.norm_2
             x1, h2, m2, r2 = ops.add_ln_fwd(x, a.view(B, t, d), n2.weight.detach(), n2.bias.detach(), 1e-5, p, rng,
@@ -352,11 +357,15 @@ class EncoderStackFunction(torch.autograd.Function):
             P, Pd = ctx.attn[:, i], ctx.attn_drop[:, i]
             ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)                 # dV = Pd^T dO
             if ops.attn_probs_supported(t, dk, T):      # dP stays in LDS (one kernel)
-                ops.attn_ds_bwd(dO4, v, P, dP, t, p, rng, layer.site_attn)    # dS = softmax'(dropout'(dO V^T))
+                sq = ops.attn_second_product_supported(dk)
+                ops.attn_ds_bwd(dO4, v, P, dP, t, p, rng, layer.site_attn,    # dS = softmax'(dropout'(dO V^T))
+                                k=k if sq else None, dq=dq if sq else None, alpha=scale)   # dQ = dS K / sqrt(dk)
+                if not sq:
+                    ops.bmm(dP, k, dq, trans_b=False, alpha=scale)
             else:
                 ops.bmm(dO4, v, dP[..., :t], trans_b=True)                    # dP = dO V^T
                 ops.softmax_bwd(dP, P, t, p, rng, layer.site_attn)            # -> dS (pad columns 0)
-            ops.bmm(dP, k, dq, trans_b=False, alpha=scale)                    # dQ = dS K / sqrt(dk)
+                ops.bmm(dP, k, dq, trans_b=False, alpha=scale)                # dQ = dS K / sqrt(dk)
             ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale)     # dK = dS^T Q / sqrt(dk)
             dqkv2, h2d = dqkv.view(M, 3 * d), L["h"].view(M, d)
             # bias gradients of q/k/v: ONE pass over dqkv into a 3d-vector, then three d-sized adds

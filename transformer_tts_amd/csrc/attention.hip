@@ -49,7 +49,30 @@ struct AttnArgs {
     float alpha, pdrop;
     const uint64_t* rng;
     uint32_t site;
+    // optional second product from the strip (DK == 128): O = strip' * X with X = V (MODE 0: attention output) or
+    // K (MODE 1: dQ), strip' = dropout(P) / dS as written to D
+    const bf16_t* xb;          // key-side rows of X, strides k_row / k_batch of its own
+    int64_t x_row, x_batch;
+    bf16_t* O;                 // (B, t, H, dk)-like output rows; nullptr = skip
+    int64_t o_row, o_batch;
+    float o_alpha;
 };
+
+// k-major B-operand image of a 64-key x 128-column tile (256-byte rows) and its ds_read_tr16 fragment read, as
+// gemm.hip's Tile<bf16,true> / read_frag: fragment of columns n0..n0+15 for k-step ks (32 keys)
+__device__ __forceinline__ int km_off(int row, int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+__device__ __forceinline__ bf16x8 km_frag(const unsigned char* lds, int n0, int ks, int lane) {
+    const int g = lane >> 4, i16 = lane & 15;
+    const int q = i16 >> 2, pp = i16 & 3;
+    const int ch = (n0 >> 3) + (pp >> 1);
+    const int r0 = ks * 32 + 8 * g + q;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + km_off(r0, ch) + 8 * (pp & 1)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + km_off(r0 + 4, ch) + 8 * (pp & 1)));
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo; u.s.hi = hi;
+    return u.v;
+}
 
 // 512 threads = 8 waves in two groups of four.  Phase 1: group gq takes key tiles gq, gq+2, ... (its own LDS tile
 // buffer, a 2-deep register ring in front of it), wave w4 of a group the 16 keys w4*16.. of the tile against all 64
@@ -107,6 +130,11 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
     if constexpr (MODE == 0)
         for (int j = tid; j < MASK_BYTES; j += 512) lmask[j] = (j < t) ? a.key_mask[(int64_t)b * t + j] : 0;   // 0 beyond t
 
+    if (sld > tp) {            // pad columns [tp, sld): read (times zero-filled X rows) by the second product
+        for (int j = tid; j < QB * (sld - tp); j += 512)
+            reinterpret_cast<bf16_t*>(strip)[(j / (sld - tp)) * sld + tp + j % (sld - tp)] = (bf16_t)0.f;
+    }
+
     // ---- phase 1: product strip
     auto compute_tile = [&](int kt) __attribute__((always_inline)) {
         if (kt >= nkt) return;
@@ -153,6 +181,7 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
 
     // ---- phase 2: rows straight from the strip; wave w owns query rows 8w .. 8w+7, two at a time
     const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
+    const bool second = (DK == 128) && a.O != nullptr;
     const int ng = (tp + 511) / 512;               // 16-byte groups per lane (<= 2)
     constexpr int R = 2;
     for (int rr = 0; rr < 8; rr += R) {
@@ -226,6 +255,7 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
                         for (int c = 0; c < 8; ++c) o[c] = (bf16_t)e[r][gi][c];
                         *reinterpret_cast<bf16x8*>(a.D + off + col) = o;
                     }
+                    if (second) *reinterpret_cast<bf16x8*>(strip + ((ql0 + r) * sld + col) * 2) = o;
                 }
             }
         } else {
@@ -277,7 +307,75 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) o[c] = (bf16_t)(pe[r][gi][c] * (ge[r][gi][c] - dot[r]));
                     *reinterpret_cast<bf16x8*>(a.D + doff[r] + col) = o;
+                    if (second) *reinterpret_cast<bf16x8*>(strip + ((ql0 + r) * sld + col) * 2) = o;
                 }
+            }
+        }
+    }
+
+    // ---- phase 3 (DK == 128): O[64 x 128] = strip' (64 x tp, now dropout(P) / dS in bf16) * X (tp x 128).
+    // Wave w: rows 16*(w&3).., columns 64*(w>>2)..; X tiles of 64 keys stream through the two key-tile buffers in
+    // the k-major image (ds_read_tr16 fragments), one barrier per tile.
+    if constexpr (DK == 128) {
+        if (second) {
+            __syncthreads();                       // strip rewritten by every wave; key-tile buffers free
+            unsigned char* xt = smem + QB * sld * 2;
+            const bf16_t* xb = a.xb + (int64_t)b * a.x_batch + (int64_t)h * a.head_stride;
+            const int rt = wave & 3, chh = wave >> 2;
+            f32x4 oacc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            uint4 xr[2];
+            auto xload = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = tid + j * 512;
+                    const int key = kt * KB + (c >> 4);
+                    xr[j] = uint4{0u, 0u, 0u, 0u};
+                    if (key < t) xr[j] = *reinterpret_cast<const uint4*>(xb + (int64_t)key * a.x_row + (c & 15) * 8);
+                }
+            };
+            auto xstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = tid + j * 512;
+                    *reinterpret_cast<uint4*>(xt + buf * 16384 + km_off(c >> 4, c & 15)) = xr[j];
+                }
+            };
+            xload(0);
+            xstore(0);
+            __syncthreads();
+            for (int kt = 0; kt < nkt; ++kt) {
+                if (kt + 1 < nkt) xload(kt + 1);
+                const unsigned char* xl = xt + (kt & 1) * 16384;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int kk = kt * KB + ks * 32;
+                    if (kk < tp) {                 // uniform
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(strip + ((rt * 16 + i16) * sld + kk + g * 8) * 2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, km_frag(xl, chh * 64 + j * 16, ks, lane), oacc[j], 0, 0, 0);
+                    }
+                }
+                if (kt + 1 < nkt) xstore((kt + 1) & 1);
+                __syncthreads();
+            }
+            // stage the 64 x 128 tile (bf16) in key-tile buffer 0, then 16-byte row-contiguous stores
+            bf16_t* ot = reinterpret_cast<bf16_t*>(xt);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ot[(rt * 16 + g * 4 + r) * 128 + chh * 64 + j * 16 + i16] = (bf16_t)(oacc[j][r] * a.o_alpha);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = tid + j * 512;
+                const int row = c >> 4;
+                if (q0 + row < t)
+                    *reinterpret_cast<uint4*>(a.O + (int64_t)b * a.o_batch + (int64_t)(q0 + row) * a.o_row + (int64_t)h * a.head_stride + (c & 15) * 8) =
+                        *reinterpret_cast<const uint4*>(ot + row * 128 + (c & 15) * 8);
             }
         }
     }
@@ -320,8 +418,10 @@ extern "C" int fs2_attn_probs_lds_bytes(int t, int dk) {
 extern "C" int fs2_attn_probs_fwd(const void* q, const void* k, int64_t row_stride, int64_t batch_stride, int head_stride,
                                   int dk, const uint8_t* key_mask, void* p_out, void* pd_out, int64_t p_batch_stride,
                                   int B, int H, int t, int tp, float alpha, float p, const uint64_t* rng, uint32_t site,
-                                  void* stream) {
+                                  const void* v, void* o_out, int64_t o_row_stride, int64_t o_batch_stride, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    FS2_REQUIRE(o_out == nullptr || (dk == 128 && v != nullptr && fs2_aligned16(v) && fs2_aligned16(o_out) && o_row_stride % 8 == 0 && o_batch_stride % 8 == 0),
+                "fs2_attn_probs_fwd: the fused P V product needs dk == 128, v, and 16-byte aligned o_out rows");
     FS2_REQUIRE(fs2_attn_probs_lds_bytes(t, dk) > 0, "fs2_attn_probs_fwd: t=%d dk=%d does not fit the LDS strip (use fs2_gemm + fs2_softmax_fwd)", t, dk);
     FS2_REQUIRE(tp == (t + 7) / 8 * 8 && tp <= 1024, "fs2_attn_probs_fwd: tp must be roundup8(t) <= 1024 (t=%d tp=%d)", t, tp);
     FS2_REQUIRE(B > 0 && H > 0 && B <= 65535 && H <= 65535, "fs2_attn_probs_fwd: bad B/H");
@@ -335,14 +435,19 @@ extern "C" int fs2_attn_probs_fwd(const void* q, const void* k, int64_t row_stri
     a.q_row = a.k_row = row_stride; a.q_batch = a.k_batch = batch_stride; a.head_stride = head_stride;
     a.key_mask = key_mask; a.P = (bf16_t*)p_out; a.D = (bf16_t*)pd_out; a.p_batch = a.d_batch = p_batch_stride;
     a.H = H; a.t = t; a.tp = tp; a.sld = strip_ld(tp); a.alpha = alpha; a.pdrop = p; a.rng = rng; a.site = site;
+    a.xb = (const bf16_t*)v; a.x_row = row_stride; a.x_batch = batch_stride;       // v lives in the same fused tensor as q, k
+    a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.o_alpha = 1.f;
     return dispatch_strip<0>(a, dk, B, st, "fs2_attn_probs_fwd");
 }
 
 extern "C" int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const void* v,
                                int64_t v_row_stride, int64_t v_batch_stride, int head_stride, int dk, const void* p_saved,
                                int64_t p_batch_stride, void* ds_out, int64_t ds_batch_stride, int B, int H, int t, int tp,
-                               float p, const uint64_t* rng, uint32_t site, void* stream) {
+                               float p, const uint64_t* rng, uint32_t site, const void* k, void* dq_out,
+                               int64_t dq_row_stride, int64_t dq_batch_stride, float dq_alpha, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    FS2_REQUIRE(dq_out == nullptr || (dk == 128 && k != nullptr && fs2_aligned16(k) && fs2_aligned16(dq_out) && dq_row_stride % 8 == 0 && dq_batch_stride % 8 == 0),
+                "fs2_attn_ds_bwd: the fused dS K product needs dk == 128, k, and 16-byte aligned dq_out rows");
     FS2_REQUIRE(fs2_attn_probs_lds_bytes(t, dk) > 0, "fs2_attn_ds_bwd: t=%d dk=%d does not fit the LDS strip (use fs2_gemm + fs2_softmax_bwd)", t, dk);
     FS2_REQUIRE(tp == (t + 7) / 8 * 8 && tp <= 1024, "fs2_attn_ds_bwd: tp must be roundup8(t) <= 1024 (t=%d tp=%d)", t, tp);
     FS2_REQUIRE(B > 0 && H > 0 && B <= 65535 && H <= 65535, "fs2_attn_ds_bwd: bad B/H");
@@ -358,5 +463,7 @@ extern "C" int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t
     a.head_stride = head_stride; a.key_mask = nullptr;
     a.P = (bf16_t*)const_cast<void*>(p_saved); a.D = (bf16_t*)ds_out; a.p_batch = p_batch_stride; a.d_batch = ds_batch_stride;
     a.H = H; a.t = t; a.tp = tp; a.sld = strip_ld(tp); a.alpha = 1.f; a.pdrop = p; a.rng = rng; a.site = site;
+    a.xb = (const bf16_t*)k; a.x_row = v_row_stride; a.x_batch = v_batch_stride;   // k lives in the same fused tensor as v
+    a.O = (bf16_t*)dq_out; a.o_row = dq_row_stride; a.o_batch = dq_batch_stride; a.o_alpha = dq_alpha;
     return dispatch_strip<1>(a, dk, B, st, "fs2_attn_ds_bwd");
 }

@@ -62,8 +62,8 @@ SIGNATURES = {
     "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
     "fs2_attn_probs_lds_bytes": [_I, _I],
-    "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
-    "fs2_attn_ds_bwd": [_P, _L, _L, _P, _L, _L, _I, _I, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _U32, _P],
+    "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P, _P, _L, _L, _P],
+    "fs2_attn_ds_bwd": [_P, _L, _L, _P, _L, _L, _I, _I, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _U32, _P, _P, _L, _L, _F, _P],
     "fs2_softmax_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_length_regulate_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "fs2_length_regulate_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -492,28 +492,42 @@ def attn_probs_supported(t, dk, dtype):
     return dtype == torch.bfloat16 and lib().fs2_attn_probs_lds_bytes(int(t), int(dk)) > 0
 
 
-def attn_probs_fwd(q, k, key_mask, p_out, p_drop, t, alpha, p=0.0, rng=None, site=0):
+def attn_second_product_supported(dk):
+    """whether attn_probs_fwd / attn_ds_bwd can also produce dropout(P) V / dS K from their LDS strip"""
+    return dk == 128 and os.environ.get("FS2_FUSED_ATTN2", "1") != "0"
+
+
+def attn_probs_fwd(q, k, key_mask, p_out, p_drop, t, alpha, p=0.0, rng=None, site=0, v=None, out=None):
     """p_out = softmax(mask_keys(alpha * q k^T)), p_drop = dropout_p(p_out) in one kernel.  q, k: (B,H,t,dk) views of
-    the fused projection (dk contiguous, common strides); p_out, p_drop: (B,H,t,tp) views as softmax_fwd takes them."""
+    the fused projection (dk contiguous, common strides); p_out, p_drop: (B,H,t,tp) views as softmax_fwd takes them.
+    With v (a view like q) and out (B,H,t,dk view of a (B,t,H,dk) tensor): also out = p_drop @ v (dk == 128)."""
     B, H, _, dk = q.shape
     tp = p_out.shape[3]
     assert q.stride() == k.stride() and q.stride(3) == 1 and q.dtype == k.dtype == torch.bfloat16
     assert p_out.stride(3) == 1 and p_out.stride(2) == tp and p_out.stride(1) == t * tp and p_drop.stride() == p_out.stride()
+    if out is not None:
+        assert v.stride() == q.stride() and out.stride(3) == 1 and out.stride(1) == q.stride(1) and out.dtype == q.dtype
     _check(lib().fs2_attn_probs_fwd(_p(q), _p(k), q.stride(2), q.stride(0), q.stride(1), dk, _p(_c(key_mask)), _p(p_out),
                                     _p(p_drop), p_out.stride(0), B, H, t, tp, float(alpha), p, _rng_ptr(rng, p), site,
-                                    _stream()), "fs2_attn_probs_fwd")
+                                    _p(v) if out is not None else None, _p(out), out.stride(2) if out is not None else 0,
+                                    out.stride(0) if out is not None else 0, _stream()), "fs2_attn_probs_fwd")
 
 
-def attn_ds_bwd(d_out, v, p_saved, ds, t, p=0.0, rng=None, site=0):
+def attn_ds_bwd(d_out, v, p_saved, ds, t, p=0.0, rng=None, site=0, k=None, dq=None, alpha=1.0):
     """ds = softmax/dropout backward of dP = d_out v^T in one kernel (dP stays in LDS).  d_out, v: (B,H,t,dk) views
-    (dk contiguous, same head stride); p_saved, ds: (B,H,t,tp) views as softmax_bwd takes them."""
+    (dk contiguous, same head stride); p_saved, ds: (B,H,t,tp) views as softmax_bwd takes them.
+    With k (a view like v) and dq (B,H,t,dk view): also dq = alpha * ds @ k (dk == 128)."""
     B, H, _, dk = v.shape
     tp = ds.shape[3]
     assert d_out.stride(3) == 1 and v.stride(3) == 1 and d_out.stride(1) == v.stride(1) and d_out.dtype == v.dtype == torch.bfloat16
     assert ds.stride(3) == 1 and ds.stride(2) == tp and ds.stride(1) == t * tp and p_saved.stride()[1:] == ds.stride()[1:]
+    if dq is not None:
+        assert k.stride() == v.stride() and dq.stride(3) == 1 and dq.stride(1) == v.stride(1) and dq.dtype == v.dtype
     _check(lib().fs2_attn_ds_bwd(_p(d_out), d_out.stride(2), d_out.stride(0), _p(v), v.stride(2), v.stride(0), v.stride(1),
                                  dk, _p(p_saved), p_saved.stride(0), _p(ds), ds.stride(0), B, H, t, tp, p,
-                                 _rng_ptr(rng, p), site, _stream()), "fs2_attn_ds_bwd")
+                                 _rng_ptr(rng, p), site, _p(k) if dq is not None else None, _p(dq),
+                                 dq.stride(2) if dq is not None else 0, dq.stride(0) if dq is not None else 0, float(alpha),
+                                 _stream()), "fs2_attn_ds_bwd")
 
 
 def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
