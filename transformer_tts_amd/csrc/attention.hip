@@ -36,6 +36,20 @@ template <int DK> struct KTile {
 // strip row length in elements: tp (+8 so that consecutive rows shift by an odd number of 16-B slots)
 static inline int strip_ld(int tp) { return ((tp / 8) % 2 == 0) ? tp + 8 : tp; }
 
+template <int N> struct IC { static constexpr int value = N; };
+
+// Branch-free 16-byte global loads: a buffer descriptor over the operand and an out-of-range offset for rows that do
+// not exist (the hardware returns zeros).  A load under `if (row < t)` puts control flow between the loads of a
+// prefetch ring and hipcc then waits vmcnt(0) at every use -- the ring degenerates to one exposed latency per tile.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 ld16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
+}
+
 struct AttnArgs {
     const bf16_t* qa;          // query-side rows (MODE 0: Q, MODE 1: dO)
     const bf16_t* kb;          // key-side rows   (MODE 0: K, MODE 1: V)
@@ -56,7 +70,10 @@ struct AttnArgs {
     bf16_t* O;                 // (B, t, H, dk)-like output rows; nullptr = skip
     int64_t o_row, o_batch;
     float o_alpha;
+    unsigned long long* dbg;   // tools/attn_phases.py: 8 shader-clock stamp slots per workgroup (nullptr normally)
 };
+
+unsigned long long* g_attn_dbg = nullptr;
 
 // k-major B-operand image of a 64-key x 128-column tile (256-byte rows) and its ds_read_tr16 fragment read, as
 // gemm.hip's Tile<bf16,true> / read_frag: fragment of columns n0..n0+15 for k-step ks (32 keys)
@@ -74,9 +91,8 @@ __device__ __forceinline__ bf16x8 km_frag(const unsigned char* lds, int n0, int 
     return u.v;
 }
 
-// 512 threads = 8 waves in two groups of four.  Phase 1: group gq takes key tiles gq, gq+2, ... (its own LDS tile
-// buffer, a 2-deep register ring in front of it), wave w4 of a group the 16 keys w4*16.. of the tile against all 64
-// query rows; the 64 x tp product strip (bf16, what the unfused GEMM would have stored) stays in LDS.
+// 512 threads = 8 waves.  Phase 1: wave w multiplies 16 keys of every 128-key super-tile against all 64 query rows;
+// the 64 x tp product strip (bf16, what the unfused GEMM would have stored) stays in LDS.
 // Phase 2: wave w owns query rows 8w .. 8w+7, two at a time.
 //   MODE 0 (forward):  strip = alpha * Q K^T;  P = softmax(mask_keys(strip));  D = dropout(P)
 //   MODE 1 (backward): strip = dO V^T = dP;    D = dS = P * (dP' - sum_j dP'_j P_j), dP' = dropout'(dP)
@@ -86,70 +102,74 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
     typedef KTile<DK> KT;
     constexpr int KS = KT::KS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gq = wave >> 2, w4 = wave & 3, gtid = tid & 255;
     const int g = lane >> 4, i16 = lane & 15;
     const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
     const int t = a.t, tp = a.tp, sld = a.sld;
     unsigned char* strip = smem;
-    unsigned char* ktile = smem + QB * sld * 2 + gq * KT::BYTES;      // this group's key tile
     unsigned char* lmask = smem + QB * sld * 2 + 2 * KT::BYTES;
     const bf16_t* qb = a.qa + (int64_t)b * a.q_batch + (int64_t)h * a.head_stride;
     const bf16_t* kb = a.kb + (int64_t)b * a.k_batch + (int64_t)h * a.head_stride;
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(qb), rs_k = make_rsrc(kb);     // per (batch, head): offsets < 2^31
 
-    constexpr int CPT = KB * KT::CPR / 256;        // 16-B chunks per thread per tile
     const int nkt = (t + KB - 1) / KB;
-    auto load_tile = [&](uint4 (&r)[CPT], int kt) __attribute__((always_inline)) {
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 0] = __builtin_amdgcn_s_memtime();
+
+    // ---- phase 1: product strip.  Wave w takes keys st*128 + w*16 .. +15 of every 128-key super-tile st and loads
+    // its key-side rows straight into MFMA fragments (lane (i16, g): 16 bytes of row i16 at k = 32*ks + 8*g): no LDS
+    // staging, no barrier, and a 4-deep ring of super-tiles in flight per wave -- the rows come from L2 with ~1.8 us
+    // latency, which a block-wide staged pipeline with one tile of lead exposed on every tile (30k of 84k cycles).
+    const int nst = (t + 127) / 128;
+    bf16x8 kf[4][KS];
+    auto load_frags = [&](auto slot, int st) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value;
+        const int row = st * 128 + wave * 16 + i16;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int c = gtid + j * 256;
-            const int row = kt * KB + c / KT::CPR, ch = c % KT::CPR;
-            r[j] = uint4{0u, 0u, 0u, 0u};
-            if (kt < nkt && row < t) r[j] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * a.k_row + ch * 8);
-        }
+        for (int ks = 0; ks < KS; ++ks)
+            kf[S][ks] = ld16(rs_k, row < t ? (unsigned)(row * (int)a.k_row + ks * 32 + g * 8) * 2u : OOB);
     };
-    auto store_tile = [&](const uint4 (&r)[CPT]) __attribute__((always_inline)) {
+    load_frags(IC<0>{}, 0); load_frags(IC<1>{}, 1); load_frags(IC<2>{}, 2); load_frags(IC<3>{}, 3);
+    // query-side rows: ONE coalesced copy of the 64 x DK tile per workgroup into LDS (the key-tile buffers are idle
+    // until phase 3), fragments from there.  Eight waves each fetching all 64 rows in fragment shape (16 rows x 64 B
+    // per instruction) cost 128 scattered load instructions per workgroup on the vector-memory path.
+    bf16x8 qf[4][KS];                              // fragments of all 64 rows (B operand: column = query row)
+    {
+        unsigned char* qt = smem + QB * sld * 2;
+        constexpr int QCH = QB * KT::CPR;          // 16-byte chunks of the tile
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int c = gtid + j * 256;
-            *reinterpret_cast<uint4*>(ktile + KT::off(c / KT::CPR, c % KT::CPR)) = r[j];
+        for (int j = 0; j < (QCH + 511) / 512; ++j) {
+            const int c = tid + j * 512;
+            if (c < QCH) {
+                const int row = c / KT::CPR, ch = c % KT::CPR;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_q, q0 + row < t ? (unsigned)((q0 + row) * (int)a.q_row + ch * 8) * 2u : OOB, 0, 0);
+                *reinterpret_cast<u32x4*>(qt + KT::off(row, ch)) = v;
+            }
         }
-    };
-    // every independent global load of the prologue is issued before the first wait
-    uint4 ra[CPT], rb[CPT];
-    load_tile(ra, gq);
-    load_tile(rb, gq + 2);
-    bf16x8 qf[4][KS];                              // query-side fragments of all 64 rows (B operand: column = query row)
+        __syncthreads();
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int row = q0 + rt * 16 + i16;
-            bf16x8 z = {};
-            qf[rt][ks] = (row < t) ? *reinterpret_cast<const bf16x8*>(qb + (int64_t)row * a.q_row + ks * 32 + g * 8) : z;
-        }
+            for (int ks = 0; ks < KS; ++ks) qf[rt][ks] = *reinterpret_cast<const bf16x8*>(qt + KT::off(rt * 16 + i16, ks * 4 + g));
+    }
     if constexpr (MODE == 0)
         for (int j = tid; j < MASK_BYTES; j += 512) lmask[j] = (j < t) ? a.key_mask[(int64_t)b * t + j] : 0;   // 0 beyond t
-
     if (sld > tp) {            // pad columns [tp, sld): read (times zero-filled X rows) by the second product
         for (int j = tid; j < QB * (sld - tp); j += 512)
             reinterpret_cast<bf16_t*>(strip)[(j / (sld - tp)) * sld + tp + j % (sld - tp)] = (bf16_t)0.f;
     }
-
-    // ---- phase 1: product strip
-    auto compute_tile = [&](int kt) __attribute__((always_inline)) {
-        if (kt >= nkt) return;
+    auto super_tile = [&](auto slot, int st) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value;
+        if (st >= nst) return;
         f32x4 acc[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 kf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const bf16x8*>(ktile + KT::off(w4 * 16 + i16, ks * 4 + g));
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[rt][ks], acc[rt], 0, 0, 0);
-        // acc[rt][r] = strip[query rt*16 + i16][key kt*64 + w4*16 + g*4 + r]
-        const int kcol = kt * KB + w4 * 16 + g * 4;
+            for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[S][ks], qf[rt][ks], acc[rt], 0, 0, 0);
+        load_frags(slot, st + 4);                  // refill the slot (rows >= t load nothing)
+        // acc[rt][r] = strip[query rt*16 + i16][key st*128 + wave*16 + g*4 + r]
+        const int kcol = st * 128 + wave * 16 + g * 4;
         if (kcol < tp) {
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) {
@@ -160,30 +180,36 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
             }
         }
     };
-    store_tile(ra);
-    __syncthreads();
-    const int nit = (nkt + 1) / 2;                 // iterations: this group's tile of iteration it is 2*it + gq
-    for (int it = 0; it < nit; it += 2) {
-        // even iteration: tile 2*it+gq is in LDS, tile 2*(it+1)+gq in rb; ra is free
-        load_tile(ra, 2 * (it + 2) + gq);
-        compute_tile(2 * it + gq);
-        __syncthreads();
-        store_tile(rb);
-        __syncthreads();
-        if (it + 1 >= nit) break;
-        // odd iteration: tile 2*(it+1)+gq is in LDS, tile 2*(it+2)+gq in ra; rb is free
-        load_tile(rb, 2 * (it + 3) + gq);
-        compute_tile(2 * (it + 1) + gq);
-        __syncthreads();
-        store_tile(ra);
-        __syncthreads();
+    if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 4] = __builtin_amdgcn_s_memtime();      // prologue issued
+    for (int st = 0; st < nst; st += 4) {
+        super_tile(IC<0>{}, st);
+        if (a.dbg != nullptr && tid == 0 && st == 0) a.dbg[blk * 8 + 5] = __builtin_amdgcn_s_memtime();  // first super-tile done
+        super_tile(IC<1>{}, st + 1); super_tile(IC<2>{}, st + 2); super_tile(IC<3>{}, st + 3);
     }
+    if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 6] = __builtin_amdgcn_s_memtime();      // wave 0 done with phase 1
+    __syncthreads();           // the strip (and the key mask / pad columns) is complete
 
+    if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 1] = __builtin_amdgcn_s_memtime();
     // ---- phase 2: rows straight from the strip; wave w owns query rows 8w .. 8w+7, two at a time
     const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
     const bool second = (DK == 128) && a.O != nullptr;
     const int ng = (tp + 511) / 512;               // 16-byte groups per lane (<= 2)
     constexpr int R = 2;
+    // MODE 1: the saved probabilities of this wave's 8 rows come from HBM -- all 16 loads are issued before the first use
+    bf16x8 pall[MODE == 1 ? 8 : 1][2];
+    const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(a.P + (int64_t)b * a.p_batch + (int64_t)h * t * tp);   // (t, tp) of this head
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8) {
+            const int qrow = q0 + wave * 8 + r8;
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int col = 8 * (lane + 64 * gi);
+                pall[r8][gi] = ld16(rs_p, (qrow < t && col < tp) ? (unsigned)(qrow * tp + col) * 2u : OOB);
+            }
+        }
+    }
+#pragma unroll
     for (int rr = 0; rr < 8; rr += R) {
         const int ql0 = wave * 8 + rr;
         if (q0 + ql0 >= t) break;                  // wave-uniform
@@ -262,18 +288,11 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
             float ge[R][2][8], pe[R][2][8];
             float dot[R];
             int64_t poff[R], doff[R];
-            bf16x8 praw[R][2];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {          // the saved probabilities come from HBM: issue all loads first
+            for (int r = 0; r < R; ++r) {
                 const int qrow = (q0 + ql0 + r < t) ? q0 + ql0 + r : t - 1;       // clamped duplicate, not stored
                 poff[r] = (int64_t)b * a.p_batch + ((int64_t)h * t + qrow) * tp;
                 doff[r] = (int64_t)b * a.d_batch + ((int64_t)h * t + qrow) * tp;
-#pragma unroll
-                for (int gi = 0; gi < 2; ++gi) {
-                    const int col = 8 * (lane + 64 * gi);
-                    praw[r][gi] = bf16x8{};
-                    if (gi < ng && col < tp) praw[r][gi] = *reinterpret_cast<const bf16x8*>(a.P + poff[r] + col);
-                }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -289,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {                              // pad columns [t,tp): dP' = P = 0
                         ge[r][gi][c] = (col + c < t) ? (float)raw[c] * ds[c] : 0.f;
-                        pe[r][gi][c] = (col + c < t) ? (float)praw[r][gi][c] : 0.f;
+                        pe[r][gi][c] = (col + c < t) ? (float)pall[rr + r][gi][c] : 0.f;
                         dot[r] += ge[r][gi][c] * pe[r][gi][c];
                     }
                 }
@@ -319,34 +338,38 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
     if constexpr (DK == 128) {
         if (second) {
             __syncthreads();                       // strip rewritten by every wave; key-tile buffers free
+            if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 2] = __builtin_amdgcn_s_memtime();
             unsigned char* xt = smem + QB * sld * 2;
             const bf16_t* xb = a.xb + (int64_t)b * a.x_batch + (int64_t)h * a.head_stride;
             const int rt = wave & 3, chh = wave >> 2;
             f32x4 oacc[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            uint4 xr[2];
-            auto xload = [&](int kt) __attribute__((always_inline)) {
+            // X tiles come from L2 (~1 us): a 4-deep register ring keeps four tile loads in flight per thread, the
+            // two LDS buffers alternate, one barrier per tile
+            u32x4 xr[8][2];
+            const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xb);
+            auto xload = [&](auto slot, int kt) __attribute__((always_inline)) {
+                constexpr int S = decltype(slot)::value;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int c = tid + j * 512;
                     const int key = kt * KB + (c >> 4);
-                    xr[j] = uint4{0u, 0u, 0u, 0u};
-                    if (key < t) xr[j] = *reinterpret_cast<const uint4*>(xb + (int64_t)key * a.x_row + (c & 15) * 8);
+                    xr[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, key < t ? (unsigned)(key * (int)a.x_row + (c & 15) * 8) * 2u : OOB, 0, 0);
                 }
             };
-            auto xstore = [&](int buf) __attribute__((always_inline)) {
+            auto xstore = [&](auto slot, int buf) __attribute__((always_inline)) {
+                constexpr int S = decltype(slot)::value;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int c = tid + j * 512;
-                    *reinterpret_cast<uint4*>(xt + buf * 16384 + km_off(c >> 4, c & 15)) = xr[j];
+                    *reinterpret_cast<u32x4*>(xt + buf * 16384 + km_off(c >> 4, c & 15)) = xr[S][j];
                 }
             };
-            xload(0);
-            xstore(0);
-            __syncthreads();
-            for (int kt = 0; kt < nkt; ++kt) {
-                if (kt + 1 < nkt) xload(kt + 1);
+            // one tile: refill the ring slot this tile came from, multiply from LDS, move the next tile to the other buffer
+            auto xstep = [&](auto slot, auto next, int kt) __attribute__((always_inline)) {
+                if (kt >= nkt) return;
+                xload(slot, kt + 8);               // keys >= t load nothing (zeros)
                 const unsigned char* xl = xt + (kt & 1) * 16384;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -358,8 +381,18 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
                             oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, km_frag(xl, chh * 64 + j * 16, ks, lane), oacc[j], 0, 0, 0);
                     }
                 }
-                if (kt + 1 < nkt) xstore((kt + 1) & 1);
+                if (kt + 1 < nkt) xstore(next, (kt + 1) & 1);
                 __syncthreads();
+            };
+            xload(IC<0>{}, 0); xload(IC<1>{}, 1); xload(IC<2>{}, 2); xload(IC<3>{}, 3);
+            xload(IC<4>{}, 4); xload(IC<5>{}, 5); xload(IC<6>{}, 6); xload(IC<7>{}, 7);
+            xstore(IC<0>{}, 0);
+            __syncthreads();
+            for (int kt = 0; kt < nkt; kt += 8) {
+                xstep(IC<0>{}, IC<1>{}, kt);     xstep(IC<1>{}, IC<2>{}, kt + 1);
+                xstep(IC<2>{}, IC<3>{}, kt + 2); xstep(IC<3>{}, IC<4>{}, kt + 3);
+                xstep(IC<4>{}, IC<5>{}, kt + 4); xstep(IC<5>{}, IC<6>{}, kt + 5);
+                xstep(IC<6>{}, IC<7>{}, kt + 6); xstep(IC<7>{}, IC<0>{}, kt + 7);
             }
             // stage the 64 x 128 tile (bf16) in key-tile buffer 0, then 16-byte row-contiguous stores
             bf16_t* ot = reinterpret_cast<bf16_t*>(xt);
@@ -377,6 +410,7 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
                     *reinterpret_cast<uint4*>(a.O + (int64_t)b * a.o_batch + (int64_t)(q0 + row) * a.o_row + (int64_t)h * a.head_stride + (c & 15) * 8) =
                         *reinterpret_cast<const uint4*>(ot + row * 128 + (c & 15) * 8);
             }
+            if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 3] = __builtin_amdgcn_s_memtime();
         }
     }
 }
@@ -408,6 +442,9 @@ int dispatch_strip(const AttnArgs& a, int dk, int B, hipStream_t st, const char*
 
 }  // namespace
 
+// measurement hook (not part of the ABI header): device buffer of 4 stamps per workgroup, or nullptr to switch off
+extern "C" void fs2_debug_attn_timer(unsigned long long* buf) { g_attn_dbg = buf; }
+
 extern "C" int fs2_attn_probs_lds_bytes(int t, int dk) {
     if (t <= 0 || t > MASK_BYTES || (dk != 32 && dk != 64 && dk != 128)) return -1;
     const int tp = (t + 7) / 8 * 8;
@@ -436,7 +473,7 @@ extern "C" int fs2_attn_probs_fwd(const void* q, const void* k, int64_t row_stri
     a.key_mask = key_mask; a.P = (bf16_t*)p_out; a.D = (bf16_t*)pd_out; a.p_batch = a.d_batch = p_batch_stride;
     a.H = H; a.t = t; a.tp = tp; a.sld = strip_ld(tp); a.alpha = alpha; a.pdrop = p; a.rng = rng; a.site = site;
     a.xb = (const bf16_t*)v; a.x_row = row_stride; a.x_batch = batch_stride;       // v lives in the same fused tensor as q, k
-    a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.o_alpha = 1.f;
+    a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.o_alpha = 1.f; a.dbg = g_attn_dbg;
     return dispatch_strip<0>(a, dk, B, st, "fs2_attn_probs_fwd");
 }
 
@@ -464,6 +501,6 @@ extern "C" int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t
     a.P = (bf16_t*)const_cast<void*>(p_saved); a.D = (bf16_t*)ds_out; a.p_batch = p_batch_stride; a.d_batch = ds_batch_stride;
     a.H = H; a.t = t; a.tp = tp; a.sld = strip_ld(tp); a.alpha = 1.f; a.pdrop = p; a.rng = rng; a.site = site;
     a.xb = (const bf16_t*)k; a.x_row = v_row_stride; a.x_batch = v_batch_stride;   // k lives in the same fused tensor as v
-    a.O = (bf16_t*)dq_out; a.o_row = dq_row_stride; a.o_batch = dq_batch_stride; a.o_alpha = dq_alpha;
+    a.O = (bf16_t*)dq_out; a.o_row = dq_row_stride; a.o_batch = dq_batch_stride; a.o_alpha = dq_alpha; a.dbg = g_attn_dbg;
     return dispatch_strip<1>(a, dk, B, st, "fs2_attn_ds_bwd");
 }
