@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
                 *reinterpret_cast<u32x4*>(qt + KT::off(row, ch)) = v;
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
         super_tile(IC<1>{}, st + 1); super_tile(IC<2>{}, st + 2); super_tile(IC<3>{}, st + 3);
     }
     if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 6] = __builtin_amdgcn_s_memtime();      // wave 0 done with phase 1
-    __syncthreads();           // the strip (and the key mask / pad columns) is complete
+    lds_barrier();           // the strip (and the key mask / pad columns) is complete
 
     if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 1] = __builtin_amdgcn_s_memtime();
     // ---- phase 2: rows straight from the strip; wave w owns query rows 8w .. 8w+7, two at a time
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
     // the k-major image (ds_read_tr16 fragments), one barrier per tile.
     if constexpr (DK == 128) {
         if (second) {
-            __syncthreads();                       // strip rewritten by every wave; key-tile buffers free
+            lds_barrier();                       // strip rewritten by every wave; key-tile buffers free
             if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 2] = __builtin_amdgcn_s_memtime();
             unsigned char* xt = smem + QB * sld * 2;
             const bf16_t* xb = a.xb + (int64_t)b * a.x_batch + (int64_t)h * a.head_stride;
@@ -382,12 +382,12 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
                     }
                 }
                 if (kt + 1 < nkt) xstore(next, (kt + 1) & 1);
-                __syncthreads();
+                lds_barrier();
             };
             xload(IC<0>{}, 0); xload(IC<1>{}, 1); xload(IC<2>{}, 2); xload(IC<3>{}, 3);
             xload(IC<4>{}, 4); xload(IC<5>{}, 5); xload(IC<6>{}, 6); xload(IC<7>{}, 7);
             xstore(IC<0>{}, 0);
-            __syncthreads();
+            lds_barrier();
             for (int kt = 0; kt < nkt; kt += 8) {
                 xstep(IC<0>{}, IC<1>{}, kt);     xstep(IC<1>{}, IC<2>{}, kt + 1);
                 xstep(IC<2>{}, IC<3>{}, kt + 2); xstep(IC<3>{}, IC<4>{}, kt + 3);
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     ot[(rt * 16 + g * 4 + r) * 128 + chh * 64 + j * 16 + i16] = (bf16_t)(oacc[j][r] * a.o_alpha);
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c = tid + j * 512;

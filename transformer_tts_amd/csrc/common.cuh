@@ -58,6 +58,15 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) 
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// ---------------------------------------------------------------- workgroup barrier for LDS hand-offs
+// __syncthreads() is a workgroup fence + barrier: once a kernel has global stores or atomics outstanding (a GEMM
+// epilogue, the probability rows of the attention kernels) the fence makes hipcc emit s_waitcnt vmcnt(0) in front
+// of EVERY later barrier, which also drains the register prefetch ring of global loads at every stage.  The LDS
+// producer/consumer hand-offs of a staged pipeline only need the wave's own LDS operations retired:
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------- wave reductions (wave = 64 lanes)
 // Four DPP steps (quad xor 1, quad xor 2, row rotate 4 and 8) leave the total of each 16-lane row in all of its
 // lanes; the four row totals are then combined through v_readlane.  No LDS crossbar (ds_bpermute, what __shfl_xor

@@ -230,7 +230,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
     };
     auto issue_load = [&](auto slot_c) {
         constexpr int SLOT = decltype(slot_c)::value;
-        if (lw >= wend) return;
+        // Always issued, also past the block's last stage (every offset is OOB then: zeros, no memory traffic): a
+        // conditionally issued load makes hipcc wait vmcnt(0) wherever a ring slot is consumed, because on the path
+        // without the issue nothing younger is outstanding -- and vmcnt(0) drains the whole ring at every stage.
         const int kb = lkb, tap = ltap;
         if (plain) {
             // wave-uniform, non-negative byte advance of this stage -> the scalar offset operand; the per-lane offsets
@@ -276,6 +278,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
         if (lkb >= p.K) { lkb = 0; ++ltap; }
         if (++lit == lk.it1) {
             if (++lw < wend) { next_work(lk); prep_work(lk); lit = lk.it0; }
+            else {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) { offA[i] = OOB; offB[i] = OOB; }
+                lit = -0x40000000;      // never reaches it1 again
+            }
         }
     };
     auto store_stage = [&](auto slot_c, auto buf_c) {
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
             // ---- staged epilogue (k-major B, or fp32 atomic accumulate): accumulators -> wave-private LDS rows.
             // The stage that follows is still in registers, so the LDS image is free between the two barriers.
             float* ew = reinterpret_cast<float*>(smem) + wave * WT * EPI_LD;
-            __syncthreads();            // every wave has finished reading the stage buffers
+            lds_barrier();            // every wave has finished reading the stage buffers
             {
                 const int g = lane >> 4, i16 = lane & 15;
 #pragma unroll
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
 #pragma unroll
                         for (int r = 0; r < 4; ++r) ew[(i * 16 + g * 4 + r) * EPI_LD + j * 16 + i16] = acc[i][j][r];
             }
-            __syncthreads();
+            lds_barrier();
             bool stored = false;
             if constexpr (sizeof(TC) == 4) {
                 if (p.accumulate) {
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
                     }
                 }
             }
-            __syncthreads();            // the epilogue image is free again before the next stage is stored
+            lds_barrier();            // the epilogue image is free again before the next stage is stored
         }
     };
 
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
         // LDS writes run under this step's MFMAs instead of sitting between them and the barrier.  Exception: a step
         // that ends a tile needs the whole LDS image for its epilogue and stores afterwards.
         if (!tile_end && s + 1 < nst) store_stage(next_c, IC<(BUF ^ 1)>{});
-        if (s + D < nst) issue_load(slot_c);
+        issue_load(slot_c);             // stage s+D (all-OOB once the block's stages are exhausted)
         const unsigned char* la = smem + BUF * 2 * G::STAGE;
         const unsigned char* lb = la + G::STAGE;
         if constexpr (!AKM && !BKM) {
@@ -520,15 +527,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
                 for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (s + 1 < nst) store_stage(next_c, IC<(BUF ^ 1)>{});
         }
-        __syncthreads();
+        lds_barrier();
     };
 
     // prologue: D stages in flight, stage 0 to LDS
     issue_load(IC<0>{});
-    if constexpr (D > 1) { if (1 < nst) issue_load(IC<1>{}); }
-    if constexpr (D > 2) { if (2 < nst) issue_load(IC<2>{}); if (3 < nst) issue_load(IC<3>{}); }
+    if constexpr (D > 1) issue_load(IC<1>{});
+    if constexpr (D > 2) { issue_load(IC<2>{}); issue_load(IC<3>{}); }
     store_stage(IC<0>{}, IC<0>{});
-    __syncthreads();
+    lds_barrier();
 
     int s = 0;
     if constexpr (D == 2) {
