@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: ~2 s of warm-up + timed steps; the first ~0.3 s on an idle MI355X run ~9 % slow (clock ramp), so a short
     # warm-up under-reports a fresh box (measured: 16+16 steps 14.5 ms/step, the same process a second time 13.4)
-    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 parity mode instead of bf16 (not the headline)")
