@@ -143,12 +143,32 @@ class VariancePredictor(nn.Module):
 
 def length_regulate(x, dur, max_len):
     """Models/varianceadaptor.py:141-184,233-249: repeat phoneme vector i dur[i] times, then zero-pad
-    (or crop: F.pad with a negative amount) each utterance to max_len."""
+    (or crop: F.pad with a negative amount) each utterance to max_len (None: the longest of the batch)."""
+    reps = [torch.repeat_interleave(x[b], dur[b].long().clamp(min=0), dim=0) for b in range(x.shape[0])]
+    if max_len is None:
+        max_len = max(r.shape[0] for r in reps)
     out = x.new_zeros(x.shape[0], max_len, x.shape[2])
-    for b in range(x.shape[0]):
-        rep = torch.repeat_interleave(x[b], dur[b].long().clamp(min=0), dim=0)[:max_len]
+    for b, rep in enumerate(reps):
+        rep = rep[:max_len]
         out[b, : rep.shape[0]] = rep
     return out
+
+
+def mel_positions(dur):
+    """the `mel_pos` the inference branch gets back from LengthRegulator.LR (:141-156, max_length=None): frame
+    positions 1..len_b, zero-padded to the longest utterance"""
+    lens = dur.long().clamp(min=0).sum(dim=1)
+    T = int(lens.max())
+    pos = torch.arange(1, T + 1, device=dur.device).unsqueeze(0).expand(dur.shape[0], -1)
+    return pos * (pos <= lens.unsqueeze(1))
+
+
+def get_mask_from_lengths(lengths):
+    """Models/varianceadaptor.py:251-259 as the inference branch calls it (:84) -- with the (B,T) position tensor, not
+    lengths: mask[b][j] = j <= mel_pos[b][j], i.e. True on valid frames (and on j = 0)."""
+    max_len = int(torch.max(lengths))
+    ids = torch.arange(0, max_len, device=lengths.device).unsqueeze(0).expand(lengths.shape[0], -1)
+    return ids <= lengths
 
 
 class VarianceAdaptor(nn.Module):
@@ -167,12 +187,27 @@ class VarianceAdaptor(nn.Module):
 
     def forward(self, x, src_mask, mel_mask, d_target, p_target, e_target):
         log_d = self.duration_predictor(x, src_mask)                       # :69
+        if d_target is None:
+            return self.infer(x, log_d)
         x = length_regulate(x, d_target, mel_mask.shape[2])                # :71-73
         p = self.pitch_predictor(x, mel_mask)                              # :95
         pe = self.pitch_embedding(torch.bucketize(p_target, self.pitch_bins.to(p_target.dtype)))   # :100
         e = self.energy_predictor(x, mel_mask)                             # :114
         ee = self.energy_embedding(torch.bucketize(e_target, self.energy_bins.to(e_target.dtype)))  # :116
         return x + pe + ee, log_d, p, e, x                                 # :122-129
+
+    def infer(self, x, log_d):
+        """Inference branch (:74-84,101-109,117-118; no perturbation): predicted durations, the variance embeddings
+        of the PREDICTED pitch / energy.  Returns the training tuple + (mel_pos, mel_mask)."""
+        dur = torch.clamp(torch.round(torch.exp(log_d) - 1.0), min=0)      # :75 (log_offset = 1)
+        x = length_regulate(x, dur, None)                                  # :82
+        mel_pos = mel_positions(dur)
+        mel_mask = get_mask_from_lengths(mel_pos)                          # :84
+        p = self.pitch_predictor(x, mel_mask)                              # :95
+        pe = self.pitch_embedding(torch.bucketize(p, self.pitch_bins.to(p.dtype)))                 # :109
+        e = self.energy_predictor(x, mel_mask)                             # :114
+        ee = self.energy_embedding(torch.bucketize(e, self.energy_bins.to(e.dtype)))               # :118
+        return x + pe + ee, log_d, p, e, x, mel_pos, mel_mask
 
 
 class PostConvNet(nn.Module):
@@ -227,10 +262,15 @@ class FastSpeech2(nn.Module):
         va.pitch_bins, va.energy_bins = va.pitch_bins.double(), va.energy_bins.double()
         return self
 
-    def forward(self, src, src_mask, mel_mask, d_target, p_target, e_target):
+    def forward(self, src, src_mask, mel_mask=None, d_target=None, p_target=None, e_target=None):
         e_out, attn_enc = self.encoder(src, src_mask)
-        va_out, log_d, p_pred, e_pred, text_dur = self.variance_adaptor(e_out, src_mask, mel_mask, d_target,
-                                                                         p_target, e_target)
+        if d_target is None:       # inference (:174-176): the variance adaptor makes the frame mask
+            va_out, log_d, p_pred, e_pred, text_dur, _, mel_mask = self.variance_adaptor(e_out, src_mask, None, None,
+                                                                                         None, None)
+            mel_mask = mel_mask.unsqueeze(1)       # (B,T) -> key mask (B,1,T); the reference relies on B == 1 here
+        else:
+            va_out, log_d, p_pred, e_pred, text_dur = self.variance_adaptor(e_out, src_mask, mel_mask, d_target,
+                                                                             p_target, e_target)
         d_out, attn_dec = self.decoder(va_out, mel_mask)
         mel_before, mel_after = self.postnet(d_out)
         return (mel_before, mel_after, log_d, p_pred, e_pred, va_out, text_dur, attn_enc, attn_dec,

@@ -142,7 +142,44 @@ def run(name):
     print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB", "loss", out["loss.total"], "train", tl)
 
 
+def run_infer(name):
+    """Inference branch: the reference's own eval-mode forward with predicted durations, exactly as
+    test_fastspeech2.py:159-171 calls it (one utterance per call, un-padded text, no targets).  -> infer_<name>.npz"""
+    cfg = CONFIGS[name]
+    torch.manual_seed(0)
+    model, hp, shapes = build_reference(cfg)
+    model.eval()
+    batch = cfg["batch"]()
+    text, text_len = batch[0], batch[4]
+    out = {"n_utt": np.int64(text.shape[0])}
+    names = ["mel_before", "mel_after", "log_d", "p_pred", "e_pred", "va_out", "text_dur"]
+    for b in range(text.shape[0]):
+        n = int(text_len[b])
+        tx = text[b:b + 1, :n]
+        pos = torch.arange(1, n + 1).unsqueeze(0)
+        src_mask = (pos != 0).unsqueeze(-2)
+        with torch.no_grad():
+            res = model(tx, src_mask, mel_mask=None, d_target=None, p_target=None, e_target=None, accent=None,
+                        spkr_emb=None, fix_mask=None, pitch_perturbation=False, duration_perturbation=False, hop_size=None)
+        dur = torch.clamp(torch.round(torch.exp(res[2]) - 1), min=0)          # test_fastspeech2.py:198
+        frac = (torch.exp(res[2]) - 1) - torch.floor(torch.exp(res[2]) - 1)
+        out[f"u{b}.text"] = tx.numpy()
+        out[f"u{b}.duration_rounded"] = dur.numpy()
+        out[f"u{b}.round_margin"] = np.float64((frac - 0.5).abs().min())       # distance of the closest call to a .5 tie
+        for k, r in zip(names, res[:7]):
+            out[f"u{b}.{k}"] = r.numpy()
+        out[f"u{b}.attn_dec_dig"] = digest(res[8])
+        print(name, "utt", b, "L", n, "T", int(dur.sum()), "round margin", float(out[f"u{b}.round_margin"]))
+    path = os.path.join(HERE, f"infer_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    for n in (list(CONFIGS) if which == "all" else [which]):
-        run(n)
+    if which.startswith("infer"):
+        for n in ("tiny", "small"):
+            run_infer(n)
+    else:
+        for n in (list(CONFIGS) if which == "all" else [which]):
+            run(n)

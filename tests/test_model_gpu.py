@@ -240,3 +240,56 @@ def test_long_sequences_and_wide_model_vs_oracle():
     for k, p in model.named_parameters():
         g = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
         torch.testing.assert_close(p.grad.cpu(), g, rtol=1e-2, atol=2e-4, msg=lambda m: f"grad {k}: {m}")
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_inference_branch_vs_reference_golden(name):
+    """eval()-mode forward with predicted durations / pitch / energy (BatchNorm running statistics,
+    nn.Dropout off) against fixtures from the reference's own inference forward (tests/golden/infer_*.npz).
+    Exact-fp32 mode: rounded durations identical, mel L1 <= 1e-4; bf16 mode: same durations on these fixtures
+    (their closest rounding margin is 1e-3) and the stated bf16 tolerance."""
+    import os
+    from helpers import GOLDEN
+    g = np.load(os.path.join(GOLDEN, f"infer_{name}.npz"), allow_pickle=False)
+    for amp in (False, True):
+        model = product_model(name, amp=amp, device="cuda")[0]
+        model.eval()
+        for b in range(int(g["n_utt"])):
+            text = torch.from_numpy(g[f"u{b}.text"]).cuda()
+            pos = torch.arange(1, text.shape[1] + 1, device="cuda").unsqueeze(0)
+            with torch.no_grad():
+                out = model(text, (pos != 0).unsqueeze(-2))
+            dur = torch.clamp(torch.round(torch.exp(out[2]) - 1), min=0).cpu().numpy()
+            if not amp:
+                assert np.array_equal(dur, g[f"u{b}.duration_rounded"]), (name, b)
+            if not np.array_equal(dur, g[f"u{b}.duration_rounded"]):
+                continue        # bf16: a duration that rounds the other way changes T; nothing to compare frame by frame
+            for i, k in enumerate(OUT_NAMES[:7]):
+                ref = g[f"u{b}.{k}"]
+                got = out[i].float().cpu().numpy()
+                assert got.shape == ref.shape, (k, got.shape, ref.shape)
+                l1 = float(np.abs(got - ref).mean())
+                assert l1 <= (MEL_L1_TOL_BF16 if amp else MEL_L1_TOL_FP32), f"amp={amp} utt {b} {k}: mean |diff| {l1:.3e}"
+        assert int(model.postnet.pre_batchnorm.num_batches_tracked) == 0
+
+
+def test_inference_batch_of_utterances_bf16():
+    """inference on a padded batch at benchmark-like sizes (the reference itself only supports B = 1 there: its frame
+    mask broadcasts against the heads): every utterance of the batch must equal its own single-utterance run"""
+    from transformer_tts_amd import synthetic
+    model = product_model("small", amp=True, device="cuda")[0]
+    model.eval()
+    batch = synthetic.make_batch(31, 3, l_range=(20, 40), dur_range=(1, 9), vocab=60)
+    text, pos_text, text_len = batch[0].cuda(), batch[2].cuda(), batch[4]
+    with torch.no_grad():
+        full = model(text, (pos_text != 0).unsqueeze(-2))
+        dur = torch.clamp(torch.round(torch.exp(full[2]) - 1), min=0) * (pos_text != 0)
+        lens = dur.sum(1).long().cpu()
+        for b in range(text.shape[0]):
+            n = int(text_len[b])
+            one = model(text[b:b + 1, :n], (pos_text[b:b + 1, :n] != 0).unsqueeze(-2))
+            T = one[0].shape[1]
+            if T != int(lens[b]):
+                continue        # bf16 noise moved a duration across a .5 boundary between the two batch shapes
+            diff = (full[1][b, :T].float() - one[1][0].float()).abs().mean()
+            assert float(diff) < MEL_L1_TOL_BF16, (b, float(diff))

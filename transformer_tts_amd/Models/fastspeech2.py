@@ -1,5 +1,6 @@
 """FastSpeech2 -- drop-in module surface of the reference's Models/fastspeech2.py (:19-241) for the
-default training branch (transformer encoder/decoder, postnet_pred, no speaker/SQ-VAE/hop/fix_mask/debug),
+default training branch and the inference branch (transformer encoder/decoder, postnet_pred, no
+speaker/SQ-VAE/hop/fix_mask/debug),
 computed by hand-written gfx950 kernels."""
 import torch
 import torch.nn as nn
@@ -50,13 +51,19 @@ class FastSpeech2(nn.Module):
                 spkr_emb=None, fix_mask=None, spkr_emb_post=None, temperature=None, pitch_perturbation=False,
                 duration_perturbation=False, hop_size=None):
         assert (self.training and not pitch_perturbation) or (not self.training)
-        if fix_mask is not None or d_target is None:
-            raise NotImplementedError("fix_mask / inference branch are later rows of SURVEY section 8(f)")
+        if fix_mask is not None:
+            raise NotImplementedError("fix_mask is outside the accelerated path (SURVEY section 8)")
         self.rt.refresh(self)           # all weight shadows in one launch (no-op if the weights did not change)
         e_outputs, attn_enc = self.encoder(src, src_mask)
-        variance_adaptor_output, log_d_prediction, p_prediction, e_prediction, _, _, text_dur_predicted = \
-            self.variance_adaptor(e_outputs, src_mask, mel_mask, d_target, p_target, e_target,
-                                  p_scheduled_sampling=getattr(self.hp, "p_scheduled_sampling", 0.0))
+        if d_target is not None:
+            variance_adaptor_output, log_d_prediction, p_prediction, e_prediction, _, _, text_dur_predicted = \
+                self.variance_adaptor(e_outputs, src_mask, mel_mask, d_target, p_target, e_target,
+                                      p_scheduled_sampling=getattr(self.hp, "p_scheduled_sampling", 0.0))
+        else:       # inference (Models/fastspeech2.py:174-176): durations, pitch, energy and the frame mask are predicted
+            assert not self.training, "the inference branch (d_target=None) runs in eval() mode, as test_fastspeech2.py does"
+            variance_adaptor_output, log_d_prediction, p_prediction, e_prediction, mel_len, mel_mask, text_dur_predicted = \
+                self.variance_adaptor(e_outputs, src_mask, mel_mask, None, None, None, p_scheduled_sampling=0.0,
+                                      pitch_perturbation=pitch_perturbation, duration_perturbation=duration_perturbation)
         d_output, attn_dec = self.decoder(variance_adaptor_output, mel_mask)
         outputs_prenet, outputs_postnet = self.postnet(d_output)
         return (outputs_prenet, outputs_postnet, log_d_prediction, p_prediction, e_prediction, variance_adaptor_output,

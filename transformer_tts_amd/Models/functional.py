@@ -240,7 +240,10 @@ class EncoderStackFunction(torch.autograd.Function):
         T = rt.dtype
         dev = src.device
         rng = rt.get_rng(dev)
-        p = enc.dropout
+        # eval(): the nn.Dropout modules of the reference are off, but attention() calls F.dropout with its default
+        # training=True (Models/modules.py:19), so the probabilities are still dropped with rate enc.dropout
+        p_att = enc.dropout
+        p = enc.dropout if enc.training else 0.0
         N, H, d = enc.N, enc.heads, enc.d_model
         dk = d // H
         B, t = src.shape[0], src.shape[1]
@@ -260,7 +263,7 @@ class EncoderStackFunction(torch.autograd.Function):
         sv["x0"], sv["mean0"], sv["rstd0"] = x, mean0, rstd0
 
         attn = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
-        attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if p > 0 else attn
+        attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if p_att > 0 else attn
         layers = []
         scale = 1.0 / math.sqrt(dk)
         for i, layer in enumerate(enc.layers):
@@ -274,13 +277,13 @@ class EncoderStackFunction(torch.autograd.Function):
             O4 = O.permute(0, 2, 1, 3)
             if ops.attn_probs_supported(t, dk, T):      # scores stay in LDS (one kernel)
                 pv = ops.attn_second_product_supported(dk)
-                ops.attn_probs_fwd(q, k, km, S, Pd, t, scale, p, rng, layer.site_attn,           # modules.py:8-20
+                ops.attn_probs_fwd(q, k, km, S, Pd, t, scale, p_att, rng, layer.site_attn,       # modules.py:8-20
                                    v=v if pv else None, out=O4 if pv else None)
                 if not pv:
                     ops.bmm(Pd, v, O4, trans_b=False)                                            # modules.py:20
             else:
                 ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)                             # modules.py:8-9
-                ops.softmax_fwd(S, Pd, km, t, p, rng, layer.site_attn)                           # modules.py:11-19
+                ops.softmax_fwd(S, Pd, km, t, p_att, rng, layer.site_attn)                       # modules.py:11-19
                 ops.bmm(Pd, v, O4, trans_b=False)                                                # modules.py:20
             a = ops.linear(O.view(M, d), rt.w_fwd(layer.attn.out.weight), layer.attn.out.bias.detach())  # :68
             n2 = layer.norm_2
@@ -406,7 +409,7 @@ class VariancePredictorFunction(torch.autograd.Function):
         rt = mod.rt
         T = rt.dtype
         rng = rt.get_rng(x.device)
-        p = mod.dropout
+        p = mod.dropout if mod.training else 0.0
         B, t, _ = x.shape
         km = mask.reshape(B, t).contiguous()
         c1 = ops.conv(x, rt.w_fwd(mod.conv1.weight), 3, 1, mod.conv1.bias.detach(), relu=True)
@@ -493,7 +496,7 @@ class PostNetFunction(torch.autograd.Function):
         rt = mod.rt
         T = rt.dtype
         rng = rt.get_rng(x.device)
-        p = mod.dropout
+        p = mod.dropout if mod.training else 0.0
         B, t, d = x.shape
         M = B * t
         mel_dim = mod.out.weight.shape[0]
@@ -506,6 +509,12 @@ class PostNetFunction(torch.autograd.Function):
         h = mel_T
         for li, (cv, bn) in enumerate(zip(convs, bns)):
             C = cv.weight.shape[0]
+            if not mod.training:        # eval(): BatchNorm1d normalises with its running statistics (postnets.py:58-59)
+                c = ops.conv(h, rt.w_fwd(cv.weight), 5, 4, cv.bias.detach())
+                mean = bn.running_mean.detach().float()
+                rstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+                h = ops.bn_tanh_fwd(c, mean, rstd, bn.weight.detach(), bn.bias.detach(), 0.0, rng, mod.sites[li])
+                continue
             sums = torch.zeros(2 * C + 4, dtype=torch.float32, device=x.device)   # [sum | sum^2 | rows,-,-,-]
             c = ops.conv(h, rt.w_fwd(cv.weight), 5, 4, cv.bias.detach(), colstats=sums)          # causal: pad 4, crop 4
             count = None

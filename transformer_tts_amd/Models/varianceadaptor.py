@@ -1,5 +1,7 @@
 """Variance adaptor: duration / pitch / energy predictors, length regulator, bucketised embeddings
-(reference: Models/varianceadaptor.py:34-259), teacher-forced training branch."""
+(reference: Models/varianceadaptor.py:34-259): teacher-forced training branch and the inference branch."""
+import random
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -31,8 +33,17 @@ class VariancePredictor(nn.Module):
 
 class LengthRegulator(nn.Module):
     def forward(self, x, duration, max_length=None):
-        assert max_length is not None, "training path: max_length = mel_mask.shape[2]"
-        return LengthRegulatorFunction.apply(x, duration, int(max_length)), None
+        """training: max_length = mel_mask.shape[2] (second value unused, as in the reference); inference
+        (max_length None): pad to the longest utterance and return the frame positions `mel_pos` (B,T) the
+        reference's LR builds (Models/varianceadaptor.py:141-156) -- one host read of the longest length."""
+        if max_length is not None:
+            return LengthRegulatorFunction.apply(x, duration, int(max_length)), None
+        duration = duration.long().clamp(min=0)
+        lens = duration.sum(dim=1)
+        T = int(lens.max())                # the output SHAPE depends on the predicted durations
+        assert T > 0, "every predicted duration rounded to zero: nothing to synthesise"
+        pos = torch.arange(1, T + 1, device=x.device).unsqueeze(0).expand(x.shape[0], -1)
+        return LengthRegulatorFunction.apply(x, duration, T), pos * (pos <= lens.unsqueeze(1))
 
 
 class VarianceAdaptor(nn.Module):
@@ -70,10 +81,11 @@ class VarianceAdaptor(nn.Module):
 
     def forward(self, x, src_mask, mel_mask=None, duration_target=None, pitch_target=None, energy_target=None,
                 max_len=None, p_scheduled_sampling=0.0, pitch_perturbation=False, duration_perturbation=False):
-        assert duration_target is not None and pitch_target is not None and energy_target is not None, \
-            "inference branch (predicted durations) is a later row of SURVEY section 8(f)"
         assert p_scheduled_sampling == 0.0
         log_duration_prediction = self.duration_predictor(x, src_mask)
+        if duration_target is None:
+            return self._infer(x, log_duration_prediction, max_len, pitch_perturbation, duration_perturbation)
+        assert pitch_target is not None and energy_target is not None
         if mel_mask is not None:
             max_len = mel_mask.shape[2]
         x, mel_len = self.length_regulator(x, duration_target, max_len)
@@ -82,4 +94,26 @@ class VarianceAdaptor(nn.Module):
         text_dur_predicted = x
         x = BucketEmbedAddFunction.apply(self, x, pitch_target, energy_target, self.pitch_embedding.weight,
                                          self.energy_embedding.weight)
+        return x, log_duration_prediction, pitch_prediction, energy_prediction, mel_len, mel_mask, text_dur_predicted
+
+    def _infer(self, x, log_duration_prediction, max_len, pitch_perturbation, duration_perturbation):
+        """Inference branch (Models/varianceadaptor.py:74-84,101-109,117-118): predicted durations
+        round(exp(log_d) - 1).clamp(0), frame mask from the regulated lengths, variance embeddings of the PREDICTED
+        pitch / energy.  Same kernels as training; the only host read is the longest utterance's length."""
+        duration_rounded = torch.clamp(torch.round(torch.exp(log_duration_prediction) - self.log_offset), min=0)
+        if duration_perturbation:                                                    # :76-81
+            rand_weight = random.sample([0.8, 0.9, 1.0, 1.1, 1.2], 1)[0]
+            print('dur', rand_weight)
+            duration_rounded = torch.round(duration_rounded * rand_weight)
+        x, mel_len = self.length_regulator(x, duration_rounded, max_len)             # :82 (mel_len = positions, as there)
+        T = x.shape[1]
+        ids = torch.arange(0, T, device=x.device).unsqueeze(0).expand(x.shape[0], -1)
+        mel_mask = ids <= mel_len                                                    # get_mask_from_lengths, :251-259
+        pitch_prediction = self.pitch_predictor(x, mel_mask)
+        if pitch_perturbation:                                                       # :103-107
+            pitch_prediction = random.sample([0.8, 0.9, 1.0, 1.1, 1.2], 1)[0] * pitch_prediction
+        energy_prediction = self.energy_predictor(x, mel_mask)
+        text_dur_predicted = x
+        x = BucketEmbedAddFunction.apply(self, x, pitch_prediction.contiguous(), energy_prediction.contiguous(),
+                                         self.pitch_embedding.weight, self.energy_embedding.weight)   # :109,118,122-125
         return x, log_duration_prediction, pitch_prediction, energy_prediction, mel_len, mel_mask, text_dur_predicted

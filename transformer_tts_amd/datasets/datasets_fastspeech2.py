@@ -5,6 +5,7 @@ Mirrors the on-disk format and the collate contract of the reference's
 :728-739, ``NumBatchSampler`` :815-845, ``DistributedSamplerWrapper`` :847-890): a script file with
 one ``<mel.npy>|<space separated ids>`` line per utterance and sibling ``*_alignment.npy`` /
 ``*_f0.npy`` / ``*_energy.npy`` files; mel pad value -0.5, stop-token pad 1.0, everything else 0.
+``TestDatasets`` / ``collate_fn_test`` (:326-411, :469-519) feed the synthesis script ``test_fastspeech2.py``.
 Speaker / accent / gender / hop / sentencepiece options are outside the accelerated path.
 """
 import numpy as np
@@ -51,6 +52,41 @@ class TrainDatasets(Dataset):
                     f0=np.load(mel_name.replace(".npy", "_f0.npy")) if self.pred_f0 else None,
                     energy=np.load(mel_name.replace(".npy", "_energy.npy")) if self.pred_energy else None,
                     mel_name=mel_name)
+
+
+class TestDatasets(Dataset):
+    """Synthesis script reader (reference ``TestDatasets`` :326-411, single-speaker case): one
+    ``<output name>|<space separated ids>`` line per utterance; no acoustic files are read."""
+
+    def __init__(self, csv_file, hp, accent_emb=False):
+        assert not accent_emb and not getattr(hp, "is_multi_speaker", False) and getattr(hp, "spm_model", None) is None \
+            and not getattr(hp, "use_hop", False) and not getattr(hp, "gender_emb", False), \
+            "speaker / accent / gender / hop / sentencepiece options are outside the accelerated path"
+        self.hp = hp
+        self.items = []
+        with open(csv_file) as f:
+            for line in f:
+                line = line.rstrip("\n")
+                if line:
+                    name, text = line.split("|")[:2]
+                    self.items.append((name, text.strip()))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, idx):
+        mel_output, text = self.items[idx]
+        ids = np.array([int(t) for t in text.split(" ")], dtype=np.int32)
+        return dict(text=ids, text_length=len(ids), mel_output=mel_output, pos_text=np.arange(1, len(ids) + 1))
+
+
+def collate_fn_test(batch):
+    """the 9-tuple of the reference's ``collate_fn_test`` (:469-519): (text, names, pos_text, text_length, spk_emb,
+    accent, gender, spk_emb_postprocess, hop_size) with the optional conditioning slots None"""
+    text = _pad1([d["text"] for d in batch], dtype=np.int32)
+    pos_text = _pad1([d["pos_text"] for d in batch], dtype=np.int32)
+    return (torch.LongTensor(text), [d["mel_output"] for d in batch], torch.LongTensor(pos_text),
+            torch.LongTensor([d["text_length"] for d in batch]), None, None, None, None, None)
 
 
 def _pad1(xs, value=0, dtype=None):
