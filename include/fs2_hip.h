@@ -81,6 +81,12 @@ typedef struct FS2Gemm {
 
 int fs2_gemm(const FS2Gemm* g, void* stream);
 
+/* Finishing pass of a split-K product whose fused epilogue could not run (few output tiles, long K: the product
+ * accumulates fp32 partial sums into `scratch` [M][N], zero on entry, with FS2Gemm.accumulate = 1, split_k > 1):
+ *   out[m][n] = act(scratch[m][n] + bias[n]) + residual[m][n]   in out_dtype;   scratch is zero again on return.  */
+int fs2_splitk_finish(float* scratch, int64_t M, int N, const float* bias, const void* residual, int res_dtype,
+                      int64_t ldr, int relu, void* out, int out_dtype, int64_t ldc, void* stream);
+
 /* Weight shadows (fp32 master (O, I, k) as in the reference state_dict -> kernel layout, dtype `dtype`):
  *  mode 0 (forward):  dst[o*dld + j*I + i]       = src[o][i][j]
  *  mode 1 (dgrad):    dst[i*dld + j*O + o]       = src[o][i][k-1-j]

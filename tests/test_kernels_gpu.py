@@ -113,6 +113,29 @@ def test_conv_matches_torch_conv1d(ops):
         close(gw, wr.grad, f"conv1d wgrad k={k}", rtol=2e-5, atol=2e-5)
 
 
+def test_splitk_forward_products(ops):
+    """few output tiles + long reduction: ops.conv / ops.linear run split-K into an fp32 scratch and finish with
+    fs2_splitk_finish (bias / ReLU / residual / cast).  Same results as the oracle, the scratch is left clean, and a
+    second call (scratch reused) gives the same answer."""
+    dtype = torch.bfloat16
+    B, t, C, N, k = 16, 128, 512, 256, 9
+    from transformer_tts_amd import ops as real_ops
+    g = real_ops.FS2Gemm(); g.dtype = real_ops.BF16
+    assert real_ops._splitk_plan(B * t, N, k * C, g, None, None, None, 1.0) > 1
+    x, w = rnd(B, t, C, dtype=dtype, seed=1), rnd(N, k * C, dtype=dtype, seed=2, scale=0.05)
+    bias, res = rnd(N, seed=3), rnd(B, t, N, dtype=dtype, seed=4)
+    for kw in (dict(bias=bias), dict(bias=bias, relu=True), dict(residual=res), dict(bias=bias, residual=res.float(), out_dtype=torch.float32)):
+        ref = P.conv(x, w, k, k // 2, **kw)
+        cu = {kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in kw.items()}
+        for _ in range(2):
+            got = ops.conv(x.cuda(), w.cuda(), k, k // 2, **cu)
+            close(got, ref, f"split-K conv {sorted(kw)}", rtol=2e-2, atol=2e-2)
+    scratch = real_ops._splitk_scratch[(torch.device("cuda", torch.cuda.current_device()), B * t, N)]
+    assert float(scratch.abs().max()) == 0.0, "fs2_splitk_finish must leave the scratch zeroed"
+    xl, wl = rnd(1000, 4096, dtype=dtype, seed=5), rnd(128, 4096, dtype=dtype, seed=6, scale=0.05)
+    close(ops.linear(xl.cuda(), wl.cuda(), bias[:128].cuda()), P.linear(xl, wl, bias[:128]), "split-K linear", rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_wgrad_and_colsum(ops, dtype):
     for M, N, K in ((300, 80, 72), (2000, 256, 1024), (77, 768, 32)):

@@ -27,6 +27,10 @@ for step in "$@"; do
     gemmcold) run gemmcold 300 python tools/gemm_bench.py cold dec_ffn enc_conv post_conv attn square "wgrad 1024" ;;
     gemmepi) run gemmepi 300 python tools/gemm_bench.py cold epi ;;
     attnph)  run attnph 200 python tools/attn_phases.py ;;
+    absk)    FS2_SPLITK_FWD=0 run absk0 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_SPLITK_FWD=1 run absk1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_SPLITK_FWD=0 run absk0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_SPLITK_FWD=1 run absk1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline ;;
     ab)      FS2_FUSED_ATTN=0 run ab0 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
              FS2_FUSED_ATTN=1 run ab1 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
              FS2_FUSED_ATTN=0 run ab0b 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline

@@ -60,6 +60,7 @@ SIGNATURES = {
     "fs2_add_ln_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_ffn_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
     "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
+    "fs2_splitk_finish": [_P, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
     "fs2_attn_probs_lds_bytes": [_I, _I],
     "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P, _P, _L, _L, _P],
@@ -175,6 +176,40 @@ def _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha, colsum=N
         g.colstats, g.colstats_mode = _p(colsum), 1
 
 
+_splitk_scratch = {}
+
+
+def _splitk_plan(M, N, k_total, g, relu_mask, colstats, colsum, alpha):
+    """split-K factor for a forward / data-gradient product with too few output tiles to fill 256 CUs and a long
+    reduction (config 2: the 6144 x 256 x (9 x 1024) encoder convolutions = 96 tiles of 128^2, which ran as 384 tiles
+    of 64^2 at ~260 TFLOP/s), or 1.  The product then accumulates into an fp32 scratch and fs2_splitk_finish applies
+    bias / ReLU / residual / cast.  FS2_SPLITK_FWD=0 switches it off (A/B measurements)."""
+    if g.dtype != BF16 or relu_mask is not None or colstats is not None or colsum is not None or alpha != 1.0:
+        return 1
+    if os.environ.get("FS2_SPLITK_FWD", "1") == "0" or N % 4 != 0:
+        return 1
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    stages = (k_total + 63) // 64
+    if tiles > 160 or stages < 48:
+        return 1
+    # >= 384 work items keeps fs2_gemm on its 128^2 tile (it switches to 64^2 below that); >= 12 stages per split
+    return int(max(1, min(-(-384 // tiles), stages // 12, 8)))
+
+
+def _splitk_run(g, M, N, split, out, bias, relu, residual):
+    key = (out.device, M, N)
+    scratch = _splitk_scratch.get(key)
+    if scratch is None:
+        scratch = _splitk_scratch[key] = torch.zeros((M, N), dtype=torch.float32, device=out.device)
+    g.split_k, g.accumulate = split, 1
+    _epilogue(g, scratch, None, False, None, None, None, 1.0)
+    _gemm_call(g)
+    _check(lib().fs2_splitk_finish(_p(scratch), M, N, _p(bias), _p(residual), _dt(residual) if residual is not None else 0,
+                                   _ld(residual) if residual is not None else 0, int(relu), _p(out), _dt(out), _ld(out),
+                                   _stream()), "fs2_splitk_finish")
+    return out
+
+
 def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, out_dtype=None,
            alpha=1.0, colsum=None):
     """out[M,N] = alpha * x[M,K] @ w[N,K]^T (+bias)(ReLU)(*mask>0)(+residual).  x, w: same dtype (f32 | bf16)."""
@@ -186,6 +221,9 @@ def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=
     g.A, g.B, g.lda, g.ldb = _p(x), _p(w), _ld(x), _ld(w)
     g.M, g.N, g.K, g.dtype = M, N, K, _dt(x)
     g.split_k = g.batch1 = g.batch2 = 1
+    split = _splitk_plan(M, N, K, g, relu_mask, colstats, colsum, alpha)
+    if split > 1:
+        return _splitk_run(g, M, N, split, out, bias, relu, residual)
     _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha, colsum)
     _gemm_call(g)
     return out
@@ -208,6 +246,10 @@ def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, 
     g.conv, g.taps, g.pad, g.seq_len = 1, taps, pad, t
     r2 = residual.view(B * t, N) if residual is not None else None
     m2 = relu_mask.view(B * t, N) if relu_mask is not None else None
+    split = _splitk_plan(B * t, N, taps * C, g, relu_mask, colstats, colsum, 1.0)
+    if split > 1:
+        _splitk_run(g, B * t, N, split, o2, bias, relu, r2)
+        return out
     _epilogue(g, o2, bias, relu, r2, m2, colstats, 1.0, colsum)
     _gemm_call(g)
     return out
