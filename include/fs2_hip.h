@@ -106,6 +106,10 @@ int fs2_cast_permute_batched(const FS2CastDesc* table, int n, int dtype, void* s
 int fs2_onehot(const int32_t* idx, void* out, int dtype, int64_t M, int nb, void* stream);
 /* out[n] += sum_m x[m][n]   (bias gradients); x is [M][N] with row stride ldx */
 int fs2_colsum(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, void* stream);
+/* as fs2_colsum, but column c is added to out[(c / seg_cols) * seg_stride + c % seg_cols]: the column blocks of one fused
+ * tensor (the q / v / k bias gradients of a fused projection) go to vectors that sit seg_stride floats apart. */
+int fs2_colsum_segmented(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, int seg_cols,
+                         int64_t seg_stride, void* stream);
 
 /* nn.Embedding gather / scatter-add (Models/encoder.py:55,84; Models/varianceadaptor.py:57,62). */
 int fs2_embedding_fwd(const int64_t* ids, const float* table, void* out, int out_dtype, int64_t n, int d, void* stream);

@@ -212,6 +212,13 @@ def colsum(x, out):
     return out
 
 
+def colsum_blocks(x, outs):
+    d = x.shape[1] // len(outs)
+    for j, o in enumerate(outs):
+        colsum(x[:, j * d:(j + 1) * d], o)
+    return outs
+
+
 # ------------------------------------------------------------------------------------------------ embedding / PE
 def embedding_fwd(ids, table, out_dtype):
     """nn.Embedding (Models/encoder.py:55,84)."""

@@ -153,9 +153,16 @@ def test_wgrad_and_colsum(ops, dtype):
         a = ops.colsum(dq.cuda()[:, sl], torch.zeros(N).cuda())
         b = P.colsum(dq[:, sl], torch.zeros(N))
         close(a, b, "colsum", rtol=1e-4, atol=1e-4 * M ** 0.5)
+        arena = rnd(3 * (N * K + N), seed=5)
+        # column sums of the three blocks straight into vectors at a constant stride (q/v/k bias gradients), and fallback
+        for regular in (True, False):
+            ba, bb = arena.clone().cuda(), arena.clone()
+            offs = [N * K + j * (N * K + N) for j in range(3)] if regular else [N * K, 3 * (N * K + N) - N, 2 * N * K + N]
+            ops.colsum_blocks(dq.cuda(), [ba[o:o + N] for o in offs])
+            P.colsum_blocks(dq, [bb[o:o + N] for o in offs])
+            close(ba, bb, f"colsum_blocks regular={regular}", rtol=1e-4, atol=1e-4 * M ** 0.5)
         # the three column blocks of dqkv in one batched launch: outputs at a constant stride inside one arena
         # (weights interleaved with their biases, as the parameter arena lays q/v/k out), and the irregular fallback
-        arena = rnd(3 * (N * K + N), seed=5)
         for regular in (True, False):
             ga, gb = arena.clone().cuda(), arena.clone()
             offs = [j * (N * K + N) for j in range(3)] if regular else [0, 2 * (N * K + N), N * K + N]

@@ -371,12 +371,9 @@ class EncoderStackFunction(torch.autograd.Function):
                 ops.bmm(dP, k, dq, trans_b=False, alpha=scale)                # dQ = dS K / sqrt(dk)
             ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale)     # dK = dS^T Q / sqrt(dk)
             dqkv2, h2d = dqkv.view(M, 3 * d), L["h"].view(M, d)
-            # bias gradients of q/k/v: ONE pass over dqkv into a 3d-vector, then three d-sized adds
+            # bias gradients of q/v/k: ONE pass over dqkv, straight into the three gradient vectors (constant stride in the arena)
             with rt.side(dqkv2):
-                bsum = rt.zeros(("qkvb", d), (3 * d,), torch.float32, dev)
-                ops.colsum(dqkv2, bsum)
-                for j, lin in enumerate((at.q_linear, at.v_linear, at.k_linear)):
-                    ops.colsum(bsum[j * d:(j + 1) * d].view(1, d), grad_of(lin.bias))
+                ops.colsum_blocks(dqkv2, [grad_of(lin.bias) for lin in (at.q_linear, at.v_linear, at.k_linear)])
                 # the three weight gradients in ONE batched split-K GEMM when they sit at a constant stride (arena)
                 ops.wgrad_batched(dqkv2, h2d, [grad_of(lin.weight) for lin in (at.q_linear, at.v_linear, at.k_linear)])
             _, wd, _ = rt.qkv(at)

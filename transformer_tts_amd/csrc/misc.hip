@@ -289,10 +289,12 @@ __global__ __launch_bounds__(TPB) void permute_add_k(float* __restrict__ scratch
     }
 }
 
-// out[n] += sum_m x[m][n]: block = 64 column-groups of 4 x 4 row-slabs
+// out[n] += sum_m x[m][n]: block = 64 column-groups of 4 x 4 row-slabs.  Segmented output: column c lands at
+// out[(c / seg_cols) * seg_stride + c % seg_cols] (the q/v/k bias gradients of one fused projection sit at a constant
+// stride in the gradient arena); seg_cols >= N is the plain vector.
 template <typename T>
 __global__ __launch_bounds__(TPB) void colsum_k(const T* __restrict__ x, int64_t M, int N, int64_t ldx,
-        float* __restrict__ out) {
+        float* __restrict__ out, int seg_cols, int64_t seg_stride) {
     __shared__ __attribute__((aligned(16))) float red[4 * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 256 + lane * 4;
@@ -314,7 +316,8 @@ __global__ __launch_bounds__(TPB) void colsum_k(const T* __restrict__ x, int64_t
     *reinterpret_cast<float4*>(red + wave * 256 + lane * 4) = acc;
     __syncthreads();
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < N) atomicAdd(out + c, red[threadIdx.x] + red[256 + threadIdx.x] + red[512 + threadIdx.x] + red[768 + threadIdx.x]);
+    if (c < N) atomicAdd(out + (int64_t)(c / seg_cols) * seg_stride + c % seg_cols,
+                         red[threadIdx.x] + red[256 + threadIdx.x] + red[512 + threadIdx.x] + red[768 + threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ optimizer
@@ -538,16 +541,27 @@ extern "C" int fs2_permute_add(float* scratch, float* grad, int O, int I, int k,
     FS2_CHECK_LAUNCH("fs2_permute_add");
     return FS2_OK;
 }
-extern "C" int fs2_colsum(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, void* stream) {
-    CHECK_DT("fs2_colsum", dtype);
-    FS2_REQUIRE(N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N, "fs2_colsum: N and ldx must be multiples of 4");
+static int colsum_launch(const char* name, const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, int seg_cols,
+                         int64_t seg_stride, void* stream) {
     if (M <= 0) return FS2_OK;
     int64_t slabs = (M + 3) / 4;
     if (slabs > 512) slabs = 512;
     dim3 grid((N + 255) / 256, (unsigned)slabs);
-    T_DISPATCH(dtype, T, { hipLaunchKernelGGL((colsum_k<T>), grid, dim3(TPB), 0, (hipStream_t)stream, (const T*)x, M, N, ldx, out); });
-    FS2_CHECK_LAUNCH("fs2_colsum");
+    T_DISPATCH(dtype, T, { hipLaunchKernelGGL((colsum_k<T>), grid, dim3(TPB), 0, (hipStream_t)stream, (const T*)x, M, N, ldx, out, seg_cols, seg_stride); });
+    FS2_CHECK_LAUNCH(name);
     return FS2_OK;
+}
+extern "C" int fs2_colsum(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, void* stream) {
+    CHECK_DT("fs2_colsum", dtype);
+    FS2_REQUIRE(N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N, "fs2_colsum: N and ldx must be multiples of 4");
+    return colsum_launch("fs2_colsum", x, dtype, M, N, ldx, out, N, 0, stream);
+}
+extern "C" int fs2_colsum_segmented(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, int seg_cols,
+                                    int64_t seg_stride, void* stream) {
+    CHECK_DT("fs2_colsum_segmented", dtype);
+    FS2_REQUIRE(N > 0 && N % 4 == 0 && ldx % 4 == 0 && ldx >= N, "fs2_colsum_segmented: N and ldx must be multiples of 4");
+    FS2_REQUIRE(seg_cols > 0 && N % seg_cols == 0 && seg_stride >= seg_cols, "fs2_colsum_segmented: need N %% seg_cols == 0 and seg_stride >= seg_cols");
+    return colsum_launch("fs2_colsum_segmented", x, dtype, M, N, ldx, out, seg_cols, seg_stride, stream);
 }
 
 extern "C" int fs2_sqnorm(const float* x, int64_t n, float* out, void* stream) {

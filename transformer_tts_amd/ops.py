@@ -49,6 +49,7 @@ SIGNATURES = {
     "fs2_cast": [_P, _I, _P, _I, _L, _P],
     "fs2_cast_permute_batched": [_P, _I, _I, _P],
     "fs2_onehot": [_P, _P, _I, _L, _I, _P],
+    "fs2_colsum_segmented": [_P, _I, _L, _I, _L, _P, _I, _L, _P],
     "fs2_colsum": [_P, _I, _L, _I, _L, _P, _P],
     "fs2_embedding_fwd": [_P, _P, _P, _I, _L, _I, _P],
     "fs2_embedding_bwd": [_P, _P, _I, _P, _L, _I, _L, _P],
@@ -414,6 +415,24 @@ def colsum(x, out):
     M, N = x.shape
     _check(lib().fs2_colsum(_p(x), _dt(x), M, N, _ld(x), _p(out), _stream()), "fs2_colsum")
     return out
+
+
+def colsum_blocks(x, outs):
+    """outs[j][n] (fp32) += sum over rows of x[:, j*n_j + n] for the equal column blocks of x: ONE launch when the
+    outputs sit at a constant address stride (parameter arena), else one launch per block."""
+    nb = len(outs)
+    M, N = x.shape
+    d = N // nb
+    ptrs = [o.data_ptr() for o in outs]
+    step = ptrs[1] - ptrs[0] if nb > 1 else 0
+    if nb > 1 and step >= 4 * d and step % 4 == 0 and all(ptrs[j + 1] - ptrs[j] == step for j in range(nb - 1)) \
+            and all(o.dtype == torch.float32 and o.numel() == d and o.is_contiguous() for o in outs):
+        _check(lib().fs2_colsum_segmented(_p(x), _dt(x), M, N, _ld(x), _p(outs[0]), d, step // 4, _stream()),
+               "fs2_colsum_segmented")
+    else:
+        for j, o in enumerate(outs):
+            colsum(x[:, j * d:(j + 1) * d], o)
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------ embedding / PE
