@@ -112,3 +112,58 @@ def test_plumbing_epoch_checkpoint_and_resume(fake_ops, tmp_path, capsys):
     assert "epoch 1 loaded" in out and "EPOCH 2 end" in out
     osd2 = torch.load(os.path.join(save, "network.optimizer.epoch2"), weights_only=True)
     assert int(osd2["state"][0]["step"]) == 16
+
+
+def test_lengths_batch_sampler_frame_budget(tmp_path):
+    """LengthsBatchSampler (reference datasets_fastspeech2.py:749-813): batches in dataset order under the padded-frame
+    budget max_len * size <= n_lengths, batch ORDER shuffled, lengths file built when missing and reused afterwards."""
+    import random
+    from types import SimpleNamespace
+    from transformer_tts_amd.datasets import datasets_fastspeech2 as D
+    script = D.write_synthetic_corpus(str(tmp_path / "corpus"), n_utt=16, seed=5)
+    hp = SimpleNamespace(mel_dim=80, mean_file=None, var_file=None, lengths_file=str(tmp_path / "lengths_built.npy"))
+    ds = D.TrainDatasets(script, hp)
+    lengths = np.array([ds[i]["mel_length"] for i in range(len(ds))])
+    budget = int(lengths.max()) * 3
+    random.seed(3)
+    s = D.LengthsBatchSampler(ds, budget, hp, lengths_file=None, shuffle=True)
+    assert np.array_equal(np.load(hp.lengths_file), lengths), "the lengths file is built from the dataset"
+    batches = sorted(list(s), key=lambda b: b[0])
+    flat = [i for b in batches for i in b]
+    assert flat == list(range(flat[-1] + 1)) and len(flat) >= len(ds) - 1, "consecutive indices, at most the last one dropped"
+    for b in batches:
+        assert lengths[b].max() * len(b) <= budget
+        nxt = b[-1] + 1
+        if nxt < len(ds) and b is not batches[-1]:
+            assert max(lengths[b].max(), lengths[nxt]) * (len(b) + 1) > budget, "a batch closes only when the next one does not fit"
+    s2 = D.LengthsBatchSampler(ds, budget, hp, lengths_file=hp.lengths_file, shuffle=False, reverse=True)
+    assert [b[0] for b in s2] == sorted((b[0] for b in batches), reverse=True)
+    assert len(s2) == len(batches)
+    # the collate function takes such a ragged batch
+    out = D.collate_fn([ds[i] for i in batches[0]])
+    assert out[1].shape[0] == len(batches[0]) and out[1].shape[1] == lengths[batches[0]].max()
+
+
+def test_epoch_with_frame_budget_batching(fake_ops, tmp_path, capsys):
+    """hp.batch_size = None, hp.max_seqlen set (reference train_fastspeech2.py:340-341): LengthsBatchSampler drives one
+    epoch with a different batch shape at (almost) every step."""
+    from transformer_tts_amd.datasets import datasets_fastspeech2 as D
+    from transformer_tts_amd import train_fastspeech2 as T
+    from transformer_tts_amd.utils import HParams
+    from transformer_tts_amd.utils.utils import fill_variables
+    script = D.write_synthetic_corpus(str(tmp_path / "synthetic16"), n_utt=16)
+    hp_file = tmp_path / "hparams.py"
+    save = str(tmp_path / "ckpt")
+    hp_file.write_text(SMALL_HP.format(save=save, script=script).replace("batch_size = 2", "batch_size = None")
+                       + f"\nmax_seqlen = 400\nlog_every = 1\nlengths_file = {str(tmp_path / 'lengths.npy')!r}\n")
+    hp = HParams()
+    hp.configure(hp_file)
+    fill_variables(hp, verbose=False)
+    assert hp.batch_size is None and hp.max_seqlen == 400
+    os.makedirs(save, exist_ok=True)
+    T.run_training(0, SimpleNamespace(n_gpus=0), hp, None)
+    out = capsys.readouterr().out
+    assert "lengths_file is not exists. Make..." in out and "EPOCH 1 end" in out
+    sizes = {int(l.split("=")[1]) for l in out.splitlines() if l.startswith("batch size")}
+    assert len(sizes) > 1, f"frame-budget batches should differ in size, got {sizes}"
+    assert os.path.exists(str(tmp_path / "lengths.npy"))

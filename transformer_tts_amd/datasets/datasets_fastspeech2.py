@@ -2,7 +2,7 @@
 
 Mirrors the on-disk format and the collate contract of the reference's
 ``datasets/datasets_fastspeech2.py`` (``TrainDatasets`` :19-174, ``collate_fn`` :521-616, ``_pad_mel``
-:728-739, ``NumBatchSampler`` :815-845, ``DistributedSamplerWrapper`` :847-890): a script file with
+:728-739, ``LengthsBatchSampler`` :749-813, ``NumBatchSampler`` :815-845, ``DistributedSamplerWrapper`` :847-890): a script file with
 one ``<mel.npy>|<space separated ids>`` line per utterance and sibling ``*_alignment.npy`` /
 ``*_f0.npy`` / ``*_energy.npy`` files; mel pad value -0.5, stop-token pad 1.0, everything else 0.
 ``TestDatasets`` / ``collate_fn_test`` (:326-411, :469-519) feed the synthesis script ``test_fastspeech2.py``.
@@ -112,6 +112,61 @@ def collate_fn(batch):
             torch.tensor([d["mel_length"] for d in batch], dtype=torch.int64),
             torch.from_numpy(_pad1([d["stop_token"] for d in batch], value=1.0, dtype=np.float32)),
             None, f0, energy, align, None, None, None, [d["mel_name"] for d in batch], [None] * len(batch))
+
+
+class LengthsBatchSampler(Sampler):
+    """Variable-size batches under a budget of padded mel frames (reference :749-813): utterances are taken in
+    dataset order and a batch is closed when  max(mel length in the batch) * (batch size + 1)  would exceed
+    ``n_lengths``; the ORDER of the batches is shuffled every epoch (or once, or reversed).  ``lengths_file`` holds
+    the mel length of every utterance (.npy); when it does not exist it is built from the dataset and saved to
+    ``hp.lengths_file``.  As in the reference the last utterance of the list is never started as a batch of its own."""
+
+    def __init__(self, dataset, n_lengths, hp, lengths_file=None, shuffle=True, shuffle_one_time=False, reverse=False):
+        import os
+        import random
+        assert not ((shuffle == reverse) and shuffle is True), "shuffle and reverse cannot set True at the same time."
+        if lengths_file is None or not os.path.exists(lengths_file):
+            print("lengths_file is not exists. Make...")
+            self.lengths_np = np.array([dataset[i]["mel_length"] for i in range(len(dataset))])
+            np.save(hp.lengths_file, self.lengths_np)
+        else:
+            print("{} is loading.".format(lengths_file))
+            self.lengths_np = np.load(lengths_file)
+            assert len(dataset) == len(self.lengths_np), \
+                "mismatch the number of lines between dataset and {}".format(lengths_file)
+        self.n_lengths = n_lengths
+        self._random = random
+        self.all_indices = self._batch_indices()
+        if shuffle_one_time:
+            random.shuffle(self.all_indices)
+        self.shuffle, self.shuffle_one_time, self.reverse = shuffle, shuffle_one_time, reverse
+
+    def _batch_indices(self):
+        count, n = 0, len(self.lengths_np)
+        all_indices = []
+        while count + 1 < n:
+            indices, max_len = [], 0
+            while count < n:
+                curr_len = int(self.lengths_np[count])
+                if max(max_len, curr_len) * (len(indices) + 1) > self.n_lengths:
+                    break
+                max_len = max(max_len, curr_len)
+                indices.append(count)
+                count += 1
+            assert indices, f"utterance {count} alone ({int(self.lengths_np[count])} frames) exceeds max_seqlen={self.n_lengths}"
+            all_indices.append(indices)
+        return all_indices
+
+    def __iter__(self):
+        if self.shuffle and not self.shuffle_one_time:
+            self._random.shuffle(self.all_indices)
+        if self.reverse:
+            self.all_indices.reverse()
+        for indices in self.all_indices:
+            yield indices
+
+    def __len__(self):
+        return len(self.all_indices)
 
 
 class NumBatchSampler(Sampler):

@@ -172,8 +172,15 @@ def train_epoch(model, optimizer, step, start_epoch, args, hp, rank):
     alignment_pred = hp.model.lower() in ("fastspeech2", "lightspeech")
     dataset_train = datasets.TrainDatasets(hp.train_script, hp, alignment_pred=alignment_pred, pitch_pred=hp.pitch_pred,
                                            energy_pred=hp.energy_pred, accent_emb=hp.accent_emb)
-    assert hp.batch_size is not None, "max_seqlen batching (LengthsBatchSampler) is a later row of SURVEY section 8(f)"
-    sampler = datasets.NumBatchSampler(dataset_train, hp.batch_size)
+    if hp.batch_size is not None:                                    # reference :338-341
+        sampler = datasets.NumBatchSampler(dataset_train, hp.batch_size)
+    elif hp.max_seqlen is not None:
+        # frame-budget batching: the batch shape changes from step to step.  Nothing in the kernels depends on the
+        # shape; GraphedTrainStep (if used) captures one hipGraph per shape it sees twice and runs the rest eagerly.
+        sampler = datasets.LengthsBatchSampler(dataset_train, hp.max_seqlen, hp, hp.lengths_file, shuffle=True,
+                                               shuffle_one_time=False)
+    else:
+        raise ValueError("set hp.batch_size or hp.max_seqlen")
     train_sampler = datasets.DistributedSamplerWrapper(sampler) if args.n_gpus > 1 else sampler
     dataloader = DataLoader(dataset_train, batch_sampler=train_sampler, num_workers=int(getattr(hp, "num_workers", 8)),
                             collate_fn=datasets.collate_fn, pin_memory=True)
