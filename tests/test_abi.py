@@ -32,10 +32,32 @@ def test_library_exports_every_declared_symbol():
 def test_argument_errors_are_reported_not_crashed():
     """host-side validation runs without a GPU: bad descriptors return FS2_EINVAL with a message"""
     from transformer_tts_amd import ops
+    lib = ops.lib()
     g = ops.FS2Gemm()
     g.M, g.N, g.K, g.dtype = 8, 8, 8, 7
-    rc = ops.lib().fs2_gemm(ctypes.byref(g), None)
-    assert rc == -1 and b"dtype" in ops.lib().fs2_last_error()
+    rc = lib.fs2_gemm(ctypes.byref(g), None)
+    assert rc == -1 and b"dtype" in lib.fs2_last_error()
+    # split-K without the fp32 accumulate epilogue / accumulate with a fused activation are contradictions
+    g = ops.FS2Gemm()
+    g.M, g.N, g.K, g.dtype, g.c_dtype, g.split_k = 128, 128, 256, 1, 1, 4
+    g.batch1 = g.batch2 = 1
+    g.lda = g.ldb = 256
+    g.ldc = 128
+    g.A, g.B, g.C = 0x10000, 0x20000, 0x30000     # never dereferenced: validation fails before any launch
+    assert lib.fs2_gemm(ctypes.byref(g), None) < 0 and b"split_k" in lib.fs2_last_error()
+    g.split_k, g.accumulate, g.c_dtype, g.relu = 1, 1, 0, 1
+    assert lib.fs2_gemm(ctypes.byref(g), None) < 0 and b"accumulate" in lib.fs2_last_error()
+    # the LDS-strip attention kernels refuse shapes whose 64 x tp strip does not fit 160 KiB or odd head sizes
+    assert lib.fs2_attn_probs_lds_bytes(925, 128) > 0 and lib.fs2_attn_probs_lds_bytes(1016, 128) > 0
+    assert lib.fs2_attn_probs_lds_bytes(1100, 128) == -1 and lib.fs2_attn_probs_lds_bytes(100, 48) == -1
+    rc = lib.fs2_attn_probs_fwd(None, None, 768, 768 * 1100, 128, 128, None, None, None, 0, 1, 2, 1100, 1104, 0.1, 0.0, None, 0,
+                                None, None, 0, 0, None)
+    assert rc < 0 and b"does not fit" in lib.fs2_last_error()
+    # softmax rows longer than the kernel's register tile, column sums with an unaligned width
+    assert lib.fs2_softmax_fwd(None, None, 1, None, 1, 1, 3000, 3000, 0, 0.0, None, 0, None) < 0 and b"tp" in lib.fs2_last_error()
+    assert lib.fs2_colsum(None, 1, 8, 6, 6, None, None) < 0 and b"multiples of 4" in lib.fs2_last_error()
+    assert lib.fs2_colsum_segmented(None, 1, 8, 12, 12, None, 5, 100, None) < 0 and b"seg_cols" in lib.fs2_last_error()
+    assert lib.fs2_splitk_finish(None, 8, 6, None, None, 0, 0, 0, None, 1, 6, None) < 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
