@@ -21,7 +21,9 @@ O = torch.empty(B, t, H, dk, device=dev, dtype=torch.bfloat16)
 dO = torch.randn(B, t, H, dk, device=dev, generator=g).to(torch.bfloat16)
 dqkv = torch.empty_like(qkv)
 rng = ops.Rng(1, dev)
-nblk = ((t + 63) // 64) * H * B
+import os
+QBT = int(os.environ.get('FS2_ATTN_QB', '64'))
+nblk = ((t + QBT - 1) // QBT) * H * B
 buf = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
 lib = ops.lib()
 lib.fs2_debug_attn_timer.argtypes = [ctypes.c_void_p]

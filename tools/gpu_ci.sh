@@ -26,7 +26,8 @@ for step in "$@"; do
     wsplit)  run wsplit 300 python tools/gemm_bench.py wsplit ;;
     gemmcold) run gemmcold 300 python tools/gemm_bench.py cold dec_ffn enc_conv post_conv attn square "wgrad 1024" ;;
     gemmepi) run gemmepi 300 python tools/gemm_bench.py cold epi ;;
-    attnph)  run attnph 200 python tools/attn_phases.py ;;
+    attnph)  FS2_ATTN_QB=64 run attnph64 200 python tools/attn_phases.py
+             FS2_ATTN_QB=32 run attnph 200 python tools/attn_phases.py ;;
     absk)    FS2_SPLITK_FWD=0 run absk0 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_SPLITK_FWD=1 run absk1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_SPLITK_FWD=0 run absk0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline

@@ -12,11 +12,12 @@
 // MFMA: S^T tile = K_tile (16 keys x dk) * Q^T, so that a lane's 4 accumulator values are 4 consecutive keys of one
 // query row (one 8-byte LDS store into the strip).  Dropout uses the same Philox counters (element offset in P >> 3)
 // as fs2_softmax_fwd, so fs2_softmax_bwd regenerates the masks unchanged.
+#include <stdlib.h>
 #include "common.cuh"
 
 namespace {
 
-constexpr int QB = 64;                 // query rows per workgroup
+constexpr int QB = 64;                 // query rows per workgroup (QBT = 32: half strips, two workgroups per CU)
 constexpr int KB = 64;                 // keys per tile
 constexpr int LDS_MAX = 160 * 1024;
 constexpr int MASK_BYTES = 1024;       // key mask of one batch element (t <= 1024 whenever the strip fits)
@@ -96,17 +97,22 @@ __device__ __forceinline__ bf16x8 km_frag(const unsigned char* lds, int n0, int 
 // Phase 2: wave w owns query rows 8w .. 8w+7, two at a time.
 //   MODE 0 (forward):  strip = alpha * Q K^T;  P = softmax(mask_keys(strip));  D = dropout(P)
 //   MODE 1 (backward): strip = dO V^T = dP;    D = dS = P * (dP' - sum_j dP'_j P_j), dP' = dropout'(dP)
-template <int DK, int MODE>
-__global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
+// QBT = query rows per workgroup: 64 (one workgroup per CU, two X-tile buffers) or 32 (strip + one X buffer <= 80 KiB and
+// <= 128 VGPRs: two workgroups per CU, so that the VALU-bound phase 2 of one overlaps the memory-bound phases of the other).
+template <int DK, int MODE, int QBT>
+__global__ __launch_bounds__(512, QBT == 32 ? 2 : 1) void attn_strip_k(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef KTile<DK> KT;
     constexpr int KS = KT::KS;
+    constexpr int RT = QBT / 16;          // row tiles of the strip
+    constexpr int RPW = QBT / 8;          // strip rows per wave in phase 2
+    constexpr int NXB = QBT == 64 ? 2 : 1;   // X / key tile buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, i16 = lane & 15;
-    const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QBT, h = blockIdx.y, b = blockIdx.z;
     const int t = a.t, tp = a.tp, sld = a.sld;
     unsigned char* strip = smem;
-    unsigned char* lmask = smem + QB * sld * 2 + 2 * KT::BYTES;
+    unsigned char* lmask = smem + QBT * sld * 2 + NXB * KT::BYTES;
     const bf16_t* qb = a.qa + (int64_t)b * a.q_batch + (int64_t)h * a.head_stride;
     const bf16_t* kb = a.kb + (int64_t)b * a.k_batch + (int64_t)h * a.head_stride;
     const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(qb), rs_k = make_rsrc(kb);     // per (batch, head): offsets < 2^31
@@ -132,10 +138,10 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
     // query-side rows: ONE coalesced copy of the 64 x DK tile per workgroup into LDS (the key-tile buffers are idle
     // until phase 3), fragments from there.  Eight waves each fetching all 64 rows in fragment shape (16 rows x 64 B
     // per instruction) cost 128 scattered load instructions per workgroup on the vector-memory path.
-    bf16x8 qf[4][KS];                              // fragments of all 64 rows (B operand: column = query row)
+    bf16x8 qf[RT][KS];                             // fragments of all strip rows (B operand: column = query row)
     {
-        unsigned char* qt = smem + QB * sld * 2;
-        constexpr int QCH = QB * KT::CPR;          // 16-byte chunks of the tile
+        unsigned char* qt = smem + QBT * sld * 2;
+        constexpr int QCH = QBT * KT::CPR;          // 16-byte chunks of the tile
 #pragma unroll
         for (int j = 0; j < (QCH + 511) / 512; ++j) {
             const int c = tid + j * 512;
@@ -147,32 +153,32 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
         }
         lds_barrier();
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qf[rt][ks] = *reinterpret_cast<const bf16x8*>(qt + KT::off(rt * 16 + i16, ks * 4 + g));
     }
     if constexpr (MODE == 0)
         for (int j = tid; j < MASK_BYTES; j += 512) lmask[j] = (j < t) ? a.key_mask[(int64_t)b * t + j] : 0;   // 0 beyond t
     if (sld > tp) {            // pad columns [tp, sld): read (times zero-filled X rows) by the second product
-        for (int j = tid; j < QB * (sld - tp); j += 512)
+        for (int j = tid; j < QBT * (sld - tp); j += 512)
             reinterpret_cast<bf16_t*>(strip)[(j / (sld - tp)) * sld + tp + j % (sld - tp)] = (bf16_t)0.f;
     }
     auto super_tile = [&](auto slot, int st) __attribute__((always_inline)) {
         constexpr int S = decltype(slot)::value;
         if (st >= nst) return;
-        f32x4 acc[4];
+        f32x4 acc[RT];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[S][ks], qf[rt][ks], acc[rt], 0, 0, 0);
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[S][ks], qf[rt][ks], acc[rt], 0, 0, 0);
         load_frags(slot, st + 4);                  // refill the slot (rows >= t load nothing)
         // acc[rt][r] = strip[query rt*16 + i16][key st*128 + wave*16 + g*4 + r]
         const int kcol = st * 128 + wave * 16 + g * 4;
         if (kcol < tp) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(acc[rt][r] * a.alpha);
@@ -196,12 +202,12 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
     const int ng = (tp + 511) / 512;               // 16-byte groups per lane (<= 2)
     constexpr int R = 2;
     // MODE 1: the saved probabilities of this wave's 8 rows come from HBM -- all 16 loads are issued before the first use
-    bf16x8 pall[MODE == 1 ? 8 : 1][2];
+    bf16x8 pall[MODE == 1 ? RPW : 1][2];
     const __amdgpu_buffer_rsrc_t rs_p = make_rsrc(a.P + (int64_t)b * a.p_batch + (int64_t)h * t * tp);   // (t, tp) of this head
     if constexpr (MODE == 1) {
 #pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-            const int qrow = q0 + wave * 8 + r8;
+        for (int r8 = 0; r8 < RPW; ++r8) {
+            const int qrow = q0 + wave * RPW + r8;
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi) {
                 const int col = 8 * (lane + 64 * gi);
@@ -210,8 +216,8 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
         }
     }
 #pragma unroll
-    for (int rr = 0; rr < 8; rr += R) {
-        const int ql0 = wave * 8 + rr;
+    for (int rr = 0; rr < RPW; rr += R) {
+        const int ql0 = wave * RPW + rr;
         if (q0 + ql0 >= t) break;                  // wave-uniform
         if constexpr (MODE == 0) {
             float e[R][2][8];
@@ -339,14 +345,16 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
         if (second) {
             lds_barrier();                       // strip rewritten by every wave; key-tile buffers free
             if (a.dbg != nullptr && tid == 0) a.dbg[blk * 8 + 2] = __builtin_amdgcn_s_memtime();
-            unsigned char* xt = smem + QB * sld * 2;
+            unsigned char* xt = smem + QBT * sld * 2;
             const bf16_t* xb = a.xb + (int64_t)b * a.x_batch + (int64_t)h * a.head_stride;
-            const int rt = wave & 3, chh = wave >> 2;
-            f32x4 oacc[4];
+            // wave tile: 16 rows x CW columns (QBT = 64: 4 row tiles x 2 column groups of 64; QBT = 32: 2 x 4 groups of 32)
+            constexpr int NCW = 8 / RT, CW = 128 / NCW, NT = CW / 16;
+            const int rt = wave % RT, cg = wave / RT;
+            f32x4 oacc[NT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // X tiles come from L2 (~1 us): a 4-deep register ring keeps four tile loads in flight per thread, the
-            // two LDS buffers alternate, one barrier per tile
+            for (int j = 0; j < NT; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // X tiles come from L2 (~1 us): an 8-deep register ring keeps eight tile loads in flight per thread; with two
+            // LDS buffers (QBT = 64) they alternate and a tile costs one barrier, with one buffer (QBT = 32) two
             u32x4 xr[8][2];
             const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(xb);
             auto xload = [&](auto slot, int kt) __attribute__((always_inline)) {
@@ -366,22 +374,27 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
                     *reinterpret_cast<u32x4*>(xt + buf * 16384 + km_off(c >> 4, c & 15)) = xr[S][j];
                 }
             };
-            // one tile: refill the ring slot this tile came from, multiply from LDS, move the next tile to the other buffer
+            // one tile: refill the ring slot this tile came from, multiply from LDS, move the next tile into LDS
             auto xstep = [&](auto slot, auto next, int kt) __attribute__((always_inline)) {
                 if (kt >= nkt) return;
                 xload(slot, kt + 8);               // keys >= t load nothing (zeros)
-                const unsigned char* xl = xt + (kt & 1) * 16384;
+                const unsigned char* xl = xt + (NXB == 2 ? (kt & 1) : 0) * 16384;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int kk = kt * KB + ks * 32;
                     if (kk < tp) {                 // uniform
                         const bf16x8 af = *reinterpret_cast<const bf16x8*>(strip + ((rt * 16 + i16) * sld + kk + g * 8) * 2);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, km_frag(xl, chh * 64 + j * 16, ks, lane), oacc[j], 0, 0, 0);
+                        for (int j = 0; j < NT; ++j)
+                            oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, km_frag(xl, cg * CW + j * 16, ks, lane), oacc[j], 0, 0, 0);
                     }
                 }
-                if (kt + 1 < nkt) xstore(next, (kt + 1) & 1);
+                if constexpr (NXB == 2) {
+                    if (kt + 1 < nkt) xstore(next, (kt + 1) & 1);
+                } else {
+                    lds_barrier();                 // every wave is done with the only buffer
+                    if (kt + 1 < nkt) xstore(next, 0);
+                }
                 lds_barrier();
             };
             xload(IC<0>{}, 0); xload(IC<1>{}, 1); xload(IC<2>{}, 2); xload(IC<3>{}, 3);
@@ -394,19 +407,19 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
                 xstep(IC<4>{}, IC<5>{}, kt + 4); xstep(IC<5>{}, IC<6>{}, kt + 5);
                 xstep(IC<6>{}, IC<7>{}, kt + 6); xstep(IC<7>{}, IC<0>{}, kt + 7);
             }
-            // stage the 64 x 128 tile (bf16) in key-tile buffer 0, then 16-byte row-contiguous stores
+            // stage the QBT x 128 tile (bf16) in X buffer 0, then 16-byte row-contiguous stores
             bf16_t* ot = reinterpret_cast<bf16_t*>(xt);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    ot[(rt * 16 + g * 4 + r) * 128 + chh * 64 + j * 16 + i16] = (bf16_t)(oacc[j][r] * a.o_alpha);
+                    ot[(rt * 16 + g * 4 + r) * 128 + cg * CW + j * 16 + i16] = (bf16_t)(oacc[j][r] * a.o_alpha);
             lds_barrier();
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < (QBT * 16 + 511) / 512; ++j) {
                 const int c = tid + j * 512;
                 const int row = c >> 4;
-                if (q0 + row < t)
+                if (row < QBT && q0 + row < t)
                     *reinterpret_cast<uint4*>(a.O + (int64_t)b * a.o_batch + (int64_t)(q0 + row) * a.o_row + (int64_t)h * a.head_stride + (c & 15) * 8) =
                         *reinterpret_cast<const uint4*>(ot + row * 128 + (c & 15) * 8);
             }
@@ -415,16 +428,16 @@ __global__ __launch_bounds__(512, 1) void attn_strip_k(const AttnArgs a) {
     }
 }
 
-template <int DK, int MODE>
+template <int DK, int MODE, int QBT>
 int launch_strip(const AttnArgs& a, int B, hipStream_t st, const char* name) {
-    const int lds = QB * a.sld * 2 + 2 * KTile<DK>::BYTES + MASK_BYTES;
+    const int lds = QBT * a.sld * 2 + (QBT == 64 ? 2 : 1) * KTile<DK>::BYTES + MASK_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_strip_k<DK, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_strip_k<DK, MODE, QBT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         attr_set = true;
     }
-    dim3 grid((a.t + QB - 1) / QB, a.H, B);
-    hipLaunchKernelGGL((attn_strip_k<DK, MODE>), grid, dim3(512), lds, st, a);
+    dim3 grid((a.t + QBT - 1) / QBT, a.H, B);
+    hipLaunchKernelGGL((attn_strip_k<DK, MODE, QBT>), grid, dim3(512), lds, st, a);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) {
         fs2_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));
@@ -433,11 +446,23 @@ int launch_strip(const AttnArgs& a, int B, hipStream_t st, const char* name) {
     return FS2_OK;
 }
 
+// rows per workgroup: 64.  The 32-row variant (two workgroups per CU, so that the VALU-bound phase 2 of one could overlap
+// the memory-bound phases of the other) is kept behind FS2_ATTN_QB=32 for measurements: at t ~ 925 it gives the same
+// throughput (254 / 214 us vs 243 / 219 us per layer) -- per-CU vector-memory and VALU throughput, not latency, bound
+// the kernel: each half-size workgroup takes as long as a full-size one alone.
+static int pick_qb(const AttnArgs& a, int dk) {
+    static const int forced = [] { const char* e = getenv("FS2_ATTN_QB"); return e ? atoi(e) : 0; }();
+    const bool fits32 = 32 * a.sld * 2 + KB * dk * 2 + MASK_BYTES <= LDS_MAX / 2;
+    if (forced == 64 || !fits32) return 64;
+    return forced == 32 ? 32 : 64;
+}
+
 template <int MODE>
 int dispatch_strip(const AttnArgs& a, int dk, int B, hipStream_t st, const char* name) {
-    if (dk == 128) return launch_strip<128, MODE>(a, B, st, name);
-    if (dk == 64) return launch_strip<64, MODE>(a, B, st, name);
-    return launch_strip<32, MODE>(a, B, st, name);
+    const bool half = pick_qb(a, dk) == 32;
+    if (dk == 128) return half ? launch_strip<128, MODE, 32>(a, B, st, name) : launch_strip<128, MODE, 64>(a, B, st, name);
+    if (dk == 64) return half ? launch_strip<64, MODE, 32>(a, B, st, name) : launch_strip<64, MODE, 64>(a, B, st, name);
+    return half ? launch_strip<32, MODE, 32>(a, B, st, name) : launch_strip<32, MODE, 64>(a, B, st, name);
 }
 
 }  // namespace
