@@ -293,3 +293,50 @@ def test_inference_batch_of_utterances_bf16():
                 continue        # bf16 noise moved a duration across a .5 boundary between the two batch shapes
             diff = (full[1][b, :T].float() - one[1][0].float()).abs().mean()
             assert float(diff) < MEL_L1_TOL_BF16, (b, float(diff))
+
+
+@pytest.mark.parametrize("heads", [2, 4])
+def test_d_model_512_config_vs_oracle(heads):
+    """SURVEY 8(f) N4 shape family: d_model 512 (two float4 groups per LayerNorm row, 2048-wide FFN), 2 heads of 256
+    (attention on the GEMM + softmax path) or 4 heads of 128 (LDS-strip attention kernels in bf16 mode): exact-fp32
+    mode against the oracle, bf16 mode within the stated tolerance; forward outputs, loss and parameter gradients."""
+    from types import SimpleNamespace
+    from golden_configs import _BASE
+    from oracle import train as otrain
+    from oracle.model import FastSpeech2 as OracleFS2
+    from transformer_tts_amd import synthetic
+    from transformer_tts_amd.train_fastspeech2 import build_model
+    from transformer_tts_amd.utils.utils import fill_variables
+    d = dict(_BASE)
+    d.update(vocab_size=50, batch_size=3, d_model_encoder=512, n_layer_encoder=1, n_head_encoder=heads,
+             ff_conv_kernel_size_encoder=9, d_model_decoder=512, n_layer_decoder=1, n_head_decoder=heads,
+             ff_conv_kernel_size_decoder=1, dropout=0.0, dropout_variance_adaptor=0.0)
+    batch = synthetic.make_batch(91, 3, l_range=(20, 41), dur_range=(2, 9), vocab=50)
+    results = {}
+    for amp in (False, True):
+        hp = SimpleNamespace(**dict(d, amp=amp))
+        fill_variables(hp, verbose=False)
+        torch.manual_seed(5)
+        omodel = OracleFS2.from_hp(hp, dropout=0.0, dropout_postnet=0.0, dropout_variance_adaptor=0.0)
+        omodel.train()
+        model = build_model(hp)
+        model.postnet.dropout = 0.0
+        model.load_state_dict(omodel.state_dict())
+        model = model.cuda().train()
+        out, total, parts = fwd_bwd(model, hp, batch_to(batch, "cuda"))
+        ototal, _, oout = otrain.forward_backward(omodel, batch)
+        for n, a, b in zip(OUT_NAMES[:2], out[:2], oout[:2]):
+            l1 = float((a.detach().float().cpu() - b.detach()).abs().mean())
+            assert l1 <= (MEL_L1_TOL_BF16 if amp else MEL_L1_TOL_FP32), f"amp={amp} {n}: mean |diff| {l1:.3e}"
+        assert abs(total.item() - ototal.item()) <= (2e-2 if amp else 5e-5) * abs(ototal.item())
+        og = dict(omodel.named_parameters())
+        num = den = 0.0
+        for k, p in model.named_parameters():
+            g = og[k].grad if og[k].grad is not None else torch.zeros_like(og[k])
+            num += float((p.grad.float().cpu() - g).pow(2).sum())
+            den += float(g.pow(2).sum())
+            if not amp:
+                torch.testing.assert_close(p.grad.cpu(), g, rtol=1e-2, atol=2e-4, msg=lambda m: f"grad {k}: {m}")
+        rel = (num / den) ** 0.5
+        assert rel < (6e-2 if amp else 1e-3), f"amp={amp}: relative gradient error {rel:.3e}"
+        results[amp] = rel
