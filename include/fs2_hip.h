@@ -77,6 +77,10 @@ typedef struct FS2Gemm {
     int32_t conv, taps, pad, seq_len;
     float alpha;
     int32_t colstats_mode; /* 0: sum and sum of squares; 1: column sums only (bias gradient) into colstats[0..N) */
+    int32_t tile_order;    /* 0: chosen by fs2_gemm; 1: output tiles walked n-fastest; 2: m-fastest with the column panels
+                              spread so that the workgroups sharing a row slab of A run at the same time on one XCD (one
+                              L2): for tall products with 2..8 column tiles, where a 128-row slab of A would otherwise be
+                              fetched from HBM once per column tile */
 } FS2Gemm;
 
 int fs2_gemm(const FS2Gemm* g, void* stream);

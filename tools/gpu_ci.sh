@@ -32,6 +32,10 @@ for step in "$@"; do
              FS2_SPLITK_FWD=1 run absk1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_SPLITK_FWD=0 run absk0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_SPLITK_FWD=1 run absk1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline ;;
+    abmf)    FS2_GEMM_MFAST=0 run abmf0 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_GEMM_MFAST=1 run abmf1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_GEMM_MFAST=0 run abmf0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_GEMM_MFAST=1 run abmf1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline ;;
     ab)      FS2_FUSED_ATTN=0 run ab0 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
              FS2_FUSED_ATTN=1 run ab1 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
              FS2_FUSED_ATTN=0 run ab0b 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline

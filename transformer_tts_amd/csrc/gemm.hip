@@ -131,9 +131,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
     const int per = (ntot + p.split_k - 1) / p.split_k;        // the host guarantees no empty split
     const int seq = p.seq_len;
 
-    // Work items are numbered tile-fastest (n, then m), then k-split, then batch; a block owns the CONTIGUOUS range
-    // [wbeg, wend): neighbouring tiles share operand panels in L2, and stepping to the next item is a few scalar
-    // increments instead of six integer divisions.
+    // Work items are numbered tile-fastest (n, then m -- or m, then n: tile_order 2), then k-split, then batch; a block
+    // owns the CONTIGUOUS range [wbeg, wend): neighbouring tiles share operand panels in L2, and stepping to the next
+    // item is a few scalar increments instead of six integer divisions.  m-fastest: the grid is a multiple of
+    // 8 * tilesN, so block L and block L + grid/tilesN walk the same row slabs of A, in step, on the same XCD
+    // (blockIdx % 8): the slab is fetched from HBM once and hit in that XCD's L2 by the other column panels.
+    const bool mfast = p.tile_order == 2;
     const int wbeg = (int)((int64_t)blockIdx.x * total_work / gridDim.x);
     const int wend = (int)((int64_t)(blockIdx.x + 1) * total_work / gridDim.x);
     auto set_batch = [&](Work& k) {
@@ -147,19 +150,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
         k.split = z % p.split_k; z /= p.split_k;
         k.b2 = z % p.batch2;
         k.b1 = z / p.batch2;
-        k.m0 = (lin / tilesN) * TM; k.n0 = (lin % tilesN) * TM;
+        if (mfast) { k.n0 = (lin / tilesM) * TM; k.m0 = (lin % tilesM) * TM; }
+        else { k.m0 = (lin / tilesN) * TM; k.n0 = (lin % tilesN) * TM; }
         set_batch(k);
         return k;
     };
     auto next_work = [&](Work& k) {
-        k.n0 += TM;
-        if (k.n0 >= p.N) {
-            k.n0 = 0; k.m0 += TM;
-            if (k.m0 >= p.M) {
-                k.m0 = 0;
-                if (++k.split == p.split_k) { k.split = 0; if (++k.b2 == p.batch2) { k.b2 = 0; ++k.b1; } }
-                set_batch(k);
-            }
+        bool wrap;
+        if (mfast) {
+            k.m0 += TM;
+            wrap = false;
+            if (k.m0 >= p.M) { k.m0 = 0; k.n0 += TM; if (k.n0 >= p.N) { k.n0 = 0; wrap = true; } }
+        } else {
+            k.n0 += TM;
+            wrap = false;
+            if (k.n0 >= p.N) { k.n0 = 0; k.m0 += TM; if (k.m0 >= p.M) { k.m0 = 0; wrap = true; } }
+        }
+        if (wrap) {
+            if (++k.split == p.split_k) { k.split = 0; if (++k.b2 == p.batch2) { k.b2 = 0; ++k.b1; } }
+            set_batch(k);
         }
     };
 
@@ -564,7 +573,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
 template <typename T, typename TC, bool AKM, bool BKM, int TM, bool DIRECT>
 int launch1(const FS2Gemm& g, int total, hipStream_t st) {
     const int slots = (TM == 128) ? 512 : 768;      // resident blocks: 2 (128-tile) / 3 (64-tile) per CU x 256 CUs
-    const int grid = total < slots ? total : slots;
+    int grid = total < slots ? total : slots;
+    if (g.tile_order == 2) {                        // column panels aligned to multiples of 8 blocks (one XCD per slab group)
+        const int unit = 8 * ((g.N + TM - 1) / TM);
+        grid = (slots / unit) * unit;
+    }
     const int lds = Geo<TM>::SMEM + (g.colstats != nullptr && g.N <= COLSTAT_LDS_N ? 2 * COLSTAT_LDS_N * 4 : 0);
     hipLaunchKernelGGL((gemm_kernel<T, TC, AKM, BKM, TM, DIRECT>), dim3(grid), dim3(256), lds, st, g, total);
     FS2_CHECK_LAUNCH("fs2_gemm");
@@ -575,6 +588,13 @@ template <typename T, typename TC>
 int launch(const FS2Gemm& g, hipStream_t st) {
     const long zdim = (long)g.batch1 * g.batch2 * g.split_k;
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * zdim;
+    if (!g.a_kmajor && !g.b_kmajor && t128 >= 384) {
+        // tall row-major products with 2..8 column tiles: walk the tiles m-fastest (see the kernel's work numbering)
+        static const bool allow = [] { const char* e = getenv("FS2_GEMM_MFAST"); return e == nullptr || e[0] != '0'; }();
+        const int tn = (g.N + 127) / 128, tm = (g.M + 127) / 128;
+        if (g.tile_order == 0 && allow && zdim == 1 && tn >= 2 && tn <= 8 && tm >= 8 * tn) const_cast<FS2Gemm&>(g).tile_order = 2;
+    }
+    if (g.tile_order != 2) const_cast<FS2Gemm&>(g).tile_order = 1;
     if (!g.a_kmajor && !g.b_kmajor) {
         if (t128 < 384) {       // too few 128-tiles to fill 256 CUs: quarter-size tiles
             const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * zdim;

@@ -37,6 +37,7 @@ class FS2Gemm(ctypes.Structure):
         ("accumulate", ctypes.c_int32), ("split_k", ctypes.c_int32), ("batch1", ctypes.c_int32),
         ("batch2", ctypes.c_int32), ("conv", ctypes.c_int32), ("taps", ctypes.c_int32), ("pad", ctypes.c_int32),
         ("seq_len", ctypes.c_int32), ("alpha", ctypes.c_float), ("colstats_mode", ctypes.c_int32),
+        ("tile_order", ctypes.c_int32),
     ]
 
 
