@@ -56,6 +56,18 @@ class GemmTimer:
     def __init__(self):
         self.records = []      # (key, flops, start, end)
         self._pool = []        # events created ahead of the instrumented steps (creation is host time)
+        self.overhead_ms = 0.0  # elapsed time of an EMPTY event pair on a busy stream (subtracted from every launch)
+
+    def calibrate(self):
+        """what a back-to-back event pair measures with nothing between the two records: the record/launch gap that
+        every bracketed kernel time contains (rocprofv3's kernel durations do not)"""
+        torch.cuda._sleep(2_000_000)
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        for s, e in pairs:
+            s.record(); e.record()
+        torch.cuda.synchronize()
+        ts = sorted(s.elapsed_time(e) for s, e in pairs)
+        self.overhead_ms = ts[len(ts) // 2]
 
     def reserve(self, n):
         self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
@@ -92,7 +104,7 @@ class GemmTimer:
     def summary(self):
         agg = {}
         for key, flops, s, e, shape, abytes in self.records:
-            ms = s.elapsed_time(e)
+            ms = max(s.elapsed_time(e) - self.overhead_ms, 1e-4)
             a = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
             a[0] += flops; a[1] += ms; a[2] += 1; a[3] += abytes
         return agg
@@ -101,7 +113,7 @@ class GemmTimer:
         agg = {}
         for key, flops, s, e, shape, abytes in self.records:
             a = agg.setdefault(key[:3] + shape, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += s.elapsed_time(e); a[2] += 1
+            a[0] += flops; a[1] += max(s.elapsed_time(e) - self.overhead_ms, 1e-4); a[2] += 1
         lines = ["variant M N K taps batch split epilogue(b=bias r=relu m=relu_mask +=residual sN=colstats a=accumulate f=fp32 out) | launches total_ms avg_us TFLOP/s"]
         for k, (fl, ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             lines.append(f"{'/'.join(k[:3])} {k[3]} {k[4]} {k[5]} {k[6]} {k[7]} {k[8]} {k[9]} | {n} {ms:.2f} {ms * 1e3 / n:.1f} "
@@ -232,6 +244,7 @@ def main():
         host_ms = (time.perf_counter() - t_e) * 1e3
         torch.cuda.synchronize()
         timer.records.clear()
+        timer.calibrate()
         n_inst = min(args.steps, POOL)
         timer.reserve(2 * 400 * n_inst)
         for i in range(n_inst):
@@ -269,7 +282,7 @@ def main():
                         achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
                         unit="GB/s" if hbm_bound else "TFLOP/s",
                         frac=round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_BF16_TFLOPS), 4), traffic=traffic,
-                        launches=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2),
+                        launches=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2), event_pair_overhead_us=round(timer.overhead_ms * 1e3, 2),
                         algorithmic_bytes_per_launch=round(by / cnt), algorithmic_flops_per_launch=round(fl / cnt),
                         achieved_tflops=round(tflops, 1), mfma_frac=round(tflops / PEAK_BF16_TFLOPS, 4),
                         achieved_gbs=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
