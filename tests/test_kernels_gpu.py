@@ -113,6 +113,31 @@ def test_conv_matches_torch_conv1d(ops):
         close(gw, wr.grad, f"conv1d wgrad k={k}", rtol=2e-5, atol=2e-5)
 
 
+def test_gemm_tile_orders_agree(ops):
+    """FS2Gemm.tile_order: the n-fastest walk and the XCD-aligned m-fastest walk compute every tile with the same
+    arithmetic -> bit-identical outputs; the automatic choice (0) picks one of them; invalid uses are rejected."""
+    import ctypes
+    from transformer_tts_amd import ops as real_ops
+    dtype = torch.bfloat16
+    M, N, K = 12800, 512, 192                     # 100 x 4 tiles of 128: "tall" for the automatic choice
+    x, w, bias = rnd(M, K, dtype=dtype, seed=1).cuda(), rnd(N, K, dtype=dtype, seed=2).cuda(), rnd(N, seed=3).cuda()
+    outs = []
+    for order in (1, 2, 0):
+        out = torch.full((M, N), float("nan"), dtype=dtype, device="cuda")
+        g = real_ops.FS2Gemm()
+        g.A, g.B, g.lda, g.ldb = x.data_ptr(), w.data_ptr(), K, K
+        g.M, g.N, g.K, g.dtype = M, N, K, real_ops.BF16
+        g.split_k = g.batch1 = g.batch2 = 1
+        g.C, g.ldc, g.c_dtype, g.bias, g.alpha, g.relu = out.data_ptr(), N, real_ops.BF16, bias.data_ptr(), 1.0, 1
+        g.tile_order = order
+        real_ops._gemm_call(g)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    close(outs[1], P.linear(x.cpu(), w.cpu(), bias.cpu(), relu=True), "m-fastest tile walk", rtol=2e-2, atol=2e-2)
+    g.tile_order, g.split_k, g.accumulate, g.c_dtype, g.relu, g.bias = 2, 2, 1, real_ops.F32, 0, None
+    assert real_ops.lib().fs2_gemm(ctypes.byref(g), None) < 0 and b"tile_order" in real_ops.lib().fs2_last_error()
+
+
 def test_splitk_forward_products(ops):
     """few output tiles + long reduction: ops.conv / ops.linear run split-K into an fp32 scratch and finish with
     fs2_splitk_finish (bias / ReLU / residual / cast).  Same results as the oracle, the scratch is left clean, and a

@@ -588,13 +588,6 @@ template <typename T, typename TC>
 int launch(const FS2Gemm& g, hipStream_t st) {
     const long zdim = (long)g.batch1 * g.batch2 * g.split_k;
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * zdim;
-    if (!g.a_kmajor && !g.b_kmajor && t128 >= 384) {
-        // tall row-major products with 2..8 column tiles: walk the tiles m-fastest (see the kernel's work numbering)
-        static const bool allow = [] { const char* e = getenv("FS2_GEMM_MFAST"); return e == nullptr || e[0] != '0'; }();
-        const int tn = (g.N + 127) / 128, tm = (g.M + 127) / 128;
-        if (g.tile_order == 0 && allow && zdim == 1 && tn >= 2 && tn <= 8 && tm >= 8 * tn) const_cast<FS2Gemm&>(g).tile_order = 2;
-    }
-    if (g.tile_order != 2) const_cast<FS2Gemm&>(g).tile_order = 1;
     if (!g.a_kmajor && !g.b_kmajor) {
         if (t128 < 384) {       // too few 128-tiles to fill 256 CUs: quarter-size tiles
             const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * zdim;
@@ -663,6 +656,18 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
     const long total = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch1 * g.batch2 * g.split_k;
     FS2_REQUIRE(total < (1L << 30), "fs2_gemm: too many work items");
     hipStream_t st = (hipStream_t)stream;
+    // tile walk: tall row-major products with 2..8 column tiles of 128 go m-fastest on an XCD-aligned grid (see the
+    // kernel's work numbering); everything else n-fastest.  FS2_GEMM_MFAST=0 disables the choice (measurements).
+    if (g.tile_order != 1 && g.tile_order != 2) {
+        static const bool allow = [] { const char* e = getenv("FS2_GEMM_MFAST"); return e == nullptr || e[0] != '0'; }();
+        const long zdim = (long)g.batch1 * g.batch2 * g.split_k;
+        const int tn = (g.N + 127) / 128, tm = (g.M + 127) / 128;
+        const bool tall = !g.a_kmajor && !g.b_kmajor && zdim == 1 && (long)tn * tm >= 384 && tn >= 2 && tn <= 8 && tm >= 8 * tn;
+        g.tile_order = (allow && tall) ? 2 : 1;
+    }
+    if (g.tile_order == 2)
+        FS2_REQUIRE(!g.a_kmajor && !g.b_kmajor && (long)g.batch1 * g.batch2 * g.split_k == 1 && (long)((g.N + 127) / 128) * ((g.M + 127) / 128) >= 384 &&
+                    (g.N + 127) / 128 <= 64, "fs2_gemm: tile_order 2 is for un-batched row-major products with at least 384 tiles of 128");
     if (g.dtype == FS2_BF16) {
         if (g.c_dtype == FS2_F32) return launch<bf16_t, float>(g, st);
         return launch<bf16_t, bf16_t>(g, st);
