@@ -113,6 +113,30 @@ def test_conv_matches_torch_conv1d(ops):
         close(gw, wr.grad, f"conv1d wgrad k={k}", rtol=2e-5, atol=2e-5)
 
 
+def test_linear_random_shapes_and_epilogues(ops):
+    """seeded sweep of ragged products (M from 1 row, N and K at their alignment minima, every epilogue combination)
+    in both compute modes against the oracle primitive"""
+    rs = np.random.default_rng(2024)
+    for case in range(24):
+        dtype = torch.bfloat16 if case % 2 else torch.float32
+        M = int(rs.choice([1, 3, 17, 64, 129, 300, 641]))
+        N = int(rs.choice([4, 8, 12, 80, 132, 256, 388])) if dtype == torch.float32 else int(rs.choice([8, 16, 80, 136, 256, 392]))
+        K = int(rs.choice([8, 24, 64, 72, 200, 512]))
+        x, w = rnd(M, K, dtype=dtype, seed=case), rnd(N, K, dtype=dtype, seed=100 + case, scale=0.3)
+        kw = {}
+        if rs.random() < 0.6:
+            kw["bias"] = rnd(N, seed=200 + case)
+        if rs.random() < 0.4:
+            kw["relu"] = True
+        if rs.random() < 0.4:
+            kw["residual"] = rnd(M, N, dtype=dtype if rs.random() < 0.5 else torch.float32, seed=300 + case)
+        if rs.random() < 0.3:
+            kw["relu_mask"] = rnd(M, N, dtype=dtype, seed=400 + case)
+        ref = P.linear(x, w, **kw)
+        got = ops.linear(x.cuda(), w.cuda(), **{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()})
+        close(got, ref, f"case {case}: {M}x{N}x{K} {dtype} {sorted(kw)}", **tol(dtype, k=K))
+
+
 def test_gemm_tile_orders_agree(ops):
     """FS2Gemm.tile_order: the n-fastest walk and the XCD-aligned m-fastest walk compute every tile with the same
     arithmetic -> bit-identical outputs; the automatic choice (0) picks one of them; invalid uses are rejected."""
@@ -313,6 +337,40 @@ def test_softmax_fwd_bwd(ops, dtype, p, t):
     assert torch.all(Pc[..., t:] == 0), "pad columns must be written as zero"
     close(Pc[..., :t].sum(-1), torch.ones(B, H, t), "rows sum to one", rtol=1e-2, atol=1e-2)
     assert float(Pc[1, :, :, lens[1]:t].abs().max()) < 1e-6, "masked keys get ~0 probability (-1e4 fill)"
+
+
+@pytest.mark.parametrize("t,H,dk", [(1, 2, 128), (8, 1, 32), (63, 2, 64), (65, 2, 128), (127, 1, 128), (129, 1, 32)])
+def test_attn_strip_kernels_at_tile_boundaries(ops, t, H, dk):
+    """single-frame sequences, one key short of / one key past the 64-key tiles and 128-key super-tiles: forward
+    probabilities (+ P V) and backward dS (+ dQ) of the LDS-strip kernels against the oracle composition"""
+    dtype = torch.bfloat16
+    B = 2
+    tp = (t + 7) // 8 * 8
+    km = torch.ones(B, t, dtype=torch.bool)
+    km[1, max(1, t // 2):] = False
+    qkv = rnd(B, t, 3, H, dk, dtype=dtype, seed=1, scale=1.2)
+    dO = rnd(B, t, H, dk, dtype=dtype, seed=2)
+    res = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda x: x.cuda()) if dev == "cuda" else (lambda x: x.clone())
+        rng = o.Rng(9, dev)
+        x, g = mv(qkv), mv(dO)
+        q, v, k = (x[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        Pb, Pd, dS = (mv(torch.full((B, H, t, tp), float("nan"), dtype=dtype)) for _ in range(3))
+        second = o.attn_second_product_supported(dk)
+        O = mv(torch.zeros(B, t, H, dk, dtype=dtype))
+        dq = mv(torch.zeros(B, t, H, dk, dtype=dtype))
+        o.attn_probs_fwd(q, k, mv(km), Pb, Pd, t, dk ** -0.5, 0.1, rng, 4, v=v if second else None,
+                         out=O.permute(0, 2, 1, 3) if second else None)
+        res[dev] = [Pb.float().cpu(), Pd.float().cpu(), O.float().cpu()]
+        Pref = mv(res["cuda"][0].to(dtype)) if dev == "cpu" else Pb     # same saved probabilities on both sides
+        o.attn_ds_bwd(g.permute(0, 2, 1, 3), v, Pref, dS, t, 0.1, rng, 4, k=k if second else None,
+                      dq=dq.permute(0, 2, 1, 3) if second else None, alpha=dk ** -0.5)
+        res[dev] += [dS.float().cpu(), dq.float().cpu()]
+    for a, b, n in zip(res["cuda"], res["cpu"], ("P", "P_drop", "P_drop @ V", "dS", "dQ")):
+        scale = b.abs().amax().clamp_min(1e-3)
+        assert float((a - b).abs().max() / scale) < 5e-2, (n, t, float((a - b).abs().max()), float(scale))
+    assert torch.all(res["cuda"][0][..., t:] == 0) and torch.all(res["cuda"][3][..., t:] == 0)
 
 
 @pytest.mark.parametrize("p", [0.0, 0.2])
