@@ -2,7 +2,13 @@
 """Headline benchmark: mel-frames/sec of a FastSpeech2 train step (d_model=256, 4+4 FFT layers, 80 mel,
 batch 48 per GPU, bf16) on 1/2/4/8 MI355X  --  BASELINE.json `metric`, configs[1] (configs[2] for N > 1).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  When the process was not started by torch.distributed.run (no WORLD_SIZE in
+the environment) bench.py starts N fresh rank processes itself -- `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 bench.py ...` as a CHILD, before anything touches the GPU here (the
+reference spawns its own ranks too: train_fastspeech2.py:368-374) -- waits for them and exits with their code; rank 0
+prints the JSON line.
 
 A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
 forward + 5 L1 losses + backward + global-norm clip + Adam (+ gradient all-reduce and SyncBatchNorm
@@ -151,6 +157,22 @@ def cpu_baseline(hp, batch):
                        f"{n_utt} utterances of the config-2 batch (T_pad {sample[1].shape[1]}, {frames} valid mel frames): {dt:.1f} s")
 
 
+def launch_ranks(n):
+    """start n rank processes of this script under torch.distributed.run (a child process; this one never initialises
+    the GPU and only relays the exit code)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,10 +193,13 @@ def main():
     from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep, build_model, train_step
     from transformer_tts_amd.utils.utils import init_weight
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # parent: no HIP call has been made in this process
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X (the product has no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -206,7 +231,8 @@ def main():
 
     # hipGraph replay of the whole step (one graph per batch shape); the GEMM event timer needs eager launches,
     # so the roofline leg below re-runs a few eager, instrumented steps after the timed region
-    use_graph = not args.no_graph and ((world == 1 and not force_dp) or os.environ.get('FS2_GRAPH_DP', '0') == '1')
+    # (also with RCCL: the all-reduces are captured into the graph; FS2_GRAPH_DP=0 keeps the multi-rank run eager)
+    use_graph = not args.no_graph and ((world == 1 and not force_dp) or os.environ.get('FS2_GRAPH_DP', '1') == '1')
     graphed = GraphedTrainStep(model, opt, hp) if use_graph else None
     run = (lambda st, b: graphed(st, b)) if use_graph else (lambda st, b: train_step(model, opt, st, b, hp))
     step = 1

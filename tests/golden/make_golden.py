@@ -28,9 +28,14 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = HERE                         # --out DIR redirects the fixtures (tests/test_golden_recipe.py regenerates into a temp dir)
 sys.dont_write_bytecode = True
-sys.path.insert(1, "/root/reference")
+# /root/reference FIRST: the repo root holds CLI shims named like the reference's scripts (train_fastspeech2.py,
+# test_fastspeech2.py); packages of the build are imported by their qualified name (transformer_tts_amd.*) only.
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+sys.path.insert(2, HERE)
 
 _t = types.ModuleType("turtle"); _t.distance = None; sys.modules["turtle"] = _t
 sys.modules["librosa"] = types.ModuleType("librosa")
@@ -38,13 +43,42 @@ _tm = types.ModuleType("torchmetrics"); _tm.StructuralSimilarityIndexMeasure = l
 sys.modules["torchmetrics"] = _tm
 _pkg = types.ModuleType("datasets"); _pkg.__path__ = ["/root/reference/datasets"]; sys.modules["datasets"] = _pkg
 
+import importlib.util  # noqa: E402
+
 import torch  # noqa: E402
 
 from transformer_tts_amd import synthetic  # noqa: E402
 from golden_configs import CONFIGS, hp_namespace, digest  # noqa: E402
 
 
-def build_reference(cfg):
+def reference_module(name, relpath):
+    """import one file of the reference BY PATH under a private module name: nothing on sys.path (the repo root has
+    scripts of the same names) can shadow it"""
+    key = "_ref_" + name
+    if key in sys.modules:
+        return sys.modules[key]
+    spec = importlib.util.spec_from_file_location(key, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[key] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def ref_trainer():
+    return reference_module("train_fastspeech2", "train_fastspeech2.py")      # guarded by __main__
+
+
+def shape_arrays(shapes):
+    """{key: shape} -> pickle-free arrays: unicode keys, (n, 4) int64 dims padded with -1"""
+    keys = sorted(shapes)
+    dims = np.full((len(keys), 4), -1, np.int64)
+    for i, k in enumerate(keys):
+        dims[i, :len(shapes[k])] = shapes[k]
+    return np.array(keys, dtype=np.str_), dims
+
+
+def build_reference_raw(cfg):
+    """the reference model as its constructor leaves it (PyTorch default initialisation under the caller's seed)"""
     from Models.fastspeech2 import FastSpeech2
     from utils.utils import fill_variables
     hp = hp_namespace(cfg)
@@ -64,13 +98,18 @@ def build_reference(cfg):
                         multi_speaker=hp.is_multi_speaker, spk_emb_dim=hp.spk_emb_dim,
                         spk_emb_architecture=hp.spk_emb_architecture)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    return model, hp, shapes
+
+
+def build_reference(cfg):
+    model, hp, shapes = build_reference_raw(cfg)
     model.load_state_dict(synthetic.recipe_state_dict(shapes, cfg["weight_seed"]))
     model.train()
     return model, hp, shapes
 
 
 def run(name):
-    import train_fastspeech2 as T  # the reference trainer module (guarded by __main__)
+    T = ref_trainer()
     cfg = CONFIGS[name]
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -79,8 +118,7 @@ def run(name):
     text, mel, pos_text, pos_mel, text_len, mel_len, stop, _, f0, energy, align = batch[:11]
     full = name != "bench"
     out = {}
-    out["shape_keys"] = np.array(sorted(shapes), dtype=object)
-    out["shape_vals"] = np.array([str(shapes[k]) for k in sorted(shapes)], dtype=object)
+    out["shape_keys"], out["shape_dims"] = shape_arrays(shapes)
     if full:
         for k, v in zip(synthetic.FIELDS[:11], batch[:11]):
             if v is not None:
@@ -137,7 +175,7 @@ def run(name):
     tl = [float(l.split("=")[1]) for l in log.getvalue().splitlines() if l.startswith("loss_total")]
     out["train.loss_total"] = np.asarray(tl, np.float64)
     out["train.start_step"] = np.int64(cfg["start_step"])
-    path = os.path.join(HERE, f"{name}.npz")
+    path = os.path.join(OUT, f"{name}.npz")
     np.savez_compressed(path, **out)
     print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB", "loss", out["loss.total"], "train", tl)
 
@@ -170,16 +208,115 @@ def run_infer(name):
             out[f"u{b}.{k}"] = r.numpy()
         out[f"u{b}.attn_dec_dig"] = digest(res[8])
         print(name, "utt", b, "L", n, "T", int(dur.sum()), "round margin", float(out[f"u{b}.round_margin"]))
-    path = os.path.join(HERE, f"infer_{name}.npz")
+    path = os.path.join(OUT, f"infer_{name}.npz")
     np.savez_compressed(path, **out)
     print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def data_hp(root):
+    """hparams of the BASELINE configs[0] plumbing run on the synthetic corpus in `root`"""
+    from golden_configs import _BASE
+    d = dict(_BASE)
+    d.update(CONFIGS["tiny"]["hp"])
+    d.update(train_script=os.path.join(root, "train.txt"), lengths_file=os.path.join(root, "lengths.npy"), vocab_size=152)
+    return SimpleNamespace(**d)
+
+
+DATA_BATCHES = ([0, 1], [2, 3, 4], [15], [5, 9, 13, 7])      # index lists fed to collate_fn (ragged, singleton, unordered)
+DATA_MAX_SEQLEN = 300
+
+
+def run_data():
+    """the reference's OWN TrainDatasets.__getitem__ + collate_fn 16-tuples
+    (datasets/datasets_fastspeech2.py:69-174,521-616), LengthsBatchSampler / NumBatchSampler batch lists (:749-845) and
+    DistributedSamplerWrapper shards (:847-919) on the synthetic corpus of configs[0].  -> data.npz"""
+    import tempfile
+    from utils.utils import fill_variables
+    from transformer_tts_amd.datasets.datasets_fastspeech2 import write_synthetic_corpus
+    D = reference_module("datasets_fastspeech2", "datasets/datasets_fastspeech2.py")
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        write_synthetic_corpus(root)
+        hp = data_hp(root)
+        with contextlib.redirect_stdout(io.StringIO()):
+            fill_variables(hp)
+        ds = D.TrainDatasets(hp.train_script, hp, alignment_pred=True, pitch_pred=True, energy_pred=True, accent_emb=False)
+        out["n_utt"] = np.int64(len(ds))
+        for bi, idx in enumerate(DATA_BATCHES):
+            tup = D.collate_fn([ds[i] for i in idx])
+            assert len(tup) == 16
+            out[f"b{bi}.index"] = np.asarray(idx, np.int64)
+            out[f"b{bi}.is_none"] = np.asarray([t is None for t in tup], np.bool_)
+            for k, t in zip(synthetic.FIELDS, tup):
+                if torch.is_tensor(t):
+                    out[f"b{bi}.{k}"] = t.numpy()
+                    out[f"b{bi}.{k}.dtype"] = np.array(str(t.dtype))
+            out[f"b{bi}.mel_name"] = np.array([os.path.basename(n) for n in tup[14]], dtype=np.str_)
+            out[f"b{bi}.hop_size_none"] = np.asarray([h is None for h in tup[15]], np.bool_)
+        with contextlib.redirect_stdout(io.StringIO()):
+            lbs = D.LengthsBatchSampler(ds, DATA_MAX_SEQLEN, hp, hp.lengths_file, shuffle=False, shuffle_one_time=False)
+        batches = list(lbs)
+        out["lbs.flat"] = np.asarray([i for b in batches for i in b], np.int64)
+        out["lbs.sizes"] = np.asarray([len(b) for b in batches], np.int64)
+        out["lbs.len"] = np.int64(len(lbs))
+        with contextlib.redirect_stdout(io.StringIO()):
+            rev = list(D.LengthsBatchSampler(ds, DATA_MAX_SEQLEN, hp, hp.lengths_file, shuffle=False, reverse=True))
+        out["lbs_rev.flat"] = np.asarray([i for b in rev for i in b], np.int64)
+        np.random.seed(5)
+        nbs = D.NumBatchSampler(ds, 3)          # 16 = 5 x 3 + 1: the ragged tail batch; order shuffled in ctor and per epoch
+        for ep in range(2):
+            bl = list(nbs)
+            out[f"nbs.ep{ep}.flat"] = np.asarray([i for b in bl for i in b], np.int64)
+            out[f"nbs.ep{ep}.sizes"] = np.asarray([len(b) for b in bl], np.int64)
+        for world in (2, 3):
+            for r in range(world):
+                w = D.DistributedSamplerWrapper(lbs, num_replicas=world, rank=r)
+                for ep in range(2):             # the reference never calls set_epoch: every epoch deals the same shard
+                    bl = list(w)
+                    out[f"dsw.w{world}.r{r}.ep{ep}.flat"] = np.asarray([i for b in bl for i in b], np.int64)
+                    out[f"dsw.w{world}.r{r}.ep{ep}.sizes"] = np.asarray([len(b) for b in bl], np.int64)
+                out[f"dsw.w{world}.r{r}.len"] = np.int64(len(w))
+    path = os.path.join(OUT, "data.npz")
+    np.savez_compressed(path, **out)
+    print("data ->", path, f"{os.path.getsize(path) / 1024:.0f} KiB", "lbs", [len(b) for b in batches])
+
+
+def run_init():
+    """the reference's ``init_weight`` (utils/utils.py:153-177) applied to the reference model built under
+    ``torch.manual_seed(0)`` (the construction draws PyTorch's default initialisations in module order, ``apply`` then
+    re-draws the Conv1d weights): digests of every state_dict entry.  -> init.npz"""
+    from utils.utils import init_weight
+    out = {}
+    for name in ("tiny", "bench"):
+        cfg = CONFIGS[name]
+        torch.manual_seed(0)
+        model, hp, shapes = build_reference_raw(cfg)
+        model.apply(init_weight)
+        keys, dims = shape_arrays({k: tuple(v.shape) for k, v in model.state_dict().items()})
+        out[f"{name}.shape_keys"], out[f"{name}.shape_dims"] = keys, dims
+        for k, v in model.state_dict().items():
+            out[f"{name}.dig.{k}"] = digest(v.float())
+        print("init", name, len(keys), "entries")
+    path = os.path.join(OUT, "init.npz")
+    np.savez_compressed(path, **out)
+    print("init ->", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    argv = sys.argv[1:]
+    if "--out" in argv:
+        i = argv.index("--out")
+        OUT = argv[i + 1]
+        os.makedirs(OUT, exist_ok=True)
+        del argv[i:i + 2]
+    which = argv[0] if argv else "all"
     if which.startswith("infer"):
         for n in ("tiny", "small"):
             run_infer(n)
+    elif which == "data":
+        run_data()
+    elif which == "init":
+        run_init()
     else:
         for n in (list(CONFIGS) if which == "all" else [which]):
             run(n)

@@ -12,11 +12,12 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def load_golden(name):
-    return np.load(os.path.join(GOLDEN, f"{name}.npz"), allow_pickle=True)
+    return np.load(os.path.join(GOLDEN, f"{name}.npz"))        # numpy's default allow_pickle=False: plain arrays only
 
 
-def golden_shapes(g):
-    return {k: eval(v) for k, v in zip(g["shape_keys"], g["shape_vals"])}
+def golden_shapes(g, prefix=""):
+    """{state_dict key: shape} from the pickle-free pair (unicode keys, (n,4) int dims padded with -1)"""
+    return {str(k): tuple(int(x) for x in d if x >= 0) for k, d in zip(g[prefix + "shape_keys"], g[prefix + "shape_dims"])}
 
 
 def oracle_model(name, dtype=torch.float32):

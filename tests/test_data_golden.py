@@ -1,0 +1,109 @@
+"""SURVEY 8(a) A16 / A17 / A18 and 8(f) N3 pinned to the REFERENCE's own outputs (tests/golden/data.npz, init.npz,
+written by tests/golden/make_golden.py data|init from the imported reference): collate_fn 16-tuples, the batch lists of
+LengthsBatchSampler / NumBatchSampler, the shards of DistributedSamplerWrapper, and init_weight under the same seed."""
+import contextlib
+import io
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from golden_configs import _BASE, CONFIGS, digest, hp_namespace
+from helpers import GOLDEN, golden_shapes
+from transformer_tts_amd import synthetic
+from transformer_tts_amd.datasets import datasets_fastspeech2 as D
+from transformer_tts_amd.utils.utils import fill_variables, init_weight
+
+MAX_SEQLEN = 300       # make_golden.DATA_MAX_SEQLEN
+
+
+@pytest.fixture(scope="module")
+def corpus(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("corpus"))
+    D.write_synthetic_corpus(root)
+    d = dict(_BASE)
+    d.update(CONFIGS["tiny"]["hp"])
+    d.update(train_script=os.path.join(root, "train.txt"), lengths_file=os.path.join(root, "lengths.npy"), vocab_size=152)
+    hp = SimpleNamespace(**d)
+    fill_variables(hp, verbose=False)
+    ds = D.TrainDatasets(hp.train_script, hp, alignment_pred=True, pitch_pred=True, energy_pred=True, accent_emb=False)
+    return ds, hp, np.load(os.path.join(GOLDEN, "data.npz"))
+
+
+def _flat(batches):
+    return np.asarray([i for b in batches for i in b], np.int64), np.asarray([len(b) for b in batches], np.int64)
+
+
+def test_collate_fn_equals_the_reference_tuples(corpus):
+    ds, hp, g = corpus
+    assert len(ds) == int(g["n_utt"])
+    bi = 0
+    while f"b{bi}.index" in g.files:
+        idx = g[f"b{bi}.index"].tolist()
+        tup = D.collate_fn([ds[i] for i in idx])
+        assert len(tup) == 16
+        np.testing.assert_array_equal(np.asarray([t is None for t in tup]), g[f"b{bi}.is_none"])
+        for k, t in zip(synthetic.FIELDS, tup):
+            if torch.is_tensor(t):
+                assert str(t.dtype) == str(g[f"b{bi}.{k}.dtype"]), (bi, k)
+                np.testing.assert_array_equal(t.numpy(), g[f"b{bi}.{k}"], err_msg=f"batch {bi} field {k}")   # bit-exact
+        assert [os.path.basename(n) for n in tup[14]] == g[f"b{bi}.mel_name"].tolist()
+        np.testing.assert_array_equal(np.asarray([h is None for h in tup[15]]), g[f"b{bi}.hop_size_none"])
+        bi += 1
+    assert bi >= 4
+
+
+def test_lengths_batch_sampler_equals_the_reference_batches(corpus):
+    ds, hp, g = corpus
+    with contextlib.redirect_stdout(io.StringIO()):
+        lbs = D.LengthsBatchSampler(ds, MAX_SEQLEN, hp, hp.lengths_file, shuffle=False)
+        rev = D.LengthsBatchSampler(ds, MAX_SEQLEN, hp, hp.lengths_file, shuffle=False, reverse=True)
+    flat, sizes = _flat(list(lbs))
+    np.testing.assert_array_equal(flat, g["lbs.flat"])
+    np.testing.assert_array_equal(sizes, g["lbs.sizes"])
+    assert len(lbs) == int(g["lbs.len"])
+    np.testing.assert_array_equal(_flat(list(rev))[0], g["lbs_rev.flat"])
+
+
+def test_num_batch_sampler_equals_the_reference_order(corpus):
+    ds, hp, g = corpus
+    np.random.seed(5)
+    nbs = D.NumBatchSampler(ds, 3)
+    for ep in range(2):
+        flat, sizes = _flat(list(nbs))
+        np.testing.assert_array_equal(flat, g[f"nbs.ep{ep}.flat"])
+        np.testing.assert_array_equal(sizes, g[f"nbs.ep{ep}.sizes"])
+
+
+def test_distributed_sampler_wrapper_equals_the_reference_shards(corpus):
+    ds, hp, g = corpus
+    with contextlib.redirect_stdout(io.StringIO()):
+        lbs = D.LengthsBatchSampler(ds, MAX_SEQLEN, hp, hp.lengths_file, shuffle=False)
+    for world in (2, 3):
+        for r in range(world):
+            w = D.DistributedSamplerWrapper(lbs, num_replicas=world, rank=r)
+            assert len(w) == int(g[f"dsw.w{world}.r{r}.len"])
+            for ep in range(2):
+                flat, sizes = _flat(list(w))
+                np.testing.assert_array_equal(flat, g[f"dsw.w{world}.r{r}.ep{ep}.flat"])
+                np.testing.assert_array_equal(sizes, g[f"dsw.w{world}.r{r}.ep{ep}.sizes"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "bench"])
+def test_init_weight_equals_the_reference_under_the_same_seed(name):
+    """Models are built in the reference's module order (clones() = deep copies of one prototype), so the default
+    initialisations and the Kaiming re-draw of init_weight consume the torch RNG identically: bit-equal tensors."""
+    from transformer_tts_amd.train_fastspeech2 import build_model
+    g = np.load(os.path.join(GOLDEN, "init.npz"))
+    hp = hp_namespace(CONFIGS[name])
+    fill_variables(hp, verbose=False)
+    hp.dropout = hp.dropout_variance_adaptor = 0.0
+    torch.manual_seed(0)
+    model = build_model(hp)
+    model.apply(init_weight)
+    sd = model.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == golden_shapes(g, prefix=f"{name}.")
+    for k, v in sd.items():
+        np.testing.assert_array_equal(digest(v.float()), g[f"{name}.dig.{k}"], err_msg=k)

@@ -52,8 +52,13 @@ def test_collate_contract(tmp_path):
     assert spk is None and b[11] is None and b[12] is None and b[13] is None and b[15] == [None] * B
     s = D.NumBatchSampler(ds, 2, shuffle=False)
     assert list(s) == [[0, 1], [2, 3], [4]]
-    w = D.DistributedSamplerWrapper(s, num_replicas=2, rank=1)
+    w = D.DistributedSamplerWrapper(s, num_replicas=2, rank=1, shuffle=False)
     assert list(w) == [[2, 3], [0, 1]] and len(w) == 2     # padded by repetition to a multiple of the world size
+    # default (shuffle=True, seed 0, as the reference's DistributedSampler base): the ranks split one permutation of the
+    # batch list, the same one every epoch (tests/test_data_golden.py pins it to the reference's own shards)
+    shards = [list(D.DistributedSamplerWrapper(s, num_replicas=2, rank=r)) for r in (0, 1)]
+    assert sorted(map(tuple, shards[0] + shards[1]))[1:] == sorted(map(tuple, [[0, 1], [2, 3], [4]])) or \
+        sorted(set(map(tuple, shards[0] + shards[1]))) == sorted(map(tuple, [[0, 1], [2, 3], [4]]))
 
 
 def test_hparams_singleton_and_template(tmp_path):

@@ -1,4 +1,6 @@
 """PostConvNet: Linear(d -> mel) + 5 causal Conv1d with BatchNorm/tanh/dropout (reference: Models/postnets.py:13-79)."""
+import copy
+
 import torch.nn as nn
 
 from .functional import PostNetFunction, Runtime, next_site
@@ -11,10 +13,14 @@ class PostConvNet(nn.Module):
         self.prev_version = prev_version
         self.dropout = dropout
         self.conv1 = nn.Conv1d(mel_dim * reduction_rate, num_hidden, kernel_size=5, padding=4)
-        self.conv_list = nn.ModuleList([nn.Conv1d(num_hidden, num_hidden, kernel_size=5, padding=4) for _ in range(3)])
+        # three COPIES of one freshly initialised module, as the reference's clones() makes them (postnets.py:10-11,32-35):
+        # one draw from the RNG stream, identical starting weights
+        proto = nn.Conv1d(num_hidden, num_hidden, kernel_size=5, padding=4)
+        self.conv_list = nn.ModuleList([copy.deepcopy(proto) for _ in range(3)])
         self.conv2 = nn.Conv1d(num_hidden, mel_dim * reduction_rate, kernel_size=5, padding=4)
         self.out = nn.Linear(num_hidden, mel_dim * reduction_rate)
-        self.batch_norm_list = nn.ModuleList([nn.BatchNorm1d(num_hidden) for _ in range(3)])
+        proto_bn = nn.BatchNorm1d(num_hidden)
+        self.batch_norm_list = nn.ModuleList([copy.deepcopy(proto_bn) for _ in range(3)])
         self.pre_batchnorm = nn.BatchNorm1d(num_hidden)
         self.sites = [next_site() for _ in range(4)]
         self.rt = runtime if runtime is not None else Runtime()

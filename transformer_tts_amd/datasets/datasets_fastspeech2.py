@@ -192,20 +192,35 @@ class NumBatchSampler(Sampler):
 
 
 class DistributedSamplerWrapper(Sampler):
-    """Shard the LIST OF BATCHES of a batch sampler over the ranks (reference :847-919): rank r takes
-    batches r, r+world, ...; the list is padded by repetition to a multiple of the world size."""
+    """Shard the LIST OF BATCHES of a batch sampler over the ranks (reference :847-919, a
+    ``torch.utils.data.DistributedSampler`` over the batch list with its default ``shuffle=True, seed=0``): the
+    list is materialised once per epoch, permuted with ``torch.randperm`` under a generator seeded ``seed + epoch``,
+    padded by repetition to a multiple of the world size, and rank r takes entries r, r+world, ...  The reference
+    never calls ``set_epoch``, so the permutation (not the batch contents) is the same every epoch."""
 
-    def __init__(self, sampler, num_replicas=None, rank=None):
+    def __init__(self, sampler, num_replicas=None, rank=None, shuffle=True, seed=0):
         import torch.distributed as dist
         self.sampler = sampler
         self.num_replicas = num_replicas if num_replicas is not None else dist.get_world_size()
         self.rank = rank if rank is not None else dist.get_rank()
+        self.shuffle, self.seed, self.epoch = shuffle, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
 
     def __iter__(self):
         batches = list(self.sampler)
-        total = -(-len(batches) // self.num_replicas) * self.num_replicas
-        batches += batches[: total - len(batches)]
-        yield from batches[self.rank:total:self.num_replicas]
+        n = len(batches)
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(n, generator=g).tolist()
+        else:
+            order = list(range(n))
+        total = -(-n // self.num_replicas) * self.num_replicas
+        while len(order) < total:                       # pad by repetition (more than once if world > 2 n)
+            order += order[: total - len(order)]
+        yield from (batches[i] for i in order[self.rank:total:self.num_replicas])
 
     def __len__(self):
         return -(-len(self.sampler) // self.num_replicas)

@@ -123,20 +123,25 @@ class GraphedTrainStep:
         if entry is None and (key not in self.seen or len(self.graphs) >= self.max_graphs):
             self.seen.add(key)
             return train_step(self.model, self.optimizer, step, d, self.hp)
-        self.optimizer.host_update()
         if entry is None:
             static = [t.to(DEVICE).clone() for t in tensors]
             g = torch.cuda.CUDAGraph()
             if self.pool is None:
                 self.pool = torch.cuda.graph_pool_handle()
             torch.cuda.synchronize()
+            # the captured launches are NOT executed: capture with the optimizer's host state untouched, then run the
+            # step through the replay below like every later occurrence of this shape
             with torch.cuda.graph(g, pool=self.pool):
                 loss, parts = step_body(self.model, self.optimizer, self.hp, *static[:4], *static[4:])
             entry = self.graphs[key] = (g, static, loss, parts)
+        self.optimizer.host_update()
         g, static, loss, parts = entry
         for dst, src in zip(static, tensors):
             dst.copy_(src, non_blocking=True)
         g.replay()
+        # the replayed Adam step rewrote the parameters through raw pointers: a forward outside the graph (evaluation or
+        # synthesis between training steps) must not reuse weight shadows derived before it
+        self.model.rt.invalidate()
         return loss, parts, static[1].shape[0]
 
 
@@ -214,6 +219,11 @@ def run_distributed(fn, args, hp):
         cleanup()
 
 
+def clip_norm(hp):
+    """max gradient norm of the reference trainer (:304-315): ``hp.clip`` under amp (None = no clipping), else 1.0"""
+    return getattr(hp, "clip", 1.0) if getattr(hp, "amp", False) else 1.0
+
+
 def build_model(hp):
     """Argument wiring of the reference (:381-389), dropout_postnet hard-coded to 0.5 there."""
     return FastSpeech2(hp=hp, src_vocab=hp.vocab_size, trg_vocab=hp.mel_dim, d_model_encoder=hp.d_model_encoder,
@@ -243,7 +253,8 @@ def run_training(rank, args, hp, port=None):
     device = torch.device("cuda", rank) if torch.cuda.is_available() else torch.device("cpu")
     model = model.to(device)
     assert hp.optimizer.lower() != "radam", "the reference's radam branch is unreachable (SURVEY section 2.1 #20)"
-    optimizer = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=1.0)
+    # reference :304-315: the amp branch clips with hp.clip (no clipping when it is None), the fp32 branch with 1.0
+    optimizer = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=clip_norm(hp))
     if args.n_gpus > 1:
         from .parallel import DataParallel
         optimizer.dp = DataParallel(model, optimizer.arena)
