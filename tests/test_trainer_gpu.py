@@ -1,0 +1,176 @@
+"""BASELINE.json configs[0] on the PRODUCT: the dataset -> DataLoader -> train_epoch -> checkpoint -> resume route of
+the shipped trainer on the HIP backend (tests/test_trainer_cpu.py runs the same route on the oracle-backed test seam,
+which checks host logic only), the graph-replay fast path of train_loop against eager launches, and the data-parallel
+path on a one-rank RCCL group."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import CONFIGS, batch_to, product_model
+from test_trainer_cpu import SMALL_HP
+
+pytestmark = pytest.mark.gpu
+
+
+def _hp(tmp_path, extra=""):
+    from transformer_tts_amd.datasets import datasets_fastspeech2 as D
+    from transformer_tts_amd.utils import HParams
+    from transformer_tts_amd.utils.utils import fill_variables
+    script = D.write_synthetic_corpus(str(tmp_path / "synthetic16"), n_utt=16)
+    hp_file = tmp_path / "hparams.py"
+    save = str(tmp_path / "ckpt")
+    hp_file.write_text(SMALL_HP.format(save=save, script=script) + extra)
+    hp = HParams()
+    hp.configure(hp_file)
+    fill_variables(hp, verbose=False)
+    os.makedirs(save, exist_ok=True)
+    return hp, save
+
+
+def _losses(out):
+    return [float(l.split("=")[1]) for l in out.splitlines() if l.startswith("loss_total")]
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_plumbing_epoch_checkpoint_resume_on_the_hip_backend(tmp_path, capsys, amp):
+    """16 synthetic utterances, batch 2, 2 epochs (8 + 8 steps), save, resume for a third epoch; the saved optimizer file
+    must load into torch.optim.Adam (the reference's optimizer) and carry step / moments."""
+    from transformer_tts_amd import ops, train_fastspeech2 as T
+    ops.lib()
+    hp, save = _hp(tmp_path, f"\namp = {amp}\nmax_epoch = 2\nlog_every = 1\n")
+    args = SimpleNamespace(n_gpus=1)
+    torch.manual_seed(0)
+    T.run_training(0, args, hp, None)
+    out = capsys.readouterr().out
+    assert "EPOCH 1 end" in out and "EPOCH 2 end" in out and "step 16 / 8" in out
+    ls = _losses(out)
+    assert len(ls) == 16 and all(np.isfinite(ls))
+    sd = torch.load(os.path.join(save, "network.epoch2"), weights_only=True, map_location="cpu")
+    assert sd["encoder.layers.0.ff.f_1.weight"].shape == (128, 32, 9) and list(sd) == list(T.build_model(hp).state_dict())
+    osd = torch.load(os.path.join(save, "network.optimizer.epoch2"), weights_only=True, map_location="cpu")
+    assert int(osd["state"][0]["step"]) == 16
+    # the file is torch.optim.Adam's format: the reference's optimizer loads it
+    ref_model = T.build_model(hp)
+    ref_model.load_state_dict(sd)
+    adam = torch.optim.Adam(ref_model.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    adam.load_state_dict(osd)
+    first = next(iter(ref_model.parameters()))
+    assert torch.equal(adam.state[first]["exp_avg"], osd["state"][0]["exp_avg"]) and float(adam.state[first]["exp_avg"].abs().sum()) > 0
+    # resume (reference :428-446): epoch counter, step, lr schedule position and moments come back
+    hp.loaded_epoch, hp.loaded_dir, hp.max_epoch = 2, save, 3
+    T.run_training(0, args, hp, None)
+    out = capsys.readouterr().out
+    # (as in the reference, the loop counter restarts at Adam's update count, i.e. one below where it stopped: 16..23)
+    assert "epoch 2 loaded" in out and "EPOCH 3 end" in out and "step 23 / 8" in out
+    osd3 = torch.load(os.path.join(save, "network.optimizer.epoch3"), weights_only=True, map_location="cpu")
+    assert int(osd3["state"][0]["step"]) == 24
+    from transformer_tts_amd.utils.utils import get_learning_rate
+    assert osd3["param_groups"][0]["lr"] == pytest.approx(get_learning_rate(23, hp.d_model_decoder, hp.warmup_factor, hp.warmup_step))
+    assert any("libfs2_hip" in l for l in open("/proc/self/maps")), "the HIP library must be the thing that ran"
+
+
+def test_frame_budget_epoch_on_the_hip_backend(tmp_path, capsys):
+    """hp.max_seqlen batching (LengthsBatchSampler): a different batch shape at almost every step, through the graph
+    stepper (first occurrence of a shape eager, second captured) for two epochs."""
+    from transformer_tts_amd import train_fastspeech2 as T
+    hp, save = _hp(tmp_path, f"\nbatch_size = None\nmax_seqlen = 400\nmax_epoch = 3\nlog_every = 1\nlengths_file = {str(tmp_path / 'lengths.npy')!r}\n")
+    T.run_training(0, SimpleNamespace(n_gpus=1), hp, None)
+    out = capsys.readouterr().out
+    assert "EPOCH 3 end" in out
+    sizes = {int(l.split("=")[1]) for l in out.splitlines() if l.startswith("batch size")}
+    assert len(sizes) > 1
+    assert all(np.isfinite(_losses(out)))
+
+
+def test_train_loop_graph_replay_gives_the_eager_first_step(tmp_path, capsys):
+    """the shipped train_loop with hp.use_graph True vs False from identical state: the first logged losses agree (same
+    Philox streams; later steps drift by float-atomic order, see test_hipgraph_replay_equals_eager_training)"""
+    from transformer_tts_amd import train_fastspeech2 as T
+    from transformer_tts_amd.Models import functional
+    firsts = []
+    for use_graph in (False, True):
+        hp, save = _hp(tmp_path / f"g{int(use_graph)}", f"\nuse_graph = {use_graph}\nlog_every = 1\nmax_epoch = 2\n")
+        functional._site_counter[0] = 5000
+        torch.manual_seed(0)
+        np.random.seed(0)
+        T.run_training(0, SimpleNamespace(n_gpus=1), hp, None)
+        firsts.append(_losses(capsys.readouterr().out))
+    assert len(firsts[0]) == len(firsts[1]) == 16
+    np.testing.assert_allclose(firsts[1][0], firsts[0][0], rtol=2e-6)
+    np.testing.assert_allclose(firsts[1], firsts[0], rtol=5e-2)        # same training trajectory
+
+
+def test_eval_forward_after_graphed_steps_sees_the_updated_weights():
+    """GraphedTrainStep must invalidate the weight shadows after a replay: an eval() forward between graphed training
+    steps equals the same forward on an eager twin that took the same steps."""
+    from transformer_tts_amd.Models import functional
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep, train_step
+    batch = batch_to(CONFIGS["small"]["batch"](), "cuda")
+    outs = []
+    for graphed in (False, True):
+        functional._site_counter[0] = 7000
+        model, hp, _ = product_model("small", amp=True, dropout=0.0, device="cuda")
+        opt = FusedAdam(model)
+        stepper = GraphedTrainStep(model, opt, hp) if graphed else None
+        for i in range(4):      # graphed: eager, capture + replay, replay, replay
+            if graphed:
+                stepper(4000 + i, batch)
+            else:
+                train_step(model, opt, 4000 + i, batch, hp)
+        if graphed:
+            assert len(stepper.graphs) == 1
+        model.eval()
+        text, pos_text = batch[0], batch[2]
+        with torch.no_grad():
+            out = model(text[:1, :9], (pos_text[:1, :9] != 0).unsqueeze(-2))
+        outs.append(out[1].float().cpu())
+        model.train()
+    assert outs[0].shape == outs[1].shape
+    assert float((outs[0] - outs[1]).abs().mean()) < 2e-2, "stale weight shadows after graph replay"
+
+
+def _one_rank_group():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)       # "nccl" is RCCL on ROCm
+    return dist
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_data_parallel_path_on_a_one_rank_rccl_group_equals_the_plain_step(graphed):
+    """parallel.DataParallel (bucketed in-place RCCL all-reduce announced from the backward, SyncBatchNorm statistics,
+    1/world folded into Adam) on a 1-rank RCCL group, eager and captured in the hipGraph, against the step without it."""
+    from transformer_tts_amd.Models import functional
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.parallel import DataParallel
+    from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep, train_step
+    dist = _one_rank_group()
+    batch = batch_to(CONFIGS["small"]["batch"](), "cuda")
+    res = []
+    for dp in (False, True):
+        functional._site_counter[0] = 9000
+        model, hp, _ = product_model("small", amp=False, dropout=0.1, device="cuda")
+        opt = FusedAdam(model)
+        if dp:
+            opt.dp = DataParallel(model, opt.arena)
+            assert opt.dp.world == 1
+        stepper = GraphedTrainStep(model, opt, hp) if graphed else None
+        losses = []
+        for i in range(3):
+            out = stepper(4000 + i, batch) if graphed else train_step(model, opt, 4000 + i, batch, hp)
+            losses.append(out[0].item())
+        torch.cuda.synchronize()
+        if dp:
+            assert not opt.dp.works and opt.dp.pending is None
+        res.append((losses, opt.arena.p.clone(), opt.arena.g.clone()))
+    np.testing.assert_allclose(res[1][0][0], res[0][0][0], rtol=2e-6)
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-3)
+    gerr = float((res[0][2] - res[1][2]).norm() / res[0][2].norm())
+    assert gerr < 5e-2, gerr

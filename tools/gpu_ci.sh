@@ -15,6 +15,8 @@ for step in "$@"; do
   case $step in
     kernels) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider ;;
     model)   run model 900 python -m pytest tests/test_model_gpu.py -q -m gpu --timeout 400 -p no:cacheprovider ;;
+    trainer) run trainer 900 python -m pytest tests/test_trainer_gpu.py -q -m gpu --timeout 400 -p no:cacheprovider ;;
+    bf16cfg) run bf16cfg 600 python -m pytest tests/test_model_gpu.py -q -m gpu --timeout 400 -p no:cacheprovider -k "benchmark_config" ;;
     smoke)   run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)   run bench 600 python bench.py ;;
     benchq)  run benchq 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report.txt ;;
@@ -40,8 +42,6 @@ for step in "$@"; do
              FS2_FUSED_ATTN=1 run ab1 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
              FS2_FUSED_ATTN=0 run ab0b 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
              FS2_FUSED_ATTN=1 run ab1b 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline ;;
-    benchs)  FS2_GEMM_DIRECT=0 run benchs 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report_staged.txt ;;
-    kernelss) FS2_GEMM_DIRECT=0 run kernelss 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider ;;
     pmcbench) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
              run pmcb1 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcb1 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap
              run pmcb2 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcb2 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap ;;

@@ -145,10 +145,62 @@ class GraphedTrainStep:
         return loss, parts, static[1].shape[0]
 
 
+class DevicePrefetcher:
+    """Iterates a loader ONE batch ahead: while step i runs, the tensors of batch i+1 (pinned by the DataLoader) are
+    copied host -> device on a separate HIP stream, so the 15.8 MB of a config-2 batch never sit on the compute stream.
+    The consumer's stream waits on the copy's event when it takes the batch."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+        self.stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+
+    def _stage(self, d):
+        if self.stream is None:
+            return d, None
+        with torch.cuda.stream(self.stream):
+            out = tuple(x.to(self.device, non_blocking=True) if torch.is_tensor(x) else x for x in d)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return out, ev
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        staged = None
+        for d in self.loader:
+            nxt = self._stage(d)
+            if staged is not None:
+                yield self._take(staged)
+            staged = nxt
+        if staged is not None:
+            yield self._take(staged)
+
+    def _take(self, staged):
+        d, ev = staged
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for x in d:
+                if torch.is_tensor(x):
+                    x.record_stream(cur)
+        return d
+
+
 def train_loop(model, optimizer, step, epoch, args, hp, rank, dataloader):
     log_every = max(1, int(getattr(hp, "log_every", 1)))
-    for d in dataloader:
-        loss, parts, batch_size = train_step(model, optimizer, step, d, hp)
+    # the fast path of the shipped trainer = the benchmarked path: hipGraph replay per batch shape (FusedAdam on the GPU;
+    # hp.use_graph = False keeps eager launches) fed by a one-batch-ahead copy stream
+    on_gpu = isinstance(optimizer, FusedAdam) and optimizer.arena.p.is_cuda
+    run = train_step
+    if on_gpu and bool(getattr(hp, "use_graph", True)):
+        stepper = getattr(optimizer, "_fs2_graphed", None)
+        if stepper is None or stepper.model is not model:
+            stepper = optimizer._fs2_graphed = GraphedTrainStep(model, optimizer, hp)
+        run = lambda m, o, st, d, h: stepper(st, d)
+    batches = DevicePrefetcher(dataloader, optimizer.arena.p.device) if on_gpu else dataloader
+    for d in batches:
+        loss, parts, batch_size = run(model, optimizer, step, d, hp)
         if step % log_every == 0:
             print(f"loss_frame_before = {parts['frame_before'].item()}")
             print(f"loss_duration = {parts['duration'].item()}")

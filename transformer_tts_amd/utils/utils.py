@@ -24,6 +24,7 @@ DEFAULTS = {
     # keys that exist only in this build
     "return_attn": True,       # keep the (B,N,H,t,t) attention maps in the 14-tuple (reference always does)
     "log_every": 1,            # print losses every N steps (the reference prints every step)
+    "use_graph": True,         # train_loop replays one hipGraph per batch shape (False: every kernel launched from Python)
 }
 
 
