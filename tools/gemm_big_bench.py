@@ -1,0 +1,89 @@
+"""Large-tile GEMM kernel (gemm_big.hip) against the 128-tile kernel (gemm.hip) on config-2 product shapes:
+results compared element-wise, both timed warm (back-to-back launches) and cold (1 GiB fill between launches)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from transformer_tts_amd import ops  # noqa: E402
+
+dev, T = "cuda", torch.bfloat16
+_flush = None
+
+
+def timeit(fn, cold, iters=10):
+    global _flush
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    if not cold:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) * 1e3 / iters
+    if _flush is None:
+        _flush = torch.empty(1 << 28, device=dev, dtype=torch.float32)
+    tot = 0.0
+    for i in range(iters):
+        _flush.fill_(float(i))
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        tot += s.elapsed_time(e)
+    return tot * 1e3 / iters
+
+
+def main():
+    cfgs = [a for a in sys.argv[1:] if a.isdigit()] or ["44"]
+    g = torch.Generator(device=dev).manual_seed(0)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g).to(T)
+    M = 44400
+    x256, x1024, x768 = r(M, 256), r(M, 1024), r(M, 768)
+    w_1024_256, w_256_1024, w_768_256, w_256_256 = r(1024, 256), r(256, 1024), r(768, 256), r(256, 256)
+    bias1024, bias256 = torch.randn(1024, device=dev), torch.randn(256, device=dev)
+    mask1024 = r(M, 1024)
+    res256 = torch.randn(M, 256, device=dev)
+    cs1024 = torch.zeros(2048, device=dev)
+    xp, wp = r(48, 925, 256), r(256, 5 * 256)
+    xv, wv = r(48, 925, 256), r(256, 3 * 256)
+    xe, we = r(48, 128, 256), r(1024, 9 * 256)
+    big_a, big_b = r(8192, 4096), r(4096, 4096)
+    cases = {
+        "ffn1 bias+relu 44400x1024x256": (lambda: ops.linear(x256, w_1024_256, bias1024, relu=True), 2.0 * M * 1024 * 256),
+        "ffn1-dgrad mask+colsum 44400x1024x256": (lambda: ops.linear(x256, w_1024_256, relu_mask=mask1024, colsum=cs1024[:1024].zero_()), 2.0 * M * 1024 * 256),
+        "ffn2 bias+res f32out 44400x256x1024": (lambda: ops.linear(x1024, w_256_1024, bias256, residual=res256, out_dtype=torch.float32), 2.0 * M * 256 * 1024),
+        "ffn2 plain 44400x256x1024": (lambda: ops.linear(x1024, w_256_1024), 2.0 * M * 256 * 1024),
+        "qkv 44400x768x256": (lambda: ops.linear(x256, w_768_256), 2.0 * M * 768 * 256),
+        "proj 44400x256x256": (lambda: ops.linear(x256, w_256_256, bias256), 2.0 * M * 256 * 256),
+        "post_conv k5 44400x256x1280": (lambda: ops.conv(xp, wp, 5, 4, bias=bias256), 2.0 * M * 256 * 1280),
+        "va_conv k3 44400x256x768": (lambda: ops.conv(xv, wv, 3, 1, bias=bias256, relu=True), 2.0 * M * 256 * 768),
+        "enc_conv1 k9 6144x1024x2304": (lambda: ops.conv(xe, we, 9, 4, bias=bias1024, relu=True), 2.0 * 6144 * 1024 * 2304),
+        "square 8192x4096x4096": (lambda: ops.linear(big_a, big_b), 2.0 * 8192 * 4096 * 4096),
+    }
+    only = [a for a in sys.argv[1:] if not a.isdigit()]
+    for name, (fn, fl) in cases.items():
+        if only and not any(o in name for o in only):
+            continue
+        os.environ["FS2_GEMM_BIG"] = "0"
+        ref = fn().float()
+        t0w, t0c = timeit(fn, False), timeit(fn, True)
+        line = f"{name:40s} old {t0w:7.1f}/{t0c:7.1f} us ({fl / t0c / 1e6:6.0f} TF cold)"
+        for cfg in cfgs:
+            os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_CFG"] = "2", cfg
+            out = fn().float()
+            err = float((out - ref).abs().max())
+            rel = err / float(ref.abs().max())
+            tw, tc = timeit(fn, False), timeit(fn, True)
+            line += f" | big{cfg} {tw:7.1f}/{tc:7.1f} us ({fl / tc / 1e6:6.0f} TF) maxrel {rel:.1e}"
+        print(line, flush=True)
+    os.environ["FS2_GEMM_BIG"] = "1"
+
+
+if __name__ == "__main__":
+    main()

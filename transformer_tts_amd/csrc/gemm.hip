@@ -27,6 +27,8 @@
 #include "common.cuh"
 #include <stdlib.h>
 
+bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc);     // gemm_big.hip
+
 namespace {
 
 template <typename T, bool KM> struct Tile {
@@ -656,6 +658,10 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
     const long total = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch1 * g.batch2 * g.split_k;
     FS2_REQUIRE(total < (1L << 30), "fs2_gemm: too many work items");
     hipStream_t st = (hipStream_t)stream;
+    {   // tall row-major bf16 products: the 256x256 / 16-wave LDS-DMA kernel (gemm_big.hip)
+        int rc = FS2_OK;
+        if (fs2_gemm_big_try(g, st, &rc)) return rc;
+    }
     // tile walk: tall row-major products with 2..8 column tiles of 128 go m-fastest on an XCD-aligned grid (see the
     // kernel's work numbering); everything else n-fastest.  FS2_GEMM_MFAST=0 disables the choice (measurements).
     if (g.tile_order != 1 && g.tile_order != 2) {

@@ -101,6 +101,10 @@ def train_step(model, optimizer, step, d, hp):
     return loss, parts, mel.shape[0]
 
 
+def _dist_alive():
+    return dist.is_available() and dist.is_initialized()
+
+
 class GraphedTrainStep:
     """train_step with the device work of each batch SHAPE captured once in a hipGraph and replayed:
     the ~600 kernel launches of a step stop costing host time (the step is launch-bound in Python otherwise).
@@ -131,7 +135,12 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             # the captured launches are NOT executed: capture with the optimizer's host state untouched, then run the
             # step through the replay below like every later occurrence of this shape
-            with torch.cuda.graph(g, pool=self.pool):
+            # Capture mode: with a process group alive, torch.distributed's watchdog thread polls the completion events of
+            # earlier eager collectives (hipEventQuery) whenever it wakes up; under the default "global" mode such a call
+            # from ANOTHER thread invalidates the capture in progress.  "thread_local" restricts the unsafe-call check to
+            # the capturing thread; work submitted to the capturing stream by the autograd thread is captured either way.
+            mode = os.environ.get("FS2_CAPTURE_ERROR_MODE") or ("thread_local" if _dist_alive() else "global")
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
                 loss, parts = step_body(self.model, self.optimizer, self.hp, *static[:4], *static[4:])
             entry = self.graphs[key] = (g, static, loss, parts)
         self.optimizer.host_update()
