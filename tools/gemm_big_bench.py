@@ -40,7 +40,8 @@ def timeit(fn, cold, iters=10):
 
 
 def main():
-    cfgs = [a for a in sys.argv[1:] if a.isdigit()] or ["44"]
+    cfgs = [a for a in sys.argv[1:] if a.isdigit()] or ["256"]
+    stamps = "stamps" in sys.argv[1:]
     g = torch.Generator(device=dev).manual_seed(0)
     r = lambda *s: torch.randn(*s, device=dev, generator=g).to(T)
     M = 44400
@@ -66,7 +67,7 @@ def main():
         "enc_conv1 k9 6144x1024x2304": (lambda: ops.conv(xe, we, 9, 4, bias=bias1024, relu=True), 2.0 * 6144 * 1024 * 2304),
         "square 8192x4096x4096": (lambda: ops.linear(big_a, big_b), 2.0 * 8192 * 4096 * 4096),
     }
-    only = [a for a in sys.argv[1:] if not a.isdigit()]
+    only = [a for a in sys.argv[1:] if not a.isdigit() and a != "stamps"]
     for name, (fn, fl) in cases.items():
         if only and not any(o in name for o in only):
             continue
@@ -75,13 +76,37 @@ def main():
         t0w, t0c = timeit(fn, False), timeit(fn, True)
         line = f"{name:40s} old {t0w:7.1f}/{t0c:7.1f} us ({fl / t0c / 1e6:6.0f} TF cold)"
         for cfg in cfgs:
-            os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_CFG"] = "2", cfg
+            os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_BM"] = "2", cfg
             out = fn().float()
             err = float((out - ref).abs().max())
             rel = err / float(ref.abs().max())
             tw, tc = timeit(fn, False), timeit(fn, True)
             line += f" | big{cfg} {tw:7.1f}/{tc:7.1f} us ({fl / tc / 1e6:6.0f} TF) maxrel {rel:.1e}"
         print(line, flush=True)
+        if stamps:
+            import ctypes
+            lib = ops.lib()
+            lib.fs2_debug_gemm_big_timer.argtypes = [ctypes.c_void_p]
+            lib.fs2_debug_gemm_big_timer.restype = None
+            for cfg in cfgs:
+                os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_BM"] = "2", cfg
+                buf = torch.zeros(256 * 2 * 8, dtype=torch.int64, device=dev)
+                lib.fs2_debug_gemm_big_timer(buf.data_ptr())
+                fn()
+                torch.cuda.synchronize()
+                lib.fs2_debug_gemm_big_timer(None)
+                b = buf.view(256, 2, 8).double()
+                act = b[:, 0, 5] > 0
+                if int(act.sum()) == 0:
+                    print("   (no stamps: this launch has a fused epilogue operand; only plain launches are stamped)")
+                    continue
+                for w, nm in ((0, "wave 0"), (1, "wave 15")):
+                    t = b[act][:, w, :5]
+                    tot = t.sum(1)
+                    sh = (t / tot[:, None]).mean(0)
+                    print(f"   bm{cfg} {nm}: blocks {int(act.sum())} stages/block {b[act][:, w, 5].mean():.1f} items {b[act][:, w, 6].mean():.2f} "
+                          f"cycles/block {tot.mean():.0f} (max {tot.max():.0f})  issue {sh[0]:.1%} epilogue {sh[1]:.1%} mfma {sh[2]:.1%} "
+                          f"dma-wait {sh[3]:.1%} barrier {sh[4]:.1%}", flush=True)
     os.environ["FS2_GEMM_BIG"] = "1"
 
 

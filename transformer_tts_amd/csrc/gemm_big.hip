@@ -6,21 +6,23 @@
 // workgroup per CU) halves the staging traffic per MFMA and reaches ~1400 in the same micro-benchmark.
 //
 // Structure
-//   * block tile BM x BN = (WR*64) x (WC*64), WR x WC waves, each wave a 64x64 output tile = 4x4 MFMA 16x16x32 tiles;
-//   * K in stages of 64 bf16 (128 B per row); two LDS stage buffers [A: BM rows][B: BN rows] x 128 B, 16-B chunk c of
-//     row r stored at c ^ ((r>>1)&7) (conflict-free ds_read_b128);
+//   * block tile BM x 256 with BM = 4 * WTM, WTM = 64 or 48 (BM = 256 or 192: chosen per launch so that the number of
+//     tiles fills the 256 CUs best); 4 x 4 waves, each wave a WTM x 64 output tile = (WTM/16) x 4 MFMA 16x16x32 tiles;
+//   * K in stages of 64 bf16 (128 B per row); two LDS stage buffers [A: BM rows][B: 256 rows] x 128 B, 16-B chunk c of
+//     row r stored at c ^ f(r) (conflict-free ds_read_b128);
 //   * staging by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass.  One wave-instruction
 //     writes 1 KiB = 8 rows linearly, so the swizzle is applied on the per-lane SOURCE address (lane -> logical chunk
-//     (lane&7) ^ ((row>>1)&7) of row lane>>3).  Rows outside the matrix, conv halo rows and the K tail use an
-//     out-of-range buffer offset: the DMA writes zeros;
-//   * operands are passed to the MFMA swapped (A-operand = weight rows, B-operand = activation rows): a lane then
-//     holds FOUR CONSECUTIVE OUTPUT COLUMNS of one output row, so the epilogue goes straight from the accumulators to
-//     8-byte (bf16) / 16-byte (fp32) global stores -- no LDS round trip, no barriers, and the LDS stays free for the
-//     next tile's first stage, which is already in flight while the epilogue runs (persistent workgroups walk a
-//     flattened stream of stages over all their tiles);
+//     (lane&7) ^ f(row) of row lane>>3).  Rows outside the matrix, conv halo rows and the K tail use an out-of-range
+//     buffer offset: the DMA writes zeros;
+//   * operands are passed to the MFMA swapped (A-operand = weight rows, B-operand = activation rows) and MFMA tile jt of
+//     a wave takes the weight rows 16*(i>>2) + 4*jt + (i&3), i = 0..15, of the wave's 64: lane (row i16, group g) then
+//     holds the SIXTEEN CONSECUTIVE OUTPUT COLUMNS 16g .. 16g+15 of its output row in acc[it][0..3][0..3].  The epilogue
+//     goes straight from the accumulators to 16-byte global stores, four lanes covering a full 128-byte line (bf16) --
+//     no LDS round trip, no barriers, and the LDS stays free for the next tile's first stage, which is already in
+//     flight while the epilogue runs (persistent workgroups walk a flattened stream of stages over all their tiles);
 //   * tile walk: workgroups b and b+8 share an XCD (round-robin dispatch).  XCD x owns the row slabs mt = x (mod 8);
 //     the column tiles of a slab are taken by different CUs of that XCD at the same time, so an A slab is fetched
-//     from HBM once and hit in that XCD's L2 by the other column tiles (placement is a speed assumption only).
+//     from HBM once and hit in that XCD's L2 by the other column tiles (placement is a speed assumption only);
 //   * fused epilogue: alpha, bias, ReLU, ReLU mask, residual (fp32 / bf16), fp32 / bf16 output, per-column statistics
 //     (BatchNorm sums or bias-gradient column sums: DPP row reduction over the 16 lanes that share a column group,
 //     LDS accumulators, one global atomic per column per workgroup).
@@ -30,34 +32,44 @@
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr unsigned OOB = 0x80000000u;
 constexpr int BIG_COLSTAT_N = 1024;
+constexpr int NW = 16, NT = 1024, BN = 256;
 
-template <int WR, int WC> struct BG {
-    static constexpr int NW = WR * WC, NT = NW * 64, BM = WR * 64, BN = WC * 64;
+// epilogue variants compiled in (template bits): the operands a launch does not have cost nothing
+constexpr int EPI_MASK = 1, EPI_RES_F32 = 2, EPI_RES_BF16 = 4, EPI_STATS = 8;
+
+template <int WTM> struct BG {
+    static constexpr int MT = WTM / 16, BM = 4 * WTM;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    static constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;     // LDS-DMA wave-instructions per wave per stage
+    static constexpr int AQ = BM / 8, BQ = BN / 8;               // LDS-DMA wave-instructions per stage (1 KiB = 8 rows each)
+    static constexpr int AI = (AQ + NW - 1) / NW, BI = BQ / NW;   // ... per wave
     static constexpr int SMEM = 2 * STAGE;
 };
 
-__device__ __forceinline__ int sw_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
+// 16-B chunk swizzles: A rows are read 16 consecutive rows per fragment; weight rows 16*(i>>2) + 4*jt + (i&3)
+__device__ __forceinline__ int fA(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int fB(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 
-template <int N> struct IC { static constexpr int value = N; };
+unsigned long long* g_big_dbg = nullptr;
 
 }  // namespace
 
-template <typename TC, int WR, int WC>
-__global__ __launch_bounds__(WR * WC * 64, WR * WC / 4) void fs2_gemm_big_kernel(const FS2Gemm p, const int tilesM, const int tilesN) {
-    typedef BG<WR, WC> G;
-    constexpr int NW = G::NW, NT = G::NT, BM = G::BM, BN = G::BN, AI = G::AI, BI = G::BI;
+extern "C" void fs2_debug_gemm_big_timer(unsigned long long* buf) { g_big_dbg = buf; }
+
+template <typename TC, int WTM, int EPI, bool STAMP>
+__global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, const int tilesM, const int tilesN, unsigned long long* dbg) {
+    typedef BG<WTM> G;
+    constexpr int MT = G::MT, BM = G::BM, AI = G::AI, BI = G::BI;
     constexpr int ESC = (int)sizeof(TC);
+    constexpr bool HAS_MASK = (EPI & EPI_MASK) != 0, RES_F32 = (EPI & EPI_RES_F32) != 0, RES_BF16 = (EPI & EPI_RES_BF16) != 0;
+    constexpr bool STATS = (EPI & EPI_STATS) != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave / WC, wc = wave % WC;
+    const int wr = wave >> 2, wc = wave & 3;
     const int g = lane >> 4, i16 = lane & 15;
 
     // ---- work of this block: items j = slot, slot + nslots, ... of its XCD group's list (slab-major, column tile fastest)
@@ -74,8 +86,7 @@ __global__ __launch_bounds__(WR * WC * 64, WR * WC / 4) void fs2_gemm_big_kernel
     const int lda = (int)p.lda, ldb = (int)p.ldb;
 
     float* cacc = reinterpret_cast<float*>(smem + G::SMEM);
-    const bool stats = p.colstats != nullptr;
-    if (stats) {
+    if constexpr (STATS) {
         for (int n = tid; n < 2 * BIG_COLSTAT_N; n += NT) cacc[n] = 0.f;      // visible after the prologue's barrier
     }
 
@@ -83,17 +94,12 @@ __global__ __launch_bounds__(WR * WC * 64, WR * WC / 4) void fs2_gemm_big_kernel
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const bf16_t*>(p.A) - (int64_t)pad * lda), 0, 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFF0, 0x00020000);
-    // epilogue operands through buffer descriptors (32-bit offsets, out-of-range offset = no access); an absent operand
-    // gets a descriptor with zero records: its loads return zeros without a branch
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFF0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)p.relu_mask, 0, p.relu_mask ? 0x7FFFFFF0 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? 0x7FFFFFF0 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
 
     // ---- LDS-DMA source coordinates of this lane: instruction i of this wave covers tile rows 8*(i*NW + wave) .. +7;
-    //      the lane fetches logical chunk (lane&7) ^ ((row>>1)&7) of row lane>>3 of those (swizzle on the source side)
+    //      the lane fetches logical chunk (lane&7) ^ f(row) of row lane>>3 of those (swizzle on the source side)
     auto dma_row = [&](int i) { return 8 * (i * NW + wave) + (lane >> 3); };
-    auto dma_k8 = [&](int i) { return ((lane & 7) ^ ((dma_row(i) >> 1) & 7)) * 8; };
+    auto a_k8 = [&](int i) { return ((lane & 7) ^ fA(dma_row(i))) * 8; };
+    auto b_k8 = [&](int i) { return ((lane & 7) ^ fB(dma_row(i))) * 8; };
 
     // ---- load cursor
     int lj = slot, lst = 0, ltap = 0, lkb = 0, lleft = nmine;
@@ -105,13 +111,13 @@ __global__ __launch_bounds__(WR * WC * 64, WR * WC / 4) void fs2_gemm_big_kernel
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int m = m0 + dma_row(i);
-            voffA[i] = (m < p.M) ? (unsigned)((m * lda + dma_k8(i)) * 2) : OOB;
+            voffA[i] = (m < p.M) ? (unsigned)((m * lda + a_k8(i)) * 2) : OOB;
             tA[i] = conv ? (m % p.seq_len) - pad : 0;
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const int n = n0 + dma_row(i);
-            voffB[i] = (n < p.N) ? (unsigned)((n * ldb + dma_k8(i)) * 2) : OOB;
+            voffB[i] = (n < p.N) ? (unsigned)((n * ldb + b_k8(i)) * 2) : OOB;
         }
     };
     auto issue = [&](int buf) __attribute__((always_inline)) {
@@ -121,13 +127,17 @@ __global__ __launch_bounds__(WR * WC * 64, WR * WC / 4) void fs2_gemm_big_kernel
         unsigned char* base = smem + buf * G::STAGE + 1024 * wave;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            bool ok = (voffA[i] != OOB) && (kb + dma_k8(i) < p.K);
-            if (conv) ok = ok && ((unsigned)(tA[i] + tap) < (unsigned)p.seq_len);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)(ok ? voffA[i] : OOB), sA, 0, 0);
+            if (i * NW + wave < G::AQ) {          // wave-uniform (BM = 192: 24 instructions for 16 waves)
+                bool ok = (voffA[i] != OOB) && (kb + a_k8(i) < p.K);
+                if (conv) ok = ok && ((unsigned)(tA[i] + tap) < (unsigned)p.seq_len);
+                // (voffset must be an int expression: an unsigned one makes the host-side instantiation of the kernel
+                //  template fail silently -- no stub, undefined symbol when the library is loaded)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)(ok ? voffA[i] : OOB), sA, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
-            const bool ok = (voffB[i] != OOB) && (kb + dma_k8(i) < p.K);
+            const bool ok = (voffB[i] != OOB) && (kb + b_k8(i) < p.K);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + G::A_BYTES + 1024 * NW * i), 16, (int)(ok ? voffB[i] : OOB), sB, 0, 0);
         }
         lkb += 64;
@@ -139,17 +149,19 @@ __global__ __launch_bounds__(WR * WC * 64, WR * WC / 4) void fs2_gemm_big_kernel
         }
     };
 
-    // ---- fragment read addresses (lane part; tile i adds i*2048, stage buffer b adds b*STAGE)
+    // ---- fragment read addresses (lane part; A tile it adds it*2048, weight tile jt adds jt*512, stage buffer b adds b*STAGE)
     int rdA[2], rdB[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        rdA[ks] = sw_off(wr * 64 + i16, ks * 4 + g);
-        rdB[ks] = G::A_BYTES + sw_off(wc * 64 + i16, ks * 4 + g);
+        const int ra = wr * WTM + i16;
+        const int rb = wc * 64 + 16 * (i16 >> 2) + (i16 & 3);
+        rdA[ks] = ra * 128 + (((ks * 4 + g) ^ fA(ra)) << 4);
+        rdB[ks] = G::A_BYTES + rb * 128 + (((ks * 4 + g) ^ fB(rb)) << 4);      // fB does not depend on jt (bits 2,3 of the row)
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -158,126 +170,176 @@ __global__ __launch_bounds__(WR * WC * 64, WR * WC / 4) void fs2_gemm_big_kernel
     bool pending = false;
     int pj = 0;
 
+    unsigned long long t_issue = 0, t_epi = 0, t_mma = 0, t_wait = 0, t_bar = 0, t_prev = 0;
+    auto stamp = [&](unsigned long long& sum) __attribute__((always_inline)) {
+        if constexpr (STAMP) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            sum += t - t_prev;
+            t_prev = t;
+        }
+    };
+
     prep_item(lj);
     issue(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (STAMP) { unsigned long long junk = 0; stamp(junk); }
 
     for (int s = 0; ; ++s) {
         const int buf = s & 1;
         if (s + 1 < nst) issue(buf ^ 1);      // stage s+1 -> the buffer every wave finished reading at the last barrier
+        stamp(t_issue);
         if (pending) {
-            // ---- epilogue of item pj: lane holds C[m0 + wr*64 + it*16 + i16][n0 + wc*64 + jt*16 + 4g + 0..3] in acc[it][jt]
+            // ---- epilogue of item pj: lane holds C[m0 + wr*WTM + it*16 + i16][n0 + wc*64 + 16g + 4jt + r] in acc[it][jt][r]
             pending = false;
             const int q = pj / tilesN, nt = pj - q * tilesN;
-            const int mb = (x + 8 * q) * BM + wr * 64 + i16;
-            const int nb = nt * BN + wc * 64 + 4 * g;
-            const bool res_f32 = p.res_dtype == FS2_F32;
+            const int mb = (x + 8 * q) * BM + wr * WTM + i16;
+            const int nb = nt * BN + wc * 64 + 16 * g;
+            const bool ok_lo = nb < p.N, ok_hi = nb + 8 < p.N;       // N is a multiple of 8
+            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFF0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
             const unsigned offC = (unsigned)((mb * (int)p.ldc + nb) * ESC);
-            const unsigned offM = (unsigned)((mb * (int)p.ldm + nb) * 2);
-            const unsigned offR = (unsigned)((mb * (int)p.ldr + nb) * (res_f32 ? 4 : 2));
-            const bool has_mask = p.relu_mask != nullptr;
+            float bias[16];
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const int n = nb + 16 * jt;
-                const bool col_ok = n < p.N;
-                const u32x4 braw = __builtin_amdgcn_raw_buffer_load_b128(rsBias, col_ok ? (unsigned)(n * 4) : OOB, 0, 0);
-                float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = make_float4(0.f, 0.f, 0.f, 0.f);
-                u32x2 mraw[4];
+            for (int j = 0; j < 4; ++j) {      // absent bias / columns >= N: zero records -> zeros
+                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsBias, (nb + 4 * j) * 4, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bias[4 * j + r] = __uint_as_float(b[r]);
+            }
+            float cs[STATS ? 16 : 1], cq[STATS ? 16 : 1];
+            if constexpr (STATS) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) { cs[c] = 0.f; cq[c] = 0.f; }
+            }
+#pragma unroll
+            for (int it = 0; it < MT; ++it) {
+                const bool row_ok = mb + 16 * it < p.M;
+                const bool oka = row_ok && ok_lo, okb = row_ok && ok_hi;
+                u32x4 mraw[2];
                 u32x4 rraw[4];
+                if constexpr (HAS_MASK) {
+                    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)p.relu_mask, 0, 0x7FFFFFF0, 0x00020000);
+                    const unsigned offM = (unsigned)((mb * (int)p.ldm + nb) * 2);
+                    const int so = 16 * it * (int)p.ldm * 2;
+                    mraw[0] = __builtin_amdgcn_raw_buffer_load_b128(rsM, oka ? offM : OOB, so, 0);
+                    mraw[1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, okb ? offM + 16 : OOB, so, 0);
+                }
+                if constexpr (RES_F32) {
+                    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, 0x7FFFFFF0, 0x00020000);
+                    const unsigned offR = (unsigned)((mb * (int)p.ldr + nb) * 4);
+                    const int so = 16 * it * (int)p.ldr * 4;
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const bool ok = col_ok && (mb + 16 * it < p.M);
-                    mraw[it] = __builtin_amdgcn_raw_buffer_load_b64(rsM, ok ? offM : OOB, (16 * it * (int)p.ldm + 16 * jt) * 2, 0);
-                    if (res_f32) rraw[it] = __builtin_amdgcn_raw_buffer_load_b128(rsR, ok ? offR : OOB, (16 * it * (int)p.ldr + 16 * jt) * 4, 0);
-                    else {
-                        const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rsR, ok ? offR : OOB, (16 * it * (int)p.ldr + 16 * jt) * 2, 0);
-                        rraw[it] = u32x4{h.x << 16, h.x & 0xFFFF0000u, h.y << 16, h.y & 0xFFFF0000u};
+                    for (int j = 0; j < 4; ++j)
+                        rraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (j < 2 ? oka : okb) ? offR + 16 * j : OOB, so, 0);
+                }
+                if constexpr (RES_BF16) {
+                    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, 0x7FFFFFF0, 0x00020000);
+                    const unsigned offR = (unsigned)((mb * (int)p.ldr + nb) * 2);
+                    const int so = 16 * it * (int)p.ldr * 2;
+                    rraw[0] = __builtin_amdgcn_raw_buffer_load_b128(rsR, oka ? offR : OOB, so, 0);
+                    rraw[1] = __builtin_amdgcn_raw_buffer_load_b128(rsR, okb ? offR + 16 : OOB, so, 0);
+                }
+                float v[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    float t = acc[it][c >> 2][c & 3] * p.alpha + bias[c];
+                    if (p.relu) t = fmaxf(t, 0.f);
+                    if constexpr (HAS_MASK) {
+                        const unsigned w = mraw[c >> 3][(c >> 1) & 3];
+                        const float mk = __uint_as_float((c & 1) ? (w & 0xFFFF0000u) : (w << 16));
+                        t = mk > 0.f ? t : 0.f;
+                    }
+                    if constexpr (RES_F32) t += __uint_as_float(rraw[c >> 2][c & 3]);
+                    if constexpr (RES_BF16) {
+                        const unsigned w = rraw[c >> 3][(c >> 1) & 3];
+                        t += __uint_as_float((c & 1) ? (w & 0xFFFF0000u) : (w << 16));
+                    }
+                    v[c] = t;
+                }
+                // The row advance goes into the per-lane offset, NOT into the scalar soffset operand: hipcc (ROCm 7.2) pads the
+                // "16-byte store followed by a VALU write of its data registers" hazard only when soffset is not a register,
+                // and with an SGPR soffset the very next instruction did overwrite v[data] -- on the MI355X a few stores per
+                // launch then wrote the clobbering value (the row index) instead of the result.
+                const unsigned so = (unsigned)(16 * it * (int)p.ldc * ESC);
+                if constexpr (ESC == 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4 * j]), __float_as_uint(v[4 * j + 1]), __float_as_uint(v[4 * j + 2]), __float_as_uint(v[4 * j + 3])},
+                                                               rsC, (j < 2 ? oka : okb) ? offC + so + 16 * j : OOB, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        union { bf16x8 h; u32x4 u; } o;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) o.h[c] = (bf16_t)v[8 * j + c];
+                        __builtin_amdgcn_raw_buffer_store_b128(o.u, rsC, (j == 0 ? oka : okb) ? offC + so + 16 * j : OOB, 0, 0);
+                        if constexpr (STATS) {      // statistics of the values as stored
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) v[8 * j + c] = (float)o.h[c];
+                        }
                     }
                 }
+                if constexpr (STATS) {
+                    if (row_ok) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const bool ok = col_ok && (mb + 16 * it < p.M);
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float t = acc[it][jt][r] * p.alpha + __uint_as_float(braw[r]);
-                        if (p.relu) t = fmaxf(t, 0.f);
-                        v[r] = t;
-                    }
-                    if (has_mask) {
-                        v[0] = __uint_as_float(mraw[it].x << 16) > 0.f ? v[0] : 0.f;
-                        v[1] = __uint_as_float(mraw[it].x & 0xFFFF0000u) > 0.f ? v[1] : 0.f;
-                        v[2] = __uint_as_float(mraw[it].y << 16) > 0.f ? v[2] : 0.f;
-                        v[3] = __uint_as_float(mraw[it].y & 0xFFFF0000u) > 0.f ? v[3] : 0.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(rraw[it][r]);
-                    const int soff = (16 * it * (int)p.ldc + 16 * jt) * ESC;
-                    if constexpr (ESC == 4) {
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                                                               rsC, ok ? offC : OOB, soff, 0);
-                    } else {
-                        union { bf16x4 h; u32x2 u; } o;
-                        o.h[0] = (bf16_t)v[0]; o.h[1] = (bf16_t)v[1]; o.h[2] = (bf16_t)v[2]; o.h[3] = (bf16_t)v[3];
-                        __builtin_amdgcn_raw_buffer_store_b64(o.u, rsC, ok ? offC : OOB, soff, 0);
-                        if (stats) {   // statistics of the values as stored
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = (float)o.h[r];
-                        }
-                    }
-                    if (stats && ok) {
-                        cs.x += v[0]; cs.y += v[1]; cs.z += v[2]; cs.w += v[3];
-                        cq.x += v[0] * v[0]; cq.y += v[1] * v[1]; cq.z += v[2] * v[2]; cq.w += v[3] * v[3];
-                    }
-                }
-                if (stats) {
-                    // the 16 lanes of a DPP row share g (the column group) and hold 16 different rows: four DPP steps
-                    // leave the row total in every lane of the row
-                    float* f[2] = {&cs.x, &cq.x};
-#pragma unroll
-                    for (int wq = 0; wq < 2; ++wq)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float sv = f[wq][e];
-                            sv += dpp_mov<0xB1>(sv); sv += dpp_mov<0x4E>(sv); sv += dpp_mov<0x124>(sv); sv += dpp_mov<0x128>(sv);
-                            f[wq][e] = sv;
-                        }
-                    if (i16 == 0 && col_ok) {
-                        atomicAdd(cacc + n + 0, cs.x); atomicAdd(cacc + n + 1, cs.y);
-                        atomicAdd(cacc + n + 2, cs.z); atomicAdd(cacc + n + 3, cs.w);
-                        if (p.colstats_mode == 0) {
-                            atomicAdd(cacc + BIG_COLSTAT_N + n + 0, cq.x); atomicAdd(cacc + BIG_COLSTAT_N + n + 1, cq.y);
-                            atomicAdd(cacc + BIG_COLSTAT_N + n + 2, cq.z); atomicAdd(cacc + BIG_COLSTAT_N + n + 3, cq.w);
-                        }
+                        for (int c = 0; c < 16; ++c) { cs[c] += v[c]; cq[c] += v[c] * v[c]; }
                     }
                 }
             }
+            if constexpr (STATS) {
+                // the 16 lanes of a DPP row share g (the column group) and hold 16 different rows: four DPP steps leave
+                // the row total in every lane of the row; lane c of the row then adds column c's total
+                float mine_s = 0.f, mine_q = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int c = 0; c < 16; ++c) {
+                    float sv = cs[c];
+                    sv += dpp_mov<0xB1>(sv); sv += dpp_mov<0x4E>(sv); sv += dpp_mov<0x124>(sv); sv += dpp_mov<0x128>(sv);
+                    mine_s = (i16 == c) ? sv : mine_s;
+                    if (p.colstats_mode == 0) {
+                        float qv = cq[c];
+                        qv += dpp_mov<0xB1>(qv); qv += dpp_mov<0x4E>(qv); qv += dpp_mov<0x124>(qv); qv += dpp_mov<0x128>(qv);
+                        mine_q = (i16 == c) ? qv : mine_q;
+                    }
+                }
+                const int n = nb + i16;
+                if (n < p.N) {
+                    atomicAdd(cacc + n, mine_s);
+                    if (p.colstats_mode == 0) atomicAdd(cacc + BIG_COLSTAT_N + n, mine_q);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            stamp(t_epi);
         }
         if (s == nst) break;
         const unsigned char* lb = smem + buf * G::STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[MT], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(lb + rdA[ks] + i * 2048);
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(lb + rdA[ks] + i * 2048);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rdB[ks] + j * 2048);
+            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rdB[ks] + j * 512);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
         }
         if (++cst == ntot) { pending = true; pj = cj; cst = 0; cj += nslots; }
+        stamp(t_mma);
         // own DMA landed, own fragment reads retired; then every wave's
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stamp(t_wait);
+        asm volatile("s_barrier" ::: "memory");
+        stamp(t_bar);
     }
 
-    if (stats) {
+    if constexpr (STATS) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave's LDS adds are done
         for (int n = tid; n < p.N; n += NT) {
             const float a = cacc[n];
@@ -288,20 +350,25 @@ __global__ __launch_bounds__(WR * WC * 64, WR * WC / 4) void fs2_gemm_big_kernel
             }
         }
     }
+    if constexpr (STAMP) {
+        if (dbg != nullptr && lane == 0 && (wave == 0 || wave == 15)) {
+            unsigned long long* o = dbg + (blockIdx.x * 2 + (wave == 0 ? 0 : 1)) * 8;
+            o[0] = t_issue; o[1] = t_epi; o[2] = t_mma; o[3] = t_wait; o[4] = t_bar; o[5] = (unsigned long long)nst; o[6] = (unsigned long long)nmine;
+        }
+    }
 }
 
 namespace {
 
-template <typename TC, int WR, int WC>
-int launch_big1(const FS2Gemm& g, hipStream_t st) {
-    typedef BG<WR, WC> G;
-    const int tilesM = (g.M + G::BM - 1) / G::BM, tilesN = (g.N + G::BN - 1) / G::BN;
-    const int lds = G::SMEM + (g.colstats != nullptr ? 2 * BIG_COLSTAT_N * 4 : 0);
+template <typename TC, int WTM, int EPI, bool STAMP>
+int launch_big2(const FS2Gemm& g, hipStream_t st) {
+    typedef BG<WTM> G;
+    const int tilesM = (g.M + G::BM - 1) / G::BM, tilesN = (g.N + BN - 1) / BN;
+    const int lds = G::SMEM + ((EPI & EPI_STATS) ? 2 * BIG_COLSTAT_N * 4 : 0);
     static bool attr_set = false;          // > 64 KiB of dynamic LDS must be allowed once per kernel
     if (!attr_set) {
-        // (voffset of the LDS-DMA builtin must be an int expression: an unsigned one makes the host-side instantiation of
-        //  the kernel template fail silently -- no stub, undefined symbol at load time)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_kernel<TC, WR, WC>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM + 2 * BIG_COLSTAT_N * 4) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_kernel<TC, WTM, EPI, STAMP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM + 2 * BIG_COLSTAT_N * 4) != hipSuccess) {
             fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the large-tile kernel");
             return FS2_ELAUNCH;
         }
@@ -309,25 +376,53 @@ int launch_big1(const FS2Gemm& g, hipStream_t st) {
     }
     const long per_xcd = (long)((tilesM + 7) / 8) * tilesN;
     const int grid = 8 * (int)(per_xcd < 32 ? per_xcd : 32);
-    hipLaunchKernelGGL((fs2_gemm_big_kernel<TC, WR, WC>), dim3(grid), dim3(G::NT), lds, st, g, tilesM, tilesN);
+    hipLaunchKernelGGL((fs2_gemm_big_kernel<TC, WTM, EPI, STAMP>), dim3(grid), dim3(NT), lds, st, g, tilesM, tilesN, g_big_dbg);
     FS2_CHECK_LAUNCH("fs2_gemm(big)");
     return FS2_OK;
 }
 
+template <typename TC, int WTM>
+int launch_big1(const FS2Gemm& g, hipStream_t st) {
+    const int res = g.residual == nullptr ? 0 : (g.res_dtype == FS2_F32 ? EPI_RES_F32 : EPI_RES_BF16);
+    const int epi = (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? EPI_STATS : 0);
+    if (g_big_dbg != nullptr && epi == 0) return launch_big2<TC, WTM, 0, true>(g, st);
+    switch (epi) {      // the combinations the model uses; anything else stays on the 128-tile kernel (checked by the caller)
+        case 0: return launch_big2<TC, WTM, 0, false>(g, st);
+        case EPI_MASK: return launch_big2<TC, WTM, EPI_MASK, false>(g, st);
+        case EPI_STATS: return launch_big2<TC, WTM, EPI_STATS, false>(g, st);
+        case EPI_MASK | EPI_STATS: return launch_big2<TC, WTM, EPI_MASK | EPI_STATS, false>(g, st);
+        case EPI_RES_F32: return launch_big2<TC, WTM, EPI_RES_F32, false>(g, st);
+        case EPI_RES_BF16: return launch_big2<TC, WTM, EPI_RES_BF16, false>(g, st);
+        case EPI_MASK | EPI_RES_F32: return launch_big2<TC, WTM, EPI_MASK | EPI_RES_F32, false>(g, st);
+        default: break;
+    }
+    fs2_set_error("fs2_gemm(big): epilogue combination %d not compiled", epi);
+    return FS2_EINVAL;
+}
+
+bool epi_compiled(const FS2Gemm& g) {
+    const int res = g.residual == nullptr ? 0 : (g.res_dtype == FS2_F32 ? EPI_RES_F32 : EPI_RES_BF16);
+    const int epi = (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? EPI_STATS : 0);
+    return epi == 0 || epi == EPI_MASK || epi == EPI_STATS || epi == (EPI_MASK | EPI_STATS) || epi == EPI_RES_F32 ||
+           epi == EPI_RES_BF16 || epi == (EPI_MASK | EPI_RES_F32);
+}
+
 }  // namespace
 
-// 0: not eligible / not chosen; otherwise the product was launched on the large-tile kernel and *rc holds the result
+// false: not eligible / not chosen; true: the product was launched on the large-tile kernel and *rc holds the result
 bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
-    // FS2_GEMM_BIG: 0 never, 1 (default) where the shape heuristic says so, 2 wherever eligible; read per call so that
-    // tests and A/B measurements can switch inside one process
+    // FS2_GEMM_BIG: 0 never, 1 (default) where the shape heuristic says so, 2 wherever eligible; FS2_GEMM_BIG_BM forces
+    // the row-slab height (192 / 256).  Read per call so that tests and A/B measurements can switch inside one process.
     const char* e1 = getenv("FS2_GEMM_BIG");
-    const char* e2 = getenv("FS2_GEMM_BIG_CFG");
-    const int mode = e1 ? atoi(e1) : 1, cfg = e2 ? atoi(e2) : 44;
+    const char* e2 = getenv("FS2_GEMM_BIG_BM");
+    const int mode = e1 ? atoi(e1) : 1;
+    int bm = e2 ? atoi(e2) : 0;
     if (mode == 0) return false;
     if (g.dtype != FS2_BF16 || g.a_kmajor || g.b_kmajor || g.accumulate || g.conv > 1) return false;
     if ((long)g.batch1 * g.batch2 * g.split_k != 1) return false;
     if (g.N % 8 != 0 || (g.colstats != nullptr && g.N > BIG_COLSTAT_N)) return false;
     if (g.conv == 1 && (g.pad < 0 || g.pad > g.taps)) return false;
+    if (!epi_compiled(g)) return false;
     {   // the epilogue addresses C / mask / residual with 32-bit byte offsets (rows up to M + 255 enter the arithmetic)
         const long rows = (long)g.M + 512;
         if (rows * g.ldc * 4 >= 0x7FFFFFF0L) return false;
@@ -335,14 +430,19 @@ bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         if (g.residual != nullptr && rows * g.ldr * 4 >= 0x7FFFFFF0L) return false;
         if (rows * g.lda * 2 >= 0x7FFFFFF0L || ((long)g.N + 512) * g.ldb * 2 >= 0x7FFFFFF0L) return false;
     }
-    const int bm = cfg == 24 ? 128 : 256, bn = cfg == 42 ? 128 : 256;
+    const long tn = (g.N + BN - 1) / BN;
+    auto fill = [&](int b) {       // fraction of the 256 CUs' rounds that carry a tile
+        const long tiles = (long)((g.M + b - 1) / b) * tn;
+        return (double)tiles / (double)(((tiles + 255) / 256) * 256);
+    };
+    if (bm != 192 && bm != 256) bm = fill(192) > fill(256) + 0.02 ? 192 : 256;
     if (mode == 1) {
-        const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
-        if (tiles < 128 || g.N < 192) return false;
+        const long tiles = (long)((g.M + bm - 1) / bm) * tn;
+        const long ktot = (long)(g.conv == 1 ? g.taps : 1) * g.K;
+        if (tiles < 128 || g.N < 192 || ktot < 512) return false;
     }
     const bool f32 = g.c_dtype == FS2_F32;
-    if (cfg == 42) *rc = f32 ? launch_big1<float, 4, 2>(g, st) : launch_big1<bf16_t, 4, 2>(g, st);
-    else if (cfg == 24) *rc = f32 ? launch_big1<float, 2, 4>(g, st) : launch_big1<bf16_t, 2, 4>(g, st);
-    else *rc = f32 ? launch_big1<float, 4, 4>(g, st) : launch_big1<bf16_t, 4, 4>(g, st);
+    if (bm == 192) *rc = f32 ? launch_big1<float, 48>(g, st) : launch_big1<bf16_t, 48>(g, st);
+    else *rc = f32 ? launch_big1<float, 64>(g, st) : launch_big1<bf16_t, 64>(g, st);
     return true;
 }
