@@ -669,3 +669,76 @@ def test_fused_bias_gradients_onehot_and_batched_shadows(ops, dtype):
         k = 30 if a_.dim() == 1 else 2
         close(a_, b_, f"fused output #{i}", **tol(dtype, k=k))
     assert torch.equal(out["cuda"][10].cpu(), out["cpu"][10]), "one-hot is exact"
+
+
+# ------------------------------------------------------------------------------------------------ large-tile GEMM (gemm_big.hip)
+@pytest.fixture
+def big_gemm(monkeypatch):
+    """route every eligible product to the 256-wide LDS-DMA kernel (FS2_GEMM_BIG=2), whatever its size"""
+    def set_bm(bm):
+        monkeypatch.setenv("FS2_GEMM_BIG", "2")
+        monkeypatch.setenv("FS2_GEMM_BIG_BM", str(bm))
+    yield set_bm
+    monkeypatch.delenv("FS2_GEMM_BIG", raising=False)
+    monkeypatch.delenv("FS2_GEMM_BIG_BM", raising=False)
+
+
+@pytest.mark.parametrize("bm", [192, 256])
+@pytest.mark.parametrize("M,N,K", [(300, 80, 72), (129, 256, 256), (1000, 1024, 8), (577, 264, 200), (2048, 512, 64)])
+def test_big_gemm_linear_epilogues(ops, big_gemm, bm, M, N, K):
+    """every fused epilogue of the large-tile kernel (bias, ReLU, ReLU mask, fp32 / bf16 residual, fp32 output, column
+    sums, BatchNorm statistics) on ragged shapes (M, N, K not multiples of the tile) against the oracle primitive"""
+    big_gemm(bm)
+    dtype = torch.bfloat16
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias, res, mask = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, dtype=dtype, seed=5)
+    for kw in (dict(), dict(bias=True, relu=True), dict(residual="f32", out_f32=True), dict(residual="bf16", bias=True),
+               dict(relu_mask=True), dict(relu_mask=True, colsum=True), dict(bias=True, colstats=True), dict(colsum=True),
+               dict(relu_mask=True, residual="f32", out_f32=True), dict(alpha=0.25)):
+        def call(o, dev):
+            mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+            cs = torch.zeros(2 * N, dtype=torch.float32, device=dev) if kw.get("colstats") else None
+            cl = torch.zeros(N, dtype=torch.float32, device=dev) if kw.get("colsum") else None
+            r = None
+            if kw.get("residual"):
+                r = mv(res if kw["residual"] == "f32" else res.to(dtype))
+            out = o.linear(mv(x), mv(w), bias=mv(bias) if kw.get("bias") else None, relu=kw.get("relu", False), residual=r,
+                           relu_mask=mv(mask) if kw.get("relu_mask") else None, colstats=cs, colsum=cl,
+                           out_dtype=torch.float32 if kw.get("out_f32") else None, alpha=kw.get("alpha", 1.0))
+            return out, cs, cl
+        (a, acs, acl), (b, bcs, bcl) = call(ops, "cuda"), call(P, "cpu")
+        close(a, b, f"big linear bm{bm} {kw}", **tol(a.dtype))
+        if acs is not None:
+            close(acs, bcs, "colstats", rtol=2e-3, atol=2e-2 * M ** 0.5)
+        if acl is not None:
+            close(acl, bcl, "colsum", rtol=2e-3, atol=2e-2 * M ** 0.5)
+
+
+@pytest.mark.parametrize("bm", [192, 256])
+@pytest.mark.parametrize("B,t,C,N,taps,pad", [(3, 37, 32, 128, 3, 1), (2, 50, 80, 256, 5, 4), (3, 37, 64, 64, 9, 4),
+                                               (2, 131, 256, 80, 5, 0), (4, 20, 32, 32, 1, 0), (5, 301, 72, 264, 9, 4)])
+def test_big_gemm_conv_geometry(ops, big_gemm, bm, B, t, C, N, taps, pad):
+    """implicit-GEMM Conv1d on the large-tile kernel: halo rows, sequence boundaries inside a row slab, K tails"""
+    big_gemm(bm)
+    dtype = torch.bfloat16
+    x, w = rnd(B, t, C, dtype=dtype, seed=1), rnd(N, taps * C, dtype=dtype, seed=2, scale=(taps * C) ** -0.5)
+    bias = rnd(N, seed=3)
+    a = ops.conv(x.cuda(), w.cuda(), taps, pad, bias=bias.cuda(), relu=True)
+    b = P.conv(x, w, taps, pad, bias=bias, relu=True)
+    close(a, b, "big conv", **tol(dtype))
+    res = rnd(B, t, N, seed=4)
+    a = ops.conv(x.cuda(), w.cuda(), taps, pad, residual=res.cuda(), out_dtype=torch.float32)
+    b = P.conv(x, w, taps, pad, residual=res, out_dtype=torch.float32)
+    close(a, b, "big conv+res f32 out", **tol(dtype))
+
+
+def test_big_gemm_is_bit_identical_to_the_128_tile_kernel(ops, monkeypatch):
+    """same k order inside every accumulator: the two kernels must agree bit for bit (44400-row decoder product)"""
+    x, w, bias = rnd(44400, 256, dtype=torch.bfloat16, seed=1).cuda(), rnd(512, 256, dtype=torch.bfloat16, seed=2).cuda(), rnd(512, seed=3).cuda()
+    monkeypatch.setenv("FS2_GEMM_BIG", "0")
+    ref = ops.linear(x, w, bias=bias, relu=True)
+    for bm in ("192", "256"):
+        monkeypatch.setenv("FS2_GEMM_BIG", "2")
+        monkeypatch.setenv("FS2_GEMM_BIG_BM", bm)
+        out = ops.linear(x, w, bias=bias, relu=True)
+        assert torch.equal(out, ref), f"bm {bm}: {(out.float() - ref.float()).abs().max().item()}"

@@ -40,7 +40,7 @@ def timeit(fn, cold, iters=10):
 
 
 def main():
-    cfgs = [a for a in sys.argv[1:] if a.isdigit()] or ["256"]
+    cfgs = [a for a in sys.argv[1:] if a.isdigit() or ":" in a] or ["256"]
     stamps = "stamps" in sys.argv[1:]
     g = torch.Generator(device=dev).manual_seed(0)
     r = lambda *s: torch.randn(*s, device=dev, generator=g).to(T)
@@ -67,7 +67,7 @@ def main():
         "enc_conv1 k9 6144x1024x2304": (lambda: ops.conv(xe, we, 9, 4, bias=bias1024, relu=True), 2.0 * 6144 * 1024 * 2304),
         "square 8192x4096x4096": (lambda: ops.linear(big_a, big_b), 2.0 * 8192 * 4096 * 4096),
     }
-    only = [a for a in sys.argv[1:] if not a.isdigit() and a != "stamps"]
+    only = [a for a in sys.argv[1:] if not a.isdigit() and ":" not in a and a != "stamps"]
     for name, (fn, fl) in cases.items():
         if only and not any(o in name for o in only):
             continue
@@ -76,7 +76,8 @@ def main():
         t0w, t0c = timeit(fn, False), timeit(fn, True)
         line = f"{name:40s} old {t0w:7.1f}/{t0c:7.1f} us ({fl / t0c / 1e6:6.0f} TF cold)"
         for cfg in cfgs:
-            os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_BM"] = "2", cfg
+            os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_BM"] = "2", cfg.split(":")[0]
+            os.environ["FS2_GEMM_BIG_ISSUE"] = cfg.split(":")[1] if ":" in cfg else "0"
             out = fn().float()
             err = float((out - ref).abs().max())
             rel = err / float(ref.abs().max())
@@ -89,7 +90,8 @@ def main():
             lib.fs2_debug_gemm_big_timer.argtypes = [ctypes.c_void_p]
             lib.fs2_debug_gemm_big_timer.restype = None
             for cfg in cfgs:
-                os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_BM"] = "2", cfg
+                os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_BM"] = "2", cfg.split(":")[0]
+                os.environ["FS2_GEMM_BIG_ISSUE"] = cfg.split(":")[1] if ":" in cfg else "0"
                 buf = torch.zeros(256 * 2 * 8, dtype=torch.int64, device=dev)
                 lib.fs2_debug_gemm_big_timer(buf.data_ptr())
                 fn()

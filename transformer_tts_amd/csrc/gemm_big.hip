@@ -39,7 +39,7 @@ constexpr int BIG_COLSTAT_N = 1024;
 constexpr int NW = 16, NT = 1024, BN = 256;
 
 // epilogue variants compiled in (template bits): the operands a launch does not have cost nothing
-constexpr int EPI_MASK = 1, EPI_RES_F32 = 2, EPI_RES_BF16 = 4, EPI_STATS = 8;
+constexpr int EPI_MASK = 1, EPI_RES_F32 = 2, EPI_RES_BF16 = 4, EPI_STATS = 8, EPI_SUMSQ = 16;   // STATS: column sums (+ SUMSQ: and sums of squares)
 
 template <int WTM> struct BG {
     static constexpr int MT = WTM / 16, BM = 4 * WTM;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
     constexpr int MT = G::MT, BM = G::BM, AI = G::AI, BI = G::BI;
     constexpr int ESC = (int)sizeof(TC);
     constexpr bool HAS_MASK = (EPI & EPI_MASK) != 0, RES_F32 = (EPI & EPI_RES_F32) != 0, RES_BF16 = (EPI & EPI_RES_BF16) != 0;
-    constexpr bool STATS = (EPI & EPI_STATS) != 0;
+    constexpr bool STATS = (EPI & EPI_STATS) != 0, SUMSQ = (EPI & EPI_SUMSQ) != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,43 +189,70 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
 
     for (int s = 0; ; ++s) {
         const int buf = s & 1;
+        // Epilogue operands that do not depend on the row loop are fetched BEFORE the next stage's DMA is issued: vmcnt
+        // retires in order, so a load issued after the DMA could only be consumed once the DMA (HBM latency) has landed.
+        const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)p.relu_mask, 0, p.relu_mask ? 0x7FFFFFF0 : 0, 0x00020000);
+        u32x4 braw[4];
+        u32x4 mraw[HAS_MASK ? MT : 1][2];
+        int pq = 0, pnt = 0;
+        if (pending) {
+            pq = pj / tilesN; pnt = pj - pq * tilesN;
+            const int mb = (x + 8 * pq) * BM + wr * WTM + i16;
+            const int nb = pnt * BN + wc * 64 + 16 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)       // absent bias / columns >= N: zero records -> zeros
+                braw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsBias, (nb + 4 * j) * 4, 0, 0);
+            if constexpr (HAS_MASK) {
+                const unsigned offM = (unsigned)((mb * (int)p.ldm + nb) * 2);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {      // the first two row tiles' masks ahead of the DMA, the rest behind it (registers)
+                    const bool row_ok = mb + 16 * it < p.M;
+                    const int so = 16 * it * (int)p.ldm * 2;
+                    mraw[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rsM, (row_ok && nb < p.N) ? offM : OOB, so, 0);
+                    mraw[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, (row_ok && nb + 8 < p.N) ? offM + 16 : OOB, so, 0);
+                }
+            }
+        }
         if (s + 1 < nst) issue(buf ^ 1);      // stage s+1 -> the buffer every wave finished reading at the last barrier
+        if constexpr (HAS_MASK) {
+            if (pending) {
+                const int mb = (x + 8 * pq) * BM + wr * WTM + i16;
+                const int nb = pnt * BN + wc * 64 + 16 * g;
+                const unsigned offM = (unsigned)((mb * (int)p.ldm + nb) * 2);
+#pragma unroll
+                for (int it = 2; it < MT; ++it) {
+                    const bool row_ok = mb + 16 * it < p.M;
+                    const int so = 16 * it * (int)p.ldm * 2;
+                    mraw[it][0] = __builtin_amdgcn_raw_buffer_load_b128(rsM, (row_ok && nb < p.N) ? offM : OOB, so, 0);
+                    mraw[it][1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, (row_ok && nb + 8 < p.N) ? offM + 16 : OOB, so, 0);
+                }
+            }
+        }
         stamp(t_issue);
         if (pending) {
             // ---- epilogue of item pj: lane holds C[m0 + wr*WTM + it*16 + i16][n0 + wc*64 + 16g + 4jt + r] in acc[it][jt][r]
             pending = false;
-            const int q = pj / tilesN, nt = pj - q * tilesN;
-            const int mb = (x + 8 * q) * BM + wr * WTM + i16;
-            const int nb = nt * BN + wc * 64 + 16 * g;
+            const int mb = (x + 8 * pq) * BM + wr * WTM + i16;
+            const int nb = pnt * BN + wc * 64 + 16 * g;
             const bool ok_lo = nb < p.N, ok_hi = nb + 8 < p.N;       // N is a multiple of 8
             const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFF0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
             const unsigned offC = (unsigned)((mb * (int)p.ldc + nb) * ESC);
             float bias[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {      // absent bias / columns >= N: zero records -> zeros
-                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsBias, (nb + 4 * j) * 4, 0, 0);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bias[4 * j + r] = __uint_as_float(b[r]);
-            }
-            float cs[STATS ? 16 : 1], cq[STATS ? 16 : 1];
+                for (int r = 0; r < 4; ++r) bias[4 * j + r] = __uint_as_float(braw[j][r]);
+            float cs[STATS ? 16 : 1], cq[SUMSQ ? 16 : 1];
             if constexpr (STATS) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) { cs[c] = 0.f; cq[c] = 0.f; }
+                for (int c = 0; c < 16; ++c) { cs[c] = 0.f; if constexpr (SUMSQ) cq[c] = 0.f; }
             }
 #pragma unroll
             for (int it = 0; it < MT; ++it) {
                 const bool row_ok = mb + 16 * it < p.M;
                 const bool oka = row_ok && ok_lo, okb = row_ok && ok_hi;
-                u32x4 mraw[2];
                 u32x4 rraw[4];
-                if constexpr (HAS_MASK) {
-                    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)p.relu_mask, 0, 0x7FFFFFF0, 0x00020000);
-                    const unsigned offM = (unsigned)((mb * (int)p.ldm + nb) * 2);
-                    const int so = 16 * it * (int)p.ldm * 2;
-                    mraw[0] = __builtin_amdgcn_raw_buffer_load_b128(rsM, oka ? offM : OOB, so, 0);
-                    mraw[1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, okb ? offM + 16 : OOB, so, 0);
-                }
                 if constexpr (RES_F32) {
                     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, 0x7FFFFFF0, 0x00020000);
                     const unsigned offR = (unsigned)((mb * (int)p.ldr + nb) * 4);
@@ -247,7 +274,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
                     float t = acc[it][c >> 2][c & 3] * p.alpha + bias[c];
                     if (p.relu) t = fmaxf(t, 0.f);
                     if constexpr (HAS_MASK) {
-                        const unsigned w = mraw[c >> 3][(c >> 1) & 3];
+                        const unsigned w = mraw[it][c >> 3][(c >> 1) & 3];
                         const float mk = __uint_as_float((c & 1) ? (w & 0xFFFF0000u) : (w << 16));
                         t = mk > 0.f ? t : 0.f;
                     }
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
                 if constexpr (STATS) {
                     if (row_ok) {
 #pragma unroll
-                        for (int c = 0; c < 16; ++c) { cs[c] += v[c]; cq[c] += v[c] * v[c]; }
+                        for (int c = 0; c < 16; ++c) { cs[c] += v[c]; if constexpr (SUMSQ) cq[c] += v[c] * v[c]; }
                     }
                 }
             }
@@ -297,7 +324,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
                     float sv = cs[c];
                     sv += dpp_mov<0xB1>(sv); sv += dpp_mov<0x4E>(sv); sv += dpp_mov<0x124>(sv); sv += dpp_mov<0x128>(sv);
                     mine_s = (i16 == c) ? sv : mine_s;
-                    if (p.colstats_mode == 0) {
+                    if constexpr (SUMSQ) {
                         float qv = cq[c];
                         qv += dpp_mov<0xB1>(qv); qv += dpp_mov<0x4E>(qv); qv += dpp_mov<0x124>(qv); qv += dpp_mov<0x128>(qv);
                         mine_q = (i16 == c) ? qv : mine_q;
@@ -306,7 +333,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
                 const int n = nb + i16;
                 if (n < p.N) {
                     atomicAdd(cacc + n, mine_s);
-                    if (p.colstats_mode == 0) atomicAdd(cacc + BIG_COLSTAT_N + n, mine_q);
+                    if constexpr (SUMSQ) atomicAdd(cacc + BIG_COLSTAT_N + n, mine_q);
                 }
             }
 #pragma unroll
@@ -344,7 +371,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
         for (int n = tid; n < p.N; n += NT) {
             const float a = cacc[n];
             if (a != 0.f) atomicAdd(p.colstats + n, a);
-            if (p.colstats_mode == 0) {
+            if constexpr (SUMSQ) {
                 const float q = cacc[BIG_COLSTAT_N + n];
                 if (q != 0.f) atomicAdd(p.colstats + p.N + n, q);
             }
@@ -384,12 +411,13 @@ int launch_big2(const FS2Gemm& g, hipStream_t st) {
 template <typename TC, int WTM>
 int launch_big1(const FS2Gemm& g, hipStream_t st) {
     const int res = g.residual == nullptr ? 0 : (g.res_dtype == FS2_F32 ? EPI_RES_F32 : EPI_RES_BF16);
-    const int epi = (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? EPI_STATS : 0);
+    const int epi = (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? (g.colstats_mode == 0 ? EPI_STATS | EPI_SUMSQ : EPI_STATS) : 0);
     if (g_big_dbg != nullptr && epi == 0) return launch_big2<TC, WTM, 0, true>(g, st);
     switch (epi) {      // the combinations the model uses; anything else stays on the 128-tile kernel (checked by the caller)
         case 0: return launch_big2<TC, WTM, 0, false>(g, st);
         case EPI_MASK: return launch_big2<TC, WTM, EPI_MASK, false>(g, st);
         case EPI_STATS: return launch_big2<TC, WTM, EPI_STATS, false>(g, st);
+        case EPI_STATS | EPI_SUMSQ: return launch_big2<TC, WTM, EPI_STATS | EPI_SUMSQ, false>(g, st);
         case EPI_MASK | EPI_STATS: return launch_big2<TC, WTM, EPI_MASK | EPI_STATS, false>(g, st);
         case EPI_RES_F32: return launch_big2<TC, WTM, EPI_RES_F32, false>(g, st);
         case EPI_RES_BF16: return launch_big2<TC, WTM, EPI_RES_BF16, false>(g, st);
@@ -402,8 +430,8 @@ int launch_big1(const FS2Gemm& g, hipStream_t st) {
 
 bool epi_compiled(const FS2Gemm& g) {
     const int res = g.residual == nullptr ? 0 : (g.res_dtype == FS2_F32 ? EPI_RES_F32 : EPI_RES_BF16);
-    const int epi = (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? EPI_STATS : 0);
-    return epi == 0 || epi == EPI_MASK || epi == EPI_STATS || epi == (EPI_MASK | EPI_STATS) || epi == EPI_RES_F32 ||
+    const int epi = (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? (g.colstats_mode == 0 ? EPI_STATS | EPI_SUMSQ : EPI_STATS) : 0);
+    return epi == (EPI_STATS | EPI_SUMSQ) || epi == 0 || epi == EPI_MASK || epi == EPI_STATS || epi == (EPI_MASK | EPI_STATS) || epi == EPI_RES_F32 ||
            epi == EPI_RES_BF16 || epi == (EPI_MASK | EPI_RES_F32);
 }
 
@@ -435,11 +463,14 @@ bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         const long tiles = (long)((g.M + b - 1) / b) * tn;
         return (double)tiles / (double)(((tiles + 255) / 256) * 256);
     };
-    if (bm != 192 && bm != 256) bm = fill(192) > fill(256) + 0.02 ? 192 : 256;
+    // (epilogues with masks / statistics keep more registers live: the 192-row tile runs them without spills)
+    const double bias192 = (g.relu_mask != nullptr || g.colstats != nullptr) ? 0.10 : -0.02;
+    if (bm != 192 && bm != 256) bm = fill(192) + bias192 > fill(256) ? 192 : 256;
     if (mode == 1) {
         const long tiles = (long)((g.M + bm - 1) / bm) * tn;
         const long ktot = (long)(g.conv == 1 ? g.taps : 1) * g.K;
-        if (tiles < 128 || g.N < 192 || ktot < 512) return false;
+        (void)ktot;
+        if (tiles < 128 || g.N < 192) return false;
     }
     const bool f32 = g.c_dtype == FS2_F32;
     if (bm == 192) *rc = f32 ? launch_big1<float, 48>(g, st) : launch_big1<bf16_t, 48>(g, st);
