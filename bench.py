@@ -81,6 +81,7 @@ class GemmTimer:
     def install(self):
         from transformer_tts_amd import ops
         self._orig = ops._gemm_call
+        self._last_tile = ops.lib().fs2_gemm_last_tile
 
         def timed(g):
             s = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
@@ -94,8 +95,7 @@ class GemmTimer:
             es, cs = (2 if g.dtype == 1 else 4), (2 if g.c_dtype == 1 else 4)
             # algorithmic bytes: every operand element once (conv: the A rows once, not once per tap)
             abytes = (es * (g.M * g.K + g.N * g.K * taps) + cs * g.M * g.N) * float(nb)
-            t128 = ((g.M + 127) // 128) * ((g.N + 127) // 128) * nb * max(1, g.split_k)
-            tile = 64 if (not g.a_kmajor and not g.b_kmajor and t128 < 384) else 128      # as fs2_gemm's launcher picks it
+            tile = self._last_tile()      # rows of the block tile the launcher picked: 64 / 128 (gemm.hip), 192 / 256 (gemm_big.hip)
             key = ("bf16" if g.dtype == 1 else "f32", "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm", tile)
             flags = ("b" if g.bias else "") + ("r" if g.relu else "") + ("m" if g.relu_mask else "") + ("+" if g.residual else "") + \
                     (f"s{g.colstats_mode}" if g.colstats else "") + ("a" if g.accumulate else "") + ("f" if g.c_dtype == 0 and g.dtype == 1 else "")
@@ -144,17 +144,24 @@ def cpu_baseline(hp, batch):
     cut = lambda n: tuple(b[:n] if torch.is_tensor(b) else b for b in batch)
     print("[cpu_baseline] warm-up step on 2 utterances ...", file=sys.stderr, flush=True)
     otrain.train_step(m, opt, 1, cut(2), hp.d_model_decoder)
-    n_utt = 48                                # the whole config-2 batch: ~10 s on the box's 16 cores
+    n_utt = 48                                # the whole config-2 batch: ~10 s per step on the box's 16 cores
     sample = cut(n_utt)
-    print(f"[cpu_baseline] timing 1 step on {n_utt} utterances with {cores} threads ...", file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    otrain.train_step(m, opt, 2, sample, hp.d_model_decoder)
-    dt = time.perf_counter() - t0
     frames = int(sample[5].sum())
-    print(f"[cpu_baseline] {dt:.1f} s", file=sys.stderr, flush=True)
-    return dict(value=round(frames / dt, 1), unit="mel-frames/s", cores=cores, kind="port",
-                sample=f"1 train step (fwd+bwd+clip+Adam, fp32 eager PyTorch oracle, reference dropout rates) on the first "
-                       f"{n_utt} utterances of the config-2 batch (T_pad {sample[1].shape[1]}, {frames} valid mel frames): {dt:.1f} s")
+    n_timed = 3                               # 1 full-size warm-up + 3 timed steps (~45 s of CPU work in all)
+    print(f"[cpu_baseline] 1 warm-up + {n_timed} timed steps on {n_utt} utterances with {cores} threads ...", file=sys.stderr, flush=True)
+    times = []
+    for i in range(n_timed + 1):
+        t0 = time.perf_counter()
+        otrain.train_step(m, opt, 2 + i, sample, hp.d_model_decoder)
+        dt = time.perf_counter() - t0
+        print(f"[cpu_baseline] step {i}: {dt:.1f} s{' (warm-up, not counted)' if i == 0 else ''}", file=sys.stderr, flush=True)
+        if i > 0:
+            times.append(dt)
+    med = sorted(times)[len(times) // 2]
+    return dict(value=round(frames / med, 1), unit="mel-frames/s", cores=cores, kind="port",
+                sample=f"median of {n_timed} train steps after one warm-up step (fwd+bwd+clip+Adam, fp32 eager PyTorch oracle, reference "
+                       f"dropout rates) on the {n_utt} utterances of the config-2 batch (T_pad {sample[1].shape[1]}, {frames} valid mel "
+                       f"frames): {med:.1f} s per step (min {min(times):.1f}, max {max(times):.1f})")
 
 
 def launch_ranks(n):
@@ -304,7 +311,8 @@ def main():
             # against the machine balance 2.5 PFLOP/s / 8 TB/s
             hbm_bound = (fl / by) < (PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
             roof = dict(bound="hbm" if hbm_bound else "mfma",
-                        kernel=f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}",
+                        kernel=(f"fs2_gemm_big_kernel<{key[0]}, {key[3]}x256 tile, 16 waves, LDS-DMA> A row-major B row-major" if key[3] >= 192 else
+                                f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}"),
                         achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
                         unit="GB/s" if hbm_bound else "TFLOP/s",
                         frac=round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_BF16_TFLOPS), 4), traffic=traffic,

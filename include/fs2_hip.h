@@ -84,6 +84,10 @@ typedef struct FS2Gemm {
 } FS2Gemm;
 
 int fs2_gemm(const FS2Gemm* g, void* stream);
+/* Rows of the block tile the last fs2_gemm call of this thread was launched with: 64 / 128 (4-wave kernel) or 192 / 256
+ * (16-wave LDS-DMA kernel for tall row-major bf16 products, 256 columns wide).  Measurement aid (bench.py groups its
+ * per-launch timings by it); FS2_GEMM_BIG=0 in the environment keeps every product on the 4-wave kernel. */
+int fs2_gemm_last_tile(void);
 
 /* Finishing pass of a split-K product whose fused epilogue could not run (few output tiles, long K: the product
  * accumulates fp32 partial sums into `scratch` [M][N], zero on entry, with FS2Gemm.accumulate = 1, split_k > 1):

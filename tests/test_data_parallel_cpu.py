@@ -98,7 +98,9 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
 
 
 def test_bucket_merging_covers_the_arena_once():
-    """grads_ready() merges adjacent module spans into buckets; finish() reduces every element exactly once."""
+    """grads_ready() merges adjacent ranges into buckets (also when one call names several separate ranges, as the
+    per-layer announcements of the encoder stacks and the two embedding tables of the variance adaptor do);
+    finish() reduces every element exactly once; a range announced twice is refused."""
     _setup()
     from helpers import product_model
     from transformer_tts_amd.optim import FusedAdam
@@ -109,11 +111,47 @@ def test_bucket_merging_covers_the_arena_once():
     dp.arena, dp.bucket_elems, dp.pending, dp.works, dp.done, dp.world, dp.pg = opt.arena, 20000, None, [], [], 1, None
     launched = []
     dp._launch = lambda lo, hi: (launched.append((lo, hi)), dp.done.append((lo, hi)))
-    for mod in (model.postnet, model.decoder, model.variance_adaptor.energy_predictor,
-                model.variance_adaptor.pitch_predictor, model.encoder.layers[1]):
-        dp.grads_ready(mod)
+    va, dec = model.variance_adaptor, model.decoder
+    dp.grads_ready(model.postnet)
+    # the announce order of EncoderStackFunction.backward: layer i without its norm_1, plus the norm that follows it
+    for i in reversed(range(len(dec.layers))):
+        nxt = dec.layers[i + 1].norm_1 if i + 1 < len(dec.layers) else dec.norm
+        dp.grads_ready([q for n, q in dec.layers[i].named_parameters() if not n.startswith("norm_1.")] + list(nxt.parameters()))
+    dp.grads_ready([dec.pe.alpha] + list(dec.embed.parameters()) + list(dec.layers[0].norm_1.parameters()))
+    dp.grads_ready([va.pitch_embedding.weight, va.energy_embedding.weight])      # two separate ranges in one call
+    dp.grads_ready(va.energy_predictor)
+    dp.grads_ready(va.pitch_predictor)
+    with pytest.raises(AssertionError):
+        dp.grads_ready(va.pitch_predictor)
     dp.finish()
     cover = np.zeros(opt.arena.numel, np.int32)
     for lo, hi in launched:
         cover[lo:hi] += 1
     assert cover.min() == 1 and cover.max() == 1
+    assert len(launched) >= 3
+
+
+def test_every_parameter_is_announced_by_the_backward():
+    """one real backward (fake backend) with a recording engine: the announcements of the backward Functions cover the
+    whole arena except nothing -- finish() has no range left to pick up -- and the last encoder layers are announced
+    before the first ones (what lets the exchange overlap the rest of backward)."""
+    T = _setup()
+    from helpers import CONFIGS, product_model
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.parallel import DataParallel
+    model, hp, _ = product_model("tiny")
+    opt = FusedAdam(model)
+    dp = DataParallel.__new__(DataParallel)
+    dp.arena, dp.bucket_elems, dp.pending, dp.works, dp.done, dp.world, dp.pg = opt.arena, 1 << 10, None, [], [], 1, None
+    order = []
+    dp._launch = lambda lo, hi: (order.append((lo, hi)), dp.done.append((lo, hi)))
+    dp.allreduce_sum = lambda t: None
+    model.rt.dp = dp
+    opt.dp = None
+    batch = CONFIGS["tiny"]["batch"]()
+    T.train_step(model, opt, 1, batch, hp)
+    announced = sum(hi - lo for lo, hi in order) + (0 if dp.pending is None else dp.pending[1] - dp.pending[0])
+    assert announced == opt.arena.numel, (announced, opt.arena.numel)
+    enc_lo, enc_hi = opt.arena.span(list(model.encoder.parameters()))
+    enc_ranges = [r for r in order if enc_lo <= r[0] < enc_hi]
+    assert len(enc_ranges) >= 2 and enc_ranges[0][0] > enc_ranges[-1][0]

@@ -74,6 +74,22 @@ class Runtime:
             self._side_dirty = False
             self._keep.clear()
 
+    # ---- data-parallel gradient exchange
+    def announce(self, params):
+        """Tell the data-parallel engine that the gradients of `params` (one contiguous arena range) have been enqueued.
+        The all-reduce has to follow BOTH this backward's data-gradient stream and the side stream carrying its weight
+        gradients; it is launched from the side stream after that stream has picked up the current one, so the
+        data-gradient chain never waits for weight-gradient GEMMs (a join here would stall it once per layer)."""
+        if self.dp is None:
+            return
+        params = list(params)
+        if self._side is not None and self._side_dirty:
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                self.dp.grads_ready(params)
+        else:
+            self.dp.grads_ready(params)
+
     # ---- weight shadows: fp32 master (reference layout) -> compute dtype, kernel layout
     def _cached(self, key, params, build):
         ver = tuple(p._version for p in params) + (self.epoch,)
@@ -378,6 +394,9 @@ class EncoderStackFunction(torch.autograd.Function):
                 ops.wgrad_batched(dqkv2, h2d, [grad_of(lin.weight) for lin in (at.q_linear, at.v_linear, at.k_linear)])
             _, wd, _ = rt.qkv(at)
             dh = ops.linear(dqkv2, wd).view(B, t, d)
+            # every gradient of this layer except norm_1's (produced by the next iteration) and the norm that follows the
+            # layer (norm_1 of layer i+1 / the final norm) is enqueued: one contiguous arena range -> exchange it now
+            rt.announce([q_ for name, q_ in layer.named_parameters() if not name.startswith("norm_1.")] + list(nn_.parameters()))
 
         n1 = enc.layers[0].norm_1
         dx0 = ops.layernorm_bwd(dh, sv["x0"], n1.weight.detach(), sv["mean0"], sv["rstd0"], grad_of(n1.weight),
@@ -391,9 +410,9 @@ class EncoderStackFunction(torch.autograd.Function):
             da0 = ops.pe_add_bwd(dx0, pe, T, grad_of(enc.pe.alpha), p, rng, enc.pe.site, dcolsum=grad_of(enc.embed.bias))
             _linear_wgrad(rt, da0.view(M, d), src.reshape(M, -1), enc.embed, bias_done=True)
             dsrc = ops.linear(da0.view(M, d), rt.w_dgrad(enc.embed.weight)).view(src.shape)
+        first = [enc.pe.alpha] + list(enc.embed.parameters()) + list(n1.parameters())
+        rt.announce(first)
         rt.side_join()
-        if rt.dp is not None:
-            rt.dp.grads_ready(enc)
         return (None, dsrc, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
 
@@ -436,6 +455,7 @@ class VariancePredictorFunction(torch.autograd.Function):
                                 grad_of(l1.bias), p, rng, mod.site1, relu_mask=True, dcolsum=grad_of(mod.conv1.bias))
         _conv_wgrad(rt, dz1, s["x"], mod.conv1, 1, bias_done=True)
         dx = ops.conv(dz1, rt.w_dgrad(mod.conv1.weight), 3, 1)
+        rt.announce(mod.parameters())
         rt.side_join()
         return (None, dx, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
@@ -480,6 +500,7 @@ class BucketEmbedAddFunction(torch.autograd.Function):
                 oh = ops.onehot(ctx.idx[j], emb.weight.shape[0], dout.dtype)
                 rt._keep.append(oh)
                 ops.wgrad(oh, d2, grad_of(emb.weight))
+        rt.announce([va.pitch_embedding.weight, va.energy_embedding.weight])
         rt.side_join()
         return (None, dout, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 
@@ -578,9 +599,8 @@ class PostNetFunction(torch.autograd.Function):
             term_T = (term if T == torch.float32 else ops.cast(term, T)).view(M, -1)
             _linear_wgrad(rt, term_T, x2, mod.out)
             dx = ops.linear(term_T, rt.w_dgrad(mod.out.weight), residual=dx)
+        rt.announce(mod.parameters())
         rt.side_join()
-        if rt.dp is not None:
-            rt.dp.grads_ready(mod)
         return (None, None if dx is None else dx.view(B, t, d)) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 

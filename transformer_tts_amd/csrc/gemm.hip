@@ -29,6 +29,9 @@
 
 bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc);     // gemm_big.hip
 
+thread_local int g_last_tile = 0;     // rows of the block tile of the last fs2_gemm launch of this thread (measurement aid)
+extern "C" int fs2_gemm_last_tile(void) { return g_last_tile; }
+
 namespace {
 
 template <typename T, bool KM> struct Tile {
@@ -590,9 +593,11 @@ template <typename T, typename TC>
 int launch(const FS2Gemm& g, hipStream_t st) {
     const long zdim = (long)g.batch1 * g.batch2 * g.split_k;
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * zdim;
+    g_last_tile = 128;
     if (!g.a_kmajor && !g.b_kmajor) {
         if (t128 < 384) {       // too few 128-tiles to fill 256 CUs: quarter-size tiles
             const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * zdim;
+            g_last_tile = 64;
             return launch1<T, TC, false, false, 64, false>(g, (int)t64, st);
         }
         return launch1<T, TC, false, false, 128, false>(g, (int)t128, st);
@@ -660,7 +665,7 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     {   // tall row-major bf16 products: the 256x256 / 16-wave LDS-DMA kernel (gemm_big.hip)
         int rc = FS2_OK;
-        if (fs2_gemm_big_try(g, st, &rc)) return rc;
+        if (fs2_gemm_big_try(g, st, &rc)) return rc;      // (sets g_last_tile to 192 / 256)
     }
     // tile walk: tall row-major products with 2..8 column tiles of 128 go m-fastest on an XCD-aligned grid (see the
     // kernel's work numbering); everything else n-fastest.  FS2_GEMM_MFAST=0 disables the choice (measurements).

@@ -57,6 +57,8 @@ unsigned long long* g_big_dbg = nullptr;
 
 }  // namespace
 
+extern thread_local int g_last_tile;     // gemm.hip
+
 extern "C" void fs2_debug_gemm_big_timer(unsigned long long* buf) { g_big_dbg = buf; }
 
 template <typename TC, int WTM, int EPI, bool STAMP>
@@ -473,6 +475,7 @@ bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         if (tiles < 128 || g.N < 192) return false;
     }
     const bool f32 = g.c_dtype == FS2_F32;
+    g_last_tile = bm;
     if (bm == 192) *rc = f32 ? launch_big1<float, 48>(g, st) : launch_big1<bf16_t, 48>(g, st);
     else *rc = f32 ? launch_big1<float, 64>(g, st) : launch_big1<bf16_t, 64>(g, st);
     return true;

@@ -45,6 +45,7 @@ class FS2Gemm(ctypes.Structure):
 _P, _I, _L, _F, _U32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
 SIGNATURES = {
     "fs2_gemm": [ctypes.POINTER(FS2Gemm), _P],
+    "fs2_gemm_last_tile": [],
     "fs2_cast_permute": [_P, _P, _I, _I, _I, _L, _I, _I, _P],
     "fs2_permute_add": [_P, _P, _I, _I, _I, _I, _P],
     "fs2_cast": [_P, _I, _P, _I, _L, _P],

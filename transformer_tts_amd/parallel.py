@@ -35,13 +35,25 @@ class DataParallel:
         self.done.append((lo, hi))
 
     def grads_ready(self, module_or_params):
+        """The gradients of these parameters are complete (enqueued on the current stream).  The parameters may cover
+        several separate arena ranges; every maximal contiguous run is merged with the pending neighbour range or
+        launched on its own once it reaches the bucket size."""
         params = list(module_or_params.parameters()) if hasattr(module_or_params, "parameters") else list(module_or_params)
-        span = self.arena.span(params)
-        if span is None:
-            return
-        lo, hi = span
+        runs = []
+        for lo, hi in sorted(r for r in (self.arena.span([q]) for q in params) if r is not None):
+            if runs and lo <= runs[-1][1]:
+                runs[-1][1] = max(runs[-1][1], hi)
+            else:
+                runs.append([lo, hi])
+        for lo, hi in runs:
+            self._ready(lo, hi)
+
+    def _ready(self, lo, hi):
+        for dlo, dhi in self.done:
+            assert hi <= dlo or lo >= dhi, f"gradient range [{lo},{hi}) announced twice"
         if self.pending is not None:
             plo, phi = self.pending
+            assert hi <= plo or lo >= phi, f"gradient range [{lo},{hi}) announced twice"
             if hi == plo or lo == phi:                       # adjacent: merge
                 lo, hi = min(lo, plo), max(hi, phi)
             else:
