@@ -368,16 +368,19 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_ln_bwd_k(const T* __restrict__ 
 
 // ================================================================ attention softmax (in place) + dropout
 // rows = (b, h, i); S row = base + b*batch_stride + (h*t + i)*tp; keys j < t; pad columns [t,tp) -> 0
+// (tq query rows per head against t keys: tq == t for self-attention; causal: key j of query i is also masked when
+//  j > i -- the decoder self-attention of the autoregressive model, reference train.py:26-58)
 template <typename T, int NG>
 __global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd_k(T* __restrict__ s, T* __restrict__ pd,
-        const uint8_t* __restrict__ key_mask, int B, int H, int t, int tp, int64_t batch_stride, float p,
+        const uint8_t* __restrict__ key_mask, int B, int H, int tq, int t, int tp, int64_t batch_stride, int causal, float p,
         const uint64_t* rng, uint32_t site) {
     const DropCtx dc = drop_ctx(rng, site, p);
-    const int64_t rows = (int64_t)B * H * t;
+    const int64_t rows = (int64_t)B * H * tq;
     ROW_LOOP(rows) {
-        const int b = (int)(row / ((int64_t)H * t));
-        const int64_t inb = row - (int64_t)b * H * t;   // h*t + i
+        const int b = (int)(row / ((int64_t)H * tq));
+        const int64_t inb = row - (int64_t)b * H * tq;   // h*tq + i
         const int64_t off = b * batch_stride + inb * tp;
+        const int jmax = causal ? (int)(inb % tq) : 0x7fffffff;      // last key a causal row may look at
         const uint8_t* km = key_mask + (int64_t)b * t;
         float4 v[NG];
         row_load<NG, T>(s + off, tp, lane, v);
@@ -392,8 +395,8 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd_k(T* __restrict__ s, T*
             for (int c = 0; c < 4; ++c) {
                 const int j = GCOL(g) + c;
                 if (j < t) {
-                    const bool keep = whole ? ((mk4 >> (8 * c)) & 0xFFu) != 0 : km[j] != 0;
-                    if (!keep) e[c] = -1e4f;          // masked_fill(mask == 0, -1e4) on keys
+                    const bool keep = (whole ? ((mk4 >> (8 * c)) & 0xFFu) != 0 : km[j] != 0) && j <= jmax;
+                    if (!keep) e[c] = -1e4f;          // masked_fill(mask == 0, -1e4)
                     mx = fmaxf(mx, e[c]);
                 } else e[c] = -3.0e38f;
             }
@@ -425,12 +428,12 @@ __global__ __launch_bounds__(ROW_BLOCK) void softmax_fwd_k(T* __restrict__ s, T*
 
 template <typename T, int NG>
 __global__ __launch_bounds__(ROW_BLOCK) void softmax_bwd_k(T* __restrict__ dp, int64_t dp_stride, const T* __restrict__ ps,
-        int64_t p_stride, int B, int H, int t, int tp, float p, const uint64_t* rng, uint32_t site) {
+        int64_t p_stride, int B, int H, int tq, int t, int tp, float p, const uint64_t* rng, uint32_t site) {
     const DropCtx dc = drop_ctx(rng, site, p);
-    const int64_t rows = (int64_t)B * H * t;
+    const int64_t rows = (int64_t)B * H * tq;
     ROW_LOOP(rows) {
-        const int b = (int)(row / ((int64_t)H * t));
-        const int64_t inb = row - (int64_t)b * H * t;
+        const int b = (int)(row / ((int64_t)H * tq));
+        const int64_t inb = row - (int64_t)b * H * tq;
         const int64_t off = b * dp_stride + inb * tp;       // in the dP / dS buffer
         const int64_t poff = b * p_stride + inb * tp;       // in the saved-probabilities buffer (= the forward's offsets)
         float4 g_[NG], pv[NG];
@@ -1024,7 +1027,7 @@ extern "C" int fs2_softmax_fwd(void* s, void* pd, int dtype, const uint8_t* key_
         return FS2_OK;
     }
     NG_DISPATCH(tp, NG, { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((softmax_fwd_k<T, NG>), grid, block, 0, st, (T*)s, (T*)pd, key_mask, B, H, t, tp, batch_stride, p, rng, site);
+        hipLaunchKernelGGL((softmax_fwd_k<T, NG>), grid, block, 0, st, (T*)s, (T*)pd, key_mask, B, H, t, t, tp, batch_stride, 0, p, rng, site);
     }); });
     FS2_CHECK_LAUNCH("fs2_softmax_fwd");
     return FS2_OK;
@@ -1048,9 +1051,42 @@ extern "C" int fs2_softmax_bwd(void* dp, int64_t dp_batch_stride, const void* ps
         return FS2_OK;
     }
     NG_DISPATCH(tp, NG, { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((softmax_bwd_k<T, NG>), grid, block, 0, st, (T*)dp, dp_batch_stride, (const T*)ps, p_batch_stride, B, H, t, tp, p, rng, site);
+        hipLaunchKernelGGL((softmax_bwd_k<T, NG>), grid, block, 0, st, (T*)dp, dp_batch_stride, (const T*)ps, p_batch_stride, B, H, t, t, tp, p, rng, site);
     }); });
     FS2_CHECK_LAUNCH("fs2_softmax_bwd");
+    return FS2_OK;
+}
+
+// rectangular / causal form: tq query rows per head, tk keys (row stride tkp); the decoder self-attention (causal) and the
+// encoder-decoder attention (tq != tk) of the autoregressive model
+extern "C" int fs2_softmax_rect_fwd(void* s, void* pd, int dtype, const uint8_t* key_mask, int B, int H, int tq, int tk, int tkp,
+                                    int64_t batch_stride, int causal, float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_DT("fs2_softmax_rect_fwd", dtype);
+    FS2_REQUIRE(tq > 0 && tk > 0 && tkp >= tk && tkp % 8 == 0 && tkp <= 2048, "fs2_softmax_rect_fwd: need 0 < tk <= tkp <= 2048, tkp %% 8 == 0 (tk=%d tkp=%d)", tk, tkp);
+    FS2_REQUIRE(!causal || tq == tk, "fs2_softmax_rect_fwd: the causal mask needs tq == tk");
+    FS2_REQUIRE(batch_stride % 4 == 0, "fs2_softmax_rect_fwd: batch_stride must be a multiple of 4");
+    FS2_REQUIRE(p == 0.f || (rng != nullptr && pd != s), "fs2_softmax_rect_fwd: dropout needs rng and a separate p_drop buffer");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid((int64_t)B * H * tq)), block(ROW_BLOCK);
+    NG_DISPATCH(tkp, NG, { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((softmax_fwd_k<T, NG>), grid, block, 0, st, (T*)s, (T*)pd, key_mask, B, H, tq, tk, tkp, batch_stride, causal, p, rng, site);
+    }); });
+    FS2_CHECK_LAUNCH("fs2_softmax_rect_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_softmax_rect_bwd(void* dp, int64_t dp_batch_stride, const void* ps, int64_t p_batch_stride, int dtype, int B,
+                                    int H, int tq, int tk, int tkp, float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_DT("fs2_softmax_rect_bwd", dtype);
+    FS2_REQUIRE(tq > 0 && tk > 0 && tkp >= tk && tkp % 8 == 0 && tkp <= 2048, "fs2_softmax_rect_bwd: need 0 < tk <= tkp <= 2048, tkp %% 8 == 0");
+    FS2_REQUIRE(dp_batch_stride % 4 == 0 && p_batch_stride % 4 == 0, "fs2_softmax_rect_bwd: batch strides must be multiples of 4");
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_softmax_rect_bwd: dropout needs rng");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid((int64_t)B * H * tq)), block(ROW_BLOCK);
+    NG_DISPATCH(tkp, NG, { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((softmax_bwd_k<T, NG>), grid, block, 0, st, (T*)dp, dp_batch_stride, (const T*)ps, p_batch_stride, B, H, tq, tk, tkp, p, rng, site);
+    }); });
+    FS2_CHECK_LAUNCH("fs2_softmax_rect_bwd");
     return FS2_OK;
 }
 
