@@ -41,6 +41,42 @@ CONFIGS = {
                   train_steps=1, start_step=4000),
 }
 
+# Autoregressive Transformer-TTS (BASELINE.json configs[3]): hparams the reference's train.py /
+# Models.transformer.Transformer read on top of the common ones.  Batches are the 8-tuple of datasets_transformer.collate_fn
+# (text, mel, pos_text, pos_mel, text_lengths, mel_lengths, stop_token, spk_emb): the first eight fields of the synthetic batch.
+_AR = dict(model="Transformer", gst=False, spk_emb_dim=None, spk_emb_architecture="", dropout_prenet=0.0, dropout_postnet=0.0,
+           positive_weight=5.0, accum_grad=1, clip=1.0)
+
+AR_CONFIGS = {
+    # d=32, 2+2 layers, 2 heads, k 3/1, ragged batch of 3
+    "ar_tiny": dict(hp=dict(_AR, vocab_size=40, batch_size=3, d_model_encoder=32, n_layer_encoder=2, n_head_encoder=2,
+                            ff_conv_kernel_size_encoder=3, d_model_decoder=32, n_layer_decoder=2, n_head_decoder=2,
+                            ff_conv_kernel_size_decoder=1),
+                    weight_seed=21, batch=lambda: synthetic.tiny_batch(seed=17, batch_size=3, vocab=40)[:8],
+                    train_steps=3, start_step=4000),
+    # d_enc 64 -> d_dec 96 (the Linear between encoder and decoder), 1+2 layers, 4 heads, k 9/5, gradient accumulation 2
+    "ar_small": dict(hp=dict(_AR, vocab_size=60, batch_size=4, d_model_encoder=64, n_layer_encoder=1, n_head_encoder=4,
+                             ff_conv_kernel_size_encoder=9, d_model_decoder=96, n_layer_decoder=2, n_head_decoder=4,
+                             ff_conv_kernel_size_decoder=5, accum_grad=2, positive_weight=3.0),
+                     weight_seed=22, batch=lambda: synthetic.make_batch(18, 4, l_range=(9, 20), dur_range=(1, 9), vocab=60)[:8],
+                     train_steps=4, start_step=4000),
+    # reduction rate 2: strided decoder inputs, (B, T/2, 160) outputs regrouped to frame rate
+    "ar_r2": dict(hp=dict(_AR, vocab_size=40, batch_size=3, d_model_encoder=32, n_layer_encoder=1, n_head_encoder=2,
+                          ff_conv_kernel_size_encoder=3, d_model_decoder=32, n_layer_decoder=1, n_head_decoder=2,
+                          ff_conv_kernel_size_decoder=1, reduction_rate=2),
+                  weight_seed=23, batch=lambda: even_frames(synthetic.tiny_batch(seed=19, batch_size=3, vocab=40)[:8]),
+                  train_steps=2, start_step=4000),
+}
+
+
+def even_frames(batch):
+    """crop the padded frame axis to an even length (train.py's reduction-rate slicing and its loss targets only line up
+    when T_pad is a multiple of the reduction rate)"""
+    text, mel, pos_text, pos_mel, tl, ml, stop, spk = batch
+    T = mel.shape[1] - (mel.shape[1] % 2)
+    return (text, mel[:, :T].contiguous(), pos_text, pos_mel[:, :T].contiguous(), tl, torch.clamp(ml, max=T),
+            stop[:, :T].contiguous(), spk)
+
 
 def hp_namespace(cfg):
     d = dict(_BASE)

@@ -42,13 +42,15 @@ sys.modules["librosa"] = types.ModuleType("librosa")
 _tm = types.ModuleType("torchmetrics"); _tm.StructuralSimilarityIndexMeasure = lambda *a, **k: None
 sys.modules["torchmetrics"] = _tm
 _pkg = types.ModuleType("datasets"); _pkg.__path__ = ["/root/reference/datasets"]; sys.modules["datasets"] = _pkg
+# train.py (the autoregressive trainer) imports tensorboard's SummaryWriter at module level and never uses it
+_tb = types.ModuleType("torch.utils.tensorboard"); _tb.SummaryWriter = lambda *a, **k: None; sys.modules["torch.utils.tensorboard"] = _tb
 
 import importlib.util  # noqa: E402
 
 import torch  # noqa: E402
 
 from transformer_tts_amd import synthetic  # noqa: E402
-from golden_configs import CONFIGS, hp_namespace, digest  # noqa: E402
+from golden_configs import AR_CONFIGS, CONFIGS, hp_namespace, digest  # noqa: E402
 
 
 def reference_module(name, relpath):
@@ -213,6 +215,130 @@ def run_infer(name):
     print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def build_reference_ar(cfg):
+    """the reference's Models.transformer.Transformer exactly as train.py:83-90 constructs it, fixture weights loaded"""
+    from Models.transformer import Transformer
+    hp = hp_namespace(cfg)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = Transformer(hp=hp, src_vocab=hp.vocab_size, trg_vocab=hp.mel_dim,
+                            d_model_encoder=hp.d_model_encoder, N_e=hp.n_layer_encoder, n_head_encoder=hp.n_head_encoder,
+                            ff_conv_kernel_size_encoder=hp.ff_conv_kernel_size_encoder, concat_after_encoder=hp.concat_after_encoder,
+                            d_model_decoder=hp.d_model_decoder, N_d=hp.n_layer_decoder, n_head_decoder=hp.n_head_decoder,
+                            ff_conv_kernel_size_decoder=hp.ff_conv_kernel_size_decoder, concat_after_decoder=hp.concat_after_decoder,
+                            reduction_rate=hp.reduction_rate, dropout=hp.dropout, dropout_prenet=hp.dropout_prenet,
+                            dropout_postnet=hp.dropout_postnet, multi_speaker=hp.is_multi_speaker, spk_emb_dim=hp.spk_emb_dim,
+                            spk_emb_architecture=hp.spk_emb_architecture)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(synthetic.recipe_state_dict(shapes, cfg["weight_seed"]))
+    model.train()
+    return model, hp, shapes
+
+
+def ar_iteration(model, optimizer, step, d, hp, R):
+    """ONE iteration of the loop body of the reference's train.py:156-262.  train.py is a script (everything lives under
+    `if __name__ == '__main__'`), so there is no function to call: this harness issues the same calls in the same order on
+    the REFERENCE model -- R.create_masks is the reference's own (train.py:38-58), the model, losses and optimizer are
+    torch / the reference's; non-amp branch (:251-257)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from utils.utils import get_learning_rate
+    lr = get_learning_rate(step, d_model=hp.d_model_decoder, warmup_factor=hp.warmup_factor, warmup_step=hp.warmup_step)   # :160
+    for g in optimizer.param_groups:
+        g["lr"] = lr
+    text, mel, pos_text, pos_mel, text_lengths, mel_lengths, stop_token, spk_emb = d                                    # :164
+    if hp.reduction_rate > 1:                                                                                             # :183-189
+        mel_input = mel[:, :-hp.reduction_rate:hp.reduction_rate, :]
+        pos_mel = pos_mel[:, :-hp.reduction_rate:hp.reduction_rate]
+    else:
+        mel_input = mel[:, :-1, :]
+        pos_mel = pos_mel[:, :-1]
+    src_mask, trg_mask = R.create_masks(pos_text, pos_mel)                                                               # :195
+    outputs_prenet, outputs_postnet, outputs_stop_token, attn_enc, attn_dec_dec, attn_dec_enc = \
+        model(text, mel_input, src_mask, trg_mask, spk_emb)                                                              # :201
+    optimizer.zero_grad()                                                                                                 # :205
+    raw = (outputs_prenet, outputs_postnet, outputs_stop_token, attn_enc, attn_dec_dec, attn_dec_enc)
+    if hp.reduction_rate > 1:                                                                                             # :207-211
+        b, t, c = outputs_prenet.shape
+        outputs_prenet = outputs_prenet.reshape(b, t * hp.reduction_rate, int(c // hp.reduction_rate))
+        outputs_postnet = outputs_postnet.reshape(b, t * hp.reduction_rate, int(c // hp.reduction_rate))
+        outputs_stop_token = outputs_stop_token.reshape(b, t * hp.reduction_rate)
+    mel_loss = nn.L1Loss()(outputs_prenet, mel[:, hp.reduction_rate:, :])                                                # :214
+    post_mel_loss = nn.L1Loss()(outputs_postnet, mel[:, hp.reduction_rate:, :])                                          # :215
+    loss_token = F.binary_cross_entropy_with_logits(outputs_stop_token, stop_token[:, hp.reduction_rate:], reduction="mean",
+                                                    pos_weight=torch.tensor(hp.positive_weight))                          # :217
+    loss = mel_loss + post_mel_loss
+    loss += loss_token
+    parts = dict(mel=mel_loss.item(), post_mel=post_mel_loss.item(), token=loss_token.item(), total=loss.item())
+    step += 1                                                                                                             # :247
+    loss /= hp.accum_grad                                                                                                 # :259
+    loss.backward()
+    if step % hp.accum_grad == 0:                                                                                         # :262-264
+        torch.nn.utils.clip_grad_norm_(model.parameters(), hp.clip)
+        optimizer.step()
+    return step, parts, raw
+
+
+def run_ar(name):
+    """the reference's autoregressive Transformer-TTS -- outputs, losses, gradients of one iteration and
+    the parameters after the first / last of `train_steps` iterations.  -> <name>.npz"""
+    R = reference_module("train_ar", "train.py")           # everything but the imports is guarded by __main__
+    R.DEVICE = torch.device("cpu")
+    cfg = AR_CONFIGS[name]
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    model, hp, shapes = build_reference_ar(cfg)
+    batch = cfg["batch"]()
+    out = {}
+    out["shape_keys"], out["shape_dims"] = shape_arrays(shapes)
+    for k, v in zip(synthetic.FIELDS[:8], batch):
+        if v is not None:
+            out[f"in.{k}"] = v.numpy()
+    # ---- one iteration: outputs, losses, gradients (the optimizer step it may take is on a throw-away optimizer)
+    hp1 = SimpleNamespace(**dict(vars(hp), accum_grad=1, clip=1e30))      # (no clipping: the recorded gradients are the raw ones)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    _, parts, raw = ar_iteration(model, opt, cfg["start_step"], batch, hp1, R)
+    names = ["outputs_prenet", "outputs_postnet", "stop_token", "attn_enc", "attn_dec_dec", "attn_dec_enc"]
+    for n, r in zip(names, raw):
+        out[f"out.{n}"] = r.detach().numpy()
+        out[f"outdig.{n}"] = digest(r.detach())
+    for k, v in parts.items():
+        out[f"loss.{k}"] = np.float64(v)
+    gsq = 0.0
+    none = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            none.append(k)
+            continue
+        g = p.grad
+        out[f"graddig.{k}"] = digest(g)
+        if g.numel() <= 4096:
+            out[f"grad.{k}"] = g.numpy().copy()
+        gsq += float((g.double() ** 2).sum())
+    out["grad_global_norm"] = np.float64(gsq ** 0.5)
+    out["grad_none"] = np.array(none, dtype=np.str_)       # parameters the reference leaves without a gradient (its post-net)
+
+    # ---- train_steps iterations on fresh weights (Adam as train.py:119)
+    model, hp, _ = build_reference_ar(cfg)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    step = cfg["start_step"]
+    tl = []
+    for s in range(cfg["train_steps"]):
+        step, parts, _ = ar_iteration(model, opt, step, batch, hp, R)
+        tl.append(parts["total"])
+        if s in (0, cfg["train_steps"] - 1):
+            tag = f"step{s + 1}"
+            for k, v in model.state_dict().items():
+                out[f"{tag}.pdig.{k}"] = digest(v.float())
+                if v.numel() <= 1024:
+                    out[f"{tag}.p.{k}"] = v.numpy().copy()
+    out["train.loss_total"] = np.asarray(tl, np.float64)
+    out["train.start_step"] = np.int64(cfg["start_step"])
+    out["train.end_step"] = np.int64(step)
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB", "loss", out["loss.total"], "train", tl, "no-grad params", len(none))
+
+
 def data_hp(root):
     """hparams of the BASELINE configs[0] plumbing run on the synthetic corpus in `root`"""
     from golden_configs import _BASE
@@ -313,6 +439,11 @@ if __name__ == "__main__":
     if which.startswith("infer"):
         for n in ("tiny", "small"):
             run_infer(n)
+    elif which == "ar":
+        for n in AR_CONFIGS:
+            run_ar(n)
+    elif which in AR_CONFIGS:
+        run_ar(which)
     elif which == "data":
         run_data()
     elif which == "init":

@@ -46,7 +46,7 @@ def check_digest(actual, dig, rtol, atol, what):
     assert abs(s_abs - dig[1]) <= rtol * abs(dig[1]) + atol * n, f"{what}: sum|x| {s_abs} vs {dig[1]}"
 
 
-_NULL_GRAD = re.compile(r"(attn\.k_linear\.bias|postnet\.conv1\.bias|postnet\.conv_list\.\d+\.bias)$")
+_NULL_GRAD = re.compile(r"(attn(_\d)?\.k_linear\.bias|postnet\.conv1\.bias|postnet\.conv_list\.\d+\.bias)$")
 
 
 def is_null_gradient_param(key):
