@@ -170,6 +170,14 @@ int fs2_softmax_fwd(void* s_inout_p, void* p_drop, int dtype, const uint8_t* key
 int fs2_softmax_bwd(void* dp_inout_ds, int64_t dp_batch_stride, const void* p_saved, int64_t p_batch_stride, int dtype,
                     int B, int H, int t, int tp, float p, const uint64_t* rng, uint32_t site, void* stream);
 
+/* Rectangular / causal form of the two entry points above, for the autoregressive Transformer-TTS decoder
+ * (Models/layers.py:108-118 with the masks of train.py:26-58): tq query rows per head against tk keys (row stride
+ * tkp >= tk, a multiple of 8); key_mask is (B, tk); causal != 0 (needs tq == tk) additionally masks key j > query i. */
+int fs2_softmax_rect_fwd(void* s_inout_p, void* p_drop, int dtype, const uint8_t* key_mask, int B, int H, int tq, int tk, int tkp,
+                         int64_t batch_stride, int causal, float p, const uint64_t* rng, uint32_t site, void* stream);
+int fs2_softmax_rect_bwd(void* dp_inout_ds, int64_t dp_batch_stride, const void* p_saved, int64_t p_batch_stride, int dtype,
+                         int B, int H, int tq, int tk, int tkp, float p, const uint64_t* rng, uint32_t site, void* stream);
+
 /* attention() scores + softmax + dropout in one kernel (Models/modules.py:8-19), bf16 only: a workgroup keeps the
  * 64 x tp score strip of its query rows in LDS, so QK^T/sqrt(d_k) never reaches HBM.
  *   q, k: rows of one head = dk contiguous bf16 at  base + b*batch_stride + i*row_stride + h*head_stride  (elements)
@@ -249,6 +257,16 @@ int fs2_l1_fwd(const void* pred, int pred_dtype, const void* target, int target_
                void* stream);
 int fs2_l1_bwd(const void* pred, int pred_dtype, const void* target, int target_mode, int64_t n, const float* gscale,
                void* dpred, int dpred_dtype, void* stream);
+
+/* Stop-token loss of the autoregressive model: F.binary_cross_entropy_with_logits(x, y, reduction='mean',
+ * pos_weight) (train.py:217).  fwd adds the mean to *loss; bwd writes dx = gscale[0] / n * dl/dx. */
+int fs2_bce_logits_fwd(const void* x, int x_dtype, const float* y, int64_t n, float pos_weight, float* loss, void* stream);
+int fs2_bce_logits_bwd(const void* x, int x_dtype, const float* y, int64_t n, float pos_weight, const float* gscale, void* dx,
+                       int dx_dtype, void* stream);
+/* nn.Dropout on a flat tensor (decoder pre-net, Models/prenets.py:30-37): out = x * keep(mask) / (1 - p); with relu_gate
+ * (may be NULL) the result is also zeroed where relu_gate <= 0 -- the backward through Dropout(ReLU(.)) in one pass. */
+int fs2_dropout(const void* x, const void* relu_gate, void* out, int dtype, int64_t n, float p, const uint64_t* rng,
+                uint32_t site, void* stream);
 
 /* clip_grad_norm_(1.0) + Adam (train_fastspeech2.py:304-315,416), flat arenas of n fp32 elements.
  *  sqnorm: out[0] += sum x^2.   adam: coef = min(1, max_norm / (sqrt(*gsq * gscale^2) + 1e-6));

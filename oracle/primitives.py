@@ -393,6 +393,60 @@ def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
     dp.copy_((pr * (g - dot)).to(dp.dtype))
 
 
+def softmax_rect_fwd(s, p_drop, key_mask, tk, causal=False, p=0.0, rng=None, site=0):
+    """attention() of Models/modules.py:9-19 for the autoregressive decoder: tq query rows against tk keys, key mask (B,tk),
+    optionally the no-peak mask of train.py:26-36 (key j > query i masked); in place; pad columns [tk,tkp) -> 0."""
+    B, H, tq, tkp = s.shape
+    v = _f(s)[..., :tk]
+    keep = (key_mask.view(B, 1, 1, tk) != 0)
+    if causal:
+        keep = keep & (torch.arange(tk).view(1, 1, 1, tk) <= torch.arange(tq).view(1, 1, tq, 1))
+    v = v.masked_fill(~keep, -1e4)
+    pr = torch.softmax(v, dim=-1)
+    full = torch.zeros((B, H, tq, tkp), dtype=_COMPUTE)
+    full[..., :tk] = pr
+    s.copy_(full.to(s.dtype))
+    if p_drop.data_ptr() != s.data_ptr() or p > 0:
+        sc = drop_scale((B, H, tq, tkp), p, rng, site, base_index=_strided_index(s))
+        p_drop.copy_((_f(s) * sc).to(s.dtype))
+
+
+def softmax_rect_bwd(dp, p_saved, tk, p=0.0, rng=None, site=0):
+    B, H, tq, tkp = dp.shape
+    sc = drop_scale((B, H, tq, tkp), p, rng, site, base_index=_strided_index(p_saved))
+    g = torch.zeros((B, H, tq, tkp), dtype=_COMPUTE)
+    g[..., :tk] = (_f(dp) * sc)[..., :tk]
+    pr = torch.zeros_like(g)
+    pr[..., :tk] = _f(p_saved)[..., :tk]
+    dot = (g * pr).sum(-1, keepdim=True)
+    dp.copy_((pr * (g - dot)).to(dp.dtype))
+
+
+def dropout(x, p, rng, site, relu_gate=None, out=None):
+    """nn.Dropout (Models/prenets.py:32,35) with the kernels' Philox stream; relu_gate: also zero where relu_gate <= 0."""
+    v = _f(x) * drop_scale(tuple(x.shape), p, rng, site)
+    if relu_gate is not None:
+        v = torch.where(_f(relu_gate) > 0, v, torch.zeros_like(v))
+    r = v.to(x.dtype)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def bce_logits_fwd(x, y, pos_weight, loss):
+    """F.binary_cross_entropy_with_logits(x, y, reduction='mean', pos_weight) (train.py:217)."""
+    import torch.nn.functional as F
+    loss += F.binary_cross_entropy_with_logits(_f(x), _f(y), reduction="mean",
+                                               pos_weight=torch.tensor(float(pos_weight), dtype=_COMPUTE)).float()
+
+
+def bce_logits_bwd(x, y, pos_weight, gscale, dx_dtype):
+    xv, yv = _f(x), _f(y)
+    d = (1 - yv) - (1 + (float(pos_weight) - 1) * yv) * torch.sigmoid(-xv)
+    return (d * _f(gscale) / x.numel()).to(dx_dtype)
+
+
 # ------------------------------------------------------------------------------------------------ variance adaptor
 def length_regulate_fwd(x, dur, T):
     """LengthRegulator.LR/expand + pad (Models/varianceadaptor.py:141-184,233-249)."""

@@ -742,3 +742,64 @@ def test_big_gemm_is_bit_identical_to_the_128_tile_kernel(ops, monkeypatch):
         monkeypatch.setenv("FS2_GEMM_BIG_BM", bm)
         out = ops.linear(x, w, bias=bias, relu=True)
         assert torch.equal(out, ref), f"bm {bm}: {(out.float() - ref.float()).abs().max().item()}"
+
+
+# ------------------------------------------------------------------------------------------------ autoregressive decoder kernels
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("tq,tk,causal", [(37, 37, True), (64, 64, True), (45, 13, False), (9, 130, False), (1, 1, True)])
+def test_softmax_rect_causal_and_cross(ops, dtype, p, tq, tk, causal):
+    """decoder self-attention (no-peak mask of train.py:26-36 on top of the key padding mask) and encoder-decoder
+    attention (tq x tk scores) through fs2_softmax_rect_fwd / _bwd, inside a (B, N, H, tq, tkp) buffer"""
+    B, H, NL = 3, 2, 2
+    tkp = (tk + 7) // 8 * 8
+    lens = [tk, max(1, tk // 2), max(1, tk - 5)]
+    km = torch.zeros(B, tk, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        km[b, :n] = True
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda x: x.cuda()) if dev == "cuda" else (lambda x: x.clone())
+        rng = o.Rng(5, dev)
+        buf = mv(rnd(B, NL, H, tq, tkp, dtype=dtype, seed=1, scale=3.0))
+        bufd = torch.zeros_like(buf) if p > 0 else buf
+        S, Pd = buf[:, 1], bufd[:, 1]
+        o.softmax_rect_fwd(S, Pd, mv(km), tk, causal, p, rng, 11)
+        dP = mv(rnd(B, H, tq, tkp, dtype=dtype, seed=2))
+        dP[..., tk:] = float("nan")
+        o.softmax_rect_bwd(dP, S, tk, p, rng, 11)
+        out[dev] = (S.clone(), Pd.clone(), dP)
+    for a, b, n in zip(out["cuda"], out["cpu"], ("P", "P_drop", "dS")):
+        close(a, b, n, **tol(dtype))
+    Pc = out["cuda"][0].float().cpu()
+    assert torch.all(Pc[..., tk:] == 0), "pad columns must be written as zero"
+    close(Pc[..., :tk].sum(-1), torch.ones(B, H, tq), "rows sum to one", rtol=1e-2, atol=1e-2)
+    if causal and tq > 1:
+        upper = torch.triu(torch.ones(tq, tk), diagonal=1).bool()
+        assert float(Pc[0][:, upper].abs().max()) < 1e-6, "future keys get ~0 probability"
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dropout_and_bce(ops, dtype):
+    n = 4099
+    x, gate = rnd(n, dtype=dtype, seed=1), rnd(n, dtype=dtype, seed=2)
+    logits, y = rnd(3, 41, dtype=dtype, seed=3, scale=2.0), torch.from_numpy((np.random.default_rng(0).random((3, 41)) < 0.2).astype(np.float32))
+    gs = torch.tensor([0.37])
+    res = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        rng = o.Rng(9, dev)
+        d0 = o.dropout(mv(x), 0.5, rng, 7)
+        d1 = o.dropout(mv(x), 0.5, rng, 7, relu_gate=mv(gate))
+        d2 = o.dropout(mv(x), 0.0, None, 7)
+        loss = torch.zeros(1, device=dev)
+        o.bce_logits_fwd(mv(logits), mv(y), 5.0, loss)
+        dx = o.bce_logits_bwd(mv(logits), mv(y), 5.0, mv(gs), torch.float32)
+        res[dev] = (d0, d1, d2, loss, dx)
+    for a, b, nme in zip(res["cuda"], res["cpu"], ("dropout", "dropout+gate", "p=0", "bce", "dbce")):
+        close(a, b, nme, **tol(dtype if nme != "dbce" else torch.float32))
+    kept = (res["cuda"][0].float() != 0).float().mean().item()
+    assert 0.42 < kept < 0.58
+    # against torch itself
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), y, pos_weight=torch.tensor(5.0))
+    assert abs(res["cuda"][3].item() - ref.item()) <= 2e-5 * abs(ref.item()) + (1e-2 if dtype == torch.bfloat16 else 0)

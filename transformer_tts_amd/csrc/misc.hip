@@ -194,6 +194,57 @@ __global__ __launch_bounds__(TPB) void l1_bwd_k(const T* __restrict__ pred, cons
     }
 }
 
+// ------------------------------------------------------------------ stop-token loss of the autoregressive model
+// F.binary_cross_entropy_with_logits(x, y, reduction='mean', pos_weight=pw) (reference train.py:217):
+//   l = (1 - y) x + (1 + (pw - 1) y) softplus(-x),  softplus(-x) = log1p(exp(-|x|)) + max(-x, 0)
+//   dl/dx = (1 - y) - (1 + (pw - 1) y) sigmoid(-x)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bce_fwd_k(const T* __restrict__ x, const float* __restrict__ y, int64_t n, float pw,
+        float* __restrict__ loss) {
+    __shared__ float lds4[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const float xv = to_f32<T>(x[i]), yv = y[i];
+        const float sp = log1pf(expf(-fabsf(xv))) + fmaxf(-xv, 0.f);
+        acc += (1.f - yv) * xv + (1.f + (pw - 1.f) * yv) * sp;
+    }
+    const float s = block_sum(acc, lds4);
+    if (threadIdx.x == 0) atomicAdd(loss, s / (float)n);
+}
+template <typename T, typename TG>
+__global__ __launch_bounds__(TPB) void bce_bwd_k(const T* __restrict__ x, const float* __restrict__ y, int64_t n, float pw,
+        const float* __restrict__ gscale, TG* __restrict__ dx) {
+    const float g = gscale[0] / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const float xv = to_f32<T>(x[i]), yv = y[i];
+        const float sig_neg = 1.f / (1.f + expf(xv));        // sigmoid(-x)
+        dx[i] = from_f32<TG>(g * ((1.f - yv) - (1.f + (pw - 1.f) * yv) * sig_neg));
+    }
+}
+
+// ------------------------------------------------------------------ plain dropout (decoder pre-net of the autoregressive model)
+// out = x * keep_scale(mask), optionally zeroed where gate <= 0 (backward through a ReLU whose output is `gate`).
+// Same Philox stream layout as every other dropout of the library: one call per 8 consecutive elements, counter = e >> 3.
+template <typename T>
+__global__ __launch_bounds__(TPB) void dropout_k(const T* __restrict__ x, const T* __restrict__ gate, T* __restrict__ out,
+        int64_t n, float p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    const int64_t n8 = (n + 7) >> 3;
+    for (int64_t q = (int64_t)blockIdx.x * TPB + threadIdx.x; q < n8; q += (int64_t)gridDim.x * TPB) {
+        float sc[8];
+        drop_scale8(dc, (uint64_t)q, sc);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int64_t e = q * 8 + c;
+            if (e < n) {
+                float v = to_f32<T>(x[e]) * sc[c];
+                if (gate != nullptr && !(to_f32<T>(gate[e]) > 0.f)) v = 0.f;
+                out[e] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ casts / weight shadows
 template <typename TS, typename TD>
 __global__ __launch_bounds__(TPB) void cast_k(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
@@ -451,6 +502,37 @@ extern "C" int fs2_l1_bwd(const void* pred, int pred_dtype, const void* target, 
     else if (dpred_dtype == FS2_F32) hipLaunchKernelGGL((l1_bwd_k<bf16_t, float>), grid, block, 0, st, (const bf16_t*)pred, target, target_mode, n, gscale, (float*)dpred);
     else hipLaunchKernelGGL((l1_bwd_k<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)pred, target, target_mode, n, gscale, (bf16_t*)dpred);
     FS2_CHECK_LAUNCH("fs2_l1_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_bce_logits_fwd(const void* x, int x_dtype, const float* y, int64_t n, float pos_weight, float* loss, void* stream) {
+    CHECK_DT("fs2_bce_logits_fwd", x_dtype);
+    FS2_REQUIRE(n > 0 && x && y && loss, "fs2_bce_logits_fwd: bad arguments");
+    T_DISPATCH(x_dtype, T, { hipLaunchKernelGGL((bce_fwd_k<T>), dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, (const T*)x, y, n, pos_weight, loss); });
+    FS2_CHECK_LAUNCH("fs2_bce_logits_fwd");
+    return FS2_OK;
+}
+extern "C" int fs2_bce_logits_bwd(const void* x, int x_dtype, const float* y, int64_t n, float pos_weight, const float* gscale,
+                                  void* dx, int dx_dtype, void* stream) {
+    CHECK_DT("fs2_bce_logits_bwd", x_dtype); CHECK_DT("fs2_bce_logits_bwd", dx_dtype);
+    FS2_REQUIRE(n > 0 && x && y && gscale && dx, "fs2_bce_logits_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(flat_grid(n)), block(TPB);
+    if (x_dtype == FS2_F32 && dx_dtype == FS2_F32) hipLaunchKernelGGL((bce_bwd_k<float, float>), grid, block, 0, st, (const float*)x, y, n, pos_weight, gscale, (float*)dx);
+    else if (x_dtype == FS2_F32) hipLaunchKernelGGL((bce_bwd_k<float, bf16_t>), grid, block, 0, st, (const float*)x, y, n, pos_weight, gscale, (bf16_t*)dx);
+    else if (dx_dtype == FS2_F32) hipLaunchKernelGGL((bce_bwd_k<bf16_t, float>), grid, block, 0, st, (const bf16_t*)x, y, n, pos_weight, gscale, (float*)dx);
+    else hipLaunchKernelGGL((bce_bwd_k<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)x, y, n, pos_weight, gscale, (bf16_t*)dx);
+    FS2_CHECK_LAUNCH("fs2_bce_logits_bwd");
+    return FS2_OK;
+}
+extern "C" int fs2_dropout(const void* x, const void* relu_gate, void* out, int dtype, int64_t n, float p, const uint64_t* rng,
+                           uint32_t site, void* stream) {
+    CHECK_DT("fs2_dropout", dtype);
+    FS2_REQUIRE(n > 0 && x && out, "fs2_dropout: bad arguments");
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_dropout: dropout needs rng");
+    FS2_REQUIRE(p >= 0.f && p < 1.f, "fs2_dropout: p must be in [0, 1)");
+    T_DISPATCH(dtype, T, { hipLaunchKernelGGL((dropout_k<T>), dim3(flat_grid((n + 7) >> 3)), dim3(TPB), 0, (hipStream_t)stream, (const T*)x, (const T*)relu_gate, (T*)out, n, p, rng, site); });
+    FS2_CHECK_LAUNCH("fs2_dropout");
     return FS2_OK;
 }
 

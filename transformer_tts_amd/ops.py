@@ -80,6 +80,11 @@ SIGNATURES = {
     "fs2_bn_tanh_fwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
     "fs2_bn_tanh_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
     "fs2_bn_tanh_bwd_apply": [_P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
+    "fs2_softmax_rect_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _I, _L, _I, _F, _P, _U32, _P],
+    "fs2_softmax_rect_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _F, _P, _U32, _P],
+    "fs2_bce_logits_fwd": [_P, _I, _P, _L, _F, _P, _P],
+    "fs2_bce_logits_bwd": [_P, _I, _P, _L, _F, _P, _P, _I, _P],
+    "fs2_dropout": [_P, _P, _P, _I, _L, _F, _P, _U32, _P],
     "fs2_l1_fwd": [_P, _I, _P, _I, _L, _P, _P],
     "fs2_l1_bwd": [_P, _I, _P, _I, _L, _P, _P, _I, _P],
     "fs2_sqnorm": [_P, _L, _P, _P],
@@ -599,6 +604,46 @@ def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
     assert p_saved.stride()[1:] == dp.stride()[1:] and p_saved.dtype == dp.dtype
     _check(lib().fs2_softmax_bwd(_p(dp), dp.stride(0), _p(p_saved), p_saved.stride(0), _dt(dp), B, H, t, tp, p,
                                  _rng_ptr(rng, p), site, _stream()), "fs2_softmax_bwd")
+
+
+def softmax_rect_fwd(s, p_drop, key_mask, tk, causal=False, p=0.0, rng=None, site=0):
+    """softmax_fwd for tq query rows per head against tk keys: s, p_drop (B,H,tq,tkp) views, key_mask (B,tk); `causal`
+    additionally masks key j > query i (tq == tk).  In place on s; pad columns [tk,tkp) -> 0."""
+    B, H, tq, tkp = s.shape
+    assert s.stride(3) == 1 and s.stride(2) == tkp and s.stride(1) == tq * tkp and p_drop.stride() == s.stride()
+    _check(lib().fs2_softmax_rect_fwd(_p(s), _p(p_drop), _dt(s), _p(_c(key_mask)), B, H, tq, tk, tkp, s.stride(0), int(causal), p,
+                                      _rng_ptr(rng, p), site, _stream()), "fs2_softmax_rect_fwd")
+
+
+def softmax_rect_bwd(dp, p_saved, tk, p=0.0, rng=None, site=0):
+    B, H, tq, tkp = dp.shape
+    assert dp.stride(3) == 1 and dp.stride(2) == tkp and dp.stride(1) == tq * tkp
+    assert p_saved.stride()[1:] == dp.stride()[1:] and p_saved.dtype == dp.dtype
+    _check(lib().fs2_softmax_rect_bwd(_p(dp), dp.stride(0), _p(p_saved), p_saved.stride(0), _dt(dp), B, H, tq, tk, tkp, p,
+                                      _rng_ptr(rng, p), site, _stream()), "fs2_softmax_rect_bwd")
+
+
+def dropout(x, p, rng, site, relu_gate=None, out=None):
+    """nn.Dropout on a contiguous tensor (same Philox stream layout as the fused dropouts); with relu_gate (same shape) the
+    result is also zeroed where relu_gate <= 0: the backward through Dropout(ReLU(.)) given the ReLU's output."""
+    x = _c(x)
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().fs2_dropout(_p(x), _p(_c(relu_gate)) if relu_gate is not None else None, _p(out), _dt(x), x.numel(), p,
+                             _rng_ptr(rng, p), site, _stream()), "fs2_dropout")
+    return out
+
+
+def bce_logits_fwd(x, y, pos_weight, loss):
+    """loss += F.binary_cross_entropy_with_logits(x, y, reduction='mean', pos_weight=pos_weight)"""
+    _check(lib().fs2_bce_logits_fwd(_p(_c(x)), _dt(x), _p(_c(y)), x.numel(), float(pos_weight), _p(loss), _stream()), "fs2_bce_logits_fwd")
+
+
+def bce_logits_bwd(x, y, pos_weight, gscale, dx_dtype):
+    dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
+    _check(lib().fs2_bce_logits_bwd(_p(_c(x)), _dt(x), _p(_c(y)), x.numel(), float(pos_weight), _p(gscale), _p(dx), _dt(dx),
+                                    _stream()), "fs2_bce_logits_bwd")
+    return dx
 
 
 # ------------------------------------------------------------------------------------------------ variance adaptor

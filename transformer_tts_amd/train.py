@@ -1,0 +1,181 @@
+"""Trainer of the autoregressive Transformer-TTS on the MI355X kernels -- the module surface of the reference's train.py
+(``nopeak_mask``, ``create_masks``, the loop body of :156-262 as ``train_step`` / ``train_loop``, the model and optimizer
+wiring of :83-119 as ``build_model`` / ``run_training``).  SURVEY.md section 8(f) N2, BASELINE.json configs[3].
+
+The reference's train.py is a script (everything under ``__main__``); the loop body is exposed here as functions so that it
+can be tested step by step against fixtures produced by the reference.  Quirks kept on purpose:
+  * ``optimizer.zero_grad()`` runs in EVERY iteration (:205), so ``hp.accum_grad`` does not accumulate: it only thins the
+    optimizer steps (one every accum_grad iterations, with the loss divided by accum_grad);
+  * the post-net built with prev_version=False returns its input (Models/postnets.py:76-79): outputs_postnet is
+    outputs_prenet, both L1 terms are equal and the post-net's parameters never receive a gradient (only its BatchNorm
+    running statistics move);
+  * the decoder sees frames 0 .. T-2 (reduction rate r: every r-th frame) and is trained against frames r .. T-1.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+from torch.utils.data import DataLoader
+
+from .Models.functional import l1_loss
+from .Models.functional_ar import bce_with_logits
+from .Models.transformer import Transformer
+from .optim import FusedAdam
+from .utils import hparams as hp
+from .utils.utils import fill_variables, get_learning_rate, init_weight, load_model, log_config
+from .datasets import datasets_fastspeech2 as datasets
+
+DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+
+def nopeak_mask(size, device=None):
+    """reference train.py:26-36: (1, size, size) boolean lower-triangular (diagonal included) mask."""
+    return torch.tril(torch.ones((1, size, size), dtype=torch.bool, device=device or DEVICE))
+
+
+def create_masks(src_pos, trg_pos, src_pad=0, trg_pad=0):
+    """reference train.py:38-58."""
+    src_mask = (src_pos != src_pad).unsqueeze(-2)
+    if trg_pos is not None:
+        trg_mask = (trg_pos != trg_pad).unsqueeze(-2)
+        trg_mask = trg_mask & nopeak_mask(trg_pos.size(1), trg_pos.device)
+    else:
+        trg_mask = None
+    return src_mask, trg_mask
+
+
+def decoder_inputs(mel, pos_mel, r):
+    """reference train.py:183-193 (transformer decoder)."""
+    if r > 1:
+        return mel[:, :-r:r, :], pos_mel[:, :-r:r]
+    return mel[:, :-1, :], pos_mel[:, :-1]
+
+
+def compute_losses(hp, outputs, mel, stop_token):
+    """reference train.py:207-220: outputs regrouped to frame rate, two L1 terms against mel[:, r:], stop-token BCE."""
+    r = hp.reduction_rate
+    outputs_prenet, outputs_postnet, outputs_stop_token = outputs[:3]
+    if r > 1:
+        b, t, c = outputs_prenet.shape
+        outputs_prenet = outputs_prenet.reshape(b, t * r, c // r)
+        outputs_postnet = outputs_postnet.reshape(b, t * r, c // r)
+        outputs_stop_token = outputs_stop_token.reshape(b, t * r)
+    target = mel[:, r:, :].contiguous()
+    parts = {"mel": l1_loss(outputs_prenet, target), "post_mel": l1_loss(outputs_postnet, target),
+             "token": bce_with_logits(outputs_stop_token, stop_token[:, r:].contiguous(), float(hp.positive_weight))}
+    loss = parts["mel"] + parts["post_mel"]
+    loss = loss + parts["token"]
+    return loss, parts
+
+
+def train_step(model, optimizer, step, d, hp):
+    """One iteration of the reference loop body (train.py:156-262, non-amp arithmetic; hp.amp selects the bf16 kernels).
+    Returns (loss tensor, parts, new step)."""
+    if hp.optimizer.lower() != "radam":
+        lr = get_learning_rate(step, hp.d_model_decoder, hp.warmup_factor, hp.warmup_step)
+        for param_group in optimizer.param_groups:
+            param_group["lr"] = lr
+    text, mel, pos_text, pos_mel, text_lengths, mel_lengths, stop_token = d[:7]
+    mv = lambda x: x.to(DEVICE, non_blocking=True)
+    text, mel, pos_text, pos_mel, stop_token = (mv(x) for x in (text, mel, pos_text, pos_mel, stop_token))
+    mel_input, pos_in = decoder_inputs(mel, pos_mel, hp.reduction_rate)
+    src_mask, trg_mask = create_masks(pos_text, pos_in)
+    fused = isinstance(optimizer, FusedAdam)
+    outputs = model(text, mel_input.contiguous(), src_mask, trg_mask, None)
+    optimizer.zero_grad()
+    loss, parts = compute_losses(hp, outputs, mel, stop_token)
+    step += 1
+    accum = int(getattr(hp, "accum_grad", 1))
+    (loss / accum if accum != 1 else loss).backward()
+    if step % accum == 0:
+        if fused:
+            optimizer.host_update()                             # Adam's step count advances only when it steps
+            optimizer.launch()                                  # global-norm clip fused into the Adam kernel
+        else:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), hp.clip)
+            optimizer.step()
+            model.rt.invalidate()
+    model.rt.get_rng(text.device).advance()
+    return loss, parts, step
+
+
+def train_loop(model, optimizer, step, epoch, hp, dataloader, log_every=1):
+    for d in dataloader:
+        loss, parts, step = train_step(model, optimizer, step, d, hp)
+        if (step - 1) % log_every == 0:
+            print(f"step {step - 1}")
+            print(f"loss_token = {parts['token'].item()}")
+            print(f"loss_frame_before = {parts['mel'].item()}")
+            print(f"loss_frame_after = {parts['post_mel'].item()}")
+            print(f"loss_total = {loss.item()}")
+            print(f"batch size = {d[1].shape[0]}")
+            assert not torch.isnan(loss), "loss is nan"
+            sys.stdout.flush()
+    if (epoch + 1) >= (hp.max_epoch - 10) or (epoch + 1) % hp.save_per_epoch >= (hp.save_per_epoch - 10) or \
+            (epoch + 1) % hp.save_per_epoch == 0:
+        torch.save(model.state_dict(), hp.save_dir + "/network.epoch{}".format(epoch + 1))
+    if (epoch + 1) % hp.save_per_epoch == 0:
+        torch.save(optimizer.state_dict(), hp.save_dir + "/network.optimizer.epoch{}".format(epoch + 1))
+    return step
+
+
+def build_model(hp):
+    """argument wiring of the reference (train.py:83-90)."""
+    return Transformer(hp=hp, src_vocab=hp.vocab_size, trg_vocab=hp.mel_dim, d_model_encoder=hp.d_model_encoder,
+                       N_e=hp.n_layer_encoder, n_head_encoder=hp.n_head_encoder,
+                       ff_conv_kernel_size_encoder=hp.ff_conv_kernel_size_encoder, concat_after_encoder=hp.concat_after_encoder,
+                       d_model_decoder=hp.d_model_decoder, N_d=hp.n_layer_decoder, n_head_decoder=hp.n_head_decoder,
+                       ff_conv_kernel_size_decoder=hp.ff_conv_kernel_size_decoder, concat_after_decoder=hp.concat_after_decoder,
+                       reduction_rate=hp.reduction_rate, dropout=hp.dropout, dropout_prenet=hp.dropout_prenet,
+                       dropout_postnet=hp.dropout_postnet, multi_speaker=hp.is_multi_speaker, spk_emb_dim=hp.spk_emb_dim,
+                       spk_emb_architecture=hp.spk_emb_architecture)
+
+
+def run_training(hp):
+    model = build_model(hp).to(DEVICE)
+    model.apply(init_weight)
+    model.train()
+    optimizer = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=hp.clip)
+    os.makedirs(hp.save_dir, exist_ok=True)
+    dataset_train = datasets.TrainDatasets(hp.train_script, hp, alignment_pred=False, pitch_pred=False, energy_pred=False,
+                                           accent_emb=False)
+    assert (hp.batch_size is None) != (hp.max_seqlen is None)
+    if hp.batch_size is not None:
+        sampler = datasets.NumBatchSampler(dataset_train, hp.batch_size)
+    else:
+        sampler = datasets.LengthsBatchSampler(dataset_train, hp.max_seqlen, hp, hp.lengths_file, shuffle=True, shuffle_one_time=False)
+    if hp.loaded_epoch is not None:
+        start_epoch = hp.loaded_epoch
+        print("epoch {} loaded".format(hp.loaded_epoch))
+        model.load_state_dict(load_model(os.path.join(hp.loaded_dir, "network.epoch{}".format(hp.loaded_epoch)), map_location=DEVICE))
+        model.rt.invalidate()
+        loaded = torch.load(os.path.join(hp.loaded_dir, "network.optimizer.epoch{}".format(hp.loaded_epoch)), map_location=DEVICE,
+                            weights_only=True)
+        optimizer.load_state_dict(loaded)
+        step = int(loaded["state"][0]["step"]) * int(getattr(hp, "accum_grad", 1))
+    else:
+        start_epoch, step = 0, 1
+    for epoch in range(start_epoch, hp.max_epoch):
+        dataloader = DataLoader(dataset_train, batch_sampler=sampler, num_workers=int(getattr(hp, "num_workers", 4)),
+                                collate_fn=datasets.collate_fn)
+        start_time = time.time()
+        step = train_loop(model, optimizer, step, epoch, hp, dataloader, max(1, int(getattr(hp, "log_every", 1))))
+        print("EPOCH {} end".format(epoch + 1))
+        print(f"elapsed time {time.time() - start_time}")
+    return step
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--hp_file", type=str, default="hparams.py")
+    args = parser.parse_args(argv)
+    hp.configure(args.hp_file)
+    fill_variables(hp)
+    log_config(hp)
+    run_training(hp)
+
+
+if __name__ == "__main__":
+    main()
