@@ -28,6 +28,8 @@ extern "C" {
 
 #define FS2_F32 0
 #define FS2_BF16 1
+#define FS2_FP8 2      /* fs2_gemm operands only: A and B OCP fp8 e4m3 (one byte per element) */
+#define FS2_BF8_FP8 3  /* fs2_gemm operands only: A OCP fp8 e5m2 (a gradient), B e4m3 (weights) */
 
 #define FS2_OK 0
 #define FS2_EINVAL (-1)   /* bad shape / alignment / argument */
@@ -81,6 +83,10 @@ typedef struct FS2Gemm {
                               spread so that the workgroups sharing a row slab of A run at the same time on one XCD (one
                               L2): for tall products with 2..8 column tiles, where a 128-row slab of A would otherwise be
                               fetched from HBM once per column tile */
+    /* fp8 operands (dtype FS2_FP8 / FS2_BF8_FP8; row-major tall products on the 16-wave kernel: K, lda, ldb multiples of 16):
+     * DEVICE scalars multiplied into alpha -- the de-quantisation factors fs2_quantize_fp8 wrote for A and B (NULL = 1). */
+    const float* scale_a;
+    const float* scale_b;
 } FS2Gemm;
 
 int fs2_gemm(const FS2Gemm* g, void* stream);
@@ -118,6 +124,14 @@ int fs2_colsum(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* o
  * tensor (the q / v / k bias gradients of a fused projection) go to vectors that sit seg_stride floats apart. */
 int fs2_colsum_segmented(const void* x, int dtype, int64_t M, int N, int64_t ldx, float* out, int seg_cols,
                          int64_t seg_stride, void* stream);
+
+/* Per-tensor fp8 quantisation with current scaling (BASELINE.json configs[4]: fp8 MFMA GEMMs).
+ *   fs2_amax:          state[0] = max(state[0], max |src|)   (state[0] zeroed by the caller beforehand)
+ *   fs2_quantize_fp8:  scale = 2^k, the largest power of two with state[0] * scale < 2^8 (e4m3, bf8 = 0) or 2^15 (e5m2,
+ *                      bf8 = 1); dst[i] = round-to-nearest-even fp8 of src[i] * scale (saturating); state[1] = 1 / scale, the
+ *                      factor fs2_gemm takes as FS2Gemm.scale_a / scale_b.  n is rounded up to 16 internally; dst must hold it. */
+int fs2_amax(const void* src, int src_dtype, int64_t n, float* state, void* stream);
+int fs2_quantize_fp8(const void* src, int src_dtype, void* dst, int bf8, int64_t n, float* state, void* stream);
 
 /* nn.Embedding gather / scatter-add (Models/encoder.py:55,84; Models/varianceadaptor.py:57,62). */
 int fs2_embedding_fwd(const int64_t* ids, const float* table, void* out, int out_dtype, int64_t n, int d, void* stream);

@@ -447,6 +447,28 @@ def bce_logits_bwd(x, y, pos_weight, gscale, dx_dtype):
     return (d * _f(gscale) / x.numel()).to(dx_dtype)
 
 
+def quantize_fp8(x, bf8=False):
+    """fs2_amax + fs2_quantize_fp8 (csrc/fp8.hip): per-tensor current scaling with a power-of-two scale 2^k, k the largest
+    integer with amax * 2^k < 2^8 (e4m3) / 2^15 (e5m2); round-to-nearest-even OCP fp8 codes as uint8; state = [amax, 2^-k]."""
+    xf = x.detach().float()
+    amax = xf.abs().max()
+    log2max, fmax, dt = (15, 57344.0, torch.float8_e5m2) if bf8 else (8, 448.0, torch.float8_e4m3fn)
+    if float(amax) > 0:
+        _, ex = torch.frexp(amax)                 # amax = m * 2^ex, m in [0.5, 1)  ->  exponent e = ex - 1
+        k = log2max - 1 - (int(ex) - 1)
+    else:
+        k = 0
+    k = max(-126, min(126, k))
+    y = (xf * (2.0 ** k)).clamp(-fmax, fmax)
+    q = y.to(dt).view(torch.uint8)
+    return q, torch.tensor([float(amax), 2.0 ** (-k)], dtype=torch.float32)
+
+
+def dequantize_fp8(q, state, bf8=False):
+    dt = torch.float8_e5m2 if bf8 else torch.float8_e4m3fn
+    return q.view(dt).to(_COMPUTE) * float(state[1])
+
+
 # ------------------------------------------------------------------------------------------------ variance adaptor
 def length_regulate_fwd(x, dur, T):
     """LengthRegulator.LR/expand + pad (Models/varianceadaptor.py:141-184,233-249)."""

@@ -803,3 +803,42 @@ def test_dropout_and_bce(ops, dtype):
     # against torch itself
     ref = torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), y, pos_weight=torch.tensor(5.0))
     assert abs(res["cuda"][3].item() - ref.item()) <= 2e-5 * abs(ref.item()) + (1e-2 if dtype == torch.bfloat16 else 0)
+
+
+# ------------------------------------------------------------------------------------------------ fp8 operand mode (configs[4])
+@pytest.mark.parametrize("bf8", [False, True])
+@pytest.mark.parametrize("src_dtype", DT)
+def test_fp8_quantisation_is_bit_exact(ops, bf8, src_dtype):
+    """fs2_amax + fs2_quantize_fp8 against torch's own float8 conversion: the power-of-two scale and every code byte"""
+    for scale, n in ((1.0, 5000), (3e-5, 4099), (700.0, 64), (0.0, 33)):
+        x = rnd(n, dtype=src_dtype, seed=3, scale=scale)
+        q, st = ops.quantize_fp8(x.cuda(), bf8)
+        qr, sr = P.quantize_fp8(x, bf8)
+        assert torch.equal(st.cpu(), sr), (st, sr)
+        assert torch.equal(q.cpu(), qr), f"{int((q.cpu() != qr).sum())} of {n} codes differ (bf8={bf8}, scale={scale})"
+
+
+@pytest.mark.parametrize("M,N,K", [(1500, 256, 256), (2048, 1024, 272), (1111, 264, 1024)])
+def test_fp8_gemm_against_the_dequantised_product(ops, M, N, K):
+    """fs2_gemm with fp8 operands (e4m3 x e4m3 forward, e5m2 x e4m3 backward): exact products of the fp8 values summed in fp32,
+    scaled by the two de-quantisation factors, + bias / ReLU, against the fp64 product of the dequantised operands"""
+    x, w, bias = rnd(M, K, dtype=torch.bfloat16, seed=1), rnd(N, K, dtype=torch.bfloat16, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    for backward in (False, True):
+        ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = True, backward
+        try:
+            out = ops.linear(x.cuda(), w.cuda(), bias=bias.cuda(), relu=not backward, out_dtype=torch.float32)
+            assert ops.lib().fs2_gemm_last_tile() == 192
+        finally:
+            ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = False, False
+        xq, sx = P.quantize_fp8(x, backward)
+        wq, sw = P.quantize_fp8(w, False)
+        ref = P.dequantize_fp8(xq, sx, backward) @ P.dequantize_fp8(wq, sw).t() + bias.double()
+        if not backward:
+            ref = ref.clamp(min=0)
+        close(out, ref.float(), f"fp8 gemm backward={backward}", rtol=2e-5, atol=2e-5 * K ** 0.5)
+        # and the quantisation error itself stays within the format's resolution (e4m3: 2^-4 relative per operand)
+        full = x.double() @ w.double().t() + bias.double()
+        if not backward:
+            full = full.clamp(min=0)
+        rel = float((out.cpu().double() - full).norm() / full.norm())
+        assert rel < (0.08 if backward else 0.04), rel

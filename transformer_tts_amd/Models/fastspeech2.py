@@ -5,6 +5,8 @@ computed by hand-written gfx950 kernels."""
 import torch
 import torch.nn as nn
 
+from .. import ops
+
 from .encoder import Encoder
 from .functional import Runtime
 from .postnets import PostConvNet
@@ -35,6 +37,7 @@ class FastSpeech2(nn.Module):
         amp = bool(getattr(hp, "amp", False))
         self.rt = Runtime(torch.bfloat16 if amp else torch.float32, seed=int(getattr(hp, "seed", 1234)))
         self.rt.return_attn = bool(getattr(hp, "return_attn", True))
+        self.rt.fp8 = amp and bool(getattr(hp, "fp8", False))     # BASELINE.json configs[4]: fp8 MFMA GEMMs
         self.encoder = Encoder(src_vocab, d_model_encoder, N_e, n_head_encoder, ff_conv_kernel_size_encoder,
                                concat_after_encoder, dropout, runtime=self.rt)
         self.use_sq_vae = False
@@ -53,6 +56,7 @@ class FastSpeech2(nn.Module):
         assert (self.training and not pitch_perturbation) or (not self.training)
         if fix_mask is not None:
             raise NotImplementedError("fix_mask is outside the accelerated path (SURVEY section 8)")
+        ops.FP8_MODE["on"] = self.rt.fp8
         self.rt.refresh(self)           # all weight shadows in one launch (no-op if the weights did not change)
         e_outputs, attn_enc = self.encoder(src, src_mask)
         if d_target is not None:

@@ -39,6 +39,7 @@ class Runtime:
         self.scratch = {}
         self.dp = None           # parallel.DataParallel or None
         self.return_attn = True
+        self.fp8 = False         # hp.fp8 (with hp.amp): row-major products quantise their operands to fp8 (ops.FP8_MODE)
         # weight-gradient GEMMs (and their scratch handling) run on a second HIP stream, concurrently with the
         # data-gradient chain of the same backward: they only feed the optimizer
         self.overlap_wgrad = True
@@ -205,6 +206,18 @@ class Runtime:
         return buf
 
 
+def fp8_bwd(fn):
+    """marks a hand-written backward for the fp8 operand mode: row-major products launched inside it quantise their A operand
+    (a gradient) to e5m2 instead of e4m3 (ops.FP8_MODE)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *grads):
+        with ops.fp8_backward():
+            return fn(ctx, *grads)
+    return wrapped
+
+
 def grad_of(p):
     """fp32 buffer the kernels accumulate d(loss)/dp into (the arena view when FusedAdam owns it)."""
     if p.grad is None:
@@ -327,6 +340,7 @@ class EncoderStackFunction(torch.autograd.Function):
         return h, attn_out
 
     @staticmethod
+    @fp8_bwd
     def backward(ctx, dh, _dattn):
         enc, sv, layers = ctx.enc, ctx.sv, ctx.layers
         rt = enc.rt
@@ -440,6 +454,7 @@ class VariancePredictorFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @fp8_bwd
     def backward(ctx, dout):
         mod, s = ctx.mod, ctx.sv
         rt = mod.rt
@@ -472,6 +487,7 @@ class LengthRegulatorFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @fp8_bwd
     def backward(ctx, dout):
         return ops.length_regulate_bwd(dout.contiguous(), ctx.starts, ctx.L), None, None
 
@@ -488,6 +504,7 @@ class BucketEmbedAddFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @fp8_bwd
     def backward(ctx, dout):
         va = ctx.va
         dout = dout.contiguous()
@@ -553,6 +570,7 @@ class PostNetFunction(torch.autograd.Function):
         return mel_pred, post
 
     @staticmethod
+    @fp8_bwd
     def backward(ctx, dmel, dpost):
         mod, s = ctx.mod, ctx.sv
         rt = mod.rt
@@ -617,6 +635,7 @@ class L1LossFunction(torch.autograd.Function):
         return loss[0]
 
     @staticmethod
+    @fp8_bwd
     def backward(ctx, g):
         gs = g.reshape(1).to(torch.float32).contiguous()
         return ops.l1_bwd(ctx.pred, ctx.target.contiguous(), gs, ctx.pred.dtype, ctx.mode), None, None

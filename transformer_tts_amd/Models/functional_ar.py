@@ -8,7 +8,7 @@ import math
 import torch
 
 from .. import ops
-from .functional import _conv_wgrad, _linear_wgrad, _tp, grad_of
+from .functional import _conv_wgrad, _linear_wgrad, _tp, fp8_bwd, grad_of
 
 
 def _heads(x2, B, t, n, H, dk):
@@ -111,6 +111,7 @@ class DecoderStackFunction(torch.autograd.Function):
         return h, a1_out, a2_out
 
     @staticmethod
+    @fp8_bwd
     def backward(ctx, dh, _da1, _da2):
         dec, sv, layers = ctx.dec, ctx.sv, ctx.layers
         attn1, attn1_drop, attn2, attn2_drop = ctx.attn
@@ -238,6 +239,7 @@ class LinearFunction(torch.autograd.Function):
         return ops.linear(x2, rt.w_fwd(mod.weight), mod.bias.detach(), out_dtype=torch.float32 if out_fp32 else None).view(B, t, N)
 
     @staticmethod
+    @fp8_bwd
     def backward(ctx, dy):
         mod, rt, x2 = ctx.mod, ctx.rt, ctx.x2
         B, t, K, N = ctx.shape
@@ -275,6 +277,7 @@ class BCEWithLogitsFunction(torch.autograd.Function):
         return loss[0]
 
     @staticmethod
+    @fp8_bwd
     def backward(ctx, g):
         gs = g.reshape(1).to(torch.float32).contiguous()
         return ops.bce_logits_bwd(ctx.x, ctx.y, ctx.pw, gs, ctx.x.dtype), None, None

@@ -4,6 +4,8 @@ kernels.  Same constructor / forward signature, same attribute names (state_dict
 import torch
 import torch.nn as nn
 
+from .. import ops
+
 from .decoder import Decoder
 from .encoder import Encoder
 from .functional import Runtime
@@ -26,6 +28,7 @@ class Transformer(nn.Module):
         amp = bool(getattr(hp, "amp", False))
         self.rt = Runtime(torch.bfloat16 if amp else torch.float32, seed=int(getattr(hp, "seed", 1234)))
         self.rt.return_attn = bool(getattr(hp, "return_attn", True))
+        self.rt.fp8 = amp and bool(getattr(hp, "fp8", False))     # BASELINE.json configs[4]: fp8 MFMA GEMMs
         self.encoder = Encoder(src_vocab, d_model_encoder, N_e, n_head_encoder, ff_conv_kernel_size_encoder, concat_after_encoder,
                                dropout=dropout, runtime=self.rt)
         self.linear = nn.Linear(d_model_encoder, d_model_decoder) if d_model_encoder != d_model_decoder else None
@@ -40,6 +43,7 @@ class Transformer(nn.Module):
         mask as the reference's create_masks builds it (train.py:38-58).  Returns the reference's 6-tuple
         (outputs_prenet, outputs_postnet, stop_token, attn_enc, attn_dec_dec, attn_dec_enc)."""
         assert spkr_emb is None, "speaker embeddings are outside the accelerated path"
+        ops.FP8_MODE["on"] = self.rt.fp8
         self.rt.refresh(self)
         e_outputs, attn_enc = self.encoder(src, src_mask)
         if self.linear is not None:

@@ -613,6 +613,23 @@ int launch(const FS2Gemm& g, hipStream_t st) {
 extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
     FS2_REQUIRE(gp != nullptr, "fs2_gemm: null descriptor");
     FS2Gemm g = *gp;
+    if (g.dtype == FS2_FP8 || g.dtype == FS2_BF8_FP8) {     // one-byte operands: the 16-wave LDS-DMA kernel only
+        FS2_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C, "fs2_gemm: empty problem / null operand");
+        FS2_REQUIRE(fs2_aligned16(g.A) && fs2_aligned16(g.B) && fs2_aligned16(g.C), "fs2_gemm: operands must be 16-byte aligned");
+        FS2_REQUIRE(g.c_dtype == FS2_F32 || g.c_dtype == FS2_BF16, "fs2_gemm: fp8 operands write fp32 or bf16");
+        FS2_REQUIRE(g.ldc % 8 == 0 && g.N % 8 == 0, "fs2_gemm: fp8 operands need N and ldc in multiples of 8");
+        if (g.split_k < 1) g.split_k = 1;
+        if (g.batch1 < 1) g.batch1 = 1;
+        if (g.batch2 < 1) g.batch2 = 1;
+        if (g.conv == 0) { g.taps = 1; g.pad = 0; if (g.seq_len <= 0) g.seq_len = 1; }
+        if (g.conv == 1) FS2_REQUIRE(g.taps >= 1 && g.seq_len > 0, "fs2_gemm: conv=1 needs taps, seq_len");
+        if (g.bias) FS2_REQUIRE(fs2_aligned16(g.bias), "fs2_gemm: bias must be 16-byte aligned");
+        int rc = FS2_OK;
+        if (fs2_gemm_big_try(g, (hipStream_t)stream, &rc)) return rc;
+        fs2_set_error("fs2_gemm: fp8 operands need a row-major un-batched product with K, lda, ldb multiples of 16, no accumulate / "
+                      "split-K, a compiled epilogue combination and 32-bit addressable operands");
+        return FS2_EINVAL;
+    }
     FS2_REQUIRE(g.dtype == FS2_F32 || g.dtype == FS2_BF16, "fs2_gemm: bad dtype %d", g.dtype);
     FS2_REQUIRE(g.c_dtype == FS2_F32 || g.c_dtype == g.dtype, "fs2_gemm: c_dtype must be f32 or the operand dtype");
     FS2_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "fs2_gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);

@@ -35,7 +35,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr unsigned OOB = 0x80000000u;
-constexpr int BIG_COLSTAT_N = 1024;
+constexpr int BIG_COLSTAT_N = 2048;      // columns whose statistics a workgroup accumulates in LDS (2 floats each)
 constexpr int NW = 16, NT = 1024, BN = 256;
 
 // epilogue variants compiled in (template bits): the operands a launch does not have cost nothing
@@ -61,11 +61,14 @@ extern thread_local int g_last_tile;     // gemm.hip
 
 extern "C" void fs2_debug_gemm_big_timer(unsigned long long* buf) { g_big_dbg = buf; }
 
-template <typename TC, int WTM, int EPI, bool STAMP>
+template <typename TC, int WTM, int EPI, bool STAMP, int OPK>
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, const int tilesM, const int tilesN, unsigned long long* dbg) {
     typedef BG<WTM> G;
     constexpr int MT = G::MT, BM = G::BM, AI = G::AI, BI = G::BI;
     constexpr int ESC = (int)sizeof(TC);
+    // operands: OPK 0 = bf16 x bf16; 1 = fp8 e4m3 x e4m3; 2 = bf8 e5m2 (A: a gradient) x fp8 e4m3 (B: weights).  One byte per
+    // element doubles the k extent of a 128-byte stage row (128 instead of 64) and of a 16-byte chunk (16 instead of 8).
+    constexpr int ES = OPK == 0 ? 2 : 1, EPC = 16 / ES, BK = 128 / ES;
     constexpr bool HAS_MASK = (EPI & EPI_MASK) != 0, RES_F32 = (EPI & EPI_RES_F32) != 0, RES_BF16 = (EPI & EPI_RES_BF16) != 0;
     constexpr bool STATS = (EPI & EPI_STATS) != 0, SUMSQ = (EPI & EPI_SUMSQ) != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
     const int nmine = items > slot ? (items - slot + nslots - 1) / nslots : 0;
     if (nmine == 0) return;
     const bool conv = p.conv == 1;
-    const int nkt = (p.K + 63) >> 6;
+    const int nkt = (p.K + BK - 1) / BK;
     const int ntot = (conv ? p.taps : 1) * nkt;
     const int nst = nmine * ntot;
     const int pad = conv ? p.pad : 0;
@@ -94,14 +97,14 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
 
     // conv: the descriptor base is moved back by `pad` rows so that the scalar stage offset (tap*lda + kb) is never negative
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<const bf16_t*>(p.A) - (int64_t)pad * lda), 0, 0x7FFFFFF0, 0x00020000);
+        (void*)(reinterpret_cast<const unsigned char*>(p.A) - (int64_t)pad * lda * ES), 0, 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFF0, 0x00020000);
 
     // ---- LDS-DMA source coordinates of this lane: instruction i of this wave covers tile rows 8*(i*NW + wave) .. +7;
     //      the lane fetches logical chunk (lane&7) ^ f(row) of row lane>>3 of those (swizzle on the source side)
     auto dma_row = [&](int i) { return 8 * (i * NW + wave) + (lane >> 3); };
-    auto a_k8 = [&](int i) { return ((lane & 7) ^ fA(dma_row(i))) * 8; };
-    auto b_k8 = [&](int i) { return ((lane & 7) ^ fB(dma_row(i))) * 8; };
+    auto a_k8 = [&](int i) { return ((lane & 7) ^ fA(dma_row(i))) * EPC; };
+    auto b_k8 = [&](int i) { return ((lane & 7) ^ fB(dma_row(i))) * EPC; };
 
     // ---- load cursor
     int lj = slot, lst = 0, ltap = 0, lkb = 0, lleft = nmine;
@@ -113,19 +116,19 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int m = m0 + dma_row(i);
-            voffA[i] = (m < p.M) ? (unsigned)((m * lda + a_k8(i)) * 2) : OOB;
+            voffA[i] = (m < p.M) ? (unsigned)((m * lda + a_k8(i)) * ES) : OOB;
             tA[i] = conv ? (m % p.seq_len) - pad : 0;
         }
 #pragma unroll
         for (int i = 0; i < BI; ++i) {
             const int n = n0 + dma_row(i);
-            voffB[i] = (n < p.N) ? (unsigned)((n * ldb + b_k8(i)) * 2) : OOB;
+            voffB[i] = (n < p.N) ? (unsigned)((n * ldb + b_k8(i)) * ES) : OOB;
         }
     };
     auto issue = [&](int buf) __attribute__((always_inline)) {
         const int kb = lkb, tap = ltap;
-        const int sA = (tap * lda + kb) * 2;
-        const int sB = (tap * p.K + kb) * 2;
+        const int sA = (tap * lda + kb) * ES;
+        const int sB = (tap * p.K + kb) * ES;
         unsigned char* base = smem + buf * G::STAGE + 1024 * wave;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
             const bool ok = (voffB[i] != OOB) && (kb + b_k8(i) < p.K);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + G::A_BYTES + 1024 * NW * i), 16, (int)(ok ? voffB[i] : OOB), sB, 0, 0);
         }
-        lkb += 64;
+        lkb += BK;
         if (lkb >= p.K) { lkb = 0; ++ltap; }
         if (++lst == ntot) {
             lst = 0; ltap = 0; lkb = 0;
@@ -152,13 +155,18 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
     };
 
     // ---- fragment read addresses (lane part; A tile it adds it*2048, weight tile jt adds jt*512, stage buffer b adds b*STAGE)
-    int rdA[2], rdB[2];
+    // bf16: k-step ks (32 k = 64 B) of a row is chunks 4ks .. 4ks+3, lane group g takes chunk 4ks + g (8 elements);
+    // fp8: k-step ks (32 k = 32 B) is chunks 2ks, 2ks+1, lane group g takes the 8 bytes (g&1) of chunk 2ks + (g>>1)
+    constexpr int NKS = ES == 2 ? 2 : 4;
+    int rdA[NKS], rdB[NKS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
         const int ra = wr * WTM + i16;
         const int rb = wc * 64 + 16 * (i16 >> 2) + (i16 & 3);
-        rdA[ks] = ra * 128 + (((ks * 4 + g) ^ fA(ra)) << 4);
-        rdB[ks] = G::A_BYTES + rb * 128 + (((ks * 4 + g) ^ fB(rb)) << 4);      // fB does not depend on jt (bits 2,3 of the row)
+        const int ch = ES == 2 ? ks * 4 + g : 2 * ks + (g >> 1);
+        const int sub = ES == 2 ? 0 : 8 * (g & 1);
+        rdA[ks] = ra * 128 + ((ch ^ fA(ra)) << 4) + sub;
+        rdB[ks] = G::A_BYTES + rb * 128 + ((ch ^ fB(rb)) << 4) + sub;      // fB does not depend on jt (bits 2,3 of the row)
     }
 
     f32x4 acc[MT][4];
@@ -245,6 +253,8 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bias[4 * j + r] = __uint_as_float(braw[j][r]);
+            // fp8 operands: the per-tensor de-quantisation factors live on the device (written by fs2_quantize_fp8)
+            const float alpha = p.alpha * (p.scale_a != nullptr ? *p.scale_a : 1.f) * (p.scale_b != nullptr ? *p.scale_b : 1.f);
             float cs[STATS ? 16 : 1], cq[SUMSQ ? 16 : 1];
             if constexpr (STATS) {
 #pragma unroll
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
                 float v[16];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
-                    float t = acc[it][c >> 2][c & 3] * p.alpha + bias[c];
+                    float t = acc[it][c >> 2][c & 3] * alpha + bias[c];
                     if (p.relu) t = fmaxf(t, 0.f);
                     if constexpr (HAS_MASK) {
                         const unsigned w = mraw[it][c >> 3][(c >> 1) & 3];
@@ -346,18 +356,37 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
         }
         if (s == nst) break;
         const unsigned char* lb = smem + buf * G::STAGE;
+        if constexpr (ES == 2) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[MT], fb[4];
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[MT], fb[4];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(lb + rdA[ks] + i * 2048);
+                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(lb + rdA[ks] + i * 2048);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rdB[ks] + j * 512);
+                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rdB[ks] + j * 512);
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                long fa[MT], fb[4];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const long*>(lb + rdA[ks] + i * 2048);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const long*>(lb + rdB[ks] + j * 512);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // swapped operands: MFMA A = weights (always e4m3), MFMA B = activations (e4m3) or gradients (e5m2)
+                        if constexpr (OPK == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
         if (++cst == ntot) { pending = true; pj = cj; cst = 0; cj += nslots; }
         stamp(t_mma);
@@ -389,14 +418,14 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
 
 namespace {
 
-template <typename TC, int WTM, int EPI, bool STAMP>
+template <typename TC, int WTM, int EPI, bool STAMP, int OPK>
 int launch_big2(const FS2Gemm& g, hipStream_t st) {
     typedef BG<WTM> G;
     const int tilesM = (g.M + G::BM - 1) / G::BM, tilesN = (g.N + BN - 1) / BN;
     const int lds = G::SMEM + ((EPI & EPI_STATS) ? 2 * BIG_COLSTAT_N * 4 : 0);
     static bool attr_set = false;          // > 64 KiB of dynamic LDS must be allowed once per kernel
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_kernel<TC, WTM, EPI, STAMP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_kernel<TC, WTM, EPI, STAMP, OPK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM + 2 * BIG_COLSTAT_N * 4) != hipSuccess) {
             fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the large-tile kernel");
             return FS2_ELAUNCH;
@@ -405,25 +434,27 @@ int launch_big2(const FS2Gemm& g, hipStream_t st) {
     }
     const long per_xcd = (long)((tilesM + 7) / 8) * tilesN;
     const int grid = 8 * (int)(per_xcd < 32 ? per_xcd : 32);
-    hipLaunchKernelGGL((fs2_gemm_big_kernel<TC, WTM, EPI, STAMP>), dim3(grid), dim3(NT), lds, st, g, tilesM, tilesN, g_big_dbg);
+    hipLaunchKernelGGL((fs2_gemm_big_kernel<TC, WTM, EPI, STAMP, OPK>), dim3(grid), dim3(NT), lds, st, g, tilesM, tilesN, g_big_dbg);
     FS2_CHECK_LAUNCH("fs2_gemm(big)");
     return FS2_OK;
 }
 
-template <typename TC, int WTM>
+template <typename TC, int WTM, int OPK>
 int launch_big1(const FS2Gemm& g, hipStream_t st) {
     const int res = g.residual == nullptr ? 0 : (g.res_dtype == FS2_F32 ? EPI_RES_F32 : EPI_RES_BF16);
     const int epi = (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? (g.colstats_mode == 0 ? EPI_STATS | EPI_SUMSQ : EPI_STATS) : 0);
-    if (g_big_dbg != nullptr && epi == 0) return launch_big2<TC, WTM, 0, true>(g, st);
+    if constexpr (OPK == 0) {
+        if (g_big_dbg != nullptr && epi == 0) return launch_big2<TC, WTM, 0, true, OPK>(g, st);
+    }
     switch (epi) {      // the combinations the model uses; anything else stays on the 128-tile kernel (checked by the caller)
-        case 0: return launch_big2<TC, WTM, 0, false>(g, st);
-        case EPI_MASK: return launch_big2<TC, WTM, EPI_MASK, false>(g, st);
-        case EPI_STATS: return launch_big2<TC, WTM, EPI_STATS, false>(g, st);
-        case EPI_STATS | EPI_SUMSQ: return launch_big2<TC, WTM, EPI_STATS | EPI_SUMSQ, false>(g, st);
-        case EPI_MASK | EPI_STATS: return launch_big2<TC, WTM, EPI_MASK | EPI_STATS, false>(g, st);
-        case EPI_RES_F32: return launch_big2<TC, WTM, EPI_RES_F32, false>(g, st);
-        case EPI_RES_BF16: return launch_big2<TC, WTM, EPI_RES_BF16, false>(g, st);
-        case EPI_MASK | EPI_RES_F32: return launch_big2<TC, WTM, EPI_MASK | EPI_RES_F32, false>(g, st);
+        case 0: return launch_big2<TC, WTM, 0, false, OPK>(g, st);
+        case EPI_MASK: return launch_big2<TC, WTM, EPI_MASK, false, OPK>(g, st);
+        case EPI_STATS: return launch_big2<TC, WTM, EPI_STATS, false, OPK>(g, st);
+        case EPI_STATS | EPI_SUMSQ: return launch_big2<TC, WTM, EPI_STATS | EPI_SUMSQ, false, OPK>(g, st);
+        case EPI_MASK | EPI_STATS: return launch_big2<TC, WTM, EPI_MASK | EPI_STATS, false, OPK>(g, st);
+        case EPI_RES_F32: return launch_big2<TC, WTM, EPI_RES_F32, false, OPK>(g, st);
+        case EPI_RES_BF16: return launch_big2<TC, WTM, EPI_RES_BF16, false, OPK>(g, st);
+        case EPI_MASK | EPI_RES_F32: return launch_big2<TC, WTM, EPI_MASK | EPI_RES_F32, false, OPK>(g, st);
         default: break;
     }
     fs2_set_error("fs2_gemm(big): epilogue combination %d not compiled", epi);
@@ -447,8 +478,10 @@ bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     const char* e2 = getenv("FS2_GEMM_BIG_BM");
     const int mode = e1 ? atoi(e1) : 1;
     int bm = e2 ? atoi(e2) : 0;
-    if (mode == 0) return false;
-    if (g.dtype != FS2_BF16 || g.a_kmajor || g.b_kmajor || g.accumulate || g.conv > 1) return false;
+    if (mode == 0 && !(g.dtype == FS2_FP8 || g.dtype == FS2_BF8_FP8)) return false;
+    const bool fp8 = g.dtype == FS2_FP8 || g.dtype == FS2_BF8_FP8;
+    if ((g.dtype != FS2_BF16 && !fp8) || g.a_kmajor || g.b_kmajor || g.accumulate || g.conv > 1) return false;
+    if (fp8 && (g.K % 16 != 0 || g.lda % 16 != 0 || g.ldb % 16 != 0)) return false;
     if ((long)g.batch1 * g.batch2 * g.split_k != 1) return false;
     if (g.N % 8 != 0 || (g.colstats != nullptr && g.N > BIG_COLSTAT_N)) return false;
     if (g.conv == 1 && (g.pad < 0 || g.pad > g.taps)) return false;
@@ -468,15 +501,21 @@ bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     // (epilogues with masks / statistics keep more registers live: the 192-row tile runs them without spills)
     const double bias192 = (g.relu_mask != nullptr || g.colstats != nullptr) ? 0.10 : -0.02;
     if (bm != 192 && bm != 256) bm = fill(192) + bias192 > fill(256) ? 192 : 256;
-    if (mode == 1) {
+    if (mode == 1 && !fp8) {
         const long tiles = (long)((g.M + bm - 1) / bm) * tn;
         const long ktot = (long)(g.conv == 1 ? g.taps : 1) * g.K;
         (void)ktot;
         if (tiles < 128 || g.N < 192) return false;
     }
     const bool f32 = g.c_dtype == FS2_F32;
+    if (fp8) {          // one-byte operands: the 192-row tile only (keeps the number of kernel instances down)
+        g_last_tile = 192;
+        if (g.dtype == FS2_FP8) *rc = f32 ? launch_big1<float, 48, 1>(g, st) : launch_big1<bf16_t, 48, 1>(g, st);
+        else *rc = f32 ? launch_big1<float, 48, 2>(g, st) : launch_big1<bf16_t, 48, 2>(g, st);
+        return true;
+    }
     g_last_tile = bm;
-    if (bm == 192) *rc = f32 ? launch_big1<float, 48>(g, st) : launch_big1<bf16_t, 48>(g, st);
-    else *rc = f32 ? launch_big1<float, 64>(g, st) : launch_big1<bf16_t, 64>(g, st);
+    if (bm == 192) *rc = f32 ? launch_big1<float, 48, 0>(g, st) : launch_big1<bf16_t, 48, 0>(g, st);
+    else *rc = f32 ? launch_big1<float, 64, 0>(g, st) : launch_big1<bf16_t, 64, 0>(g, st);
     return true;
 }

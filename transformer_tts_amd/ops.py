@@ -38,6 +38,7 @@ class FS2Gemm(ctypes.Structure):
         ("batch2", ctypes.c_int32), ("conv", ctypes.c_int32), ("taps", ctypes.c_int32), ("pad", ctypes.c_int32),
         ("seq_len", ctypes.c_int32), ("alpha", ctypes.c_float), ("colstats_mode", ctypes.c_int32),
         ("tile_order", ctypes.c_int32),
+        ("scale_a", ctypes.c_void_p), ("scale_b", ctypes.c_void_p),
     ]
 
 
@@ -46,6 +47,8 @@ _P, _I, _L, _F, _U32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_f
 SIGNATURES = {
     "fs2_gemm": [ctypes.POINTER(FS2Gemm), _P],
     "fs2_gemm_last_tile": [],
+    "fs2_amax": [_P, _I, _L, _P, _P],
+    "fs2_quantize_fp8": [_P, _I, _P, _I, _L, _P, _P],
     "fs2_cast_permute": [_P, _P, _I, _I, _I, _L, _I, _I, _P],
     "fs2_permute_add": [_P, _P, _I, _I, _I, _I, _P],
     "fs2_cast": [_P, _I, _P, _I, _L, _P],
@@ -218,6 +221,57 @@ def _splitk_run(g, M, N, split, out, bias, relu, residual):
     return out
 
 
+# ---- fp8 operand mode (BASELINE.json configs[4]): per-tensor current scaling, e4m3 for activations / weights, e5m2 for gradients
+FP8, BF8_FP8 = 2, 3
+FP8_MODE = {"on": False, "backward": False}      # set by Runtime (hp.fp8) and by the autograd Functions' backward
+
+
+class fp8_backward:
+    """context of a hand-written backward: row-major products inside it quantise their A operand (a gradient) to e5m2"""
+
+    def __enter__(self):
+        self.prev = FP8_MODE["backward"]
+        FP8_MODE["backward"] = True
+
+    def __exit__(self, *exc):
+        FP8_MODE["backward"] = self.prev
+
+
+def quantize_fp8(x, bf8=False):
+    """x (bf16 / fp32, contiguous rows) -> (uint8 tensor of the same shape holding OCP e4m3 (or e5m2) codes, state) with
+    state = device float[2] {amax, 1/scale}; scale is the largest power of two that keeps amax * scale below 2^8 (2^15)."""
+    x = _c(x)
+    n = x.numel()
+    state = torch.zeros(2, dtype=torch.float32, device=x.device)
+    q = torch.empty(((n + 15) // 16 * 16,), dtype=torch.uint8, device=x.device)
+    _check(lib().fs2_amax(_p(x), _dt(x), n, _p(state), _stream()), "fs2_amax")
+    _check(lib().fs2_quantize_fp8(_p(x), _dt(x), _p(q), int(bf8), n, _p(state), _stream()), "fs2_quantize_fp8")
+    return q[:n].view(x.shape), state
+
+
+def _fp8_eligible(g, M, N, K_total_row, x, w, residual=None, relu_mask=None, stats=False):
+    """products the fp8 mode takes: bf16 operands, contiguous rows with K a multiple of 16, N a multiple of 8, enough rows for
+    the 16-wave kernel to make sense, and an epilogue combination that kernel is compiled for (gemm_big.hip epi_compiled)"""
+    if not (FP8_MODE["on"] and g.dtype == BF16 and M >= 1024 and N % 8 == 0 and g.K % 16 == 0 and x.stride(-1) == 1 and
+            w.stride(-1) == 1 and x.stride(-2) == x.shape[-1] and w.stride(-2) == w.shape[-1]):
+        return False
+    if stats and (N > 2048 or residual is not None):
+        return False
+    if residual is not None and relu_mask is not None and residual.dtype != torch.float32:
+        return False
+    return True
+
+
+def _fp8_operands(g, x2, w):
+    """quantise both operands of a row-major product and point the descriptor at them"""
+    xq, sx = quantize_fp8(x2, bf8=FP8_MODE["backward"])
+    wq, sw = quantize_fp8(w, bf8=False)
+    g.A, g.B, g.lda, g.ldb = _p(xq), _p(wq), xq.stride(-2), wq.stride(-2)
+    g.dtype = BF8_FP8 if FP8_MODE["backward"] else FP8
+    g.scale_a, g.scale_b = _p(sx[1:]), _p(sw[1:])
+    return (xq, sx, wq, sw)          # keep alive until the launch is enqueued (stream-ordered allocator reuse is safe after)
+
+
 def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, out_dtype=None,
            alpha=1.0, colsum=None):
     """out[M,N] = alpha * x[M,K] @ w[N,K]^T (+bias)(ReLU)(*mask>0)(+residual).  x, w: same dtype (f32 | bf16)."""
@@ -232,8 +286,10 @@ def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=
     split = _splitk_plan(M, N, K, g, relu_mask, colstats, colsum, alpha)
     if split > 1:
         return _splitk_run(g, M, N, split, out, bias, relu, residual)
+    keep = _fp8_operands(g, x, w) if _fp8_eligible(g, M, N, K, x, w, residual, relu_mask, colstats is not None or colsum is not None) else None
     _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha, colsum)
     _gemm_call(g)
+    del keep
     return out
 
 
@@ -258,8 +314,10 @@ def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, 
     if split > 1:
         _splitk_run(g, B * t, N, split, o2, bias, relu, r2)
         return out
+    keep = _fp8_operands(g, x2, w) if _fp8_eligible(g, B * t, N, C, x2, w, residual, relu_mask, colstats is not None or colsum is not None) else None
     _epilogue(g, o2, bias, relu, r2, m2, colstats, 1.0, colsum)
     _gemm_call(g)
+    del keep
     return out
 
 
