@@ -44,14 +44,17 @@ PEAK_HBM_GBS = 8000.0           # HBM3E spec peak (6.3 TB/s achievable), same ta
 POOL = 8                        # pre-built batches cycled
 
 
-def bench_hp(amp=True):
+def bench_hp(amp=True, workload="cfg2", fp8=False):
     from types import SimpleNamespace
     from golden_configs import _BASE, CONFIGS
     from transformer_tts_amd.utils.utils import fill_variables
     d = dict(_BASE)
     d.update(CONFIGS["bench"]["hp"])
+    if workload == "cfg4":      # BASELINE.json configs[4]: d_model 512, 6+6 FFT layers, batch 64 per GPU, fp8 MFMA GEMMs
+        d.update(batch_size=64, d_model_encoder=512, n_layer_encoder=6, n_head_encoder=4, d_model_decoder=512, n_layer_decoder=6,
+                 n_head_decoder=4)
     hp = SimpleNamespace(**d)
-    hp.amp, hp.dropout, hp.dropout_variance_adaptor = amp, 0.1, 0.5
+    hp.amp, hp.dropout, hp.dropout_variance_adaptor, hp.fp8 = amp, 0.1, 0.5, fp8
     fill_variables(hp, verbose=False)
     return hp
 
@@ -192,6 +195,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--gemm-report", type=str, default=None, help="write per-shape GEMM timings to this file")
     ap.add_argument("--no-overlap", action="store_true", help="keep the weight-gradient GEMMs on the main stream (profiling)")
+    ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2",
+                    help="cfg2 = BASELINE.json configs[1] (the headline, default); cfg4 = configs[4] (d_model 512, 6+6 layers, batch 64/GPU)")
+    ap.add_argument("--fp8", action="store_true", help="fp8 operand mode of the row-major GEMMs (configs[4]; not the headline)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -218,7 +224,8 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     ops.lib()
 
-    hp = bench_hp(amp=not args.fp32)
+    hp = bench_hp(amp=not args.fp32, workload=args.workload, fp8=args.fp8)
+    BATCH = hp.batch_size
     torch.manual_seed(1234)
     model = build_model(hp)
     model.apply(init_weight)
@@ -232,7 +239,7 @@ def main():
         opt.dp = DataParallel(model, opt.arena)
 
     # synthetic batches, resident in HBM before the timed region; different data on every rank
-    pool = [tuple(b.to(dev) if torch.is_tensor(b) else b for b in synthetic.benchmark_batch(2024 + 1000 * rank + i, 48))
+    pool = [tuple(b.to(dev) if torch.is_tensor(b) else b for b in synthetic.benchmark_batch(2024 + 1000 * rank + i, BATCH))
             for i in range(POOL)]
     frames = [int(b[5].sum()) for b in pool]
 
@@ -324,16 +331,21 @@ def main():
                         all_variants={"/".join(str(x) for x in k): dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), gbs=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
                                                          ms=round(v[1], 2), launches=v[2]) for k, v in agg.items()})
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             cpu = cpu_baseline(hp, synthetic.benchmark_batch(2024, 48))
         line = {
             "metric": "mel-frames/sec (train step) FastSpeech2 d_model=256", "value": round(done / dt, 1),
             "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
             "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: FastSpeech2 d_model=256, 4+4 FFT layers (H=2, k_enc=9, k_dec=1), "
-                                   "80-mel, batch 48/GPU (L_pad<=128, T_pad~925), fwd+bwd+clip+Adam, dropout 0.1/0.5/0.5",
-                       "global_batch": 48 * world, "parallelism": f"dp{world}", "padded_frames_per_step": 48 * 925,
+            "vs_baseline": None, "dtype": "f32" if args.fp32 else ("fp8" if args.fp8 else "bf16"), "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[1]: FastSpeech2 d_model=256, 4+4 FFT layers (H=2, k_enc=9, k_dec=1), "
+                                    "80-mel, batch 48/GPU (L_pad<=128, T_pad~925), fwd+bwd+clip+Adam, dropout 0.1/0.5/0.5")
+                       if args.workload == "cfg2" else
+                       ("BASELINE.json configs[4]: FastSpeech2 d_model=512, 6+6 FFT layers (H=4, k_enc=9, k_dec=1), 80-mel, batch "
+                        "64/GPU, fwd+bwd+clip+Adam, dropout 0.1/0.5/0.5, " + ("fp8 e4m3/e5m2 operands in the row-major GEMMs"
+                                                                              if args.fp8 else "bf16 operands")),
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}",
+                       "padded_frames_per_step": int(sum(b[1].shape[0] * b[1].shape[1] for b in pool) / len(pool)),
                        "launch": "hipGraph replay per batch shape" if use_graph else "eager"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -57,6 +57,8 @@ class FastSpeech2(nn.Module):
         if fix_mask is not None:
             raise NotImplementedError("fix_mask is outside the accelerated path (SURVEY section 8)")
         ops.FP8_MODE["on"] = self.rt.fp8
+        if self.rt.fp8:
+            ops.fp8_begin_step(src.device)
         self.rt.refresh(self)           # all weight shadows in one launch (no-op if the weights did not change)
         e_outputs, attn_enc = self.encoder(src, src_mask)
         if d_target is not None:

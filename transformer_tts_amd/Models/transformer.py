@@ -44,6 +44,8 @@ class Transformer(nn.Module):
         (outputs_prenet, outputs_postnet, stop_token, attn_enc, attn_dec_dec, attn_dec_enc)."""
         assert spkr_emb is None, "speaker embeddings are outside the accelerated path"
         ops.FP8_MODE["on"] = self.rt.fp8
+        if self.rt.fp8:
+            ops.fp8_begin_step(src.device)
         self.rt.refresh(self)
         e_outputs, attn_enc = self.encoder(src, src_mask)
         if self.linear is not None:

@@ -9,12 +9,31 @@ constexpr int TPB = 256;
 
 __device__ __forceinline__ float absf_bits(float v) { return __uint_as_float(__float_as_uint(v) & 0x7FFFFFFFu); }
 
+// 16 bytes per lane per load (8 bf16 / 4 f32): scalar 2-byte loads run these streaming kernels at less than half the rate
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { static constexpr int N = 4; typedef float4 type; };
+template <> struct Vec16<bf16_t> { static constexpr int N = 8; typedef bf16x8 type; };
+template <typename T> __device__ __forceinline__ void unpack16(const typename Vec16<T>::type& v, float* e);
+template <> __device__ __forceinline__ void unpack16<float>(const float4& v, float* e) { e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w; }
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const bf16x8& v, float* e) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) e[c] = (float)v[c];
+}
+
 template <typename T>
 __global__ __launch_bounds__(TPB) void amax_k(const T* __restrict__ x, int64_t n, float* __restrict__ state) {
+    constexpr int VN = Vec16<T>::N;
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-        const float v = absf_bits(to_f32<T>(x[i]));
-        m = (v == v) ? fmaxf(m, v) : m;          // NaNs do not define the range
+    const int64_t nv = n / VN;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
+        float e[VN];
+        unpack16<T>(reinterpret_cast<const typename Vec16<T>::type*>(x)[i], e);
+#pragma unroll
+        for (int c = 0; c < VN; ++c) { const float v = absf_bits(e[c]); m = (v == v) ? fmaxf(m, v) : m; }   // NaNs do not define the range
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - nv * VN)) {
+        const float v = absf_bits(to_f32<T>(x[nv * VN + threadIdx.x]));
+        m = (v == v) ? fmaxf(m, v) : m;
     }
     m = wave_max(m);
     // non-negative floats order like their bit patterns: integer atomicMax
@@ -39,25 +58,38 @@ __global__ __launch_bounds__(TPB) void quant_k(const T* __restrict__ x, unsigned
     float inv;
     const float scale = pow2_scale(state[0], LOG2MAX, &inv);
     if (blockIdx.x == 0 && threadIdx.x == 0) state[1] = inv;
-    const int64_t nw = (n + 3) >> 2;              // one 32-bit word = 4 fp8 per iteration
-    for (int64_t w = (int64_t)blockIdx.x * TPB + threadIdx.x; w < nw; w += (int64_t)gridDim.x * TPB) {
+    // 16 source elements -> one 16-byte store of fp8 codes per iteration (two or four 16-byte loads)
+    constexpr int VN = Vec16<T>::N;
+    const int64_t n16 = n >> 4;
+    auto pack = [&](const float* v) {
+        int word = 0;
+        float c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = fminf(fmaxf(v[j] * scale, -FMAX), FMAX);   // saturate (|t| < 2^LOG2MAX <= FMAX anyway; NaN -> NaN)
+        if constexpr (BF8) {
+            word = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], word, false);
+            word = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], word, true);
+        } else {
+            word = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], word, false);
+            word = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], word, true);
+        }
+        return (unsigned)word;
+    };
+    for (int64_t q = (int64_t)blockIdx.x * TPB + threadIdx.x; q < n16; q += (int64_t)gridDim.x * TPB) {
+        float e[16];
+#pragma unroll
+        for (int j = 0; j < 16 / VN; ++j) unpack16<T>(reinterpret_cast<const typename Vec16<T>::type*>(x)[q * (16 / VN) + j], e + j * VN);
+        uint4 o;
+        o.x = pack(e); o.y = pack(e + 4); o.z = pack(e + 8); o.w = pack(e + 12);
+        reinterpret_cast<uint4*>(dst)[q] = o;
+    }
+    // tail (< 16 elements): one word per thread of the first block
+    const int64_t t0 = n16 << 4;
+    if (blockIdx.x == 0 && threadIdx.x < 4 && t0 + 4 * threadIdx.x < n) {
         float v[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int64_t i = 4 * w + c;
-            float t = i < n ? to_f32<T>(x[i]) * scale : 0.f;
-            t = fminf(fmaxf(t, -FMAX), FMAX);     // saturate (the scale keeps |t| < 2^LOG2MAX <= FMAX anyway; NaN -> NaN)
-            v[c] = t;
-        }
-        int word = 0;
-        if constexpr (BF8) {
-            word = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], word, false);
-            word = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], word, true);
-        } else {
-            word = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], word, false);
-            word = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], word, true);
-        }
-        dst[w] = (unsigned)word;
+        for (int c = 0; c < 4; ++c) { const int64_t i = t0 + 4 * threadIdx.x + c; v[c] = i < n ? to_f32<T>(x[i]) : 0.f; }
+        dst[(t0 >> 2) + threadIdx.x] = pack(v);
     }
 }
 
@@ -71,8 +103,9 @@ inline int flat_grid(int64_t n) {
 extern "C" int fs2_amax(const void* src, int src_dtype, int64_t n, float* state, void* stream) {
     FS2_REQUIRE(src_dtype == FS2_F32 || src_dtype == FS2_BF16, "fs2_amax: bad dtype %d", src_dtype);
     FS2_REQUIRE(n > 0 && src && state, "fs2_amax: bad arguments");
-    if (src_dtype == FS2_F32) hipLaunchKernelGGL((amax_k<float>), dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, (const float*)src, n, state);
-    else hipLaunchKernelGGL((amax_k<bf16_t>), dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, (const bf16_t*)src, n, state);
+    FS2_REQUIRE(fs2_aligned16(src), "fs2_amax: src must be 16-byte aligned");
+    if (src_dtype == FS2_F32) hipLaunchKernelGGL((amax_k<float>), dim3(flat_grid((n + 3) >> 2)), dim3(TPB), 0, (hipStream_t)stream, (const float*)src, n, state);
+    else hipLaunchKernelGGL((amax_k<bf16_t>), dim3(flat_grid((n + 7) >> 3)), dim3(TPB), 0, (hipStream_t)stream, (const bf16_t*)src, n, state);
     FS2_CHECK_LAUNCH("fs2_amax");
     return FS2_OK;
 }
@@ -82,7 +115,8 @@ extern "C" int fs2_quantize_fp8(const void* src, int src_dtype, void* dst, int b
     FS2_REQUIRE(n > 0 && src && dst && state, "fs2_quantize_fp8: bad arguments");
     FS2_REQUIRE((reinterpret_cast<uintptr_t>(dst) & 3u) == 0, "fs2_quantize_fp8: dst must be 4-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(flat_grid((n + 3) >> 2)), block(TPB);
+    FS2_REQUIRE(fs2_aligned16(src) && fs2_aligned16(dst), "fs2_quantize_fp8: src and dst must be 16-byte aligned");
+    dim3 grid(flat_grid((n + 15) >> 4)), block(TPB);
     if (src_dtype == FS2_F32) {
         if (bf8) hipLaunchKernelGGL((quant_k<float, true>), grid, block, 0, st, (const float*)src, (unsigned*)dst, n, state);
         else hipLaunchKernelGGL((quant_k<float, false>), grid, block, 0, st, (const float*)src, (unsigned*)dst, n, state);

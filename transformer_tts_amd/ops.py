@@ -237,12 +237,33 @@ class fp8_backward:
         FP8_MODE["backward"] = self.prev
 
 
+_FP8_STATES = {"buf": None, "idx": 0}
+
+
+def fp8_begin_step(device, slots=4096):
+    """one zero-fill for all {amax, 1/scale} pairs of a training step (instead of one tiny fill per quantised tensor)"""
+    buf = _FP8_STATES["buf"]
+    if buf is None or buf.device != device:
+        buf = _FP8_STATES["buf"] = torch.zeros((slots, 2), dtype=torch.float32, device=device)
+    else:
+        buf.zero_()
+    _FP8_STATES["idx"] = 0
+
+
+def _fp8_state(device):
+    buf, i = _FP8_STATES["buf"], _FP8_STATES["idx"]
+    if buf is None or buf.device != device or i >= buf.shape[0]:
+        return torch.zeros(2, dtype=torch.float32, device=device)
+    _FP8_STATES["idx"] = i + 1
+    return buf[i]
+
+
 def quantize_fp8(x, bf8=False):
     """x (bf16 / fp32, contiguous rows) -> (uint8 tensor of the same shape holding OCP e4m3 (or e5m2) codes, state) with
     state = device float[2] {amax, 1/scale}; scale is the largest power of two that keeps amax * scale below 2^8 (2^15)."""
     x = _c(x)
     n = x.numel()
-    state = torch.zeros(2, dtype=torch.float32, device=x.device)
+    state = _fp8_state(x.device)
     q = torch.empty(((n + 15) // 16 * 16,), dtype=torch.uint8, device=x.device)
     _check(lib().fs2_amax(_p(x), _dt(x), n, _p(state), _stream()), "fs2_amax")
     _check(lib().fs2_quantize_fp8(_p(x), _dt(x), _p(q), int(bf8), n, _p(state), _stream()), "fs2_quantize_fp8")
