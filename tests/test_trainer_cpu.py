@@ -172,3 +172,27 @@ def test_epoch_with_frame_budget_batching(fake_ops, tmp_path, capsys):
     sizes = {int(l.split("=")[1]) for l in out.splitlines() if l.startswith("batch size")}
     assert len(sizes) > 1, f"frame-budget batches should differ in size, got {sizes}"
     assert os.path.exists(str(tmp_path / "lengths.npy"))
+
+
+def test_module_surface_functions_of_the_reference_trainer(fake_ops):
+    """npeak_mask / create_masks (all three task branches) / mse_loss_arelbo / loss_mel"""
+    import numpy as np
+    import torch.nn.functional as F
+    from types import SimpleNamespace
+    from transformer_tts_amd import train_fastspeech2 as T
+    m = T.npeak_mask(4)
+    assert m.shape == (1, 4, 4) and m.dtype == torch.bool
+    assert np.array_equal(m[0].cpu().numpy(), np.triu(np.ones((4, 4)), k=1) == 0)
+    pos_s, pos_t = torch.tensor([[1, 2, 3, 0]]), torch.tensor([[1, 2, 0]])
+    s, t = T.create_masks(pos_s, pos_t, task="fastspeech2")
+    assert s.shape == (1, 1, 4) and t.shape == (1, 1, 3) and t.tolist() == [[[True, True, False]]]
+    s, t = T.create_masks(pos_s.to(T.DEVICE), pos_t.to(T.DEVICE))
+    assert t.shape == (1, 3, 3) and t[0].cpu().tolist() == [[True, False, False], [True, True, False], [True, True, False]]
+    assert T.create_masks(pos_s, None)[1] is None
+    a, b = torch.randn(3, 7, 5), torch.randn(3, 7, 5)
+    assert torch.allclose(T.mse_loss_arelbo(a, b), 0.5 * 35 * torch.log(torch.mean((a - b) ** 2)))
+    pred, y = torch.randn(2, 9, 80), torch.randn(2, 9, 80)
+    hp = SimpleNamespace(channel_weight=(2.0, 0.5))
+    assert abs(T.loss_mel(hp, pred, y).item() - F.l1_loss(pred, y).item()) < 1e-6
+    ref = 2.0 * F.l1_loss(pred[:, :, :20], y[:, :, :20]) + 0.5 * F.l1_loss(pred[:, :, 20:], y[:, :, 20:])
+    assert abs(T.loss_mel(hp, pred, y, channel_wise=True).item() - ref.item()) < 1e-6

@@ -37,11 +37,39 @@ random.seed(77)
 DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
+def npeak_mask(size):
+    """reference :42-53: (1, size, size) boolean lower-triangular mask (diagonal included) on DEVICE."""
+    return torch.tril(torch.ones((1, size, size), dtype=torch.bool, device=DEVICE))
+
+
 def create_masks(src_pos, trg_pos, task="transformer", src_pad=0, trg_pad=0, debug=False):
-    """(B,t) positions -> (B,1,t) bool key masks.  Only the FastSpeech2 branch of the reference
-    (:69-70) is on this path; the causal mask of the AR Transformer is a later row."""
-    assert not debug and task.lower() in ("fastspeech2", "lightspeech")
-    return (src_pos != src_pad).unsqueeze(-2), (trg_pos != trg_pad).unsqueeze(-2)
+    """reference :55-82.  (B,t) positions -> (B,1,t) bool key masks for the FastSpeech2 / LightSpeech tasks; for the general
+    transformer task the target mask is additionally combined with the no-peak mask -> (B,t,t).  (debug: the +-3 context
+    window of the reference is computed and then unused there; it is not reproduced.)"""
+    assert not debug, "the reference's debug branch builds a context-window mask it never uses"
+    src_mask = (src_pos != src_pad).unsqueeze(-2)
+    if task.lower() in ("fastspeech2", "lightspeech"):
+        return src_mask, (trg_pos != trg_pad).unsqueeze(-2)
+    if trg_pos is None:
+        return src_mask, None
+    trg_mask = (trg_pos != trg_pad).unsqueeze(-2)
+    return src_mask, trg_mask & npeak_mask(trg_pos.size(1)).to(trg_pos.device)
+
+
+def mse_loss_arelbo(input, target):
+    """reference :85-88 ("Preventing Posterior Collapse Induced by Oversmoothing in Gaussian VAE"): plain torch arithmetic on
+    the caller's tensors -- a host-level helper of the module surface, not on the FastSpeech2 hot path (no call site there)."""
+    return 0.5 * (target.numel() // target.size(0)) * torch.log(torch.mean((input - target) ** 2))
+
+
+def loss_mel(hp, pred, y, channel_wise=False, loss="l1", channel_weight=None):
+    """reference :90-98: nn.L1Loss over every element, or two weighted L1 terms over mel channels [0,20) and [20,M) when
+    channel_wise (hp.channel_weight).  Computed by the fused L1 kernel (with its hand-written backward)."""
+    if channel_wise:
+        print("channel")
+        return hp.channel_weight[0] * l1_loss(pred[:, :, :20].contiguous(), y[:, :, :20].contiguous()) + \
+            hp.channel_weight[1] * l1_loss(pred[:, :, 20:].contiguous(), y[:, :, 20:].contiguous())
+    return l1_loss(pred, y)
 
 
 def compute_losses(hp, outputs, mel, alignment, f0, energy):
