@@ -842,3 +842,45 @@ def test_fp8_gemm_against_the_dequantised_product(ops, M, N, K):
             full = full.clamp(min=0)
         rel = float((out.cpu().double() - full).norm() / full.norm())
         assert rel < (0.08 if backward else 0.04), rel
+
+
+# ------------------------------------------------------------------------------------------------ 16-wave weight-gradient GEMM
+@pytest.fixture
+def big_km(monkeypatch):
+    monkeypatch.setenv("FS2_GEMM_BIG_KM", "2")
+    yield
+    monkeypatch.delenv("FS2_GEMM_BIG_KM", raising=False)
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 256, 256), (3000, 1024, 264), (129, 80, 72), (5000, 136, 520), (64, 8, 8)])
+def test_big_km_wgrad(ops, big_km, M, N, K):
+    """gemm_big_km.hip (in-workgroup k-split, LDS-DMA k-major images, LDS reduction, row-contiguous atomics): dW += dy^T x on
+    ragged shapes (reduction tails, column edges), accumulating onto a non-zero gradient"""
+    dy, x = rnd(M, N, dtype=torch.bfloat16, seed=1), rnd(M, K, dtype=torch.bfloat16, seed=2)
+    g0 = rnd(N, K, seed=3)
+    a = ops.wgrad(dy.cuda(), x.cuda(), g0.clone().cuda())
+    assert ops.lib().fs2_gemm_last_tile() == 129
+    b = P.wgrad(dy, x, g0.clone())
+    close(a, b, "big km wgrad", rtol=2e-3, atol=2e-3 * M ** 0.5)
+
+
+def test_big_km_wgrad_batched_and_conv(ops, big_km):
+    M, d = 2500, 256
+    dy, x = rnd(M, 3 * d, dtype=torch.bfloat16, seed=1), rnd(M, d, dtype=torch.bfloat16, seed=2)
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        arena = torch.zeros(3 * (d * d + d), device=dev)
+        outs = [arena[j * (d * d + d):j * (d * d + d) + d * d].view(d, d) for j in range(3)]
+        o.wgrad_batched(mv(dy), mv(x), outs)
+        if dev == "cuda":
+            assert ops.lib().fs2_gemm_last_tile() == 129
+            got = [t.clone() for t in outs]
+        else:
+            for a, b in zip(got, outs):
+                close(a, b, "big km batched wgrad", rtol=2e-3, atol=2e-3 * M ** 0.5)
+    for (B, t, C, N, taps, pad) in ((7, 301, 72, 264, 9, 4), (5, 450, 256, 256, 5, 4), (9, 200, 80, 256, 3, 1)):
+        dyc, xc = rnd(B, t, N, dtype=torch.bfloat16, seed=3), rnd(B, t, C, dtype=torch.bfloat16, seed=4)
+        a = ops.conv_wgrad(dyc.cuda(), xc.cuda(), taps, pad, torch.zeros(N, taps * C).cuda())
+        assert ops.lib().fs2_gemm_last_tile() == 129
+        b = P.conv_wgrad(dyc, xc, taps, pad, torch.zeros(N, taps * C))
+        close(a, b, f"big km conv wgrad taps={taps}", rtol=2e-3, atol=2e-3 * (B * t) ** 0.5)

@@ -67,7 +67,32 @@ def main():
         "enc_conv1 k9 6144x1024x2304": (lambda: ops.conv(xe, we, 9, 4, bias=bias1024, relu=True), 2.0 * 6144 * 1024 * 2304),
         "square 8192x4096x4096": (lambda: ops.linear(big_a, big_b), 2.0 * 8192 * 4096 * 4096),
     }
+    # weight gradients (k-major operands): FS2_GEMM_BIG_KM 0 (4-wave kernel) against 2 (16-wave kernel, gemm_big_km.hip)
+    dy1024, dy256, dy768 = r(M, 1024), r(M, 256), r(M, 768)
+    xk3, dyk = r(48, 925, 256), r(48, 925, 256)
+    xe9, dye = r(48, 128, 256), r(48, 128, 1024)
+    wcases = {
+        "wgrad ffn1 1024x256 red 44400": (lambda: ops.wgrad(dy1024, x256, torch.zeros(1024, 256, device=dev)), 2.0 * M * 1024 * 256),
+        "wgrad ffn2 256x1024 red 44400": (lambda: ops.wgrad(dy256, x1024, torch.zeros(256, 1024, device=dev)), 2.0 * M * 1024 * 256),
+        "wgrad proj 256x256 red 44400": (lambda: ops.wgrad(dy256, x256, torch.zeros(256, 256, device=dev)), 2.0 * M * 256 * 256),
+        "wgrad qkv 3x(256x256) red 44400": (lambda: ops.wgrad(dy768, x256, torch.zeros(768, 256, device=dev)), 2.0 * M * 768 * 256),
+        "conv_wgrad k3 256x(3x256) red 44400": (lambda: ops.conv_wgrad(dyk, xk3, 3, 1, torch.zeros(256, 768, device=dev)), 2.0 * M * 256 * 768),
+        "conv_wgrad k5 256x(5x256) red 44400": (lambda: ops.conv_wgrad(dyk, xk3, 5, 4, torch.zeros(256, 1280, device=dev)), 2.0 * M * 256 * 1280),
+        "conv_wgrad k9 1024x(9x256) red 6144": (lambda: ops.conv_wgrad(dye, xe9, 9, 4, torch.zeros(1024, 2304, device=dev)), 2.0 * 6144 * 1024 * 2304),
+    }
     only = [a for a in sys.argv[1:] if not a.isdigit() and ":" not in a and a != "stamps"]
+    for name, (fn, fl) in wcases.items():
+        if only and not any(o in name for o in only):
+            continue
+        os.environ["FS2_GEMM_BIG_KM"] = "0"
+        ref = fn().float()
+        t0w, t0c = timeit(fn, False), timeit(fn, True)
+        os.environ["FS2_GEMM_BIG_KM"] = "2"
+        out = fn().float()
+        rel = float((out - ref).abs().max() / ref.abs().max())
+        tw, tc = timeit(fn, False), timeit(fn, True)
+        print(f"{name:40s} 4-wave {t0w:7.1f}/{t0c:7.1f} us ({fl / t0c / 1e6:6.0f} TF cold) | 16-wave {tw:7.1f}/{tc:7.1f} us ({fl / tc / 1e6:6.0f} TF) maxrel {rel:.1e}", flush=True)
+    os.environ["FS2_GEMM_BIG_KM"] = "1"
     for name, (fn, fl) in cases.items():
         if only and not any(o in name for o in only):
             continue

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc);     // gemm_big.hip
+bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc);  // gemm_big_km.hip
 
 thread_local int g_last_tile = 0;     // rows of the block tile of the last fs2_gemm launch of this thread (measurement aid)
 extern "C" int fs2_gemm_last_tile(void) { return g_last_tile; }
@@ -683,6 +684,7 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
     {   // tall row-major bf16 products: the 256x256 / 16-wave LDS-DMA kernel (gemm_big.hip)
         int rc = FS2_OK;
         if (fs2_gemm_big_try(g, st, &rc)) return rc;      // (sets g_last_tile to 192 / 256)
+        if (fs2_gemm_big_km_try(g, st, &rc)) return rc;   // decoder-side weight gradients (g_last_tile 129)
     }
     // tile walk: tall row-major products with 2..8 column tiles of 128 go m-fastest on an XCD-aligned grid (see the
     // kernel's work numbering); everything else n-fastest.  FS2_GEMM_MFAST=0 disables the choice (measurements).

@@ -1,0 +1,268 @@
+// Weight-gradient GEMM for gfx950, 16-wave form: C[Mo][No] (fp32) += alpha * sum_k A[k][m] * B[k'][n] with BOTH operands
+// k-major (the reduction index -- batch x time -- is the row index of the two row-major activation tensors), the decoder-side
+// weight gradients of the model: reduction length ~44 k rows, outputs of 256 x 256 ... 1024 x 256 (x taps).
+//
+// These products are bound by the cross-workgroup reduction: with 256 CUs and a handful of output tiles the reduction has to be
+// split ~16-64 ways, and every workgroup then adds its fp32 partial tile to memory with float atomics (~1.3 TB/s chip-wide,
+// i.e. one 256-byte wave-instruction per ~50 ns per CU).  The design therefore keeps the partial tile per CU SMALL
+// (128 x 128 = 64 KiB, 12.8 us of atomics) and gets its MFMA work per staged byte from splitting K INSIDE the workgroup:
+//   * block = 16 waves = 4 k-groups x (2 x 2 waves of 64 x 64): a stage is 128 reduction rows of a 128(m) x 128(n) output
+//     tile; k-group g multiplies rows 32g .. 32g+31 of the stage (one MFMA k-step), every wave 4 x 4 MFMA 16x16x32 tiles;
+//   * LDS-DMA staging (buffer_load_dwordx4 ... lds) into two 64 KiB stage buffers [A: 128 k][128 m] [B: 128 k][128 n], rows
+//     of 256 B, 16-B chunk c of row r at c ^ (((r&3)<<2) | ((r>>2)&3)) (image (b) of the CDNA4 guide, T10) read with
+//     ds_read_b64_tr_b16; the swizzle is applied on the per-lane source address (one wave-instruction writes 4 rows linearly);
+//     reduction rows past K / outside the sequence (conv taps) and columns past the matrix use an out-of-range offset (zeros);
+//   * at the end of a work item the four k-groups sum their accumulators with a two-round tree through LDS (plain 16-byte
+//     accesses; LDS float atomics ran this at ~0.35 lanes per clock) and all 16 waves flush the 128 x 128 total with
+//     row-contiguous float atomics (256 B per wave-instruction: the full-rate shape);
+//   * persistent workgroups, one per CU; work items (output tile x tap x batch x k-split) numbered so that neighbouring items
+//     share their reduction range (operand slabs hit in L2) and dealt to the 8 XCD groups in contiguous chunks.
+#include "common.cuh"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr unsigned OOB = 0x80000000u;
+constexpr int NT = 1024, NW = 16, TM = 128, TN = 128, BK = 128;
+constexpr int OP_BYTES = BK * 256, STAGE = 2 * OP_BYTES, SMEM = 2 * STAGE;      // 32 KiB per operand per stage
+
+__device__ __forceinline__ int km_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ int km_off(int row, int ch) { return row * 256 + ((ch ^ km_f(row)) << 4); }
+
+// fragment of the 16 columns o0 .. o0+15 for the 32 reduction rows r0k .. r0k+31 of an image
+__device__ __forceinline__ bf16x8 km_frag(const unsigned char* img, int o0, int r0k, int lane) {
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    const int ch = (o0 >> 3) + (pp >> 1), r0 = r0k + 8 * g + q;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + km_off(r0, ch) + 8 * (pp & 1)));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + km_off(r0 + 4, ch) + 8 * (pp & 1)));
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = lo; u.s.hi = hi;
+    return u.v;
+}
+
+}  // namespace
+
+extern thread_local int g_last_tile;     // gemm.hip
+
+__global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
+                                                                  const int nitems) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
+    const int g = lane >> 4, i16 = lane & 15;
+
+    // ---- items of this block: XCD group x = blockIdx & 7 owns the contiguous range [x*per_x, (x+1)*per_x) of item numbers,
+    //      its workgroups (slot = blockIdx >> 3) take them round-robin
+    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int per_x = (nitems + 7) >> 3;
+    const int ibeg = x * per_x, iend = min(nitems, ibeg + per_x);
+    const int have = iend - ibeg;
+    const int nmine = have > slot ? (have - slot + nslots - 1) / nslots : 0;
+    if (nmine == 0) return;
+
+    const int tiles = tilesM * tilesN;
+    const int taps = p.conv == 2 ? p.batch2 : 1;
+    const int nb2 = p.conv == 2 ? 1 : p.batch2;
+    const int Kb = p.Kb > 0 ? p.Kb : p.K;
+    const int nstk = (p.K + BK - 1) / BK;                   // stages of the whole reduction
+    const int per = (nstk + splits - 1) / splits;           // (the host made every split non-empty)
+    const int lda = (int)p.lda, ldb = (int)p.ldb;
+    const int seq = p.seq_len;
+
+    struct Item { int m0, n0, tap, st0, st1; int64_t aoff, boff, coff; };
+    auto decode = [&](int j) {
+        // item number -> (tile fastest, then k-split, then tap, then batch): neighbours share the reduction range
+        Item it;
+        int z = ibeg + j;
+        const int tile = z % tiles; z /= tiles;
+        const int sp = z % splits; z /= splits;
+        it.tap = z % taps; z /= taps;
+        const int b2 = z % nb2, b1 = z / nb2;
+        it.m0 = (tile / tilesN) * TM; it.n0 = (tile % tilesN) * TN;
+        it.st0 = sp * per; it.st1 = min(nstk, it.st0 + per);
+        const int c2 = p.conv == 2 ? it.tap : b2;
+        it.aoff = b1 * p.sA1 + (p.conv == 2 ? 0 : b2 * p.sA2);
+        it.boff = b1 * p.sB1 + (p.conv == 2 ? 0 : b2 * p.sB2);
+        it.coff = b1 * p.sC1 + c2 * p.sC2;
+        return it;
+    };
+
+    // ---- LDS-DMA: instruction i of this wave covers image rows 4*(i*NW + wave) .. +3 of A (i = 0,1) and of B (i = 0,1);
+    //      the lane fetches logical chunk (lane&15) ^ f(row) of row lane>>4 of those
+    auto dma_row = [&](int i) { return 4 * (i * NW + wave) + (lane >> 4); };
+    auto dma_col = [&](int i) { return ((lane & 15) ^ km_f(dma_row(i))) * 8; };
+
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    bool colA[2], colB[2];
+    Item ck;
+    int lst = 0;                          // next stage to stage
+    auto prep = [&](const Item& k) {
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const bf16_t*>(p.A) + k.aoff), 0, 0x7FFFFFF0, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const bf16_t*>(p.B) + k.boff), 0, 0x7FFFFFF0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            colA[i] = k.m0 + dma_col(i) < p.M;
+            colB[i] = k.n0 + dma_col(i) < p.N;
+        }
+    };
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        const int kb = lst * BK;
+        const int shiftB = p.conv == 2 ? ck.tap - p.pad : 0;
+        unsigned char* base = smem + buf * STAGE + 1024 * wave;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kk = kb + dma_row(i);
+            const bool ok = colA[i] && kk < p.K;
+            const unsigned off = (unsigned)((kk * lda + ck.m0 + dma_col(i)) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)(ok ? off : OOB), 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kk = kb + dma_row(i);
+            bool ok = colB[i] && kk < Kb;
+            if (p.conv == 2) { const int tt = (kk % seq) + shiftB; ok = ok && tt >= 0 && tt < seq; }
+            const unsigned off = (unsigned)(((kk + shiftB) * ldb + ck.n0 + dma_col(i)) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + OP_BYTES + 1024 * NW * i), 16, (int)(ok ? off : OOB), 0, 0, 0);
+        }
+        ++lst;
+    };
+
+    f32x4 acc[4][4];
+
+    for (int j = slot; j < have; j += nslots) {
+        ck = decode(j);
+        prep(ck);
+        lst = ck.st0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        issue(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int nst = ck.st1 - ck.st0;
+        for (int s = 0; s < nst; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < nst) issue(buf ^ 1);      // stage s+1 -> the buffer every wave finished with at the last barrier
+            const unsigned char* la = smem + buf * STAGE;
+            const unsigned char* lb = la + OP_BYTES;
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = km_frag(la, wr * 64 + i * 16, 32 * kg, lane);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) fb[jj] = km_frag(lb, wc * 64 + jj * 16, 32 * kg, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+            // own DMA landed, own fragment reads retired; then every wave's
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // ---- the four k-groups hold partial sums of the same 128 x 128 tile: a two-round tree through LDS (both stage buffers
+        //      are free: nothing is staged across work items), plain 16-byte accesses in accumulator order (LDS float atomics
+        //      ran this reduction at ~0.35 lanes per clock: 90 us per tile)
+        float4* red4 = reinterpret_cast<float4*>(smem);
+        const int wslot = (wave & 3) * 1024 + lane;               // per (wr, wc) wave position: 16 float4 per lane, lane-linear
+        if (kg >= 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    red4[(kg - 2) * 4096 + wslot + (i * 4 + jj) * 64] = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kg < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 v = red4[kg * 4096 + wslot + (i * 4 + jj) * 64];
+                    acc[i][jj][0] += v.x; acc[i][jj][1] += v.y; acc[i][jj][2] += v.z; acc[i][jj][3] += v.w;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    red4[wslot + (i * 4 + jj) * 64] = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        float* red = reinterpret_cast<float*>(smem + STAGE);      // the total, row-major [128][128] fp32, in the second buffer
+        if (kg == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 v = red4[wslot + (i * 4 + jj) * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        red[(wr * 64 + i * 16 + g * 4 + r) * TN + wc * 64 + jj * 16 + i16] = acc[i][jj][r] + (&v.x)[r];
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // ---- flush with row-contiguous float atomics (256 B per wave-instruction: the full-rate shape), 8 rows per wave
+        float* __restrict__ C = reinterpret_cast<float*>(p.C) + ck.coff;
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr;
+            const int m = ck.m0 + row;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = ck.n0 + h * 64 + lane;
+                const float v = red[row * TN + h * 64 + lane];
+                if (m < p.M && n < p.N) atomicAdd(C + (int64_t)m * p.ldc + n, v * p.alpha);
+            }
+        }
+        // the LDS is free again before the next item's first stage is staged
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+// false: not eligible / not chosen; true: launched, *rc holds the result
+bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc) {
+    // FS2_GEMM_BIG_KM: 0 never, 1 (default) where the shape heuristic says so, 2 wherever eligible (tests, A/B measurements)
+    const char* e1 = getenv("FS2_GEMM_BIG_KM");
+    const int mode = e1 ? atoi(e1) : 1;
+    if (mode == 0) return false;
+    if (g.dtype != FS2_BF16 || g.c_dtype != FS2_F32 || !g.a_kmajor || !g.b_kmajor || !g.accumulate) return false;
+    if (g.conv != 0 && g.conv != 2) return false;
+    if (g.bias || g.residual || g.relu_mask || g.colstats || g.relu) return false;
+    const long rowsA = (long)g.K + 16, rowsB = (long)(g.Kb > 0 ? g.Kb : g.K) + 64;
+    if (rowsA * g.lda * 2 >= 0x7FFFFFF0L || rowsB * g.ldb * 2 >= 0x7FFFFFF0L) return false;
+    const int tilesM = (g.M + TM - 1) / TM, tilesN = (g.N + TN - 1) / TN;
+    const long nb = (long)g.batch1 * g.batch2;
+    const long base = (long)tilesM * tilesN * nb;             // work items before the k-split
+    const int nstk = (g.K + BK - 1) / BK;
+    if (mode == 1 && (g.K < 16384 || base > 96)) return false;   // long reductions onto few output tiles: the decoder side
+    // k-split: about one item per CU, at least 2 stages per split
+    int splits = (int)(256 / base);                           // never more items than CUs: a second round would double the time
+    if (splits > nstk / 2) splits = nstk / 2 > 0 ? nstk / 2 : 1;
+    if (splits < 1) splits = 1;
+    const int per = (nstk + splits - 1) / splits;
+    splits = (nstk + per - 1) / per;                          // no empty split
+    const long nitems = base * splits;
+    if (nitems >= (1L << 30)) return false;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+            fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the weight-gradient kernel");
+            *rc = FS2_ELAUNCH;
+            return true;
+        }
+        attr_set = true;
+    }
+    const long per_x = (nitems + 7) / 8;
+    const int grid = 8 * (int)(per_x < 32 ? per_x : 32);
+    g_last_tile = 129;          // (measurement aid: the 16-wave weight-gradient kernel)
+    hipLaunchKernelGGL(fs2_gemm_big_km_kernel, dim3(grid), dim3(NT), SMEM, st, g, tilesM, tilesN, splits, (int)nitems);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) { fs2_set_error("fs2_gemm(big km): launch failed: %s", hipGetErrorString(e_)); *rc = FS2_ELAUNCH; return true; }
+    *rc = FS2_OK;
+    return true;
+}
