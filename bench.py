@@ -44,7 +44,7 @@ PEAK_HBM_GBS = 8000.0           # HBM3E spec peak (6.3 TB/s achievable), same ta
 POOL = 8                        # pre-built batches cycled
 
 
-def bench_hp(amp=True, workload="cfg2", fp8=False):
+def bench_hp(amp=True, workload="cfg2", fp8=False, return_attn=False):
     from types import SimpleNamespace
     from golden_configs import _BASE, CONFIGS
     from transformer_tts_amd.utils.utils import fill_variables
@@ -55,6 +55,7 @@ def bench_hp(amp=True, workload="cfg2", fp8=False):
                  n_head_decoder=4)
     hp = SimpleNamespace(**d)
     hp.amp, hp.dropout, hp.dropout_variance_adaptor, hp.fp8 = amp, 0.1, 0.5, fp8
+    hp.return_attn = return_attn        # the training loop never reads the attention maps (reference train_fastspeech2.py:173-174,283-287: only commented-out plotting code touches them)
     fill_variables(hp, verbose=False)
     return hp
 
@@ -197,6 +198,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="keep the weight-gradient GEMMs on the main stream (profiling)")
     ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2",
                     help="cfg2 = BASELINE.json configs[1] (the headline, default); cfg4 = configs[4] (d_model 512, 6+6 layers, batch 64/GPU)")
+    ap.add_argument("--return-attn", action="store_true",
+                    help="hp.return_attn=True: keep the (B,N,H,t,t) attention maps (LDS-strip kernels) instead of the flash kernels")
     ap.add_argument("--fp8", action="store_true", help="fp8 operand mode of the row-major GEMMs (configs[4]; not the headline)")
     args = ap.parse_args()
 
@@ -224,7 +227,7 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     ops.lib()
 
-    hp = bench_hp(amp=not args.fp32, workload=args.workload, fp8=args.fp8)
+    hp = bench_hp(amp=not args.fp32, workload=args.workload, fp8=args.fp8, return_attn=args.return_attn)
     BATCH = hp.batch_size
     torch.manual_seed(1234)
     model = build_model(hp)
@@ -346,6 +349,8 @@ def main():
                                                                               if args.fp8 else "bf16 operands")),
                        "global_batch": BATCH * world, "parallelism": f"dp{world}",
                        "padded_frames_per_step": int(sum(b[1].shape[0] * b[1].shape[1] for b in pool) / len(pool)),
+                       "attention": ("hp.return_attn=True: LDS-strip kernels, attention maps written to HBM" if args.return_attn or args.fp32
+                                     else "hp.return_attn=False: flash kernels (no (t x t) tensor in HBM; the loop never reads the maps)"),
                        "launch": "hipGraph replay per batch shape" if use_graph else "eager"},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -177,6 +177,28 @@ def test_benchmark_config_bf16_within_stated_tolerance(return_attn):
             assert abs(l2 - dig[2]) <= 0.10 * dig[2], f"grad {k}: l2 {l2} vs {dig[2]}"
 
 
+def test_flash_and_strip_attention_draw_the_same_masks():
+    """hp.return_attn False (flash kernels: no probabilities in HBM) against True (LDS-strip kernels) on the benchmark
+    configuration with dropout 0.2: the Philox counters are those of the (B,N,H,t,tp) layout in both modes, so the two runs
+    see the same masks everywhere and differ by bf16 rounding only."""
+    res = {}
+    model, hp, g = product_model("bench", amp=True, dropout=0.2, device="cuda", return_attn=True)
+    batch = batch_to(CONFIGS["bench"]["batch"](), "cuda")
+    for ra in (True, False):
+        model.rt.return_attn = ra           # same model: same call-site ids, same rng offset
+        out, total, parts = fwd_bwd(model, hp, batch)
+        assert (out[7] is None) == (not ra) and (out[8] is None) == (not ra)
+        res[ra] = (total.item(), {k: p.grad.double().flatten().cpu() for k, p in model.named_parameters()}, out[1].double().cpu())
+    assert abs(res[True][0] - res[False][0]) <= 5e-3 * abs(res[True][0]), (res[True][0], res[False][0])
+    a, b = res[True][2], res[False][2]
+    assert float((a - b).abs().mean()) <= 2e-2 * max(1.0, float(a.abs().mean()))
+    for k, ga in res[True][1].items():
+        gb = res[False][1][k]
+        if ga.numel() >= 1024 and not is_null_gradient_param(k) and float(ga.norm()) > 1e-6:
+            cos = float(ga @ gb / (ga.norm() * gb.norm() + 1e-30))
+            assert cos > 0.97, (k, cos)
+
+
 def test_dropout_statistics_and_replay():
     """p > 0 cannot be bit-matched with the reference's RNG: check the keep rate / scaling of the always-on
     attention dropout (Models/modules.py:19) and that two steps draw different masks while backward replays

@@ -291,8 +291,15 @@ class EncoderStackFunction(torch.autograd.Function):
         h, mean0, rstd0 = ops.layernorm_fwd(x, n1.weight.detach(), n1.bias.detach(), T)         # layers.py:31
         sv["x0"], sv["mean0"], sv["rstd0"] = x, mean0, rstd0
 
-        attn = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
-        attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if p_att > 0 else attn
+        # hp.return_attn = False: the maps are not wanted -> flash kernels, no (t x t) tensor in HBM; the Philox counters are
+        # those of the (B,N,H,t,tp) layout either way, so both modes draw the same dropout masks
+        flash = (not rt.return_attn) and ops.flash_attn_supported(t, dk, T)
+        if flash:
+            attn = attn_drop = None
+            stats = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
+        else:
+            attn = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
+            attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if p_att > 0 else attn
         layers = []
         scale = 1.0 / math.sqrt(dk)
         for i, layer in enumerate(enc.layers):
@@ -301,16 +308,19 @@ class EncoderStackFunction(torch.autograd.Function):
             qkv = ops.linear(h.view(M, d), wf, bqkv)                                             # modules.py:49-51
             q5 = qkv.view(B, t, 3, H, dk)
             q, v, k = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))                        # (B,H,t,dk) views
-            S, Pd = attn[:, i], attn_drop[:, i]
             O = torch.empty((B, t, H, dk), dtype=T, device=dev)
             O4 = O.permute(0, 2, 1, 3)
-            if ops.attn_probs_supported(t, dk, T):      # scores stay in LDS (one kernel)
+            if flash:                                   # modules.py:8-20 in one kernel, row statistics only
+                ops.flash_attn_fwd(q, k, v, km, O4, stats[i], t, scale, N * H * t * tp, p_att, rng, layer.site_attn)
+            elif ops.attn_probs_supported(t, dk, T):    # scores stay in LDS (one kernel)
+                S, Pd = attn[:, i], attn_drop[:, i]
                 pv = ops.attn_second_product_supported(dk)
                 ops.attn_probs_fwd(q, k, km, S, Pd, t, scale, p_att, rng, layer.site_attn,       # modules.py:8-20
                                    v=v if pv else None, out=O4 if pv else None)
                 if not pv:
                     ops.bmm(Pd, v, O4, trans_b=False)                                            # modules.py:20
             else:
+                S, Pd = attn[:, i], attn_drop[:, i]
                 ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)                             # modules.py:8-9
                 ops.softmax_fwd(S, Pd, km, t, p_att, rng, layer.site_attn)                       # modules.py:11-19
                 ops.bmm(Pd, v, O4, trans_b=False)                                                # modules.py:20
@@ -334,8 +344,9 @@ class EncoderStackFunction(torch.autograd.Function):
 
         ctx.enc, ctx.sv, ctx.layers, ctx.attn, ctx.attn_drop = enc, sv, layers, attn, attn_drop
         ctx.src, ctx.km = src, km
+        ctx.flash, ctx.stats = flash, (stats if flash else None)
         ctx.set_materialize_grads(False)
-        attn_out = attn_drop[..., :t]
+        attn_out = attn_drop[..., :t] if not flash else torch.empty(0, dtype=T, device=dev)
         ctx.mark_non_differentiable(attn_out)
         return h, attn_out
 
@@ -357,7 +368,11 @@ class EncoderStackFunction(torch.autograd.Function):
         scale = 1.0 / math.sqrt(dk)
         dh = dh.contiguous()
         dx = None                       # fp32 gradient w.r.t. the residual stream coming from above
-        dP = torch.empty((B, H, t, tp), dtype=T, device=dev)
+        flash = ctx.flash
+        if flash:
+            aux = torch.empty((B, H, t, 4), dtype=torch.float32, device=dev)
+        else:
+            dP = torch.empty((B, H, t, tp), dtype=T, device=dev)
         for i in reversed(range(N)):
             layer, L = enc.layers[i], layers[i]
             nn_ = enc.layers[i + 1].norm_1 if i + 1 < N else enc.norm
@@ -387,19 +402,23 @@ class EncoderStackFunction(torch.autograd.Function):
             dqkv = torch.empty((B, t, 3 * d), dtype=T, device=dev)
             d5 = dqkv.view(B, t, 3, H, dk)
             dq, dv, dk_ = (d5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
-            P, Pd = ctx.attn[:, i], ctx.attn_drop[:, i]
-            ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)                 # dV = Pd^T dO
-            if ops.attn_probs_supported(t, dk, T):      # dP stays in LDS (one kernel)
-                sq = ops.attn_second_product_supported(dk)
-                ops.attn_ds_bwd(dO4, v, P, dP, t, p, rng, layer.site_attn,    # dS = softmax'(dropout'(dO V^T))
-                                k=k if sq else None, dq=dq if sq else None, alpha=scale)   # dQ = dS K / sqrt(dk)
-                if not sq:
-                    ops.bmm(dP, k, dq, trans_b=False, alpha=scale)
+            if flash:                                   # probabilities recomputed from q, k and the row statistics
+                ops.flash_attn_bwd(q, k, v, ctx.km, L["O"].permute(0, 2, 1, 3), dO4, ctx.stats[i], aux, dq, dk_, dv, t, scale,
+                                   N * H * t * tp, p, rng, layer.site_attn)
             else:
-                ops.bmm(dO4, v, dP[..., :t], trans_b=True)                    # dP = dO V^T
-                ops.softmax_bwd(dP, P, t, p, rng, layer.site_attn)            # -> dS (pad columns 0)
-                ops.bmm(dP, k, dq, trans_b=False, alpha=scale)                # dQ = dS K / sqrt(dk)
-            ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale)     # dK = dS^T Q / sqrt(dk)
+                P, Pd = ctx.attn[:, i], ctx.attn_drop[:, i]
+                ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)             # dV = Pd^T dO
+                if ops.attn_probs_supported(t, dk, T):  # dP stays in LDS (one kernel)
+                    sq = ops.attn_second_product_supported(dk)
+                    ops.attn_ds_bwd(dO4, v, P, dP, t, p, rng, layer.site_attn,                 # dS = softmax'(dropout'(dO V^T))
+                                    k=k if sq else None, dq=dq if sq else None, alpha=scale)   # dQ = dS K / sqrt(dk)
+                    if not sq:
+                        ops.bmm(dP, k, dq, trans_b=False, alpha=scale)
+                else:
+                    ops.bmm(dO4, v, dP[..., :t], trans_b=True)                # dP = dO V^T
+                    ops.softmax_bwd(dP, P, t, p, rng, layer.site_attn)        # -> dS (pad columns 0)
+                    ops.bmm(dP, k, dq, trans_b=False, alpha=scale)            # dQ = dS K / sqrt(dk)
+                ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale) # dK = dS^T Q / sqrt(dk)
             dqkv2, h2d = dqkv.view(M, 3 * d), L["h"].view(M, d)
             # bias gradients of q/v/k: ONE pass over dqkv, straight into the three gradient vectors (constant stride in the arena)
             with rt.side(dqkv2):
