@@ -222,21 +222,25 @@ int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_s
 
 /* attention() of Models/modules.py:7-21 WITHOUT the probability tensors in HBM (hp.return_attn = False), bf16, d_k = 128,
  * t <= 1024.  Forward: o_out[b][i][h][:] = dropout(softmax(mask_keys(alpha q k^T)))[i][:] v and, per query row,
- * stats[b][h][i] = {maximum of the masked scaled scores, sum of exp(score - maximum)} (fp32 pairs).  Backward recomputes the
- * probabilities from q, k and stats, regenerates the dropout mask (same Philox counters as fs2_attn_probs_fwd: element offset
- * b*p_batch_stride + (h*t + i)*tp + key of the virtual (B,[..],H,t,tp) tensor, so both paths draw the same mask) and writes
- * dq = alpha dS k, dk = alpha dS^T q, dv = dropout(P)^T d_out; aux is a (B,H,t,4) fp32 workspace it fills itself.
+ * stats[b][h][i] = {maximum of the masked scaled scores, sum of exp(score - maximum)} (fp32 pairs).  With p > 0 it draws the
+ * dropout mask from the Philox counters of fs2_attn_probs_fwd (element offset b*p_batch_stride + (h*t + i)*tp + key of the
+ * virtual (B,[..],H,t,tp) tensor, so both paths draw the same mask) and stashes it, one bit per probability, in keep_bits
+ * (fs2_flash_attn_keep_words(B, H, t) 16-bit words; may be NULL when p == 0).  Backward recomputes the probabilities from
+ * q, k and stats, reads the keep-bits and writes dq = alpha dS k, dk = alpha dS^T q, dv = dropout(P)^T d_out; aux is a
+ * (B,H,t,4) fp32 workspace it fills itself.  Key tiles whose keys are all masked are skipped (their probabilities are
+ * exp(-1e4 - max) = 0 in fp32 whenever the row has an unmasked key; a row without one is computed in full).
  *   q, k, v: rows of one head = 128 contiguous bf16 at  base + b*batch_stride + i*row_stride + h*head_stride  (elements);
  *   o / d_out / dq,dk,dv rows likewise with their own row and batch strides (dq, dk, dv share g_*_stride).           */
+int64_t fs2_flash_attn_keep_words(int B, int H, int t);
 int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                        const uint8_t* key_mask, void* o_out, int64_t o_row_stride, int64_t o_batch_stride, float* stats,
-                       int64_t p_batch_stride, int B, int H, int t, int tp, float alpha, float p, const uint64_t* rng,
-                       uint32_t site, void* stream);
+                       uint16_t* keep_bits, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha, float p,
+                       const uint64_t* rng, uint32_t site, void* stream);
 int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                        const uint8_t* key_mask, const void* o_saved, int64_t o_row_stride, int64_t o_batch_stride,
-                       const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats, float* aux,
-                       void* dq, void* dk, void* dv, int64_t g_row_stride, int64_t g_batch_stride, int64_t p_batch_stride,
-                       int B, int H, int t, int tp, float alpha, float p, const uint64_t* rng, uint32_t site, void* stream);
+                       const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats,
+                       const uint16_t* keep_bits, float* aux, void* dq, void* dk, void* dv, int64_t g_row_stride,
+                       int64_t g_batch_stride, int B, int H, int t, float alpha, float p, void* stream);
 
 /* LengthRegulator (Models/varianceadaptor.py:141-184,233-249): out[b][f] = x[b][i] for the phoneme i whose
  * duration interval contains frame f, 0 beyond sum(dur) or max_len.  starts is a [B][L+1] int32 workspace

@@ -501,7 +501,8 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
     O = torch.full((B, t, H, dk), float("nan"), dtype=dtype, device="cuda")
     stats = torch.full((B, H, t, 2), float("nan"), device="cuda")
     p_batch = NL * H * t * tp
-    ops.flash_attn_fwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), stats, t, dk ** -0.5, p_batch, p, rng, 11)
+    keep = torch.empty(ops.flash_attn_keep_words(B, H, t), dtype=torch.int16, device="cuda") if p > 0 else None
+    ops.flash_attn_fwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), stats, keep, t, dk ** -0.5, p_batch, p, rng, 11)
     # the oracle composition rounds the scores to bf16 before the softmax (as the unfused reference does in bf16), this path
     # keeps them in fp32: compare against the scale of the output
     err = float((O.float().cpu() - O_ref.float()).abs().max() / O_ref.float().abs().amax().clamp_min(1e-2))
@@ -515,12 +516,12 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
     dqkv = torch.full((B, t, 3, H, dk), float("nan"), dtype=dtype, device="cuda")
     dq, dv, dk_ = (dqkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
     aux = torch.empty((B, H, t, 4), device="cuda")
-    ops.flash_attn_bwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), g.permute(0, 2, 1, 3), stats, aux, dq, dk_, dv, t, dk ** -0.5,
-                       p_batch, p, rng, 11)
+    ops.flash_attn_bwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), g.permute(0, 2, 1, 3), stats, keep, aux, dq, dk_, dv, t, dk ** -0.5, p)
     got, ref = dqkv.float().cpu(), dqkv_ref.float()
     assert torch.isfinite(got).all()
     for j, n in enumerate(("dQ", "dV", "dK")):
-        scale = ref[:, :, j].abs().amax().clamp_min(0.4)       # t = 1: dS = 0 exactly; delta = rowsum(dO * bf16(O)) leaves rounding noise ~1e-2
+        # t = 1: dS = 0 exactly and the reference holds rounding noise; here delta = rowsum(dO * bf16(O)) leaves ~3e-2 |dO| |K| / sqrt(dk)
+        scale = ref[:, :, j].abs().amax().clamp_min(1.0 if t == 1 else 0.05)
         err = float((got[:, :, j] - ref[:, :, j]).abs().max() / scale)
         assert err < 3e-2, (n, t, err)
     if p > 0 and t >= 63:
@@ -532,7 +533,7 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
         xe = eye.cuda()
         qe, ve, ke = (xe[:, :, j].permute(0, 2, 1, 3) for j in range(3))
         Oe = torch.zeros((B, t, H, dk), dtype=dtype, device="cuda")
-        ops.flash_attn_fwd(qe, ke, ve, km.cuda(), Oe.permute(0, 2, 1, 3), stats, t, dk ** -0.5, p_batch, p, rng, 11)
+        ops.flash_attn_fwd(qe, ke, ve, km.cuda(), Oe.permute(0, 2, 1, 3), stats, torch.empty_like(keep), t, dk ** -0.5, p_batch, p, rng, 11)
         pd_flash = Oe.permute(0, 2, 1, 3)[..., :n].float().cpu()
         big = P_ref[..., :n].float() > 1e-3
         assert torch.equal((pd_flash == 0) & big, (Pd_ref[..., :n].float() == 0) & big)

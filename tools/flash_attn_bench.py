@@ -15,6 +15,9 @@ g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(B, t, 3, H, dk, device=dev, generator=g).to(torch.bfloat16)
 q, v, k = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
 km = torch.ones(B, t, dtype=torch.bool, device=dev)
+if len(sys.argv) >= 5 and sys.argv[4] == "ragged":       # prefix masks, lengths uniform in [0.45 t, t] (mean ~0.72 t as in the bench)
+    lens = torch.linspace(0.45 * t, t, B).round().long()
+    km = (torch.arange(t)[None, :] < lens[:, None]).to(dev)
 P = torch.empty(B, H, t, tp, device=dev, dtype=torch.bfloat16)
 Pd = torch.empty_like(P)
 dS = torch.empty_like(P)
@@ -26,6 +29,7 @@ dqkv = torch.empty_like(qkv)
 dq, dv, dk_ = (dqkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
 stats = torch.empty(B, H, t, 2, device=dev)
 aux = torch.empty(B, H, t, 4, device=dev)
+keep = torch.empty(ops.flash_attn_keep_words(B, H, t), dtype=torch.int16, device=dev)
 rng = ops.Rng(1, dev)
 alpha = dk ** -0.5
 pb = H * t * tp
@@ -55,11 +59,11 @@ def strip_bwd():
 
 
 def flash_fwd():
-    ops.flash_attn_fwd(q, k, v, km, O4, stats, t, alpha, pb, 0.1, rng, 3)
+    ops.flash_attn_fwd(q, k, v, km, O4, stats, keep, t, alpha, pb, 0.1, rng, 3)
 
 
 def flash_bwd():
-    ops.flash_attn_bwd(q, k, v, km, O4, dO4, stats, aux, dq, dk_, dv, t, alpha, pb, 0.1, rng, 3)
+    ops.flash_attn_bwd(q, k, v, km, O4, dO4, stats, keep, aux, dq, dk_, dv, t, alpha, 0.1)
 
 
 flops = 2.0 * B * H * t * t * dk

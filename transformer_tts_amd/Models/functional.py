@@ -297,6 +297,8 @@ class EncoderStackFunction(torch.autograd.Function):
         if flash:
             attn = attn_drop = None
             stats = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
+            # dropout keep-bits, one bit per probability (the only (t x t)-sized state of this mode: t*t/8 bytes per head)
+            keep = torch.empty((N, ops.flash_attn_keep_words(B, H, t)), dtype=torch.int16, device=dev) if p_att > 0 else None
         else:
             attn = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
             attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if p_att > 0 else attn
@@ -311,7 +313,8 @@ class EncoderStackFunction(torch.autograd.Function):
             O = torch.empty((B, t, H, dk), dtype=T, device=dev)
             O4 = O.permute(0, 2, 1, 3)
             if flash:                                   # modules.py:8-20 in one kernel, row statistics only
-                ops.flash_attn_fwd(q, k, v, km, O4, stats[i], t, scale, N * H * t * tp, p_att, rng, layer.site_attn)
+                ops.flash_attn_fwd(q, k, v, km, O4, stats[i], keep[i] if keep is not None else None, t, scale, N * H * t * tp, p_att,
+                                   rng, layer.site_attn)
             elif ops.attn_probs_supported(t, dk, T):    # scores stay in LDS (one kernel)
                 S, Pd = attn[:, i], attn_drop[:, i]
                 pv = ops.attn_second_product_supported(dk)
@@ -344,7 +347,7 @@ class EncoderStackFunction(torch.autograd.Function):
 
         ctx.enc, ctx.sv, ctx.layers, ctx.attn, ctx.attn_drop = enc, sv, layers, attn, attn_drop
         ctx.src, ctx.km = src, km
-        ctx.flash, ctx.stats = flash, (stats if flash else None)
+        ctx.flash, ctx.stats, ctx.keep = flash, (stats if flash else None), (keep if flash else None)
         ctx.set_materialize_grads(False)
         attn_out = attn_drop[..., :t] if not flash else torch.empty(0, dtype=T, device=dev)
         ctx.mark_non_differentiable(attn_out)
@@ -403,8 +406,8 @@ class EncoderStackFunction(torch.autograd.Function):
             d5 = dqkv.view(B, t, 3, H, dk)
             dq, dv, dk_ = (d5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
             if flash:                                   # probabilities recomputed from q, k and the row statistics
-                ops.flash_attn_bwd(q, k, v, ctx.km, L["O"].permute(0, 2, 1, 3), dO4, ctx.stats[i], aux, dq, dk_, dv, t, scale,
-                                   N * H * t * tp, p, rng, layer.site_attn)
+                ops.flash_attn_bwd(q, k, v, ctx.km, L["O"].permute(0, 2, 1, 3), dO4, ctx.stats[i],
+                                   ctx.keep[i] if ctx.keep is not None else None, aux, dq, dk_, dv, t, scale, p)
             else:
                 P, Pd = ctx.attn[:, i], ctx.attn_drop[:, i]
                 ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)             # dV = Pd^T dO

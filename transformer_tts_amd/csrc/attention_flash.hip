@@ -18,7 +18,16 @@
 //
 // Dropout: one Philox call covers 8 consecutive keys of one query.  A wave's 16 x 64 tile needs 128 calls = 2 per lane; each
 // lane turns its two calls into 16 keep-bits and the tile's owners fetch them with one cross-lane move per 4 (forward, dQ:
-// ds_bpermute) or 1 (dK/dV: DPP row_share) elements.
+// ds_bpermute) or 1 (dK/dV: DPP row_share) elements.  The forward kernel is the only one that runs Philox (the integer
+// multiplies are quarter rate and the loop is VALU-bound): it stashes the keep-bits, ONE BIT per probability (16-bit words
+// [b][h][key tile][query][16-key group]), and the two backward kernels read them back.  The factor 1/(1-p) is applied to the
+// accumulators at the end, not per element.
+//
+// Masks: the workgroup finds kfull = number of leading unmasked keys and kmax = last unmasked key + 1 of its batch row.  Tiles
+// below kfull run without any mask arithmetic; tiles at or beyond kmax are skipped: every key in them is masked, its
+// probability is exp(-1e4 - m) = 0 in fp32 as soon as one unmasked key exists (kmax > 0; otherwise nothing is skipped and the
+// uniform distribution of the reference comes out), so O, dQ receive nothing from them and their dK, dV rows are zero.
+// Softmax in the exp2 domain: p = exp2(s * (alpha log2 e) - m * (alpha log2 e)) is one fma + v_exp_f32.
 #include <stdlib.h>
 #include "common.cuh"
 
@@ -40,25 +49,43 @@ __device__ __forceinline__ bf16x8 ld16(__amdgpu_buffer_rsrc_t rs, unsigned byte_
 __device__ __forceinline__ int img_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 __device__ __forceinline__ int img_off(int row, int ch) { return row * 256 + ((ch ^ img_f(row)) << 4); }
 
-// operand rows r0 + i16, k-step ks (32 columns): the 16 bytes of chunk 4ks + g
-__device__ __forceinline__ bf16x8 row_frag(const unsigned char* img, int r0, int ks, int lane) {
-    return *reinterpret_cast<const bf16x8*>(img + img_off(r0 + (lane & 15), 4 * ks + (lane >> 4)));
-}
-// transposed operand: column 16ct + i16 of the rows {rA + 4g + q} u {rB + 4g + q}, q = 0..3
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int rA, int rB, int ct, int lane) {
+// LDS byte addresses of this lane's fragment reads inside an image at offset 0; everything else (which image, which buffer,
+// which 16-row tile) is a compile-time constant that lands in the instruction's offset field.  img_off(r0 + x, ch) =
+// 256 r0 + img_off(x, ch) for r0 % 16 == 0 because the swizzle only looks at the row's low 4 bits.
+struct FragAddr {
+    unsigned row[4];        // operand rows i16 (+ r0), k-step ks: chunk 4ks + g
+    unsigned tr[8];         // transposed operand, column tile ct: row 4g + q (+ rA / rB), chunk 2ct + (pp >> 1), half pp & 1
+};
+__device__ __forceinline__ FragAddr frag_addr(int lane, unsigned lds0) {
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
-    const int ch = 2 * ct + (pp >> 1), sub = 8 * (pp & 1);
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + img_off(rA + 4 * g + q, ch) + sub));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + img_off(rB + 4 * g + q, ch) + sub));
+    FragAddr fa;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fa.row[ks] = lds0 + img_off(i16, 4 * ks + g);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) fa.tr[ct] = lds0 + img_off(4 * g + q, 2 * ct + (pp >> 1)) + 8 * (pp & 1);
+    return fa;
+}
+typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8;
+template <int N> struct IC { static constexpr int value = N; };
+
+// operand rows r0 + i16 of the image at byte offset OFF, k-step ks (32 columns)
+template <int OFF> __device__ __forceinline__ bf16x8 row_frag(const FragAddr& fa, int ks) {
+    return *reinterpret_cast<lds_bf16x8*>(fa.row[ks] + OFF);
+}
+// transposed operand: column 16ct + i16 of the rows {rA + 4g + q} u {rA + 16 + 4g + q}, q = 0..3; OFF = image offset + 256 rA
+template <int OFF> __device__ __forceinline__ bf16x8 tr_frag(const FragAddr& fa, int ct) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>(fa.tr[ct] + OFF));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>(fa.tr[ct] + OFF + 16 * 256));
     union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
     u.s.lo = lo; u.s.hi = hi;
     return u.v;
 }
-// 16 x 16 product tile over the 128 columns: rows r0.. of the LDS image against the register fragments bf (B operand)
-__device__ __forceinline__ f32x4 tile128(const unsigned char* img, int r0, const bf16x8 (&bf)[4], int lane) {
+// 16 x 16 product tile over the 128 columns: rows r0.. of the LDS image (OFF = image offset + 256 r0) against the register
+// fragments bf (B operand)
+template <int OFF> __device__ __forceinline__ f32x4 tile128(const FragAddr& fa, const bf16x8 (&bf)[4]) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(img, r0, ks, lane), bf[ks], acc, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<OFF>(fa, ks), bf[ks], acc, 0, 0, 0);
     return acc;
 }
 __device__ __forceinline__ bf16x8 pack8(const float (&a)[4], const float (&b)[4]) {
@@ -95,6 +122,10 @@ template <int N> __device__ __forceinline__ unsigned row_share(unsigned v) {    
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xF, 0xF, false);
 }
 
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float MASKED_NAT = -1e4f;     // masked_fill value of the reference (Models/modules.py:12-14), scaled-score domain
+constexpr float NOKEY = -3.0e38f;       // keys that do not exist: exp2() = 0
+
 struct FlashArgs {
     const bf16_t *q, *k, *v;            // rows of one head: 128 contiguous bf16 at base + b*batch + i*row + h*head
     int64_t row, batch;                 // element strides of q / k / v (one fused projection tensor)
@@ -103,18 +134,49 @@ struct FlashArgs {
     bf16_t* O;                          // attention output (written by forward, read by backward), rows at O + b*o_batch + i*o_row + h*head
     int64_t o_row, o_batch;
     float* stats;                       // (B, H, t, 2): {row maximum of the masked scaled scores, sum of exponentials}
+    uint16_t* keep;                     // (B, H, nkt, t, 4) keep-bits of the dropout: bit j of word [b][h][kt][q][g] = key 64kt + 16g + j
     int64_t p_batch;                    // batch stride of the virtual P tensor (dropout counters)
-    int H, t, tp;
+    int B, H, t, tp, nkt;
     float alpha, pdrop;
     const uint64_t* rng;
     uint32_t site;
     // backward
     const bf16_t* dO;                   // rows at dO + b*do_batch + i*do_row + h*head
     int64_t do_row, do_batch;
-    float* aux;                         // (B, H, t, 4) workspace: {m, 1/l, delta = rowsum(dO * O), 0}: dQ kernel -> dK/dV kernel
+    float* aux;                         // (B, H, t, 4) workspace: {-m log2 e, 1/l, delta = rowsum(dO * O), 0}: dQ kernel -> dK/dV kernel
     bf16_t *dq, *dk, *dv;               // rows at d? + b*g_batch + i*g_row + h*head
     int64_t g_row, g_batch;
 };
+
+// Work item of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs; the row blocks of one (batch, head) pair -- which
+// stream the same K/V (or Q/dO) tiles -- are given to ONE XCD (one L2), and the pairs go round-robin over the XCDs so that a
+// batch sorted by length does not leave one XCD with all the long sequences.  Grid = 8 * ceil(B H / 8) * nblk.
+__device__ __forceinline__ bool flash_item(const FlashArgs& a, int& blk, int& h, int& b) {
+    const int nblk = (a.t + 127) >> 7;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int pair = (int)(blockIdx.x & 7) + 8 * (slot / nblk);
+    if (pair >= a.B * a.H) return false;
+    blk = slot % nblk;
+    h = pair % a.H;
+    b = pair / a.H;
+    return true;
+}
+
+// kfull = number of leading unmasked keys, kmax = last unmasked key + 1 of one batch row (optionally copies the row to LDS,
+// zero padded to MASK_BYTES).  red: two LDS words.  Ends with a barrier.
+__device__ __forceinline__ void scan_mask(const uint8_t* km_row, int t, unsigned char* lmask, int* red, int tid) {
+    if (tid == 0) { red[0] = t; red[1] = 0; }
+    __syncthreads();
+    for (int j = tid; j < MASK_BYTES; j += 512) {
+        const unsigned char mk = j < t ? km_row[j] : 0;
+        if (lmask) lmask[j] = mk;
+        if (j < t) {
+            if (mk) atomicMax(&red[1], j + 1);
+            else atomicMin(&red[0], j);
+        }
+    }
+    __syncthreads();
+}
 
 // stage one 64-row tile: instruction i (0,1) of wave w covers tile rows 4*(8i + w) .. +3; lane -> row lane>>4, logical chunk
 // (lane&15) ^ f(row); rows >= t use an out-of-range offset (zeros)
@@ -130,101 +192,130 @@ __device__ __forceinline__ void stage_tile(const __amdgpu_buffer_rsrc_t rs, unsi
     }
 }
 
-// masked, scaled score of a key: masked_fill(mask == 0, -1e4) (modules.py:12-14); keys that do not exist -> exp() = 0
-__device__ __forceinline__ float mask_score(float s, float alpha, unsigned mk_byte, bool exists) {
-    float v = s * alpha;
-    v = mk_byte != 0 ? v : -1e4f;
-    return exists ? v : -3.0e38f;
+__device__ __forceinline__ float and_mask(float v, int msk) { return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & msk); }
+__device__ __forceinline__ int keep_mask(unsigned bits, unsigned pos) { return __builtin_amdgcn_sbfe((int)bits, pos, 1u); }   // bit -> 0 / ~0
+
+// raw scores S^T of one 64-key tile (image at byte offset KOFF) against the wave's 16 queries: x[T][r] = key 64kt + 16T + 4g + r,
+// query i16.  masked (workgroup-uniform): the tile holds masked or non-existent keys -- keys with mask 0 get the raw value whose
+// scaled score is -1e4 (masked_fill), keys >= t get NOKEY.  The MFMA work is common to both cases, only the element-wise fix-ups
+// sit under the branch (two instantiated copies of a whole step cost ~100 spilled registers in the dQ kernel).
+template <int KOFF>
+__device__ __forceinline__ void score_tiles(const bool masked, const FragAddr& fa, const bf16x8 (&qf)[4], const unsigned char* lmask, int kt,
+                                            int t, float masked_raw, int lane, float (&x)[4][4], float& tmax) {
+    const int g = lane >> 4;
+    auto one = [&](auto TC) {
+        constexpr int T = decltype(TC)::value;
+        const f32x4 s = tile128<KOFF + 4096 * T>(fa, qf);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[T][r] = s[r];
+        if (masked) {
+            const int key0 = 64 * kt + 16 * T + 4 * g;
+            const unsigned mk = *reinterpret_cast<const unsigned*>(lmask + key0);        // key0 % 4 == 0; bytes >= t are 0
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x[T][r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? x[T][r] : masked_raw;
+                x[T][r] = (key0 + r < t) ? x[T][r] : NOKEY;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, x[T][r]);
+    };
+    one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{});
 }
 
 // ------------------------------------------------------------------------------------------------ forward
 // O = dropout(softmax(mask(alpha Q K^T))) V, stats = {m, l}.  Wave: 16 queries (columns of the transposed score tiles).
+// LDS: K images [2][TILE] at 0, V images [2][TILE] at 2 TILE, key mask, two reduction words.
+template <bool DROP>
 __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int blk, h, b;
+    if (!flash_item(a, blk, h, b)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z, t = a.t;
-    const int qrow = blockIdx.x * 128 + wave * 16 + i16;
+    const int t = a.t;
+    const int qrow = blk * 128 + wave * 16 + i16;
     unsigned char* kimg = smem;                       // [2][TILE]
     unsigned char* vimg = smem + 2 * TILE;            // [2][TILE]
     unsigned char* lmask = smem + 4 * TILE;
+    int* red = reinterpret_cast<int*>(smem + 4 * TILE + MASK_BYTES);
+    const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
     const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
     const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
     const int rowst = (int)a.row;
-    for (int j = tid; j < MASK_BYTES; j += 512) lmask[j] = (j < t) ? a.key_mask[(int64_t)b * t + j] : 0;
-
+    stage_tile(rs_k, kimg, 0, t, rowst, wave, lane);
+    stage_tile(rs_v, vimg, 0, t, rowst, wave, lane);
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = ld16(rs_q, qrow < t ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
+    scan_mask(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
+    const int kfull = red[0], kmax = red[1];
+    const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
 
-    const int nkt = (t + 63) >> 6;
-    stage_tile(rs_k, kimg, 0, t, rowst, wave, lane);
-    stage_tile(rs_v, vimg, 0, t, rowst, wave, lane);
     const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
     const int64_t prow = (int64_t)b * a.p_batch + ((int64_t)h * t + (qrow < t ? qrow : 0)) * a.tp;
-    float m = -3.0e38f, l = 0.f;
+    uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t + (qrow < t ? qrow : 0)) * 4 + g;
+    const float c2 = a.alpha * LOG2E, masked_raw = MASKED_NAT / a.alpha;
+    float m = NOKEY, l = 0.f;            // m: running maximum of the RAW scores
     f32x4 oacc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
+    auto tile = [&](const int kt, auto BUFC) {
+        constexpr int BUF = decltype(BUFC)::value;
+        constexpr int KOFF = BUF * TILE, VOFF = 2 * TILE + BUF * TILE;
         if (kt + 1 < nkt) {
-            stage_tile(rs_k, kimg + (buf ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
-            stage_tile(rs_v, vimg + (buf ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
         }
-        const unsigned char* ki = kimg + buf * TILE;
-        const unsigned char* vi = vimg + buf * TILE;
-        // keep-bits of query i16, keys 64kt + 16g .. +15
-        const unsigned mybits = dc.on ? drop_bits16(dc, (uint64_t)(prow + 64 * kt + 16 * g)) : 0xFFFFu;
-        // ---- S^T tiles: x[T][r] = score of key 64kt + 16T + 4g + r against query i16
+        unsigned mybits = 0;
+        if (DROP) {                       // keep-bits of query i16, keys 64kt + 16g .. +15; stashed for the backward kernels
+            mybits = drop_bits16(dc, (uint64_t)(prow + 64 * kt + 16 * g));
+            if (qrow < t) keep[(int64_t)kt * t * 4] = (uint16_t)mybits;
+        }
         float x[4][4];
-        float tmax = -3.0e38f;
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            const f32x4 s = tile128(ki, 16 * T, qf, lane);
-            const int key0 = 64 * kt + 16 * T + 4 * g;
-            const unsigned mk = *reinterpret_cast<const unsigned*>(lmask + key0);        // key0 % 4 == 0; bytes >= t are 0
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                x[T][r] = mask_score(s[r], a.alpha, (mk >> (8 * r)) & 0xFFu, key0 + r < t);
-                tmax = fmaxf(tmax, x[T][r]);
-            }
-        }
+        float tmax = NOKEY;
+        score_tiles<KOFF>(64 * (kt + 1) > kfull, fa, qf, lmask, kt, t, masked_raw, lane, x, tmax);
         tmax = xor16_32_max(tmax);
-        const float m_new = fmaxf(m, tmax);
-        const float corr = __expf(m - m_new);
-        l *= corr;
+        if (__any(tmax > m)) {           // a new row maximum somewhere in the wave: rescale
+            const float m_new = fmaxf(m, tmax);
+            const float corr = __builtin_amdgcn_exp2f((m - m_new) * c2);
+            l *= corr;
 #pragma unroll
-        for (int d = 0; d < 8; ++d)
+            for (int d = 0; d < 8; ++d)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) oacc[d][r] *= corr;
-        m = m_new;
+                for (int r = 0; r < 4; ++r) oacc[d][r] *= corr;
+            m = m_new;
+        }
+        const float nm = -m * c2;
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            const unsigned bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
+            unsigned bT = 0;
+            if (DROP) bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pv = __expf(x[T][r] - m);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[T][r], c2, nm));
                 l += pv;
-                x[T][r] = ((bT >> r) & 1u) ? pv * dc.scale : 0.f;
+                x[T][r] = DROP ? and_mask(pv, keep_mask(bT, r)) : pv;
             }
         }
         // ---- O^T += V^T P^T: k-step kp covers the keys of score tiles 2kp, 2kp+1 (in the accumulators' own order)
+        const bf16x8 pb0 = pack8(x[0], x[1]), pb1 = pack8(x[2], x[3]);
 #pragma unroll
-        for (int kp = 0; kp < 2; ++kp) {
-            const bf16x8 pb = pack8(x[2 * kp], x[2 * kp + 1]);
+        for (int d = 0; d < 8; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VOFF>(fa, d), pb0, oacc[d], 0, 0, 0);
 #pragma unroll
-            for (int d = 0; d < 8; ++d)
-                oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(vi, 32 * kp, 32 * kp + 16, d, lane), pb, oacc[d], 0, 0, 0);
-        }
+        for (int d = 0; d < 8; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VOFF + 8192>(fa, d), pb1, oacc[d], 0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, IC<0>{});
+        if (kt + 1 < nkt) tile(kt + 1, IC<1>{});
     }
     l = xor16_32_sum(l);
     if (qrow < t) {
-        const float inv = 1.f / l;
+        const float inv = dc.scale / l;             // 1/(1-p) of the kept probabilities, applied once
         bf16_t* orow = a.O + (int64_t)b * a.o_batch + (int64_t)qrow * a.o_row + (int64_t)h * a.head;
 #pragma unroll
         for (int d = 0; d < 8; ++d) {           // oacc[d][r] = O[qrow][16d + 4g + r]
@@ -233,29 +324,79 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
             for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(oacc[d][r] * inv);
             *reinterpret_cast<bf16x4*>(orow + 16 * d + 4 * g) = o;
         }
-        if (g == 0) *reinterpret_cast<float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2) = make_float2(m, l);
+        if (g == 0) *reinterpret_cast<float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2) = make_float2(m * a.alpha, l);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ aux)
-// Per wave 16 queries; recomputes S^T and dPd^T = V dO^T per 64-key tile, dS^T = P (dPd keep c - delta) (0 at masked keys:
-// masked_fill's backward), dQ^T += K^T dS^T.  Also writes aux = {m, 1/l, delta, 0} per query for the dK/dV kernel.
+// Per wave 16 queries; recomputes S^T and dPd^T = V dO^T per 64-key tile, dS^T = P (dPd keep / (1-p) - delta) (0 at masked keys:
+// masked_fill's backward), dQ^T += K^T dS^T.  Also writes aux = {-m log2 e, 1/l, delta, 0} per query for the dK/dV kernel.
+template <bool DROP, int KOFF, int VOFF>
+__device__ __forceinline__ void dq_tiles(const bool masked, const FragAddr& fa, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
+                                         const unsigned char* lmask, int kt, int t, float masked_raw, float c2, float nm2, float linv,
+                                         float delta, float scale, unsigned mybits, int lane, f32x4 (&dqacc)[8]) {
+    const int g = lane >> 4, i16 = lane & 15;
+    auto pair = [&](auto KPC) {
+        constexpr int kp = decltype(KPC)::value;
+        float ds[2][4];
+        auto one = [&](auto UC) {
+            constexpr int u = decltype(UC)::value, T = 2 * kp + u;
+            __builtin_amdgcn_sched_barrier(0);          // keep the operand reads of later tiles from being hoisted (register pressure)
+            const f32x4 s = tile128<KOFF + 4096 * T>(fa, qf);
+            const f32x4 dp = tile128<VOFF + 4096 * T>(fa, dof);
+            const int key0 = 64 * kt + 16 * T + 4 * g;
+            float v[4] = {s[0], s[1], s[2], s[3]};
+            unsigned mk = 0x01010101u, bT = 0;
+            if (masked) {
+                mk = *reinterpret_cast<const unsigned*>(lmask + key0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? v[r] : masked_raw;
+                    v[r] = (key0 + r < t) ? v[r] : NOKEY;
+                }
+            }
+            if (DROP) bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pn = __builtin_amdgcn_exp2f(__builtin_fmaf(v[r], c2, nm2)) * linv;
+                const float t1 = DROP ? and_mask(dp[r], keep_mask(bT, r)) : dp[r];
+                ds[u][r] = pn * __builtin_fmaf(t1, scale, -delta);
+            }
+            if (masked) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[u][r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? ds[u][r] : 0.f;      // masked_fill's backward
+            }
+        };
+        one(IC<0>{}); one(IC<1>{});
+        const bf16x8 dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dqacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<KOFF + 8192 * kp>(fa, d), dsb, dqacc[d], 0, 0, 0);
+    };
+    pair(IC<0>{}); pair(IC<1>{});
+}
+
+template <bool DROP>
 __global__ __launch_bounds__(512, 4) void flash_bwd_dq_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int blk, h, b;
+    if (!flash_item(a, blk, h, b)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z, t = a.t;
-    const int qrow = blockIdx.x * 128 + wave * 16 + i16;
+    const int t = a.t;
+    const int qrow = blk * 128 + wave * 16 + i16;
     unsigned char* kimg = smem;
     unsigned char* vimg = smem + 2 * TILE;
     unsigned char* lmask = smem + 4 * TILE;
+    int* red = reinterpret_cast<int*>(smem + 4 * TILE + MASK_BYTES);
+    const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
     const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
     const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
     const __amdgpu_buffer_rsrc_t rs_do = make_rsrc(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head);
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.O + (int64_t)b * a.o_batch + (int64_t)h * a.head);
     const int rowst = (int)a.row;
-    for (int j = tid; j < MASK_BYTES; j += 512) lmask[j] = (j < t) ? a.key_mask[(int64_t)b * t + j] : 0;
+    stage_tile(rs_k, kimg, 0, t, rowst, wave, lane);
+    stage_tile(rs_v, vimg, 0, t, rowst, wave, lane);
 
     bf16x8 qf[4], dof[4];
     float delta = 0.f;
@@ -268,58 +409,40 @@ __global__ __launch_bounds__(512, 4) void flash_bwd_dq_k(const FlashArgs a) {
         for (int c = 0; c < 8; ++c) delta += (float)dof[ks][c] * (float)of[c];
     }
     delta = xor16_32_sum(delta);
-    float m = 0.f, linv = 0.f;
+    float nm2 = 0.f, linv = 0.f;
     if (qrow < t) {
         const float2 st = *reinterpret_cast<const float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2);
-        m = st.x;
+        nm2 = -st.x * LOG2E;
         linv = 1.f / st.y;
-        if (g == 0) *reinterpret_cast<float4*>(a.aux + (((int64_t)b * a.H + h) * t + qrow) * 4) = make_float4(m, linv, delta, 0.f);
+        if (g == 0) *reinterpret_cast<float4*>(a.aux + (((int64_t)b * a.H + h) * t + qrow) * 4) = make_float4(nm2, linv, delta, 0.f);
     }
-
-    const int nkt = (t + 63) >> 6;
-    stage_tile(rs_k, kimg, 0, t, rowst, wave, lane);
-    stage_tile(rs_v, vimg, 0, t, rowst, wave, lane);
-    const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
-    const int64_t prow = (int64_t)b * a.p_batch + ((int64_t)h * t + (qrow < t ? qrow : 0)) * a.tp;
+    scan_mask(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
+    const int kfull = red[0], kmax = red[1];
+    const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
+    const float scale = DROP ? 65536.f / (65536.f - (float)(uint32_t)(a.pdrop * 65536.f + 0.5f)) : 1.f;
+    const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t + (qrow < t ? qrow : 0)) * 4 + g;
+    const float c2 = a.alpha * LOG2E, masked_raw = MASKED_NAT / a.alpha;
     f32x4 dqacc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) dqacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned bits_next = DROP ? keep[0] : 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
+    auto tile = [&](const int kt, auto BUFC) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const unsigned mybits = bits_next;
         if (kt + 1 < nkt) {
-            stage_tile(rs_k, kimg + (buf ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
-            stage_tile(rs_v, vimg + (buf ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            if (DROP) bits_next = keep[(int64_t)(kt + 1) * t * 4];
         }
-        const unsigned char* ki = kimg + buf * TILE;
-        const unsigned char* vi = vimg + buf * TILE;
-        const unsigned mybits = dc.on ? drop_bits16(dc, (uint64_t)(prow + 64 * kt + 16 * g)) : 0xFFFFu;
-#pragma unroll
-        for (int kp = 0; kp < 2; ++kp) {
-            float ds[2][4];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int T = 2 * kp + u;
-                const f32x4 s = tile128(ki, 16 * T, qf, lane);
-                const f32x4 dp = tile128(vi, 16 * T, dof, lane);
-                const int key0 = 64 * kt + 16 * T + 4 * g;
-                const unsigned mk = *reinterpret_cast<const unsigned*>(lmask + key0);
-                const unsigned bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned mb = (mk >> (8 * r)) & 0xFFu;
-                    const float pn = __expf(mask_score(s[r], a.alpha, mb, key0 + r < t) - m) * linv;
-                    const float kc = ((bT >> r) & 1u) ? dc.scale : 0.f;
-                    ds[u][r] = mb != 0 ? pn * (dp[r] * kc - delta) : 0.f;
-                }
-            }
-            const bf16x8 dsb = pack8(ds[0], ds[1]);
-#pragma unroll
-            for (int d = 0; d < 8; ++d)
-                dqacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(ki, 32 * kp, 32 * kp + 16, d, lane), dsb, dqacc[d], 0, 0, 0);
-        }
+        dq_tiles<DROP, BUF * TILE, 2 * TILE + BUF * TILE>(64 * (kt + 1) > kfull, fa, qf, dof, lmask, kt, t, masked_raw, c2, nm2, linv, delta,
+                                                          scale, mybits, lane, dqacc);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, IC<0>{});
+        if (kt + 1 < nkt) tile(kt + 1, IC<1>{});
     }
     if (qrow < t) {
         bf16_t* drow = a.dq + (int64_t)b * a.g_batch + (int64_t)qrow * a.g_row + (int64_t)h * a.head;
@@ -336,31 +459,48 @@ __global__ __launch_bounds__(512, 4) void flash_bwd_dq_k(const FlashArgs a) {
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // Per wave 16 keys (K and V fragments in registers); streams Q, dO and aux tiles of 64 queries.  S = Q K^T and dPd = dO V^T in
 // the layout D[query 4g + r][key i16]; dV^T += dO^T Pd, dK^T += Q^T dS (contraction over the queries, operands as above).
+// LDS: Q images [2][TILE] at 0, dO images [2][TILE] at 2 TILE, aux [2][AUX_BYTES], two reduction words.
+template <int T> __device__ __forceinline__ void row_share4(unsigned bits, unsigned (&kb)[4]) {
+    kb[0] = row_share<4 * T>(bits); kb[1] = row_share<4 * T + 1>(bits); kb[2] = row_share<4 * T + 2>(bits); kb[3] = row_share<4 * T + 3>(bits);
+}
+
+template <bool DROP>
 __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int blk, h, b;
+    if (!flash_item(a, blk, h, b)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z, t = a.t;
-    const int kb0 = blockIdx.x * 128 + wave * 16;
+    const int t = a.t;
+    const int kb0 = blk * 128 + wave * 16;
     const int key = kb0 + i16;
     unsigned char* qimg = smem;                         // [2][TILE]
     unsigned char* doimg = smem + 2 * TILE;             // [2][TILE]
     unsigned char* auximg = smem + 4 * TILE;            // [2][AUX_BYTES]
+    int* red = reinterpret_cast<int*>(smem + 4 * TILE + 2 * AUX_BYTES);
+    const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
     const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
     const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
     const __amdgpu_buffer_rsrc_t rs_do = make_rsrc(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head);
     const __amdgpu_buffer_rsrc_t rs_aux = make_rsrc(a.aux + (((int64_t)b * a.H + h) * t) * 4);
     const int rowst = (int)a.row, dorow = (int)a.do_row;
-
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = ld16(rs_k, key < t ? (unsigned)((key * rowst + 32 * ks + 8 * g) * 2) : OOB);
-        vf[ks] = ld16(rs_v, key < t ? (unsigned)((key * rowst + 32 * ks + 8 * g) * 2) : OOB);
-    }
     const bool kvalid = key < t;
-    const unsigned mkb = kvalid ? a.key_mask[(int64_t)b * t + key] : 0;
+    const int64_t goff = (int64_t)b * a.g_batch + (int64_t)key * a.g_row + (int64_t)h * a.head;
+
+    scan_mask(a.key_mask + (int64_t)b * t, t, nullptr, red, tid);
+    const int kmax = red[1];
+    if (kmax > 0 && blk * 128 >= kmax) {     // every key of this block is masked: zero probability, zero gradients
+        if (kvalid) {
+            const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                *reinterpret_cast<bf16x4*>(a.dv + goff + 16 * d + 4 * g) = z;
+                *reinterpret_cast<bf16x4*>(a.dk + goff + 16 * d + 4 * g) = z;
+            }
+        }
+        return;
+    }
 
     auto stage = [&](int qt, int buf) {
         stage_tile(rs_q, qimg + buf * TILE, 64 * qt, t, rowst, wave, lane);
@@ -373,114 +513,141 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     };
     const int nqt = (t + 63) >> 6;
     stage(0, 0);
-    const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
-    const int64_t pbase = (int64_t)b * a.p_batch + (int64_t)h * t * a.tp + kb0;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = ld16(rs_k, kvalid ? (unsigned)((key * rowst + 32 * ks + 8 * g) * 2) : OOB);
+        vf[ks] = ld16(rs_v, kvalid ? (unsigned)((key * rowst + 32 * ks + 8 * g) * 2) : OOB);
+    }
+    const bool on = kvalid && a.key_mask[(int64_t)b * t + (kvalid ? key : 0)] != 0;
+    // exp2 argument of this lane's key: s * cl + bl - m log2 e  (masked key: -1e4 log2 e; key that does not exist: NOKEY)
+    const float cl = on ? a.alpha * LOG2E : 0.f;
+    const float bl = !kvalid ? NOKEY : (on ? 0.f : MASKED_NAT * LOG2E);
+    const float ml = on ? 1.f : 0.f;                   // masked_fill's backward
+    const float scale = DROP ? 65536.f / (65536.f - (float)(uint32_t)(a.pdrop * 65536.f + 0.5f)) : 1.f;
+    // keep-bits of the wave's 16 keys for query 64qt + 16(i16>>2) + 4g + (i16&3): element (T, r) = (i16>>2, i16&3) of this
+    // lane's row of 16 lanes
+    const int qsub = 16 * (i16 >> 2) + 4 * g + (i16 & 3);
+    const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt + (kb0 >> 6)) * t) * 4 + ((kb0 >> 4) & 3);
+    unsigned bits_next = (DROP && qsub < t) ? keep[(int64_t)qsub * 4] : 0;
     f32x4 dvacc[8], dkacc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) { dvacc[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dkacc[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    for (int qt = 0; qt < nqt; ++qt) {
-        const int buf = qt & 1;
-        if (qt + 1 < nqt) stage(qt + 1, buf ^ 1);
-        const unsigned char* qi = qimg + buf * TILE;
-        const unsigned char* di = doimg + buf * TILE;
-        const float4* aux = reinterpret_cast<const float4*>(auximg + buf * AUX_BYTES);
-        // keep-bits of the wave's 16 keys for query 64qt + 16(i16>>2) + 4g + (i16&3): the element (T, r) = (i16>>2, i16&3) of
-        // this lane's row of 16 lanes
-        unsigned mybits = 0xFFFFu;
-        if (dc.on) {
-            const int qq = 64 * qt + 16 * (i16 >> 2) + 4 * g + (i16 & 3);
-            mybits = drop_bits16(dc, (uint64_t)(pbase + (int64_t)(qq < t ? qq : 0) * a.tp));
+    auto tile = [&](const int qt, auto BUFC) {
+        constexpr int BUF = decltype(BUFC)::value;
+        constexpr int QOFF = BUF * TILE, DOFF = 2 * TILE + BUF * TILE;
+        const unsigned mybits = bits_next;
+        if (qt + 1 < nqt) {
+            stage(qt + 1, BUF ^ 1);
+            const int qq = 64 * (qt + 1) + qsub;
+            if (DROP) bits_next = qq < t ? keep[(int64_t)qq * 4] : 0;
         }
-#pragma unroll
-        for (int kp = 0; kp < 2; ++kp) {
+        const float4* aux = reinterpret_cast<const float4*>(auximg + BUF * AUX_BYTES);
+        auto pair = [&](auto KPC) {
+            constexpr int kp = decltype(KPC)::value;
             float pd[2][4], ds[2][4];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int T = 2 * kp + u;
-                const f32x4 s = tile128(qi, 16 * T, kf, lane);
-                const f32x4 dp = tile128(di, 16 * T, vf, lane);
-                unsigned kb[4];
-                if (T == 0) { kb[0] = row_share<0>(mybits); kb[1] = row_share<1>(mybits); kb[2] = row_share<2>(mybits); kb[3] = row_share<3>(mybits); }
-                else if (T == 1) { kb[0] = row_share<4>(mybits); kb[1] = row_share<5>(mybits); kb[2] = row_share<6>(mybits); kb[3] = row_share<7>(mybits); }
-                else if (T == 2) { kb[0] = row_share<8>(mybits); kb[1] = row_share<9>(mybits); kb[2] = row_share<10>(mybits); kb[3] = row_share<11>(mybits); }
-                else { kb[0] = row_share<12>(mybits); kb[1] = row_share<13>(mybits); kb[2] = row_share<14>(mybits); kb[3] = row_share<15>(mybits); }
+            auto one = [&](auto UC) {
+                constexpr int u = decltype(UC)::value, T = 2 * kp + u;
+                __builtin_amdgcn_sched_barrier(0);      // as in dq_tiles
+                const f32x4 s = tile128<QOFF + 4096 * T>(fa, kf);
+                const f32x4 dp = tile128<DOFF + 4096 * T>(fa, vf);
+                unsigned kb[4] = {0, 0, 0, 0};
+                if (DROP) row_share4<T>(mybits, kb);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float4 ax = aux[16 * T + 4 * g + r];                         // {m, 1/l, delta, -}; zeros for q >= t
-                    const float pn = kvalid ? __expf(mask_score(s[r], a.alpha, mkb, true) - ax.x) * ax.y : 0.f;
-                    const float kc = ((kb[r] >> i16) & 1u) ? dc.scale : 0.f;
-                    pd[u][r] = pn * kc;
-                    ds[u][r] = mkb != 0 ? pn * (dp[r] * kc - ax.z) : 0.f;
+                    const float4 ax = aux[16 * T + 4 * g + r];                         // {-m log2 e, 1/l, delta, -}; zeros for q >= t
+                    const float pn = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cl, bl) + ax.x) * ax.y;
+                    float t1 = dp[r], pk = pn;
+                    if (DROP) {
+                        const int msk = keep_mask(kb[r], (unsigned)i16);
+                        t1 = and_mask(t1, msk);
+                        pk = and_mask(pn, msk);
+                    }
+                    pd[u][r] = pk;
+                    ds[u][r] = (pn * ml) * __builtin_fmaf(t1, scale, -ax.z);
                 }
-            }
+            };
+            one(IC<0>{}); one(IC<1>{});
             const bf16x8 pdb = pack8(pd[0], pd[1]);
             const bf16x8 dsb = pack8(ds[0], ds[1]);
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
-                dvacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(di, 32 * kp, 32 * kp + 16, d, lane), pdb, dvacc[d], 0, 0, 0);
-                dkacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(qi, 32 * kp, 32 * kp + 16, d, lane), dsb, dkacc[d], 0, 0, 0);
+                dvacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DOFF + 8192 * kp>(fa, d), pdb, dvacc[d], 0, 0, 0);
+                dkacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<QOFF + 8192 * kp>(fa, d), dsb, dkacc[d], 0, 0, 0);
             }
-        }
+        };
+        pair(IC<0>{}); pair(IC<1>{});
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int qt = 0; qt < nqt; qt += 2) {
+        tile(qt, IC<0>{});
+        if (qt + 1 < nqt) tile(qt + 1, IC<1>{});
     }
     if (kvalid) {
-        const int64_t off = (int64_t)b * a.g_batch + (int64_t)key * a.g_row + (int64_t)h * a.head;
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
             bf16x4 ov, ok;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { ov[r] = (bf16_t)dvacc[d][r]; ok[r] = (bf16_t)(dkacc[d][r] * a.alpha); }
-            *reinterpret_cast<bf16x4*>(a.dv + off + 16 * d + 4 * g) = ov;
-            *reinterpret_cast<bf16x4*>(a.dk + off + 16 * d + 4 * g) = ok;
+            for (int r = 0; r < 4; ++r) { ov[r] = (bf16_t)(dvacc[d][r] * scale); ok[r] = (bf16_t)(dkacc[d][r] * a.alpha); }
+            *reinterpret_cast<bf16x4*>(a.dv + goff + 16 * d + 4 * g) = ov;
+            *reinterpret_cast<bf16x4*>(a.dk + goff + 16 * d + 4 * g) = ok;
         }
     }
 }
 
 int check_common(const char* who, const void* q, const void* k, const void* v, int64_t row, int64_t batch, int head, int B, int H, int t,
-                 int tp, int64_t p_batch, float p, const uint64_t* rng) {
+                 float p, const void* keep_bits) {
     FS2_REQUIRE(q && k && v, "%s: null argument", who);
-    FS2_REQUIRE(t > 0 && t <= MASK_BYTES && tp == (t + 7) / 8 * 8, "%s: need 0 < t <= 1024 and tp = roundup8(t) (t=%d tp=%d)", who, t, tp);
-    FS2_REQUIRE(B > 0 && H > 0 && B <= 65535 && H <= 65535, "%s: bad B/H", who);
-    FS2_REQUIRE(row % 8 == 0 && batch % 8 == 0 && head % 8 == 0 && p_batch % 8 == 0, "%s: strides must be multiples of 8 elements", who);
+    FS2_REQUIRE(t > 0 && t <= MASK_BYTES, "%s: need 0 < t <= 1024 (t=%d)", who, t);
+    FS2_REQUIRE(B > 0 && H > 0 && (int64_t)B * H * ((t + 127) / 128) < (1 << 28), "%s: bad B/H", who);
+    FS2_REQUIRE(row % 8 == 0 && batch % 8 == 0 && head % 8 == 0, "%s: strides must be multiples of 8 elements", who);
     FS2_REQUIRE(fs2_aligned16(q) && fs2_aligned16(k) && fs2_aligned16(v), "%s: pointers must be 16-byte aligned", who);
     FS2_REQUIRE((int64_t)(t + 64) * row * 2 < 0x7FFFFFF0LL, "%s: one (batch, head) slice exceeds 2 GiB", who);
-    FS2_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || rng != nullptr), "%s: bad dropout arguments", who);
+    FS2_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || keep_bits != nullptr), "%s: dropout needs the keep-bits buffer", who);
     return FS2_OK;
 }
 
+int flash_grid(int B, int H, int t) { return 8 * ((B * H + 7) / 8) * ((t + 127) / 128); }
+
 }  // namespace
+
+extern "C" int64_t fs2_flash_attn_keep_words(int B, int H, int t) { return (int64_t)B * H * ((t + 63) / 64) * t * 4; }
 
 extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                                   const uint8_t* key_mask, void* o_out, int64_t o_row_stride, int64_t o_batch_stride, float* stats,
-                                  int64_t p_batch_stride, int B, int H, int t, int tp, float alpha, float p, const uint64_t* rng,
-                                  uint32_t site, void* stream) {
-    const int rc = check_common("fs2_flash_attn_fwd", q, k, v, row_stride, batch_stride, head_stride, B, H, t, tp, p_batch_stride, p, rng);
+                                  uint16_t* keep_bits, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha, float p,
+                                  const uint64_t* rng, uint32_t site, void* stream) {
+    const int rc = check_common("fs2_flash_attn_fwd", q, k, v, row_stride, batch_stride, head_stride, B, H, t, p, keep_bits);
     if (rc != FS2_OK) return rc;
     FS2_REQUIRE(key_mask && o_out && stats, "fs2_flash_attn_fwd: null argument");
+    FS2_REQUIRE(tp == (t + 7) / 8 * 8 && p_batch_stride % 8 == 0, "fs2_flash_attn_fwd: need tp = roundup8(t) and p_batch_stride %% 8 == 0");
     FS2_REQUIRE(o_row_stride % 4 == 0 && o_batch_stride % 4 == 0 && fs2_aligned16(o_out), "fs2_flash_attn_fwd: output rows must be 8-byte aligned");
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_flash_attn_fwd: dropout needs rng");
     FlashArgs a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.row = row_stride; a.batch = batch_stride; a.head = head_stride;
-    a.key_mask = key_mask; a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.stats = stats; a.p_batch = p_batch_stride;
-    a.H = H; a.t = t; a.tp = tp; a.alpha = alpha; a.pdrop = p; a.rng = rng; a.site = site;
-    const int lds = 4 * TILE + MASK_BYTES;
+    a.key_mask = key_mask; a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.stats = stats; a.keep = keep_bits;
+    a.p_batch = p_batch_stride; a.B = B; a.H = H; a.t = t; a.tp = tp; a.nkt = (t + 63) / 64; a.alpha = alpha; a.pdrop = p; a.rng = rng; a.site = site;
+    const int lds = 4 * TILE + MASK_BYTES + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(flash_fwd_k, dim3((t + 127) / 128, H, B), dim3(512), lds, (hipStream_t)stream, a);
+    if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<true>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(flash_fwd_k<false>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
     FS2_CHECK_LAUNCH("fs2_flash_attn_fwd");
     return FS2_OK;
 }
 
 extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                                   const uint8_t* key_mask, const void* o_saved, int64_t o_row_stride, int64_t o_batch_stride,
-                                  const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats, float* aux,
-                                  void* dq, void* dk, void* dv, int64_t g_row_stride, int64_t g_batch_stride, int64_t p_batch_stride,
-                                  int B, int H, int t, int tp, float alpha, float p, const uint64_t* rng, uint32_t site, void* stream) {
-    const int rc = check_common("fs2_flash_attn_bwd", q, k, v, row_stride, batch_stride, head_stride, B, H, t, tp, p_batch_stride, p, rng);
+                                  const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats,
+                                  const uint16_t* keep_bits, float* aux, void* dq, void* dk, void* dv, int64_t g_row_stride,
+                                  int64_t g_batch_stride, int B, int H, int t, float alpha, float p, void* stream) {
+    const int rc = check_common("fs2_flash_attn_bwd", q, k, v, row_stride, batch_stride, head_stride, B, H, t, p, keep_bits);
     if (rc != FS2_OK) return rc;
     FS2_REQUIRE(key_mask && o_saved && d_out && stats && aux && dq && dk && dv, "fs2_flash_attn_bwd: null argument");
     FS2_REQUIRE(o_row_stride % 8 == 0 && o_batch_stride % 8 == 0 && do_row_stride % 8 == 0 && do_batch_stride % 8 == 0 && g_row_stride % 4 == 0 &&
@@ -492,20 +659,27 @@ extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, i
     FlashArgs a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.row = row_stride; a.batch = batch_stride; a.head = head_stride;
     a.key_mask = key_mask; a.O = (bf16_t*)const_cast<void*>(o_saved); a.o_row = o_row_stride; a.o_batch = o_batch_stride;
-    a.stats = const_cast<float*>(stats); a.p_batch = p_batch_stride;
-    a.H = H; a.t = t; a.tp = tp; a.alpha = alpha; a.pdrop = p; a.rng = rng; a.site = site;
+    a.stats = const_cast<float*>(stats); a.keep = const_cast<uint16_t*>(keep_bits);
+    a.B = B; a.H = H; a.t = t; a.tp = (t + 7) / 8 * 8; a.nkt = (t + 63) / 64; a.alpha = alpha; a.pdrop = p;
     a.dO = (const bf16_t*)d_out; a.do_row = do_row_stride; a.do_batch = do_batch_stride; a.aux = aux;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.g_row = g_row_stride; a.g_batch = g_batch_stride;
-    const int lds_q = 4 * TILE + MASK_BYTES, lds_kv = 4 * TILE + 2 * AUX_BYTES;
+    const int lds_q = 4 * TILE + MASK_BYTES + 16, lds_kv = 4 * TILE + 2 * AUX_BYTES + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
         attr_set = true;
     }
-    const dim3 grid((t + 127) / 128, H, B);
-    hipLaunchKernelGGL(flash_bwd_dq_k, grid, dim3(512), lds_q, (hipStream_t)stream, a);
-    hipLaunchKernelGGL(flash_bwd_dkv_k, grid, dim3(512), lds_kv, (hipStream_t)stream, a);
+    const dim3 grid(flash_grid(B, H, t));
+    if (p > 0.f) {
+        hipLaunchKernelGGL(flash_bwd_dq_k<true>, grid, dim3(512), lds_q, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(flash_bwd_dkv_k<true>, grid, dim3(512), lds_kv, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(flash_bwd_dq_k<false>, grid, dim3(512), lds_q, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(flash_bwd_dkv_k<false>, grid, dim3(512), lds_kv, (hipStream_t)stream, a);
+    }
     FS2_CHECK_LAUNCH("fs2_flash_attn_bwd");
     return FS2_OK;
 }

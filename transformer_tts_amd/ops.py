@@ -70,9 +70,9 @@ SIGNATURES = {
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
     "fs2_attn_probs_lds_bytes": [_I, _I],
     "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P, _P, _L, _L, _P],
-    "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
-    "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _L, _L, _L, _I, _I, _I, _I, _F, _F, _P,
-                           _U32, _P],
+    "fs2_flash_attn_keep_words": [_I, _I, _I],          # returns int64
+    "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
+    "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _F, _F, _P],
     "fs2_attn_ds_bwd": [_P, _L, _L, _P, _L, _L, _I, _I, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _U32, _P, _P, _L, _L, _F, _P],
     "fs2_softmax_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_length_regulate_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -117,6 +117,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
         l.fs2_last_error.restype = ctypes.c_char_p
+        l.fs2_flash_attn_keep_words.restype = ctypes.c_int64
         l.fs2_abi_version.restype = ctypes.c_int
         _lib = l
     return _lib
@@ -685,31 +686,42 @@ def flash_attn_supported(t, dk, dtype):
     return dtype == torch.bfloat16 and dk == 128 and 0 < t <= 1024
 
 
-def flash_attn_fwd(q, k, v, key_mask, out, stats, t, alpha, p_batch, p=0.0, rng=None, site=0):
+def flash_attn_keep_words(B, H, t):
+    """number of int16 words of the keep-bit stash of one flash_attn_fwd call (one bit per probability)"""
+    return int(lib().fs2_flash_attn_keep_words(int(B), int(H), int(t)))
+
+
+def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0, rng=None, site=0):
     """out = dropout_p(softmax(mask_keys(alpha q k^T))) v without the probabilities in HBM; stats (B,H,t,2) fp32 = row maximum
-    and sum of exponentials.  q, k, v: (B,H,t,128) views of the fused projection; out: (B,H,t,128) view of a (B,t,H,128)
-    tensor; p_batch: batch stride of the virtual (B,[layers],H,t,tp) probability tensor (Philox counters of attn_probs_fwd)."""
+    and sum of exponentials; keep: int16 tensor of flash_attn_keep_words(B,H,t) words receiving the dropout keep-bits (None when
+    p == 0).  q, k, v: (B,H,t,128) views of the fused projection; out: (B,H,t,128) view of a (B,t,H,128) tensor; p_batch: batch
+    stride of the virtual (B,[layers],H,t,tp) probability tensor (Philox counters of attn_probs_fwd)."""
     B, H, _, dk = q.shape
     assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1 and q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
     assert out.stride(3) == 1 and out.stride(1) == q.stride(1) and stats.is_contiguous() and stats.dtype == torch.float32
     assert stats.numel() == B * H * t * 2 and dk == 128
+    if p > 0:
+        assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t)
     _check(lib().fs2_flash_attn_fwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(out),
-                                    out.stride(2), out.stride(0), _p(stats), int(p_batch), B, H, t, (t + 7) // 8 * 8, float(alpha), p,
-                                    _rng_ptr(rng, p), site, _stream()), "fs2_flash_attn_fwd")
+                                    out.stride(2), out.stride(0), _p(stats), _p(keep) if p > 0 else None, int(p_batch), B, H, t,
+                                    (t + 7) // 8 * 8, float(alpha), p, _rng_ptr(rng, p), site, _stream()), "fs2_flash_attn_fwd")
 
 
-def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, aux, dq, dk_, dv, t, alpha, p_batch, p=0.0, rng=None, site=0):
-    """backward of flash_attn_fwd: dq, dk_, dv (B,H,t,128) views with common strides; aux: (B,H,t,4) fp32 workspace."""
+def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv, t, alpha, p=0.0):
+    """backward of flash_attn_fwd: dq, dk_, dv (B,H,t,128) views with common strides; keep: the forward's keep-bits; aux:
+    (B,H,t,4) fp32 workspace."""
     B, H, _, dk = q.shape
     assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1 and dk == 128
     assert out.stride(3) == 1 and d_out.stride(3) == 1 and out.stride(1) == d_out.stride(1) == q.stride(1)
     assert dq.stride() == dk_.stride() == dv.stride() and dq.stride(3) == 1 and dq.stride(1) == q.stride(1)
     assert all(x.dtype == torch.bfloat16 for x in (q, k, v, out, d_out, dq, dk_, dv))
     assert stats.is_contiguous() and aux.is_contiguous() and aux.dtype == torch.float32 and aux.numel() == B * H * t * 4
+    if p > 0:
+        assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t)
     _check(lib().fs2_flash_attn_bwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(out),
-                                    out.stride(2), out.stride(0), _p(d_out), d_out.stride(2), d_out.stride(0), _p(stats), _p(aux),
-                                    _p(dq), _p(dk_), _p(dv), dq.stride(2), dq.stride(0), int(p_batch), B, H, t, (t + 7) // 8 * 8,
-                                    float(alpha), p, _rng_ptr(rng, p), site, _stream()), "fs2_flash_attn_bwd")
+                                    out.stride(2), out.stride(0), _p(d_out), d_out.stride(2), d_out.stride(0), _p(stats),
+                                    _p(keep) if p > 0 else None, _p(aux), _p(dq), _p(dk_), _p(dv), dq.stride(2), dq.stride(0), B, H, t,
+                                    float(alpha), p, _stream()), "fs2_flash_attn_bwd")
 
 
 def softmax_bwd(dp, p_saved, t, p=0.0, rng=None, site=0):
