@@ -32,6 +32,8 @@ aux = torch.empty(B, H, t, 4, device=dev)
 keep = torch.empty(ops.flash_attn_keep_words(B, H, t), dtype=torch.int16, device=dev)
 rng = ops.Rng(1, dev)
 alpha = dk ** -0.5
+import os
+PD = float(os.environ.get('FLASH_P', '0.1'))
 pb = H * t * tp
 
 
@@ -49,21 +51,21 @@ def timeit(fn, n=20):
 
 
 def strip_fwd():
-    ops.attn_probs_fwd(q, k, km, P, Pd, t, alpha, 0.1, rng, 3, v=v, out=O4)
+    ops.attn_probs_fwd(q, k, km, P, Pd, t, alpha, PD, rng, 3, v=v, out=O4)
 
 
 def strip_bwd():
     ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)
-    ops.attn_ds_bwd(dO4, v, P, dS, t, 0.1, rng, 3, k=k, dq=dq, alpha=alpha)
+    ops.attn_ds_bwd(dO4, v, P, dS, t, PD, rng, 3, k=k, dq=dq, alpha=alpha)
     ops.bmm(dS, q, dk_, trans_a=True, trans_b=False, alpha=alpha)
 
 
 def flash_fwd():
-    ops.flash_attn_fwd(q, k, v, km, O4, stats, keep, t, alpha, pb, 0.1, rng, 3)
+    ops.flash_attn_fwd(q, k, v, km, O4, stats, keep, t, alpha, pb, PD, rng, 3)
 
 
 def flash_bwd():
-    ops.flash_attn_bwd(q, k, v, km, O4, dO4, stats, keep, aux, dq, dk_, dv, t, alpha, 0.1)
+    ops.flash_attn_bwd(q, k, v, km, O4, dO4, stats, keep, aux, dq, dk_, dv, t, alpha, PD)
 
 
 flops = 2.0 * B * H * t * t * dk

@@ -164,10 +164,11 @@ __device__ __forceinline__ bool flash_item(const FlashArgs& a, int& blk, int& h,
 
 // kfull = number of leading unmasked keys, kmax = last unmasked key + 1 of one batch row (optionally copies the row to LDS,
 // zero padded to MASK_BYTES).  red: two LDS words.  Ends with a barrier.
+template <int NT = 512>
 __device__ __forceinline__ void scan_mask(const uint8_t* km_row, int t, unsigned char* lmask, int* red, int tid) {
     if (tid == 0) { red[0] = t; red[1] = 0; }
     __syncthreads();
-    for (int j = tid; j < MASK_BYTES; j += 512) {
+    for (int j = tid; j < MASK_BYTES; j += NT) {
         const unsigned char mk = j < t ? km_row[j] : 0;
         if (lmask) lmask[j] = mk;
         if (j < t) {
@@ -178,16 +179,17 @@ __device__ __forceinline__ void scan_mask(const uint8_t* km_row, int t, unsigned
     __syncthreads();
 }
 
-// stage one 64-row tile: instruction i (0,1) of wave w covers tile rows 4*(8i + w) .. +3; lane -> row lane>>4, logical chunk
-// (lane&15) ^ f(row); rows >= t use an out-of-range offset (zeros)
+// stage one 64-row tile with NW waves: instruction i of wave w covers tile rows 4*(NW i + w) .. +3; lane -> row lane>>4, logical
+// chunk (lane&15) ^ f(row); rows >= t use an out-of-range offset (zeros)
+template <int NW = 8>
 __device__ __forceinline__ void stage_tile(const __amdgpu_buffer_rsrc_t rs, unsigned char* dst, int row0, int t, int row_stride,
                                            int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = 4 * (8 * i + wave) + (lane >> 4);
+    for (int i = 0; i < 16 / NW; ++i) {
+        const int r = 4 * (NW * i + wave) + (lane >> 4);
         const int ch = (lane & 15) ^ img_f(r);
         const int row = row0 + r;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + 1024 * (8 * i + wave)), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + 1024 * (NW * i + wave)), 16,
                                                  (int)(row < t ? (unsigned)((row * row_stride + ch * 8) * 2) : OOB), 0, 0, 0);
     }
 }
@@ -195,39 +197,25 @@ __device__ __forceinline__ void stage_tile(const __amdgpu_buffer_rsrc_t rs, unsi
 __device__ __forceinline__ float and_mask(float v, int msk) { return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & msk); }
 __device__ __forceinline__ int keep_mask(unsigned bits, unsigned pos) { return __builtin_amdgcn_sbfe((int)bits, pos, 1u); }   // bit -> 0 / ~0
 
-// raw scores S^T of one 64-key tile (image at byte offset KOFF) against the wave's 16 queries: x[T][r] = key 64kt + 16T + 4g + r,
-// query i16.  masked (workgroup-uniform): the tile holds masked or non-existent keys -- keys with mask 0 get the raw value whose
-// scaled score is -1e4 (masked_fill), keys >= t get NOKEY.  The MFMA work is common to both cases, only the element-wise fix-ups
-// sit under the branch (two instantiated copies of a whole step cost ~100 spilled registers in the dQ kernel).
-template <int KOFF>
-__device__ __forceinline__ void score_tiles(const bool masked, const FragAddr& fa, const bf16x8 (&qf)[4], const unsigned char* lmask, int kt,
-                                            int t, float masked_raw, int lane, float (&x)[4][4], float& tmax) {
-    const int g = lane >> 4;
-    auto one = [&](auto TC) {
-        constexpr int T = decltype(TC)::value;
-        const f32x4 s = tile128<KOFF + 4096 * T>(fa, qf);
+// ------------------------------------------------------------------------------------------------ forward
+// O = dropout(softmax(mask(alpha Q K^T))) V, stats = {m, l}.  Workgroup = 4 waves x 32 queries (two 16-query sub-tiles per
+// wave: every K / V fragment read from LDS feeds two MFMAs, which halves the LDS bytes per flop against 8 waves x 16 queries,
+// and two independent workgroups share each SIMD, so one's softmax arithmetic runs beside the other's matrix work).
+// LDS: K images [2][TILE] at 0, V images [2][TILE] at 2 TILE, key mask, two reduction words.
+constexpr int FQ_WAVES = 4, FQ_THREADS = 256;
+
+// masked (workgroup-uniform): the tile holds masked or non-existent keys -- keys with mask 0 get the raw value whose scaled
+// score is -1e4 (masked_fill), keys >= t get NOKEY.  The MFMA work is common to both cases; only these fix-ups sit under a branch.
+__device__ __forceinline__ void mask_fix(float (&v)[4], unsigned mk, int key0, int t, float masked_raw) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[T][r] = s[r];
-        if (masked) {
-            const int key0 = 64 * kt + 16 * T + 4 * g;
-            const unsigned mk = *reinterpret_cast<const unsigned*>(lmask + key0);        // key0 % 4 == 0; bytes >= t are 0
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                x[T][r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? x[T][r] : masked_raw;
-                x[T][r] = (key0 + r < t) ? x[T][r] : NOKEY;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, x[T][r]);
-    };
-    one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{});
+    for (int r = 0; r < 4; ++r) {
+        v[r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? v[r] : masked_raw;
+        v[r] = (key0 + r < t) ? v[r] : NOKEY;
+    }
 }
 
-// ------------------------------------------------------------------------------------------------ forward
-// O = dropout(softmax(mask(alpha Q K^T))) V, stats = {m, l}.  Wave: 16 queries (columns of the transposed score tiles).
-// LDS: K images [2][TILE] at 0, V images [2][TILE] at 2 TILE, key mask, two reduction words.
 template <bool DROP>
-__global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
+__global__ __launch_bounds__(FQ_THREADS, 2) void flash_fwd_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int blk, h, b;
     if (!flash_item(a, blk, h, b)) return;
@@ -235,7 +223,7 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
     const int t = a.t;
-    const int qrow = blk * 128 + wave * 16 + i16;
+    const int q0 = blk * 128 + wave * 32 + i16;        // sub-tile s: query q0 + 16 s
     unsigned char* kimg = smem;                       // [2][TILE]
     unsigned char* vimg = smem + 2 * TILE;            // [2][TILE]
     unsigned char* lmask = smem + 4 * TILE;
@@ -244,139 +232,143 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
     const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
     const int rowst = (int)a.row;
-    stage_tile(rs_k, kimg, 0, t, rowst, wave, lane);
-    stage_tile(rs_v, vimg, 0, t, rowst, wave, lane);
-    bf16x8 qf[4];
+    stage_tile<FQ_WAVES>(rs_k, kimg, 0, t, rowst, wave, lane);
+    stage_tile<FQ_WAVES>(rs_v, vimg, 0, t, rowst, wave, lane);
+    bf16x8 qf[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = ld16(rs_q, qrow < t ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
-    scan_mask(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[s][ks] = ld16(rs_q, q0 + 16 * s < t ? (unsigned)(((q0 + 16 * s) * rowst + 32 * ks + 8 * g) * 2) : OOB);
+    scan_mask<FQ_THREADS>(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
     const int kfull = red[0], kmax = red[1];
     const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
 
     const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
-    const int64_t prow = (int64_t)b * a.p_batch + ((int64_t)h * t + (qrow < t ? qrow : 0)) * a.tp;
-    uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t + (qrow < t ? qrow : 0)) * 4 + g;
+    const int qc0 = q0 < t ? q0 : 0, qc1 = q0 + 16 < t ? q0 + 16 : 0;
+    const int64_t pbase = (int64_t)b * a.p_batch + (int64_t)h * t * a.tp + 16 * g;
+    uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t) * 4 + g;
     const float c2 = a.alpha * LOG2E, masked_raw = MASKED_NAT / a.alpha;
-    float m = NOKEY, l = 0.f;            // m: running maximum of the RAW scores
-    f32x4 oacc[8];
+    float m[2] = {NOKEY, NOKEY}, l[2] = {0.f, 0.f};          // m: running maximum of the RAW scores
+    f32x4 oacc[2][8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) oacc[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     auto tile = [&](const int kt, auto BUFC) {
         constexpr int BUF = decltype(BUFC)::value;
         constexpr int KOFF = BUF * TILE, VOFF = 2 * TILE + BUF * TILE;
         if (kt + 1 < nkt) {
-            stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
-            stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile<FQ_WAVES>(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile<FQ_WAVES>(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
         }
-        unsigned mybits = 0;
-        if (DROP) {                       // keep-bits of query i16, keys 64kt + 16g .. +15; stashed for the backward kernels
-            mybits = drop_bits16(dc, (uint64_t)(prow + 64 * kt + 16 * g));
-            if (qrow < t) keep[(int64_t)kt * t * 4] = (uint16_t)mybits;
+        unsigned mybits[2] = {0, 0};
+        if (DROP) {                       // keep-bits of queries q0, q0 + 16, keys 64kt + 16g .. +15; stashed for the backward kernels
+            mybits[0] = drop_bits16(dc, (uint64_t)(pbase + (int64_t)qc0 * a.tp + 64 * kt));
+            mybits[1] = drop_bits16(dc, (uint64_t)(pbase + (int64_t)qc1 * a.tp + 64 * kt));
+            if (q0 < t) keep[((int64_t)kt * t + q0) * 4] = (uint16_t)mybits[0];
+            if (q0 + 16 < t) keep[((int64_t)kt * t + q0 + 16) * 4] = (uint16_t)mybits[1];
         }
-        float x[4][4];
-        float tmax = NOKEY;
-        score_tiles<KOFF>(64 * (kt + 1) > kfull, fa, qf, lmask, kt, t, masked_raw, lane, x, tmax);
-        tmax = xor16_32_max(tmax);
-        if (__any(tmax > m)) {           // a new row maximum somewhere in the wave: rescale
-            const float m_new = fmaxf(m, tmax);
-            const float corr = __builtin_amdgcn_exp2f((m - m_new) * c2);
-            l *= corr;
+        // ---- S^T tiles: x[s][T][r] = score of key 64kt + 16T + 4g + r against query q0 + 16 s
+        const bool masked = 64 * (kt + 1) > kfull;
+        float x[2][4][4];
+        float tmax[2] = {NOKEY, NOKEY};
+        auto scores = [&](auto TC) {
+            constexpr int T = decltype(TC)::value;
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < 8; ++d)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oacc[d][r] *= corr;
-            m = m_new;
-        }
-        const float nm = -m * c2;
-#pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            unsigned bT = 0;
-            if (DROP) bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[T][r], c2, nm));
-                l += pv;
-                x[T][r] = DROP ? and_mask(pv, keep_mask(bT, r)) : pv;
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kfrag = row_frag<KOFF + 4096 * T>(fa, ks);
+                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[0][ks], sa, 0, 0, 0);
+                sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[1][ks], sb, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { x[0][T][r] = sa[r]; x[1][T][r] = sb[r]; }
+            if (masked) {
+                const int key0 = 64 * kt + 16 * T + 4 * g;
+                const unsigned mk = *reinterpret_cast<const unsigned*>(lmask + key0);        // key0 % 4 == 0; bytes >= t are 0
+                mask_fix(x[0][T], mk, key0, t, masked_raw);
+                mask_fix(x[1][T], mk, key0, t, masked_raw);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { tmax[0] = fmaxf(tmax[0], x[0][T][r]); tmax[1] = fmaxf(tmax[1], x[1][T][r]); }
+        };
+        scores(IC<0>{}); scores(IC<1>{}); scores(IC<2>{}); scores(IC<3>{});
+        bf16x8 pb[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float tm = xor16_32_max(tmax[s]);
+            if (__any(tm > m[s])) {           // a new row maximum somewhere in the wave: rescale
+                const float m_new = fmaxf(m[s], tm);
+                const float corr = __builtin_amdgcn_exp2f((m[s] - m_new) * c2);
+                l[s] *= corr;
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[s][d][r] *= corr;
+                m[s] = m_new;
+            }
+            const float nm = -m[s] * c2;
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                unsigned bT = 0;
+                if (DROP) bT = (unsigned)__shfl((int)mybits[s], i16 + 16 * T, 64) >> (4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[s][T][r], c2, nm));
+                    l[s] += pv;
+                    x[s][T][r] = DROP ? and_mask(pv, keep_mask(bT, r)) : pv;
+                }
+            }
+            pb[s][0] = pack8(x[s][0], x[s][1]);
+            pb[s][1] = pack8(x[s][2], x[s][3]);
         }
         // ---- O^T += V^T P^T: k-step kp covers the keys of score tiles 2kp, 2kp+1 (in the accumulators' own order)
-        const bf16x8 pb0 = pack8(x[0], x[1]), pb1 = pack8(x[2], x[3]);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VOFF>(fa, d), pb0, oacc[d], 0, 0, 0);
+        for (int d = 0; d < 8; ++d) {
+            const bf16x8 vfrag = tr_frag<VOFF>(fa, d);
+            oacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[0][0], oacc[0][d], 0, 0, 0);
+            oacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[1][0], oacc[1][d], 0, 0, 0);
+        }
 #pragma unroll
-        for (int d = 0; d < 8; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VOFF + 8192>(fa, d), pb1, oacc[d], 0, 0, 0);
+        for (int d = 0; d < 8; ++d) {
+            const bf16x8 vfrag = tr_frag<VOFF + 8192>(fa, d);
+            oacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[0][1], oacc[0][d], 0, 0, 0);
+            oacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[1][1], oacc[1][d], 0, 0, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     for (int kt = 0; kt < nkt; kt += 2) {
         tile(kt, IC<0>{});
         if (kt + 1 < nkt) tile(kt + 1, IC<1>{});
     }
-    l = xor16_32_sum(l);
-    if (qrow < t) {
-        const float inv = dc.scale / l;             // 1/(1-p) of the kept probabilities, applied once
-        bf16_t* orow = a.O + (int64_t)b * a.o_batch + (int64_t)qrow * a.o_row + (int64_t)h * a.head;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {           // oacc[d][r] = O[qrow][16d + 4g + r]
-            bf16x4 o;
+    for (int s = 0; s < 2; ++s) {
+        const float lsum = xor16_32_sum(l[s]);
+        const int qrow = q0 + 16 * s;
+        if (qrow < t) {
+            const float inv = dc.scale / lsum;             // 1/(1-p) of the kept probabilities, applied once
+            bf16_t* orow = a.O + (int64_t)b * a.o_batch + (int64_t)qrow * a.o_row + (int64_t)h * a.head;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(oacc[d][r] * inv);
-            *reinterpret_cast<bf16x4*>(orow + 16 * d + 4 * g) = o;
+            for (int d = 0; d < 8; ++d) {           // oacc[s][d][r] = O[qrow][16d + 4g + r]
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(oacc[s][d][r] * inv);
+                *reinterpret_cast<bf16x4*>(orow + 16 * d + 4 * g) = o;
+            }
+            if (g == 0) *reinterpret_cast<float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2) = make_float2(m[s] * a.alpha, lsum);
         }
-        if (g == 0) *reinterpret_cast<float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2) = make_float2(m * a.alpha, l);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ aux)
-// Per wave 16 queries; recomputes S^T and dPd^T = V dO^T per 64-key tile, dS^T = P (dPd keep / (1-p) - delta) (0 at masked keys:
-// masked_fill's backward), dQ^T += K^T dS^T.  Also writes aux = {-m log2 e, 1/l, delta, 0} per query for the dK/dV kernel.
-template <bool DROP, int KOFF, int VOFF>
-__device__ __forceinline__ void dq_tiles(const bool masked, const FragAddr& fa, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
-                                         const unsigned char* lmask, int kt, int t, float masked_raw, float c2, float nm2, float linv,
-                                         float delta, float scale, unsigned mybits, int lane, f32x4 (&dqacc)[8]) {
-    const int g = lane >> 4, i16 = lane & 15;
-    auto pair = [&](auto KPC) {
-        constexpr int kp = decltype(KPC)::value;
-        float ds[2][4];
-        auto one = [&](auto UC) {
-            constexpr int u = decltype(UC)::value, T = 2 * kp + u;
-            __builtin_amdgcn_sched_barrier(0);          // keep the operand reads of later tiles from being hoisted (register pressure)
-            const f32x4 s = tile128<KOFF + 4096 * T>(fa, qf);
-            const f32x4 dp = tile128<VOFF + 4096 * T>(fa, dof);
-            const int key0 = 64 * kt + 16 * T + 4 * g;
-            float v[4] = {s[0], s[1], s[2], s[3]};
-            unsigned mk = 0x01010101u, bT = 0;
-            if (masked) {
-                mk = *reinterpret_cast<const unsigned*>(lmask + key0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? v[r] : masked_raw;
-                    v[r] = (key0 + r < t) ? v[r] : NOKEY;
-                }
-            }
-            if (DROP) bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pn = __builtin_amdgcn_exp2f(__builtin_fmaf(v[r], c2, nm2)) * linv;
-                const float t1 = DROP ? and_mask(dp[r], keep_mask(bT, r)) : dp[r];
-                ds[u][r] = pn * __builtin_fmaf(t1, scale, -delta);
-            }
-            if (masked) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ds[u][r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? ds[u][r] : 0.f;      // masked_fill's backward
-            }
-        };
-        one(IC<0>{}); one(IC<1>{});
-        const bf16x8 dsb = pack8(ds[0], ds[1]);
-#pragma unroll
-        for (int d = 0; d < 8; ++d) dqacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<KOFF + 8192 * kp>(fa, d), dsb, dqacc[d], 0, 0, 0);
-    };
-    pair(IC<0>{}); pair(IC<1>{});
-}
-
+// Same shape as the forward (4 waves x 32 queries); recomputes S^T and dPd^T = V dO^T per 64-key tile, dS^T = P (dPd keep / (1-p) -
+// delta) (0 at masked keys: masked_fill's backward), dQ^T += K^T dS^T.  Also writes aux = {-m log2 e, 1/l, delta, 0} per query for
+// the dK/dV kernel.
 template <bool DROP>
-__global__ __launch_bounds__(512, 4) void flash_bwd_dq_k(const FlashArgs a) {
+__global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int blk, h, b;
     if (!flash_item(a, blk, h, b)) return;
@@ -384,7 +376,7 @@ __global__ __launch_bounds__(512, 4) void flash_bwd_dq_k(const FlashArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
     const int t = a.t;
-    const int qrow = blk * 128 + wave * 16 + i16;
+    const int q0 = blk * 128 + wave * 32 + i16;
     unsigned char* kimg = smem;
     unsigned char* vimg = smem + 2 * TILE;
     unsigned char* lmask = smem + 4 * TILE;
@@ -395,63 +387,131 @@ __global__ __launch_bounds__(512, 4) void flash_bwd_dq_k(const FlashArgs a) {
     const __amdgpu_buffer_rsrc_t rs_do = make_rsrc(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head);
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.O + (int64_t)b * a.o_batch + (int64_t)h * a.head);
     const int rowst = (int)a.row;
-    stage_tile(rs_k, kimg, 0, t, rowst, wave, lane);
-    stage_tile(rs_v, vimg, 0, t, rowst, wave, lane);
+    stage_tile<FQ_WAVES>(rs_k, kimg, 0, t, rowst, wave, lane);
+    stage_tile<FQ_WAVES>(rs_v, vimg, 0, t, rowst, wave, lane);
 
-    bf16x8 qf[4], dof[4];
-    float delta = 0.f;
+    bf16x8 qf[2][4], dof[2][4];
+    float delta[2], nm2[2] = {0.f, 0.f}, linv[2] = {0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = ld16(rs_q, qrow < t ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
-        dof[ks] = ld16(rs_do, qrow < t ? (unsigned)((qrow * (int)a.do_row + 32 * ks + 8 * g) * 2) : OOB);
-        const bf16x8 of = ld16(rs_o, qrow < t ? (unsigned)((qrow * (int)a.o_row + 32 * ks + 8 * g) * 2) : OOB);
+    for (int s = 0; s < 2; ++s) {
+        const int qrow = q0 + 16 * s;
+        float dl = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) delta += (float)dof[ks][c] * (float)of[c];
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[s][ks] = ld16(rs_q, qrow < t ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
+            dof[s][ks] = ld16(rs_do, qrow < t ? (unsigned)((qrow * (int)a.do_row + 32 * ks + 8 * g) * 2) : OOB);
+            const bf16x8 of = ld16(rs_o, qrow < t ? (unsigned)((qrow * (int)a.o_row + 32 * ks + 8 * g) * 2) : OOB);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dl += (float)dof[s][ks][c] * (float)of[c];
+        }
+        delta[s] = xor16_32_sum(dl);
+        if (qrow < t) {
+            const float2 st = *reinterpret_cast<const float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2);
+            nm2[s] = -st.x * LOG2E;
+            linv[s] = 1.f / st.y;
+            if (g == 0) *reinterpret_cast<float4*>(a.aux + (((int64_t)b * a.H + h) * t + qrow) * 4) = make_float4(nm2[s], linv[s], delta[s], 0.f);
+        }
     }
-    delta = xor16_32_sum(delta);
-    float nm2 = 0.f, linv = 0.f;
-    if (qrow < t) {
-        const float2 st = *reinterpret_cast<const float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2);
-        nm2 = -st.x * LOG2E;
-        linv = 1.f / st.y;
-        if (g == 0) *reinterpret_cast<float4*>(a.aux + (((int64_t)b * a.H + h) * t + qrow) * 4) = make_float4(nm2, linv, delta, 0.f);
-    }
-    scan_mask(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
+    scan_mask<FQ_THREADS>(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
     const int kfull = red[0], kmax = red[1];
     const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
     const float scale = DROP ? 65536.f / (65536.f - (float)(uint32_t)(a.pdrop * 65536.f + 0.5f)) : 1.f;
-    const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t + (qrow < t ? qrow : 0)) * 4 + g;
+    const int qc0 = q0 < t ? q0 : 0, qc1 = q0 + 16 < t ? q0 + 16 : 0;
+    const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t) * 4 + g;
     const float c2 = a.alpha * LOG2E, masked_raw = MASKED_NAT / a.alpha;
-    f32x4 dqacc[8];
+    f32x4 dqacc[2][8];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) dqacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    unsigned bits_next = DROP ? keep[0] : 0;
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) dqacc[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned bits_next[2] = {0, 0};
+    if (DROP) { bits_next[0] = keep[(int64_t)qc0 * 4]; bits_next[1] = keep[(int64_t)qc1 * 4]; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     auto tile = [&](const int kt, auto BUFC) {
         constexpr int BUF = decltype(BUFC)::value;
-        const unsigned mybits = bits_next;
+        constexpr int KOFF = BUF * TILE, VOFF = 2 * TILE + BUF * TILE;
+        const unsigned mybits[2] = {bits_next[0], bits_next[1]};
         if (kt + 1 < nkt) {
-            stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
-            stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
-            if (DROP) bits_next = keep[(int64_t)(kt + 1) * t * 4];
+            stage_tile<FQ_WAVES>(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile<FQ_WAVES>(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            if (DROP) {
+                bits_next[0] = keep[((int64_t)(kt + 1) * t + qc0) * 4];
+                bits_next[1] = keep[((int64_t)(kt + 1) * t + qc1) * 4];
+            }
         }
-        dq_tiles<DROP, BUF * TILE, 2 * TILE + BUF * TILE>(64 * (kt + 1) > kfull, fa, qf, dof, lmask, kt, t, masked_raw, c2, nm2, linv, delta,
-                                                          scale, mybits, lane, dqacc);
+        const bool masked = 64 * (kt + 1) > kfull;
+        auto pair = [&](auto KPC) {
+            constexpr int kp = decltype(KPC)::value;
+            float ds[2][2][4];                               // [sub-tile][u][r]
+            auto one = [&](auto UC) {
+                constexpr int u = decltype(UC)::value, T = 2 * kp + u;
+                __builtin_amdgcn_sched_barrier(0);          // keep the operand reads of later tiles from being hoisted (register pressure)
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, pa = sa, pbb = sa;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kfrag = row_frag<KOFF + 4096 * T>(fa, ks);
+                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[0][ks], sa, 0, 0, 0);
+                    sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[1][ks], sb, 0, 0, 0);
+                    const bf16x8 vfrag = row_frag<VOFF + 4096 * T>(fa, ks);
+                    pa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, dof[0][ks], pa, 0, 0, 0);
+                    pbb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, dof[1][ks], pbb, 0, 0, 0);
+                }
+                const int key0 = 64 * kt + 16 * T + 4 * g;
+                float v[2][4] = {{sa[0], sa[1], sa[2], sa[3]}, {sb[0], sb[1], sb[2], sb[3]}};
+                const float dp[2][4] = {{pa[0], pa[1], pa[2], pa[3]}, {pbb[0], pbb[1], pbb[2], pbb[3]}};
+                unsigned mk = 0x01010101u;
+                if (masked) {
+                    mk = *reinterpret_cast<const unsigned*>(lmask + key0);
+                    mask_fix(v[0], mk, key0, t, masked_raw);
+                    mask_fix(v[1], mk, key0, t, masked_raw);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    unsigned bT = 0;
+                    if (DROP) bT = (unsigned)__shfl((int)mybits[s], i16 + 16 * T, 64) >> (4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pn = __builtin_amdgcn_exp2f(__builtin_fmaf(v[s][r], c2, nm2[s])) * linv[s];
+                        const float t1 = DROP ? and_mask(dp[s][r], keep_mask(bT, r)) : dp[s][r];
+                        ds[s][u][r] = pn * __builtin_fmaf(t1, scale, -delta[s]);
+                    }
+                }
+                if (masked) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ds[s][u][r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? ds[s][u][r] : 0.f;      // masked_fill's backward
+                }
+            };
+            one(IC<0>{}); one(IC<1>{});
+            const bf16x8 dsa = pack8(ds[0][0], ds[0][1]), dsb = pack8(ds[1][0], ds[1][1]);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const bf16x8 kfrag = tr_frag<KOFF + 8192 * kp>(fa, d);
+                dqacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, dsa, dqacc[0][d], 0, 0, 0);
+                dqacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, dsb, dqacc[1][d], 0, 0, 0);
+            }
+        };
+        pair(IC<0>{}); pair(IC<1>{});
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     for (int kt = 0; kt < nkt; kt += 2) {
         tile(kt, IC<0>{});
         if (kt + 1 < nkt) tile(kt + 1, IC<1>{});
     }
-    if (qrow < t) {
-        bf16_t* drow = a.dq + (int64_t)b * a.g_batch + (int64_t)qrow * a.g_row + (int64_t)h * a.head;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            bf16x4 o;
+    for (int s = 0; s < 2; ++s) {
+        const int qrow = q0 + 16 * s;
+        if (qrow < t) {
+            bf16_t* drow = a.dq + (int64_t)b * a.g_batch + (int64_t)qrow * a.g_row + (int64_t)h * a.head;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(dqacc[d][r] * a.alpha);
-            *reinterpret_cast<bf16x4*>(drow + 16 * d + 4 * g) = o;
+            for (int d = 0; d < 8; ++d) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(dqacc[s][d][r] * a.alpha);
+                *reinterpret_cast<bf16x4*>(drow + 16 * d + 4 * g) = o;
+            }
         }
     }
 }
@@ -636,8 +696,8 @@ extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, i
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<true>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(flash_fwd_k<false>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
+    if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<true>, dim3(flash_grid(B, H, t)), dim3(FQ_THREADS), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(flash_fwd_k<false>, dim3(flash_grid(B, H, t)), dim3(FQ_THREADS), lds, (hipStream_t)stream, a);
     FS2_CHECK_LAUNCH("fs2_flash_attn_fwd");
     return FS2_OK;
 }
@@ -674,10 +734,10 @@ extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, i
     }
     const dim3 grid(flash_grid(B, H, t));
     if (p > 0.f) {
-        hipLaunchKernelGGL(flash_bwd_dq_k<true>, grid, dim3(512), lds_q, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(flash_bwd_dq_k<true>, grid, dim3(FQ_THREADS), lds_q, (hipStream_t)stream, a);
         hipLaunchKernelGGL(flash_bwd_dkv_k<true>, grid, dim3(512), lds_kv, (hipStream_t)stream, a);
     } else {
-        hipLaunchKernelGGL(flash_bwd_dq_k<false>, grid, dim3(512), lds_q, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(flash_bwd_dq_k<false>, grid, dim3(FQ_THREADS), lds_q, (hipStream_t)stream, a);
         hipLaunchKernelGGL(flash_bwd_dkv_k<false>, grid, dim3(512), lds_kv, (hipStream_t)stream, a);
     }
     FS2_CHECK_LAUNCH("fs2_flash_attn_bwd");
