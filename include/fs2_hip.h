@@ -227,7 +227,8 @@ int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_s
  * virtual (B,[..],H,t,tp) tensor, so both paths draw the same mask) and stashes it, one bit per probability, in keep_bits
  * (fs2_flash_attn_keep_words(B, H, t) 16-bit words; may be NULL when p == 0).  Backward recomputes the probabilities from
  * q, k and stats, reads the keep-bits and writes dq = alpha dS k, dk = alpha dS^T q, dv = dropout(P)^T d_out; aux is a
- * (B,H,t,4) fp32 workspace it fills itself.  Key tiles whose keys are all masked are skipped (their probabilities are
+ * (B,H,t,4) fp32 workspace it fills itself; dbias_q/k/v (optional, H*128 floats each) receive += the column sums of dq / dk / dv
+ * (the bias gradients of the three projections, Models/modules.py:49-51).  Key tiles whose keys are all masked are skipped (their probabilities are
  * exp(-1e4 - max) = 0 in fp32 whenever the row has an unmasked key; a row without one is computed in full).
  *   q, k, v: rows of one head = 128 contiguous bf16 at  base + b*batch_stride + i*row_stride + h*head_stride  (elements);
  *   o / d_out / dq,dk,dv rows likewise with their own row and batch strides (dq, dk, dv share g_*_stride).           */
@@ -240,7 +241,8 @@ int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, int64_t row_
                        const uint8_t* key_mask, const void* o_saved, int64_t o_row_stride, int64_t o_batch_stride,
                        const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats,
                        const uint16_t* keep_bits, float* aux, void* dq, void* dk, void* dv, int64_t g_row_stride,
-                       int64_t g_batch_stride, int B, int H, int t, float alpha, float p, void* stream);
+                       int64_t g_batch_stride, float* dbias_q, float* dbias_k, float* dbias_v, int B, int H, int t, float alpha,
+                       float p, void* stream);
 
 /* LengthRegulator (Models/varianceadaptor.py:141-184,233-249): out[b][f] = x[b][i] for the phoneme i whose
  * duration interval contains frame f, 0 beyond sum(dur) or max_len.  starts is a [B][L+1] int32 workspace

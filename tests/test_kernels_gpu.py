@@ -516,7 +516,16 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
     dqkv = torch.full((B, t, 3, H, dk), float("nan"), dtype=dtype, device="cuda")
     dq, dv, dk_ = (dqkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
     aux = torch.empty((B, H, t, 4), device="cuda")
-    ops.flash_attn_bwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), g.permute(0, 2, 1, 3), stats, keep, aux, dq, dk_, dv, t, dk ** -0.5, p)
+    dbias = [torch.full((H * dk,), 0.5, device="cuda") for _ in range(3)]         # accumulated into: += column sums
+    ops.flash_attn_bwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), g.permute(0, 2, 1, 3), stats, keep, aux, dq, dk_, dv, t, dk ** -0.5, p,
+                       dbias=dbias)
+    for x, j, n in zip(dbias, (0, 2, 1), ("dbias_q", "dbias_k", "dbias_v")):
+        # the kernel sums its fp32 accumulators, the comparison sums the bf16 rows it stored: B*t rounding errors of 2^-9 relative
+        # (the k column sums are exactly zero in real arithmetic -- sum_k dS = 0 -- so there this noise is all there is)
+        rows = dqkv[:, :, j].float()
+        ref_sum = rows.sum((0, 1)).reshape(-1).cpu() + 0.5
+        noise = 4.0 * (B * t) ** 0.5 * 2.0 ** -9 * float(rows.abs().max())
+        close(x.cpu(), ref_sum, n, rtol=2e-2, atol=2e-2 + noise)
     got, ref = dqkv.float().cpu(), dqkv_ref.float()
     assert torch.isfinite(got).all()
     for j, n in enumerate(("dQ", "dV", "dK")):
@@ -748,6 +757,26 @@ def test_fused_bias_gradients_onehot_and_batched_shadows(ops, dtype):
         k = 30 if a_.dim() == 1 else 2
         close(a_, b_, f"fused output #{i}", **tol(dtype, k=k))
     assert torch.equal(out["cuda"][10].cpu(), out["cpu"][10]), "one-hot is exact"
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("O,I,k", [(70, 130, 9), (33, 65, 3), (100, 72, 1), (256, 1024, 9), (512, 80, 5)])
+def test_cast_permute_batched_tile_edges(ops, dtype, O, I, k):
+    """the one-launch shadow refresh at shapes that do not divide its 16 x 64 / 64 x 16 tiles, odd leading dimensions included
+    (a fused q/v/k shadow writes into column / row blocks of a wider tensor): exact against the oracle's permutes"""
+    w = rnd(O, I, k, seed=3) if k > 1 else rnd(O, I, seed=3)
+    res = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        wd = w.to(dev)
+        f = torch.zeros(O, k * I + 3, dtype=dtype, device=dev)[:, :k * I]       # row stride k*I + 3: unaligned pairs
+        g = torch.zeros(I, k * O, dtype=dtype, device=dev)
+        table = o.make_cast_table([(wd, f, 0), (wd, g, 1)], dev)
+        o.cast_permute_batched(table, 2, dtype)
+        res[dev] = (f.float().cpu(), g.float().cpu())
+    assert torch.equal(res["cuda"][0], res["cpu"][0]) and torch.equal(res["cuda"][1], res["cpu"][1])
+    w3 = w.reshape(O, I, k)
+    assert torch.equal(res["cuda"][0], w3.permute(0, 2, 1).reshape(O, k * I).to(dtype).float())
+    assert torch.equal(res["cuda"][1], w3.flip(2).permute(1, 2, 0).reshape(I, k * O).to(dtype).float())
 
 
 # ------------------------------------------------------------------------------------------------ large-tile GEMM (gemm_big.hip)

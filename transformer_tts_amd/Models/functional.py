@@ -407,7 +407,8 @@ class EncoderStackFunction(torch.autograd.Function):
             dq, dv, dk_ = (d5[:, :, j].permute(0, 2, 1, 3) for j in range(3))
             if flash:                                   # probabilities recomputed from q, k and the row statistics
                 ops.flash_attn_bwd(q, k, v, ctx.km, L["O"].permute(0, 2, 1, 3), dO4, ctx.stats[i],
-                                   ctx.keep[i] if ctx.keep is not None else None, aux, dq, dk_, dv, t, scale, p)
+                                   ctx.keep[i] if ctx.keep is not None else None, aux, dq, dk_, dv, t, scale, p,
+                                   dbias=[grad_of(lin.bias) for lin in (at.q_linear, at.k_linear, at.v_linear)])   # bias sums fused
             else:
                 P, Pd = ctx.attn[:, i], ctx.attn_drop[:, i]
                 ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)             # dV = Pd^T dO
@@ -425,7 +426,8 @@ class EncoderStackFunction(torch.autograd.Function):
             dqkv2, h2d = dqkv.view(M, 3 * d), L["h"].view(M, d)
             # bias gradients of q/v/k: ONE pass over dqkv, straight into the three gradient vectors (constant stride in the arena)
             with rt.side(dqkv2):
-                ops.colsum_blocks(dqkv2, [grad_of(lin.bias) for lin in (at.q_linear, at.v_linear, at.k_linear)])
+                if not flash:
+                    ops.colsum_blocks(dqkv2, [grad_of(lin.bias) for lin in (at.q_linear, at.v_linear, at.k_linear)])
                 # the three weight gradients in ONE batched split-K GEMM when they sit at a constant stride (arena)
                 ops.wgrad_batched(dqkv2, h2d, [grad_of(lin.weight) for lin in (at.q_linear, at.v_linear, at.k_linear)])
             _, wd, _ = rt.qkv(at)

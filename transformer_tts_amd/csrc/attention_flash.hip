@@ -126,6 +126,33 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float MASKED_NAT = -1e4f;     // masked_fill value of the reference (Models/modules.py:12-14), scaled-score domain
 constexpr float NOKEY = -3.0e38f;       // keys that do not exist: exp2() = 0
 
+// total of each 16-lane row in all of its lanes (quad xor 1, quad xor 2, row rotate 4 and 8)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x128>(v);
+    return v;
+}
+// bias gradient of a projection = column sums of its gradient rows: acc[d][r] is this lane's value for column 16d + 4g + r of one
+// row (the lane's i16 selects the row); rows of the workgroup are summed through DPP, then LDS, then one global atomic per
+// column per workgroup.  lds: 128 floats nobody else uses any more; NT threads; ends with a barrier-free tail.
+template <int NT>
+__device__ __forceinline__ void block_colsum(const f32x4 (&acc)[8], float factor, float* lds, float* out, int tid, int lane) {
+    const int g = lane >> 4, i16 = lane & 15;
+    if (tid < 128) lds[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float tot = row16_sum(acc[d][r]);
+            if (i16 == 0) atomicAdd(&lds[16 * d + 4 * g + r], tot * factor);
+        }
+    __syncthreads();
+    if (tid < 128) atomicAdd(out + tid, lds[tid]);
+}
+
 struct FlashArgs {
     const bf16_t *q, *k, *v;            // rows of one head: 128 contiguous bf16 at base + b*batch + i*row + h*head
     int64_t row, batch;                 // element strides of q / k / v (one fused projection tensor)
@@ -146,6 +173,7 @@ struct FlashArgs {
     float* aux;                         // (B, H, t, 4) workspace: {-m log2 e, 1/l, delta = rowsum(dO * O), 0}: dQ kernel -> dK/dV kernel
     bf16_t *dq, *dk, *dv;               // rows at d? + b*g_batch + i*g_row + h*head
     int64_t g_row, g_batch;
+    float *dbq, *dbk, *dbv;             // optional bias gradients of the three projections (H*128 floats each): += column sums of dq / dk / dv
 };
 
 // Work item of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs; the row blocks of one (batch, head) pair -- which
@@ -500,6 +528,14 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
         tile(kt, IC<0>{});
         if (kt + 1 < nkt) tile(kt + 1, IC<1>{});
     }
+    if (a.dbq != nullptr) {               // rows that do not exist hold zeros
+        f32x4 both[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) both[d][r] = dqacc[0][d][r] + dqacc[1][d][r];
+        block_colsum<FQ_THREADS>(both, a.alpha, reinterpret_cast<float*>(smem), a.dbq + h * 128, tid, lane);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int qrow = q0 + 16 * s;
@@ -645,6 +681,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
         tile(qt, IC<0>{});
         if (qt + 1 < nqt) tile(qt + 1, IC<1>{});
     }
+    if (a.dbk != nullptr) block_colsum<512>(dkacc, a.alpha, reinterpret_cast<float*>(smem), a.dbk + h * 128, tid, lane);
+    if (a.dbv != nullptr) block_colsum<512>(dvacc, scale, reinterpret_cast<float*>(smem) + 128, a.dbv + h * 128, tid, lane);
     if (kvalid) {
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
@@ -706,7 +744,8 @@ extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, i
                                   const uint8_t* key_mask, const void* o_saved, int64_t o_row_stride, int64_t o_batch_stride,
                                   const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats,
                                   const uint16_t* keep_bits, float* aux, void* dq, void* dk, void* dv, int64_t g_row_stride,
-                                  int64_t g_batch_stride, int B, int H, int t, float alpha, float p, void* stream) {
+                                  int64_t g_batch_stride, float* dbias_q, float* dbias_k, float* dbias_v, int B, int H, int t, float alpha,
+                                  float p, void* stream) {
     const int rc = check_common("fs2_flash_attn_bwd", q, k, v, row_stride, batch_stride, head_stride, B, H, t, p, keep_bits);
     if (rc != FS2_OK) return rc;
     FS2_REQUIRE(key_mask && o_saved && d_out && stats && aux && dq && dk && dv, "fs2_flash_attn_bwd: null argument");
@@ -723,6 +762,7 @@ extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, i
     a.B = B; a.H = H; a.t = t; a.tp = (t + 7) / 8 * 8; a.nkt = (t + 63) / 64; a.alpha = alpha; a.pdrop = p;
     a.dO = (const bf16_t*)d_out; a.do_row = do_row_stride; a.do_batch = do_batch_stride; a.aux = aux;
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.g_row = g_row_stride; a.g_batch = g_batch_stride;
+    a.dbq = dbias_q; a.dbk = dbias_k; a.dbv = dbias_v;
     const int lds_q = 4 * TILE + MASK_BYTES + 16, lds_kv = 4 * TILE + 2 * AUX_BYTES + 16;
     static bool attr_set = false;
     if (!attr_set) {

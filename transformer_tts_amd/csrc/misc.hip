@@ -266,11 +266,18 @@ __global__ __launch_bounds__(TPB) void cast_permute_k(const float* __restrict__ 
         }
     }
 }
-// One block iteration = a tile of 32 o x 32 i x k source elements staged in LDS: the source is read in contiguous
+template <typename T> __device__ __forceinline__ void store2(T* p, float a, float b);
+template <> __device__ __forceinline__ void store2<float>(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+template <> __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t v; v[0] = (bf16_t)a; v[1] = (bf16_t)b;
+    *reinterpret_cast<bf16x2_t*>(p) = v;
+}
+// One block iteration = a tile of 16 o x 64 i x k (forward shadow) or 64 o x 16 i x k (data-gradient shadow) source elements staged in LDS: the source is read in contiguous
 // runs of 32*k floats per o, the shadows are written in runs of 32 contiguous elements ([o][j*I + i] or [i][j*O + o]).
 template <typename T>
 __global__ __launch_bounds__(TPB) void cast_permute_batched_k(const FS2CastDesc* __restrict__ table) {
-    __shared__ float tile[32 * (32 * 9 + 1)];
+    __shared__ float tile[64 * (16 * 9 + 1) > 16 * (64 * 9 + 1) ? 64 * (16 * 9 + 1) : 16 * (64 * 9 + 1)];
     const FS2CastDesc d = table[blockIdx.y];
     const int O = d.O, I = d.I, k = d.k;
     const float* __restrict__ src = d.src;
@@ -293,28 +300,40 @@ __global__ __launch_bounds__(TPB) void cast_permute_batched_k(const FS2CastDesc*
         }
         return;
     }
-    const int to = (O + 31) / 32, ti = (I + 31) / 32;
-    const int run = 32 * k, ldt = run + 1;                 // +1: the transposed reads below hit distinct banks
+    // tile = TO_ o x TI_ i x k source elements: the long side is the one the destination runs along (mode 0: 64 consecutive i =
+    // 128-byte runs of bf16; mode 1: 64 consecutive o), the source is read in contiguous runs of TI_*k floats per o
+    const int TO_ = d.mode == 0 ? 16 : 64, TI_ = d.mode == 0 ? 64 : 16;
+    const int to = (O + TO_ - 1) / TO_, ti = (I + TI_ - 1) / TI_;
+    const int run = TI_ * k, ldt = run + 1;                // +1: the transposed reads below hit distinct banks
     for (int t = blockIdx.x; t < to * ti; t += gridDim.x) {
-        const int o0 = (t / ti) * 32, i0 = (t % ti) * 32;
+        const int o0 = (t / ti) * TO_, i0 = (t % ti) * TI_;
         __syncthreads();
-        for (int e = threadIdx.x; e < 32 * run; e += TPB) {
+        for (int e = threadIdx.x; e < TO_ * run; e += TPB) {
             const int oo = e / run, r = e % run;           // r = ii*k + j
             const int o = o0 + oo, i = i0 + r / k;
             tile[oo * ldt + r] = (o < O && i < I) ? src[((int64_t)o * I + i0) * k + r] : 0.f;
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < 32 * run; e += TPB) {
-            if (d.mode == 0) {          // dst[o][j*I + i]: 32 consecutive i per (o, j)
-                const int ii = e % 32, j = (e / 32) % k, oo = e / (32 * k);
+        // two consecutive destination elements per thread (one 4-byte store for bf16)
+        for (int e = threadIdx.x; e < TO_ * run / 2; e += TPB) {
+            if (d.mode == 0) {          // dst[o][j*I + i]: 64 consecutive i per (o, j)
+                const int ii = (e % 32) * 2, j = (e / 32) % k, oo = e / (32 * k);
                 const int o = o0 + oo, i = i0 + ii;
-                if (o < O && i < I)
-                    reinterpret_cast<T*>(d.dst)[(int64_t)o * d.dld + (int64_t)j * I + i] = from_f32<T>(tile[oo * ldt + ii * k + j]);
-            } else {                    // dst[i][j*O + o]: 32 consecutive o per (i, j), taps flipped
-                const int oo = e % 32, j = (e / 32) % k, ii = e / (32 * k);
+                if (o < O && i < I) {
+                    T* dp = reinterpret_cast<T*>(d.dst) + (int64_t)o * d.dld + (int64_t)j * I + i;
+                    const float a = tile[oo * ldt + ii * k + j], b = tile[oo * ldt + (ii + 1) * k + j];
+                    if (i + 1 < I && (((uintptr_t)dp) & (2 * sizeof(T) - 1)) == 0) store2<T>(dp, a, b);
+                    else { dp[0] = from_f32<T>(a); if (i + 1 < I) dp[1] = from_f32<T>(b); }
+                }
+            } else {                    // dst[i][j*O + o]: 64 consecutive o per (i, j), taps flipped
+                const int oo = (e % 32) * 2, j = (e / 32) % k, ii = e / (32 * k);
                 const int o = o0 + oo, i = i0 + ii;
-                if (o < O && i < I)
-                    reinterpret_cast<T*>(d.dst)[(int64_t)i * d.dld + (int64_t)j * O + o] = from_f32<T>(tile[oo * ldt + ii * k + (k - 1 - j)]);
+                if (o < O && i < I) {
+                    T* dp = reinterpret_cast<T*>(d.dst) + (int64_t)i * d.dld + (int64_t)j * O + o;
+                    const float a = tile[oo * ldt + ii * k + (k - 1 - j)], b = tile[(oo + 1) * ldt + ii * k + (k - 1 - j)];
+                    if (o + 1 < O && (((uintptr_t)dp) & (2 * sizeof(T) - 1)) == 0) store2<T>(dp, a, b);
+                    else { dp[0] = from_f32<T>(a); if (o + 1 < O) dp[1] = from_f32<T>(b); }
+                }
             }
         }
     }

@@ -72,7 +72,8 @@ SIGNATURES = {
     "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P, _P, _L, _L, _P],
     "fs2_flash_attn_keep_words": [_I, _I, _I],          # returns int64
     "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
-    "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _F, _F, _P],
+    "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _F, _F,
+                           _P],
     "fs2_attn_ds_bwd": [_P, _L, _L, _P, _L, _L, _I, _I, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _U32, _P, _P, _L, _L, _F, _P],
     "fs2_softmax_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_length_regulate_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -707,9 +708,10 @@ def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0
                                     (t + 7) // 8 * 8, float(alpha), p, _rng_ptr(rng, p), site, _stream()), "fs2_flash_attn_fwd")
 
 
-def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv, t, alpha, p=0.0):
+def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv, t, alpha, p=0.0, dbias=None):
     """backward of flash_attn_fwd: dq, dk_, dv (B,H,t,128) views with common strides; keep: the forward's keep-bits; aux:
-    (B,H,t,4) fp32 workspace."""
+    (B,H,t,4) fp32 workspace; dbias: optional (dbias_q, dbias_k, dbias_v) fp32 vectors of H*128 that receive += the column sums of
+    dq / dk / dv (the projections' bias gradients)."""
     B, H, _, dk = q.shape
     assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1 and dk == 128
     assert out.stride(3) == 1 and d_out.stride(3) == 1 and out.stride(1) == d_out.stride(1) == q.stride(1)
@@ -718,9 +720,12 @@ def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv,
     assert stats.is_contiguous() and aux.is_contiguous() and aux.dtype == torch.float32 and aux.numel() == B * H * t * 4
     if p > 0:
         assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t)
+    if dbias is not None:
+        assert all(x.dtype == torch.float32 and x.is_contiguous() and x.numel() == H * dk for x in dbias)
     _check(lib().fs2_flash_attn_bwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(out),
                                     out.stride(2), out.stride(0), _p(d_out), d_out.stride(2), d_out.stride(0), _p(stats),
-                                    _p(keep) if p > 0 else None, _p(aux), _p(dq), _p(dk_), _p(dv), dq.stride(2), dq.stride(0), B, H, t,
+                                    _p(keep) if p > 0 else None, _p(aux), _p(dq), _p(dk_), _p(dv), dq.stride(2), dq.stride(0),
+                                    *((_p(x) for x in dbias) if dbias is not None else (None, None, None)), B, H, t,
                                     float(alpha), p, _stream()), "fs2_flash_attn_bwd")
 
 
