@@ -113,6 +113,18 @@ def test_conv_matches_torch_conv1d(ops):
         close(gw, wr.grad, f"conv1d wgrad k={k}", rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("O,I,k", [(24, 16, 5), (70, 130, 9), (33, 65, 3), (256, 1024, 9), (5, 7, 12), (80, 256, 5)])
+def test_permute_add_exact(ops, O, I, k):
+    """grad[o][i][j] += scratch[o][j*I + i] (tiled kernel for k <= 9, flat kernel otherwise), with and without re-zeroing"""
+    scr, g0 = rnd(O, k * I, seed=1), rnd(O, I, k, seed=2)
+    want = g0 + scr.view(O, k, I).permute(0, 2, 1)
+    for rezero in (False, True):
+        s_, g_ = scr.cuda(), g0.cuda()
+        ops.permute_add(s_, g_, rezero=rezero)
+        assert torch.equal(g_.cpu(), want)
+        assert torch.equal(s_.cpu(), torch.zeros_like(scr) if rezero else scr)
+
+
 def test_linear_random_shapes_and_epilogues(ops):
     """seeded sweep of ragged products (M from 1 row, N and K at their alignment minima, every epilogue combination)
     in both compute modes against the oracle primitive"""

@@ -68,8 +68,15 @@ def flash_bwd():
     ops.flash_attn_bwd(q, k, v, km, O4, dO4, stats, keep, aux, dq, dk_, dv, t, alpha, PD)
 
 
+dbias = [torch.zeros(H * dk, device=dev) for _ in range(3)]
+
+
+def flash_bwd_bias():
+    ops.flash_attn_bwd(q, k, v, km, O4, dO4, stats, keep, aux, dq, dk_, dv, t, alpha, PD, dbias=dbias)
+
+
 flops = 2.0 * B * H * t * t * dk
 for name, fn, units in (("strip fwd", strip_fwd, 2), ("strip bwd (+2 bmm)", strip_bwd, 4), ("flash fwd", flash_fwd, 2),
-                        ("flash bwd (dQ + dK/dV)", flash_bwd, 7)):
+                        ("flash bwd (dQ + dK/dV)", flash_bwd, 7), ("flash bwd + bias sums", flash_bwd_bias, 7)):
     us = timeit(fn)
     print(f"{name:26s} {us:8.1f} us   {units * flops / us * 1e-6:7.1f} TFLOP/s (executed products)")

@@ -225,11 +225,9 @@ __device__ __forceinline__ void stage_tile(const __amdgpu_buffer_rsrc_t rs, unsi
 __device__ __forceinline__ float and_mask(float v, int msk) { return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & msk); }
 __device__ __forceinline__ int keep_mask(unsigned bits, unsigned pos) { return __builtin_amdgcn_sbfe((int)bits, pos, 1u); }   // bit -> 0 / ~0
 
-// ------------------------------------------------------------------------------------------------ forward
-// O = dropout(softmax(mask(alpha Q K^T))) V, stats = {m, l}.  Workgroup = 4 waves x 32 queries (two 16-query sub-tiles per
-// wave: every K / V fragment read from LDS feeds two MFMAs, which halves the LDS bytes per flop against 8 waves x 16 queries,
-// and two independent workgroups share each SIMD, so one's softmax arithmetic runs beside the other's matrix work).
-// LDS: K images [2][TILE] at 0, V images [2][TILE] at 2 TILE, key mask, two reduction words.
+// dQ kernel shape: workgroup = 4 waves x 32 queries (two 16-query sub-tiles per wave: every K / V fragment read from LDS feeds two
+// MFMAs; two independent workgroups per CU).  The forward kernel measured faster as 8 waves x 16 queries (4 waves per SIMD:
+// 55.7 vs 60.6 us per launch averaged over the model's eight attention layers).
 constexpr int FQ_WAVES = 4, FQ_THREADS = 256;
 
 // masked (workgroup-uniform): the tile holds masked or non-existent keys -- keys with mask 0 get the raw value whose scaled
@@ -242,8 +240,39 @@ __device__ __forceinline__ void mask_fix(float (&v)[4], unsigned mk, int key0, i
     }
 }
 
+// raw scores S^T of one 64-key tile (image at byte offset KOFF) against the wave's 16 queries: x[T][r] = key 64kt + 16T + 4g + r,
+// query i16.  masked (workgroup-uniform): the tile holds masked or non-existent keys -- keys with mask 0 get the raw value whose
+// scaled score is -1e4 (masked_fill), keys >= t get NOKEY.  The MFMA work is common to both cases, only the element-wise fix-ups
+// sit under the branch (two instantiated copies of a whole step cost ~100 spilled registers in the dQ kernel).
+template <int KOFF>
+__device__ __forceinline__ void score_tiles(const bool masked, const FragAddr& fa, const bf16x8 (&qf)[4], const unsigned char* lmask, int kt,
+                                            int t, float masked_raw, int lane, float (&x)[4][4], float& tmax) {
+    const int g = lane >> 4;
+    auto one = [&](auto TC) {
+        constexpr int T = decltype(TC)::value;
+        const f32x4 s = tile128<KOFF + 4096 * T>(fa, qf);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[T][r] = s[r];
+        if (masked) {
+            const int key0 = 64 * kt + 16 * T + 4 * g;
+            const unsigned mk = *reinterpret_cast<const unsigned*>(lmask + key0);        // key0 % 4 == 0; bytes >= t are 0
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x[T][r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? x[T][r] : masked_raw;
+                x[T][r] = (key0 + r < t) ? x[T][r] : NOKEY;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, x[T][r]);
+    };
+    one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{});
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// O = dropout(softmax(mask(alpha Q K^T))) V, stats = {m, l}.  Wave: 16 queries (columns of the transposed score tiles).
+// LDS: K images [2][TILE] at 0, V images [2][TILE] at 2 TILE, key mask, two reduction words.
 template <bool DROP>
-__global__ __launch_bounds__(FQ_THREADS, 2) void flash_fwd_k(const FlashArgs a) {
+__global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int blk, h, b;
     if (!flash_item(a, blk, h, b)) return;
@@ -251,7 +280,7 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_fwd_k(const FlashArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
     const int t = a.t;
-    const int q0 = blk * 128 + wave * 32 + i16;        // sub-tile s: query q0 + 16 s
+    const int qrow = blk * 128 + wave * 16 + i16;
     unsigned char* kimg = smem;                       // [2][TILE]
     unsigned char* vimg = smem + 2 * TILE;            // [2][TILE]
     unsigned char* lmask = smem + 4 * TILE;
@@ -260,134 +289,87 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_fwd_k(const FlashArgs a) 
     const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
     const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
     const int rowst = (int)a.row;
-    stage_tile<FQ_WAVES>(rs_k, kimg, 0, t, rowst, wave, lane);
-    stage_tile<FQ_WAVES>(rs_v, vimg, 0, t, rowst, wave, lane);
-    bf16x8 qf[2][4];
+    stage_tile(rs_k, kimg, 0, t, rowst, wave, lane);
+    stage_tile(rs_v, vimg, 0, t, rowst, wave, lane);
+    bf16x8 qf[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            qf[s][ks] = ld16(rs_q, q0 + 16 * s < t ? (unsigned)(((q0 + 16 * s) * rowst + 32 * ks + 8 * g) * 2) : OOB);
-    scan_mask<FQ_THREADS>(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = ld16(rs_q, qrow < t ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
+    scan_mask(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
     const int kfull = red[0], kmax = red[1];
     const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
 
     const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
-    const int qc0 = q0 < t ? q0 : 0, qc1 = q0 + 16 < t ? q0 + 16 : 0;
-    const int64_t pbase = (int64_t)b * a.p_batch + (int64_t)h * t * a.tp + 16 * g;
-    uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t) * 4 + g;
+    const int64_t prow = (int64_t)b * a.p_batch + ((int64_t)h * t + (qrow < t ? qrow : 0)) * a.tp;
+    uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t + (qrow < t ? qrow : 0)) * 4 + g;
     const float c2 = a.alpha * LOG2E, masked_raw = MASKED_NAT / a.alpha;
-    float m[2] = {NOKEY, NOKEY}, l[2] = {0.f, 0.f};          // m: running maximum of the RAW scores
-    f32x4 oacc[2][8];
+    float m = NOKEY, l = 0.f;            // m: running maximum of the RAW scores
+    f32x4 oacc[8];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int d = 0; d < 8; ++d) oacc[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < 8; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     auto tile = [&](const int kt, auto BUFC) {
         constexpr int BUF = decltype(BUFC)::value;
         constexpr int KOFF = BUF * TILE, VOFF = 2 * TILE + BUF * TILE;
         if (kt + 1 < nkt) {
-            stage_tile<FQ_WAVES>(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
-            stage_tile<FQ_WAVES>(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
         }
-        unsigned mybits[2] = {0, 0};
-        if (DROP) {                       // keep-bits of queries q0, q0 + 16, keys 64kt + 16g .. +15; stashed for the backward kernels
-            mybits[0] = drop_bits16(dc, (uint64_t)(pbase + (int64_t)qc0 * a.tp + 64 * kt));
-            mybits[1] = drop_bits16(dc, (uint64_t)(pbase + (int64_t)qc1 * a.tp + 64 * kt));
-            if (q0 < t) keep[((int64_t)kt * t + q0) * 4] = (uint16_t)mybits[0];
-            if (q0 + 16 < t) keep[((int64_t)kt * t + q0 + 16) * 4] = (uint16_t)mybits[1];
+        unsigned mybits = 0;
+        if (DROP) {                       // keep-bits of query i16, keys 64kt + 16g .. +15; stashed for the backward kernels
+            mybits = drop_bits16(dc, (uint64_t)(prow + 64 * kt + 16 * g));
+            if (qrow < t) keep[(int64_t)kt * t * 4] = (uint16_t)mybits;
         }
-        // ---- S^T tiles: x[s][T][r] = score of key 64kt + 16T + 4g + r against query q0 + 16 s
-        const bool masked = 64 * (kt + 1) > kfull;
-        float x[2][4][4];
-        float tmax[2] = {NOKEY, NOKEY};
-        auto scores = [&](auto TC) {
-            constexpr int T = decltype(TC)::value;
-            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+        float x[4][4];
+        float tmax = NOKEY;
+        score_tiles<KOFF>(64 * (kt + 1) > kfull, fa, qf, lmask, kt, t, masked_raw, lane, x, tmax);
+        tmax = xor16_32_max(tmax);
+        if (__any(tmax > m)) {           // a new row maximum somewhere in the wave: rescale
+            const float m_new = fmaxf(m, tmax);
+            const float corr = __builtin_amdgcn_exp2f((m - m_new) * c2);
+            l *= corr;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kfrag = row_frag<KOFF + 4096 * T>(fa, ks);
-                sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[0][ks], sa, 0, 0, 0);
-                sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[1][ks], sb, 0, 0, 0);
+            for (int d = 0; d < 8; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[d][r] *= corr;
+            m = m_new;
+        }
+        const float nm = -m * c2;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            unsigned bT = 0;
+            if (DROP) bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[T][r], c2, nm));
+                l += pv;
+                x[T][r] = DROP ? and_mask(pv, keep_mask(bT, r)) : pv;
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { x[0][T][r] = sa[r]; x[1][T][r] = sb[r]; }
-            if (masked) {
-                const int key0 = 64 * kt + 16 * T + 4 * g;
-                const unsigned mk = *reinterpret_cast<const unsigned*>(lmask + key0);        // key0 % 4 == 0; bytes >= t are 0
-                mask_fix(x[0][T], mk, key0, t, masked_raw);
-                mask_fix(x[1][T], mk, key0, t, masked_raw);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { tmax[0] = fmaxf(tmax[0], x[0][T][r]); tmax[1] = fmaxf(tmax[1], x[1][T][r]); }
-        };
-        scores(IC<0>{}); scores(IC<1>{}); scores(IC<2>{}); scores(IC<3>{});
-        bf16x8 pb[2][2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float tm = xor16_32_max(tmax[s]);
-            if (__any(tm > m[s])) {           // a new row maximum somewhere in the wave: rescale
-                const float m_new = fmaxf(m[s], tm);
-                const float corr = __builtin_amdgcn_exp2f((m[s] - m_new) * c2);
-                l[s] *= corr;
-#pragma unroll
-                for (int d = 0; d < 8; ++d)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) oacc[s][d][r] *= corr;
-                m[s] = m_new;
-            }
-            const float nm = -m[s] * c2;
-#pragma unroll
-            for (int T = 0; T < 4; ++T) {
-                unsigned bT = 0;
-                if (DROP) bT = (unsigned)__shfl((int)mybits[s], i16 + 16 * T, 64) >> (4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[s][T][r], c2, nm));
-                    l[s] += pv;
-                    x[s][T][r] = DROP ? and_mask(pv, keep_mask(bT, r)) : pv;
-                }
-            }
-            pb[s][0] = pack8(x[s][0], x[s][1]);
-            pb[s][1] = pack8(x[s][2], x[s][3]);
         }
         // ---- O^T += V^T P^T: k-step kp covers the keys of score tiles 2kp, 2kp+1 (in the accumulators' own order)
+        const bf16x8 pb0 = pack8(x[0], x[1]), pb1 = pack8(x[2], x[3]);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            const bf16x8 vfrag = tr_frag<VOFF>(fa, d);
-            oacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[0][0], oacc[0][d], 0, 0, 0);
-            oacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[1][0], oacc[1][d], 0, 0, 0);
-        }
+        for (int d = 0; d < 8; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VOFF>(fa, d), pb0, oacc[d], 0, 0, 0);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            const bf16x8 vfrag = tr_frag<VOFF + 8192>(fa, d);
-            oacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[0][1], oacc[0][d], 0, 0, 0);
-            oacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[1][1], oacc[1][d], 0, 0, 0);
-        }
+        for (int d = 0; d < 8; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VOFF + 8192>(fa, d), pb1, oacc[d], 0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     for (int kt = 0; kt < nkt; kt += 2) {
         tile(kt, IC<0>{});
         if (kt + 1 < nkt) tile(kt + 1, IC<1>{});
     }
+    l = xor16_32_sum(l);
+    if (qrow < t) {
+        const float inv = dc.scale / l;             // 1/(1-p) of the kept probabilities, applied once
+        bf16_t* orow = a.O + (int64_t)b * a.o_batch + (int64_t)qrow * a.o_row + (int64_t)h * a.head;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const float lsum = xor16_32_sum(l[s]);
-        const int qrow = q0 + 16 * s;
-        if (qrow < t) {
-            const float inv = dc.scale / lsum;             // 1/(1-p) of the kept probabilities, applied once
-            bf16_t* orow = a.O + (int64_t)b * a.o_batch + (int64_t)qrow * a.o_row + (int64_t)h * a.head;
+        for (int d = 0; d < 8; ++d) {           // oacc[d][r] = O[qrow][16d + 4g + r]
+            bf16x4 o;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {           // oacc[s][d][r] = O[qrow][16d + 4g + r]
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(oacc[s][d][r] * inv);
-                *reinterpret_cast<bf16x4*>(orow + 16 * d + 4 * g) = o;
-            }
-            if (g == 0) *reinterpret_cast<float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2) = make_float2(m[s] * a.alpha, lsum);
+            for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(oacc[d][r] * inv);
+            *reinterpret_cast<bf16x4*>(orow + 16 * d + 4 * g) = o;
         }
+        if (g == 0) *reinterpret_cast<float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2) = make_float2(m * a.alpha, l);
     }
 }
 
@@ -734,8 +716,8 @@ extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, i
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<true>, dim3(flash_grid(B, H, t)), dim3(FQ_THREADS), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(flash_fwd_k<false>, dim3(flash_grid(B, H, t)), dim3(FQ_THREADS), lds, (hipStream_t)stream, a);
+    if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<true>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(flash_fwd_k<false>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
     FS2_CHECK_LAUNCH("fs2_flash_attn_fwd");
     return FS2_OK;
 }

@@ -273,6 +273,64 @@ template <> __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, f
     bf16x2_t v; v[0] = (bf16_t)a; v[1] = (bf16_t)b;
     *reinterpret_cast<bf16x2_t*>(p) = v;
 }
+// tiles of one descriptor with the tap count as a compile-time constant (the index arithmetic divides by k per element:
+// with a run-time k those divisions, not the memory system, set the kernel's time)
+template <typename T, int KC, int MODE>
+__device__ __forceinline__ void cast_tiles(const FS2CastDesc& d, float* tile) {
+    const int O = d.O, I = d.I;
+    constexpr int k = KC;
+    const float* __restrict__ src = d.src;
+    // tile = TO_ o x TI_ i x k source elements: the long side is the one the destination runs along (mode 0: 64 consecutive i =
+    // 128-byte runs of bf16; mode 1: 64 consecutive o), the source is read in contiguous runs of TI_*k floats per o
+    constexpr int TO_ = MODE == 0 ? 16 : 64, TI_ = MODE == 0 ? 64 : 16;
+    const int to = (O + TO_ - 1) / TO_, ti = (I + TI_ - 1) / TI_;
+    constexpr int run = TI_ * k, ldt = run + 1;            // +1: the transposed reads below hit distinct banks
+    for (int t = blockIdx.x; t < to * ti; t += gridDim.x) {
+        const int o0 = (t / ti) * TO_, i0 = (t % ti) * TI_;
+        __syncthreads();
+        if (i0 + TI_ <= I && ((int64_t)I * k) % 4 == 0 && (((uintptr_t)src) & 15) == 0) {       // whole runs: 16-byte loads
+            constexpr int run4 = run / 4;
+            for (int e = threadIdx.x; e < TO_ * run4; e += TPB) {
+                const int oo = e / run4, r = (e % run4) * 4;
+                const int o = o0 + oo;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (o < O) v = *reinterpret_cast<const float4*>(src + ((int64_t)o * I + i0) * k + r);
+                float* tp = tile + oo * ldt + r;
+                tp[0] = v.x; tp[1] = v.y; tp[2] = v.z; tp[3] = v.w;
+            }
+        } else {
+            for (int e = threadIdx.x; e < TO_ * run; e += TPB) {
+                const int oo = e / run, r = e % run;           // r = ii*k + j
+                const int o = o0 + oo, i = i0 + r / k;
+                tile[oo * ldt + r] = (o < O && i < I) ? src[((int64_t)o * I + i0) * k + r] : 0.f;
+            }
+        }
+        __syncthreads();
+        // two consecutive destination elements per thread (one 4-byte store for bf16)
+        for (int e = threadIdx.x; e < TO_ * run / 2; e += TPB) {
+            if (MODE == 0) {            // dst[o][j*I + i]: 64 consecutive i per (o, j)
+                const int ii = (e % 32) * 2, j = (e / 32) % k, oo = e / (32 * k);
+                const int o = o0 + oo, i = i0 + ii;
+                if (o < O && i < I) {
+                    T* dp = reinterpret_cast<T*>(d.dst) + (int64_t)o * d.dld + (int64_t)j * I + i;
+                    const float a = tile[oo * ldt + ii * k + j], b = tile[oo * ldt + (ii + 1) * k + j];
+                    if (i + 1 < I && (((uintptr_t)dp) & (2 * sizeof(T) - 1)) == 0) store2<T>(dp, a, b);
+                    else { dp[0] = from_f32<T>(a); if (i + 1 < I) dp[1] = from_f32<T>(b); }
+                }
+            } else {                    // dst[i][j*O + o]: 64 consecutive o per (i, j), taps flipped
+                const int oo = (e % 32) * 2, j = (e / 32) % k, ii = e / (32 * k);
+                const int o = o0 + oo, i = i0 + ii;
+                if (o < O && i < I) {
+                    T* dp = reinterpret_cast<T*>(d.dst) + (int64_t)i * d.dld + (int64_t)j * O + o;
+                    const float a = tile[oo * ldt + ii * k + (k - 1 - j)], b = tile[(oo + 1) * ldt + ii * k + (k - 1 - j)];
+                    if (o + 1 < O && (((uintptr_t)dp) & (2 * sizeof(T) - 1)) == 0) store2<T>(dp, a, b);
+                    else { dp[0] = from_f32<T>(a); if (o + 1 < O) dp[1] = from_f32<T>(b); }
+                }
+            }
+        }
+    }
+}
+
 // One block iteration = a tile of 16 o x 64 i x k (forward shadow) or 64 o x 16 i x k (data-gradient shadow) source elements staged in LDS: the source is read in contiguous
 // runs of 32*k floats per o, the shadows are written in runs of 32 contiguous elements ([o][j*I + i] or [i][j*O + o]).
 template <typename T>
@@ -300,42 +358,16 @@ __global__ __launch_bounds__(TPB) void cast_permute_batched_k(const FS2CastDesc*
         }
         return;
     }
-    // tile = TO_ o x TI_ i x k source elements: the long side is the one the destination runs along (mode 0: 64 consecutive i =
-    // 128-byte runs of bf16; mode 1: 64 consecutive o), the source is read in contiguous runs of TI_*k floats per o
-    const int TO_ = d.mode == 0 ? 16 : 64, TI_ = d.mode == 0 ? 64 : 16;
-    const int to = (O + TO_ - 1) / TO_, ti = (I + TI_ - 1) / TI_;
-    const int run = TI_ * k, ldt = run + 1;                // +1: the transposed reads below hit distinct banks
-    for (int t = blockIdx.x; t < to * ti; t += gridDim.x) {
-        const int o0 = (t / ti) * TO_, i0 = (t % ti) * TI_;
-        __syncthreads();
-        for (int e = threadIdx.x; e < TO_ * run; e += TPB) {
-            const int oo = e / run, r = e % run;           // r = ii*k + j
-            const int o = o0 + oo, i = i0 + r / k;
-            tile[oo * ldt + r] = (o < O && i < I) ? src[((int64_t)o * I + i0) * k + r] : 0.f;
-        }
-        __syncthreads();
-        // two consecutive destination elements per thread (one 4-byte store for bf16)
-        for (int e = threadIdx.x; e < TO_ * run / 2; e += TPB) {
-            if (d.mode == 0) {          // dst[o][j*I + i]: 64 consecutive i per (o, j)
-                const int ii = (e % 32) * 2, j = (e / 32) % k, oo = e / (32 * k);
-                const int o = o0 + oo, i = i0 + ii;
-                if (o < O && i < I) {
-                    T* dp = reinterpret_cast<T*>(d.dst) + (int64_t)o * d.dld + (int64_t)j * I + i;
-                    const float a = tile[oo * ldt + ii * k + j], b = tile[oo * ldt + (ii + 1) * k + j];
-                    if (i + 1 < I && (((uintptr_t)dp) & (2 * sizeof(T) - 1)) == 0) store2<T>(dp, a, b);
-                    else { dp[0] = from_f32<T>(a); if (i + 1 < I) dp[1] = from_f32<T>(b); }
-                }
-            } else {                    // dst[i][j*O + o]: 64 consecutive o per (i, j), taps flipped
-                const int oo = (e % 32) * 2, j = (e / 32) % k, ii = e / (32 * k);
-                const int o = o0 + oo, i = i0 + ii;
-                if (o < O && i < I) {
-                    T* dp = reinterpret_cast<T*>(d.dst) + (int64_t)i * d.dld + (int64_t)j * O + o;
-                    const float a = tile[oo * ldt + ii * k + (k - 1 - j)], b = tile[(oo + 1) * ldt + ii * k + (k - 1 - j)];
-                    if (o + 1 < O && (((uintptr_t)dp) & (2 * sizeof(T) - 1)) == 0) store2<T>(dp, a, b);
-                    else { dp[0] = from_f32<T>(a); if (o + 1 < O) dp[1] = from_f32<T>(b); }
-                }
-            }
-        }
+    switch (k) {
+        case 1: if (d.mode == 0) cast_tiles<T, 1, 0>(d, tile); else cast_tiles<T, 1, 1>(d, tile); break;
+        case 2: if (d.mode == 0) cast_tiles<T, 2, 0>(d, tile); else cast_tiles<T, 2, 1>(d, tile); break;
+        case 3: if (d.mode == 0) cast_tiles<T, 3, 0>(d, tile); else cast_tiles<T, 3, 1>(d, tile); break;
+        case 4: if (d.mode == 0) cast_tiles<T, 4, 0>(d, tile); else cast_tiles<T, 4, 1>(d, tile); break;
+        case 5: if (d.mode == 0) cast_tiles<T, 5, 0>(d, tile); else cast_tiles<T, 5, 1>(d, tile); break;
+        case 6: if (d.mode == 0) cast_tiles<T, 6, 0>(d, tile); else cast_tiles<T, 6, 1>(d, tile); break;
+        case 7: if (d.mode == 0) cast_tiles<T, 7, 0>(d, tile); else cast_tiles<T, 7, 1>(d, tile); break;
+        case 8: if (d.mode == 0) cast_tiles<T, 8, 0>(d, tile); else cast_tiles<T, 8, 1>(d, tile); break;
+        default: if (d.mode == 0) cast_tiles<T, 9, 0>(d, tile); else cast_tiles<T, 9, 1>(d, tile); break;
     }
 }
 template <typename T>
@@ -356,6 +388,35 @@ __global__ __launch_bounds__(TPB) void permute_add_k(float* __restrict__ scratch
         const int64_t si = ((int64_t)o * k + j) * I + i;
         grad[e] += scratch[si];
         if (rezero) scratch[si] = 0.f;     // each scratch element is read exactly once: leave it zeroed for the next user
+    }
+}
+
+// The same through LDS tiles (k <= 9): for 4 output channels and 64 input channels at a time the k source runs of 64 floats
+// ([o][j][i0 .. i0+63], 256 B each) are read contiguously and the 64*k destination floats of each o ([o][i0 .. i0+63][0..k)) are
+// written contiguously -- the flat kernel above reads the scratch at a stride of I floats.
+__global__ __launch_bounds__(TPB) void permute_add_tiled_k(float* __restrict__ scratch, float* __restrict__ grad, int O, int I, int k,
+        int rezero) {
+    __shared__ float tile[4][9][65];
+    const int nib = (I + 63) / 64, items = ((O + 3) / 4) * nib;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int o0 = (item / nib) * 4, i0 = (item % nib) * 64;
+        for (int idx = threadIdx.x; idx < 4 * k * 64; idx += TPB) {
+            const int ii = idx & 63, j = (idx >> 6) % k, oo = idx / (64 * k);
+            const int o = o0 + oo, i = i0 + ii;
+            if (o < O && i < I) {
+                const int64_t si = ((int64_t)o * k + j) * I + i;
+                tile[oo][j][ii] = scratch[si];
+                if (rezero) scratch[si] = 0.f;
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 4 * 64 * k; idx += TPB) {
+            const int e = idx % (64 * k), oo = idx / (64 * k);
+            const int ii = e / k, j = e - ii * k;
+            const int o = o0 + oo, i = i0 + ii;
+            if (o < O && i < I) grad[((int64_t)o * I + i) * k + j] += tile[oo][j][ii];
+        }
+        __syncthreads();
     }
 }
 
@@ -638,7 +699,13 @@ extern "C" int fs2_splitk_finish(float* scratch, int64_t M, int N, const float* 
 extern "C" int fs2_permute_add(float* scratch, float* grad, int O, int I, int k, int rezero, void* stream) {
     FS2_REQUIRE(O > 0 && I > 0 && k > 0, "fs2_permute_add: bad shape");
     const int64_t n = (int64_t)O * I * k;
-    hipLaunchKernelGGL(permute_add_k, dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, scratch, grad, O, I, k, rezero);
+    if (k <= 9 && k > 1) {
+        int64_t items = (int64_t)((O + 3) / 4) * ((I + 63) / 64);
+        if (items > 2048) items = 2048;
+        hipLaunchKernelGGL(permute_add_tiled_k, dim3((unsigned)items), dim3(TPB), 0, (hipStream_t)stream, scratch, grad, O, I, k, rezero);
+    } else {
+        hipLaunchKernelGGL(permute_add_k, dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, scratch, grad, O, I, k, rezero);
+    }
     FS2_CHECK_LAUNCH("fs2_permute_add");
     return FS2_OK;
 }
