@@ -179,10 +179,23 @@ __global__ __launch_bounds__(TPB) void l1_fwd_k(const T* __restrict__ pred, cons
         int64_t n, float* __restrict__ loss) {
     __shared__ float lds4[4];
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+    int64_t done = 0;
+    if constexpr (sizeof(T) == 4) {       // fp32 predictions against fp32 targets: 16-byte loads
+        if (mode == 0 && ((((uintptr_t)pred) | ((uintptr_t)tgt)) & 15) == 0) {
+            const int64_t n4 = n >> 2;
+            const float4* p4 = reinterpret_cast<const float4*>(pred);
+            const float4* t4 = reinterpret_cast<const float4*>(tgt);
+            for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+                const float4 a = p4[i], b = t4[i];
+                acc += (fabsf(a.x - b.x) + fabsf(a.y - b.y)) + (fabsf(a.z - b.z) + fabsf(a.w - b.w));
+            }
+            done = n4 << 2;
+        }
+    }
+    for (int64_t i = done + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
         acc += fabsf(to_f32<T>(pred[i]) - l1_target<T>(tgt, mode, i));
     const float s = block_sum(acc, lds4);
-    if (threadIdx.x == 0) atomicAdd(loss, s / (float)n);
+    if (threadIdx.x == 0) atomicAdd(loss, s / (float)n);      // one address: the launcher keeps the grid at <= 256 blocks
 }
 template <typename T, typename TG>
 __global__ __launch_bounds__(TPB) void l1_bwd_k(const T* __restrict__ pred, const void* __restrict__ tgt, int mode,
@@ -567,7 +580,8 @@ extern "C" int fs2_l1_fwd(const void* pred, int pred_dtype, const void* target, 
                           void* stream) {
     CHECK_DT("fs2_l1_fwd", pred_dtype);
     FS2_REQUIRE(n > 0 && (target_mode == 0 || target_mode == 1), "fs2_l1_fwd: bad n/target_mode");
-    T_DISPATCH(pred_dtype, T, { hipLaunchKernelGGL((l1_fwd_k<T>), dim3(flat_grid(n)), dim3(TPB), 0, (hipStream_t)stream, (const T*)pred, target, target_mode, n, loss); });
+    const int blocks = flat_grid(n >> 2) < 256 ? (flat_grid(n >> 2) < 1 ? 1 : flat_grid(n >> 2)) : 256;      // every block ends with one atomic on the same address
+    T_DISPATCH(pred_dtype, T, { hipLaunchKernelGGL((l1_fwd_k<T>), dim3(blocks), dim3(TPB), 0, (hipStream_t)stream, (const T*)pred, target, target_mode, n, loss); });
     FS2_CHECK_LAUNCH("fs2_l1_fwd");
     return FS2_OK;
 }
