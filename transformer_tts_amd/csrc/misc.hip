@@ -469,7 +469,13 @@ __global__ __launch_bounds__(TPB) void sqnorm_k(const float* __restrict__ x, int
     __shared__ float lds4[4];
     float acc = 0.f;
     const int64_t nv = n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    for (; i + stride < nv; i += 2 * stride) {          // two independent loads in flight per thread
+        const float4 v = reinterpret_cast<const float4*>(x)[i], w = reinterpret_cast<const float4*>(x)[i + stride];
+        acc += ((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) + ((w.x * w.x + w.y * w.y) + (w.z * w.z + w.w * w.w));
+    }
+    if (i < nv) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
         acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
@@ -748,7 +754,8 @@ extern "C" int fs2_colsum_segmented(const void* x, int dtype, int64_t M, int N, 
 
 extern "C" int fs2_sqnorm(const float* x, int64_t n, float* out, void* stream) {
     FS2_REQUIRE(n > 0 && fs2_aligned16(x), "fs2_sqnorm: n > 0 and 16-byte aligned x required");
-    hipLaunchKernelGGL(sqnorm_k, dim3(flat_grid(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, x, n, out);
+    const int blocks = flat_grid(n >> 2) < 768 ? flat_grid(n >> 2) : 768;      // every block ends with one atomic on `out`: contended atomics serialise
+    hipLaunchKernelGGL(sqnorm_k, dim3(blocks), dim3(TPB), 0, (hipStream_t)stream, x, n, out);
     FS2_CHECK_LAUNCH("fs2_sqnorm");
     return FS2_OK;
 }
