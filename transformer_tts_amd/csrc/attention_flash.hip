@@ -5,8 +5,8 @@
 // other kernel of the library (element offset of P[b, h, q, key] in the (B, [layers], H, t, tp) layout, >> 3), so this path and
 // the LDS-strip path (attention.hip) draw IDENTICAL masks and differ only by rounding.
 //
-// Common structure (all three kernels): a workgroup = 8 waves owns 128 rows of one (batch, head) -- queries in the forward and
-// dQ kernels, keys in the dK/dV kernel --, 16 rows per wave, held as MFMA fragments in registers; the other side streams through
+// Common structure (all three kernels): a workgroup owns 128 rows of one (batch, head) -- queries in the forward and dQ kernels,
+// keys in the dK/dV kernel -- as 8 waves x 16 rows (forward, dK/dV) or 4 waves x 2 x 16 rows (dQ), held as MFMA fragments in registers; the other side streams through
 // LDS in tiles of 64 rows x 128 columns by LDS-DMA (buffer_load_dwordx4 ... lds), double buffered, in the dual-use image of the
 // CDNA4 guide (T10, image (b): 256-byte rows, 16-byte chunk c of row r at c ^ (((r&3)<<2) | ((r>>2)&3))), which serves both the
 // row reads (ds_read_b128: operand rows) and the transposed reads (ds_read_b64_tr_b16: the same tile as the k-major operand of
