@@ -566,6 +566,8 @@ class PostNetFunction(torch.autograd.Function):
         bns = [mod.pre_batchnorm] + list(mod.batch_norm_list)
         inputs, cs, stats = [], [], []
         h = mel_T
+        Cmax = max(cv.weight.shape[0] for cv in convs)
+        sums_all = torch.zeros((len(convs), 2 * Cmax + 4), dtype=torch.float32, device=x.device) if mod.training else None   # one memset
         for li, (cv, bn) in enumerate(zip(convs, bns)):
             C = cv.weight.shape[0]
             if not mod.training:        # eval(): BatchNorm1d normalises with its running statistics (postnets.py:58-59)
@@ -574,7 +576,7 @@ class PostNetFunction(torch.autograd.Function):
                 rstd = torch.rsqrt(bn.running_var.detach().float() + bn.eps)
                 h = ops.bn_tanh_fwd(c, mean, rstd, bn.weight.detach(), bn.bias.detach(), 0.0, rng, mod.sites[li])
                 continue
-            sums = torch.zeros(2 * C + 4, dtype=torch.float32, device=x.device)   # [sum | sum^2 | rows,-,-,-]
+            sums = sums_all[li, :2 * C + 4]                                     # [sum | sum^2 | rows,-,-,-]
             c = ops.conv(h, rt.w_fwd(cv.weight), 5, 4, cv.bias.detach(), colstats=sums)          # causal: pad 4, crop 4
             count = None
             if rt.dp is not None:       # SyncBatchNorm: one all-reduce of [sums, row count] over the ranks
@@ -611,11 +613,12 @@ class PostNetFunction(torch.autograd.Function):
             dpost_T = dpost if T == torch.float32 else ops.cast(dpost, T)
             _conv_wgrad(rt, dpost_T, s["h_last"], mod.conv2, 4)
             dh = ops.conv(dpost_T, rt.w_dgrad(mod.conv2.weight), 5, 0)
+            red_all = torch.zeros((4, 2 * max(cv.weight.shape[0] for cv in convs[:4])), dtype=torch.float32, device=x.device)   # one memset
             for li in reversed(range(4)):
                 cv, bn = convs[li], bns[li]
                 C = cv.weight.shape[0]
                 mean, rstd, count = s["stats"][li]
-                red = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+                red = red_all[li, :2 * C]
                 ops.bn_tanh_bwd_reduce(dh, s["cs"][li], mean, rstd, bn.weight.detach(), bn.bias.detach(), red, p, rng,
                                        mod.sites[li])
                 # affine grads come from the LOCAL sums (as SyncBatchNorm does; the DP gradient average
