@@ -8,7 +8,7 @@
 // Common structure (all three kernels): a workgroup owns 128 rows of one (batch, head) -- queries in the forward and dQ kernels,
 // keys in the dK/dV kernel -- as 8 waves x 16 rows (forward, dK/dV) or 4 waves x 2 x 16 rows (dQ), held as MFMA fragments in registers; the other side streams through
 // LDS in tiles of 64 rows x 128 columns by LDS-DMA (buffer_load_dwordx4 ... lds), double buffered, in the dual-use image of the
-// CDNA4 guide (T10, image (b): 256-byte rows, 16-byte chunk c of row r at c ^ (((r&3)<<2) | ((r>>2)&3))), which serves both the
+// CDNA4 guide (T10: 256-byte rows, 16-byte chunk c of row r at c ^ f(r); f below), which serves both the
 // row reads (ds_read_b128: operand rows) and the transposed reads (ds_read_b64_tr_b16: the same tile as the k-major operand of
 // the second product).  Score tiles are computed TRANSPOSED relative to the product that consumes them, so that an accumulator
 // tile is already the next MFMA's operand: with D = A B, lane (i16, g) holds D[4g + r][i16]; two 16-row tiles T, T+1 give the
@@ -46,7 +46,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 __device__ __forceinline__ bf16x8 ld16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
 }
-__device__ __forceinline__ int img_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+// chunk swizzle of the 64-row x 256-byte images: chunk c of row r sits at c ^ ((r & 7) << 1).  With 64 banks of 4 bytes a row is one
+// bank period, so a read is conflict-free when the lanes of a service group touch distinct 16-byte chunks: the transposed reads
+// (groups of 32 lanes = 8 consecutive rows x one aligned 32-byte pair) get pair index ct ^ (r & 7), all different; the row
+// reads (groups of 16 lanes = 16 rows, half of them on chunk c and half on c ^ 1) get (c ^ 2(r & 7)) and its odd neighbour for
+// the row 8 further on.  (The T10 image (b) swizzle ((r&3)<<2 | (r>>2)&3) is 2-way on both access patterns of these kernels:
+// 40 % of the LDS cycles of the dK/dV kernel were conflicts.)
+__device__ __forceinline__ int img_f(int r) { return (r & 7) << 1; }
 __device__ __forceinline__ int img_off(int row, int ch) { return row * 256 + ((ch ^ img_f(row)) << 4); }
 
 // LDS byte addresses of this lane's fragment reads inside an image at offset 0; everything else (which image, which buffer,
@@ -625,6 +631,14 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
         const float4* aux = reinterpret_cast<const float4*>(auximg + BUF * AUX_BYTES);
         auto pair = [&](auto KPC) {
             constexpr int kp = decltype(KPC)::value;
+            // the transposed fragments of this k-step depend only on the staged tile: their reads are issued BEFORE the score /
+            // element-wise phase, so that the 16 MFMAs below do not run at the pace of one LDS round trip each (the compiler
+            // otherwise keeps a single fragment of lookahead; the kernel has the registers: 2 waves per SIMD)
+            bf16x8 fdo[8], fq[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) fdo[d] = tr_frag<DOFF + 8192 * kp>(fa, d);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) fq[d] = tr_frag<QOFF + 8192 * kp>(fa, d);
             float pd[2][4], ds[2][4];
             auto one = [&](auto UC) {
                 constexpr int u = decltype(UC)::value, T = 2 * kp + u;
@@ -652,8 +666,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
             const bf16x8 dsb = pack8(ds[0], ds[1]);
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
-                dvacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DOFF + 8192 * kp>(fa, d), pdb, dvacc[d], 0, 0, 0);
-                dkacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<QOFF + 8192 * kp>(fa, d), dsb, dkacc[d], 0, 0, 0);
+                dvacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdo[d], pdb, dvacc[d], 0, 0, 0);
+                dkacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[d], dsb, dkacc[d], 0, 0, 0);
             }
         };
         pair(IC<0>{}); pair(IC<1>{});
