@@ -235,8 +235,12 @@ int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_s
 int64_t fs2_flash_attn_keep_words(int B, int H, int t);
 int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                        const uint8_t* key_mask, void* o_out, int64_t o_row_stride, int64_t o_batch_stride, float* stats,
-                       uint16_t* keep_bits, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha, float p,
-                       const uint64_t* rng, uint32_t site, void* stream);
+                       uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
+                       float p, const uint64_t* rng, uint32_t site, void* stream);
+/* the same keep-bits ahead of time (then pass pregenerated = 1 to fs2_flash_attn_fwd, which reads instead of drawing them): a host
+ * that knows the shapes of the next layers generates their masks on a side stream while the matrix pipes are busy elsewhere */
+int fs2_flash_attn_keep_bits(uint16_t* keep_bits, int64_t p_batch_stride, int B, int H, int t, int tp, float p, const uint64_t* rng,
+                             uint32_t site, void* stream);
 int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                        const uint8_t* key_mask, const void* o_saved, int64_t o_row_stride, int64_t o_batch_stride,
                        const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats,

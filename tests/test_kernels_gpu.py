@@ -525,6 +525,16 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
     s = s.masked_fill(~km[:, None, None, :], -1e4)
     close(stats[..., 0].cpu(), s.amax(-1), "row maximum", rtol=1e-3, atol=2e-3)
     close(stats[..., 1].cpu(), torch.exp(s - s.amax(-1, keepdim=True)).sum(-1), "sum of exponentials", rtol=2e-3, atol=1e-3)
+    if p > 0:       # masks drawn ahead of time by fs2_flash_attn_keep_bits: the same bits, the same output
+        keep2 = torch.empty_like(keep)
+        ops.flash_keep_bits(keep2, B, H, t, p_batch, p, rng, 11)
+        O2, stats2 = torch.empty_like(O), torch.empty_like(stats)
+        ops.flash_attn_fwd(q, k, v, km.cuda(), O2.permute(0, 2, 1, 3), stats2, keep2, t, dk ** -0.5, p_batch, p, rng, 11, pregenerated=True)
+        assert torch.equal(O2, O) and torch.equal(stats2, stats)
+        nkt = (t + 63) // 64
+        kk = torch.arange(nkt * 4, device="cuda").view(nkt, 1, 4) * 16 < torch.tensor([t, max(1, t // 2), max(1, t - 5)], device="cuda").view(B, 1, 1, 1, 1)
+        a_, b_ = keep.view(B, H, nkt, t, 4), keep2.view(B, H, nkt, t, 4)      # words of key tiles the forward skipped are never written
+        assert torch.equal(a_[kk.expand_as(a_)], b_[kk.expand_as(b_)])
     dqkv = torch.full((B, t, 3, H, dk), float("nan"), dtype=dtype, device="cuda")
     dq, dv, dk_ = (dqkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
     aux = torch.empty((B, H, t, 4), device="cuda")

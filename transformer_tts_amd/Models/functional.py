@@ -12,6 +12,7 @@ bf16 mode, torch.float32 in the exact-fp32 parity mode); the residual stream is 
 """
 import contextlib
 import math
+import os
 
 import torch
 
@@ -304,6 +305,14 @@ class EncoderStackFunction(torch.autograd.Function):
             attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if p_att > 0 else attn
         layers = []
         scale = 1.0 / math.sqrt(dk)
+        # Drawing the masks of layers 1.. on the side stream beside layer 0 (fs2_flash_attn_keep_bits) measured SLOWER than letting
+        # every forward kernel draw its own (9.77 vs 9.69 ms/step, A/B on one box): the generator competes with the kernels it was
+        # meant to hide under.  Kept behind FS2_FLASH_PREGEN=1 for measurements.
+        pregen = flash and keep is not None and N > 1 and rt.overlap_wgrad and os.environ.get("FS2_FLASH_PREGEN", "0") == "1"
+        if pregen:
+            with rt.side(src):
+                for i in range(1, N):
+                    ops.flash_keep_bits(keep[i], B, H, t, N * H * t * tp, p_att, rng, enc.layers[i].site_attn)
         for i, layer in enumerate(enc.layers):
             L = {}
             wf, _, bqkv = rt.qkv(layer.attn)
@@ -313,8 +322,10 @@ class EncoderStackFunction(torch.autograd.Function):
             O = torch.empty((B, t, H, dk), dtype=T, device=dev)
             O4 = O.permute(0, 2, 1, 3)
             if flash:                                   # modules.py:8-20 in one kernel, row statistics only
+                if pregen and i == 1:
+                    rt.side_join()
                 ops.flash_attn_fwd(q, k, v, km, O4, stats[i], keep[i] if keep is not None else None, t, scale, N * H * t * tp, p_att,
-                                   rng, layer.site_attn)
+                                   rng, layer.site_attn, pregenerated=pregen and i >= 1)
             elif ops.attn_probs_supported(t, dk, T):    # scores stay in LDS (one kernel)
                 S, Pd = attn[:, i], attn_drop[:, i]
                 pv = ops.attn_second_product_supported(dk)

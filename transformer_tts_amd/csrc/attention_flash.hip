@@ -277,7 +277,8 @@ __device__ __forceinline__ void score_tiles(const bool masked, const FragAddr& f
 // ------------------------------------------------------------------------------------------------ forward
 // O = dropout(softmax(mask(alpha Q K^T))) V, stats = {m, l}.  Wave: 16 queries (columns of the transposed score tiles).
 // LDS: K images [2][TILE] at 0, V images [2][TILE] at 2 TILE, key mask, two reduction words.
-template <bool DROP>
+// DROP: 0 no dropout; 1 draw the keep-bits (Philox) and stash them; 2 read bits that fs2_flash_attn_keep_bits wrote beforehand
+template <int DROP>
 __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int blk, h, b;
@@ -312,17 +313,19 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     f32x4 oacc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned bits_next = DROP == 2 ? keep[0] : 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     auto tile = [&](const int kt, auto BUFC) {
         constexpr int BUF = decltype(BUFC)::value;
         constexpr int KOFF = BUF * TILE, VOFF = 2 * TILE + BUF * TILE;
+        unsigned mybits = bits_next;
         if (kt + 1 < nkt) {
             stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
             stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            if (DROP == 2) bits_next = keep[(int64_t)(kt + 1) * t * 4];
         }
-        unsigned mybits = 0;
-        if (DROP) {                       // keep-bits of query i16, keys 64kt + 16g .. +15; stashed for the backward kernels
+        if (DROP == 1) {                  // keep-bits of query i16, keys 64kt + 16g .. +15; stashed for the backward kernels
             mybits = drop_bits16(dc, (uint64_t)(prow + 64 * kt + 16 * g));
             if (qrow < t) keep[(int64_t)kt * t * 4] = (uint16_t)mybits;
         }
@@ -344,12 +347,12 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
             unsigned bT = 0;
-            if (DROP) bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
+            if (DROP != 0) bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[T][r], c2, nm));
                 l += pv;
-                x[T][r] = DROP ? and_mask(pv, keep_mask(bT, r)) : pv;
+                x[T][r] = DROP != 0 ? and_mask(pv, keep_mask(bT, r)) : pv;
             }
         }
         // ---- O^T += V^T P^T: k-step kp covers the keys of score tiles 2kp, 2kp+1 (in the accumulators' own order)
@@ -691,6 +694,24 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     }
 }
 
+// keep-bits of one layer ahead of its forward kernel (the host runs this on a side stream beside the previous layer's GEMMs, whose
+// vector ALUs are idle): thread = one 16-bit word [b][h][kt][q][g] = keys 64kt + 16g .. +15 of query q, the same Philox counters
+// as flash_fwd_k<1> draws itself
+__global__ __launch_bounds__(256) void flash_keep_bits_k(uint16_t* __restrict__ keep, int64_t p_batch, int B, int H, int t, int tp, int nkt,
+        float p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    const int64_t n = (int64_t)B * H * nkt * t * 4;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < n; w += (int64_t)gridDim.x * 256) {
+        const int g = (int)(w & 3);
+        int64_t r = w >> 2;
+        const int q = (int)(r % t); r /= t;
+        const int kt = (int)(r % nkt); r /= nkt;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        keep[w] = (uint16_t)drop_bits16(dc, (uint64_t)(b * p_batch + ((int64_t)h * t + q) * tp + 64 * kt + 16 * g));
+    }
+}
+
 int check_common(const char* who, const void* q, const void* k, const void* v, int64_t row, int64_t batch, int head, int B, int H, int t,
                  float p, const void* keep_bits) {
     FS2_REQUIRE(q && k && v, "%s: null argument", who);
@@ -711,14 +732,14 @@ extern "C" int64_t fs2_flash_attn_keep_words(int B, int H, int t) { return (int6
 
 extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                                   const uint8_t* key_mask, void* o_out, int64_t o_row_stride, int64_t o_batch_stride, float* stats,
-                                  uint16_t* keep_bits, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha, float p,
-                                  const uint64_t* rng, uint32_t site, void* stream) {
+                                  uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
+                                  float p, const uint64_t* rng, uint32_t site, void* stream) {
     const int rc = check_common("fs2_flash_attn_fwd", q, k, v, row_stride, batch_stride, head_stride, B, H, t, p, keep_bits);
     if (rc != FS2_OK) return rc;
     FS2_REQUIRE(key_mask && o_out && stats, "fs2_flash_attn_fwd: null argument");
     FS2_REQUIRE(tp == (t + 7) / 8 * 8 && p_batch_stride % 8 == 0, "fs2_flash_attn_fwd: need tp = roundup8(t) and p_batch_stride %% 8 == 0");
     FS2_REQUIRE(o_row_stride % 4 == 0 && o_batch_stride % 4 == 0 && fs2_aligned16(o_out), "fs2_flash_attn_fwd: output rows must be 8-byte aligned");
-    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_flash_attn_fwd: dropout needs rng");
+    FS2_REQUIRE(p == 0.f || pregenerated || rng != nullptr, "fs2_flash_attn_fwd: dropout needs rng");
     FlashArgs a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.row = row_stride; a.batch = batch_stride; a.head = head_stride;
     a.key_mask = key_mask; a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.stats = stats; a.keep = keep_bits;
@@ -726,13 +747,28 @@ extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, i
     const int lds = 4 * TILE + MASK_BYTES + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<true>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(flash_fwd_k<false>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
+    if (p > 0.f && pregenerated) hipLaunchKernelGGL(flash_fwd_k<2>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
+    else if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<1>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(flash_fwd_k<0>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
     FS2_CHECK_LAUNCH("fs2_flash_attn_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_flash_attn_keep_bits(uint16_t* keep_bits, int64_t p_batch_stride, int B, int H, int t, int tp, float p, const uint64_t* rng,
+                                       uint32_t site, void* stream) {
+    FS2_REQUIRE(keep_bits && rng && p > 0.f && p < 1.f, "fs2_flash_attn_keep_bits: need a buffer, rng and 0 < p < 1");
+    FS2_REQUIRE(B > 0 && H > 0 && t > 0 && t <= MASK_BYTES && tp == (t + 7) / 8 * 8 && p_batch_stride % 8 == 0, "fs2_flash_attn_keep_bits: bad shape");
+    const int nkt = (t + 63) / 64;
+    const int64_t n = (int64_t)B * H * nkt * t * 4;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(flash_keep_bits_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, keep_bits, p_batch_stride, B, H, t, tp, nkt, p, rng, site);
+    FS2_CHECK_LAUNCH("fs2_flash_attn_keep_bits");
     return FS2_OK;
 }
 

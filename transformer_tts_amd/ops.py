@@ -71,7 +71,8 @@ SIGNATURES = {
     "fs2_attn_probs_lds_bytes": [_I, _I],
     "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P, _P, _L, _L, _P],
     "fs2_flash_attn_keep_words": [_I, _I, _I],          # returns int64
-    "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
+    "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _P, _I, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
+    "fs2_flash_attn_keep_bits": [_P, _L, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _F, _F,
                            _P],
     "fs2_attn_ds_bwd": [_P, _L, _L, _P, _L, _L, _I, _I, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _U32, _P, _P, _L, _L, _F, _P],
@@ -692,7 +693,14 @@ def flash_attn_keep_words(B, H, t):
     return int(lib().fs2_flash_attn_keep_words(int(B), int(H), int(t)))
 
 
-def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0, rng=None, site=0):
+def flash_keep_bits(keep, B, H, t, p_batch, p, rng, site):
+    """draw the dropout keep-bits of one flash_attn_fwd call ahead of time (pass pregenerated=True to that call)"""
+    assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t) and p > 0
+    _check(lib().fs2_flash_attn_keep_bits(_p(keep), int(p_batch), B, H, t, (t + 7) // 8 * 8, p, _rng_ptr(rng, p), site, _stream()),
+           "fs2_flash_attn_keep_bits")
+
+
+def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0, rng=None, site=0, pregenerated=False):
     """out = dropout_p(softmax(mask_keys(alpha q k^T))) v without the probabilities in HBM; stats (B,H,t,2) fp32 = row maximum
     and sum of exponentials; keep: int16 tensor of flash_attn_keep_words(B,H,t) words receiving the dropout keep-bits (None when
     p == 0).  q, k, v: (B,H,t,128) views of the fused projection; out: (B,H,t,128) view of a (B,t,H,128) tensor; p_batch: batch
@@ -704,7 +712,7 @@ def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0
     if p > 0:
         assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t)
     _check(lib().fs2_flash_attn_fwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(out),
-                                    out.stride(2), out.stride(0), _p(stats), _p(keep) if p > 0 else None, int(p_batch), B, H, t,
+                                    out.stride(2), out.stride(0), _p(stats), _p(keep) if p > 0 else None, int(bool(pregenerated)), int(p_batch), B, H, t,
                                     (t + 7) // 8 * 8, float(alpha), p, _rng_ptr(rng, p), site, _stream()), "fs2_flash_attn_fwd")
 
 
