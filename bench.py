@@ -195,7 +195,8 @@ def main():
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 parity mode instead of bf16 (not the headline)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--gemm-report", type=str, default=None, help="write per-shape GEMM timings to this file")
-    ap.add_argument("--no-overlap", action="store_true", help="keep the weight-gradient GEMMs on the main stream (profiling)")
+    ap.add_argument("--no-overlap", action="store_true", help="(default) keep the weight-gradient GEMMs on the main stream")
+    ap.add_argument("--overlap", action="store_true", help="run the weight-gradient GEMMs on a second stream (measured slower: DESIGN.md)")
     ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2",
                     help="cfg2 = BASELINE.json configs[1] (the headline, default); cfg4 = configs[4] (d_model 512, 6+6 layers, batch 64/GPU)")
     ap.add_argument("--return-attn", action="store_true",
@@ -235,8 +236,7 @@ def main():
     model.train()
     model = model.to(dev)
     opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=1.0)
-    if args.no_overlap:
-        model.rt.overlap_wgrad = False
+    model.rt.overlap_wgrad = bool(args.overlap) and not args.no_overlap
     if world > 1 or force_dp:
         from transformer_tts_amd.parallel import DataParallel
         opt.dp = DataParallel(model, opt.arena)

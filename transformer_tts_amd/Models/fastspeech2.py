@@ -37,6 +37,7 @@ class FastSpeech2(nn.Module):
         amp = bool(getattr(hp, "amp", False))
         self.rt = Runtime(torch.bfloat16 if amp else torch.float32, seed=int(getattr(hp, "seed", 1234)))
         self.rt.return_attn = bool(getattr(hp, "return_attn", True))
+        self.rt.overlap_wgrad = bool(getattr(hp, "overlap_wgrad", False))
         self.rt.fp8 = amp and bool(getattr(hp, "fp8", False))     # BASELINE.json configs[4]: fp8 MFMA GEMMs
         self.encoder = Encoder(src_vocab, d_model_encoder, N_e, n_head_encoder, ff_conv_kernel_size_encoder,
                                concat_after_encoder, dropout, runtime=self.rt)

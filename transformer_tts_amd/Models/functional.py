@@ -41,9 +41,12 @@ class Runtime:
         self.dp = None           # parallel.DataParallel or None
         self.return_attn = True
         self.fp8 = False         # hp.fp8 (with hp.amp): row-major products quantise their operands to fp8 (ops.FP8_MODE)
-        # weight-gradient GEMMs (and their scratch handling) run on a second HIP stream, concurrently with the
-        # data-gradient chain of the same backward: they only feed the optimizer
-        self.overlap_wgrad = True
+        # weight-gradient GEMMs (and their scratch handling) can run on a second HIP stream, concurrently with the data-gradient
+        # chain of the same backward (they only feed the optimizer).  That paid while kernels left CUs idle (round 1: -0.6 ms);
+        # with today's kernels the two streams only compete (A/B on one box: 9.56 ms/step on one stream, 9.65 on two), so it is
+        # off unless hp.overlap_wgrad / bench.py --overlap asks for it.  The gradient all-reduce overlaps either way: RCCL runs on
+        # its own stream behind the point of the backward that announced the bucket.
+        self.overlap_wgrad = False
         self._side = None
         self._side_dirty = False
         self._keep = []

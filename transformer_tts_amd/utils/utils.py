@@ -23,6 +23,7 @@ DEFAULTS = {
     "use_hop": False,
     # keys that exist only in this build
     "return_attn": True,       # keep the (B,N,H,t,t) attention maps in the 14-tuple (reference always does)
+    "overlap_wgrad": False,    # weight-gradient GEMMs on a second HIP stream (measured slower on a saturated GPU: DESIGN.md section 4)
     "log_every": 1,            # print losses every N steps (the reference prints every step)
     "use_graph": True,         # train_loop replays one hipGraph per batch shape (False: every kernel launched from Python)
 }
