@@ -813,7 +813,7 @@ def big_gemm(monkeypatch):
     monkeypatch.delenv("FS2_GEMM_BIG_BM", raising=False)
 
 
-@pytest.mark.parametrize("bm", [192, 256])
+@pytest.mark.parametrize("bm", [128, 192, 256])
 @pytest.mark.parametrize("M,N,K", [(300, 80, 72), (129, 256, 256), (1000, 1024, 8), (577, 264, 200), (2048, 512, 64)])
 def test_big_gemm_linear_epilogues(ops, big_gemm, bm, M, N, K):
     """every fused epilogue of the large-tile kernel (bias, ReLU, ReLU mask, fp32 / bf16 residual, fp32 output, column
@@ -844,7 +844,7 @@ def test_big_gemm_linear_epilogues(ops, big_gemm, bm, M, N, K):
             close(acl, bcl, "colsum", rtol=2e-3, atol=2e-2 * M ** 0.5)
 
 
-@pytest.mark.parametrize("bm", [192, 256])
+@pytest.mark.parametrize("bm", [128, 192, 256])
 @pytest.mark.parametrize("B,t,C,N,taps,pad", [(3, 37, 32, 128, 3, 1), (2, 50, 80, 256, 5, 4), (3, 37, 64, 64, 9, 4),
                                                (2, 131, 256, 80, 5, 0), (4, 20, 32, 32, 1, 0), (5, 301, 72, 264, 9, 4)])
 def test_big_gemm_conv_geometry(ops, big_gemm, bm, B, t, C, N, taps, pad):
@@ -867,7 +867,7 @@ def test_big_gemm_is_bit_identical_to_the_128_tile_kernel(ops, monkeypatch):
     x, w, bias = rnd(44400, 256, dtype=torch.bfloat16, seed=1).cuda(), rnd(512, 256, dtype=torch.bfloat16, seed=2).cuda(), rnd(512, seed=3).cuda()
     monkeypatch.setenv("FS2_GEMM_BIG", "0")
     ref = ops.linear(x, w, bias=bias, relu=True)
-    for bm in ("192", "256"):
+    for bm in ("128", "192", "256"):
         monkeypatch.setenv("FS2_GEMM_BIG", "2")
         monkeypatch.setenv("FS2_GEMM_BIG_BM", bm)
         out = ops.linear(x, w, bias=bias, relu=True)

@@ -473,7 +473,7 @@ bool epi_compiled(const FS2Gemm& g) {
 // false: not eligible / not chosen; true: the product was launched on the large-tile kernel and *rc holds the result
 bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     // FS2_GEMM_BIG: 0 never, 1 (default) where the shape heuristic says so, 2 wherever eligible; FS2_GEMM_BIG_BM forces
-    // the row-slab height (192 / 256).  Read per call so that tests and A/B measurements can switch inside one process.
+    // the row-slab height (128 / 192 / 256).  Read per call so that tests and A/B measurements can switch inside one process.
     const char* e1 = getenv("FS2_GEMM_BIG");
     const char* e2 = getenv("FS2_GEMM_BIG_BM");
     const int mode = e1 ? atoi(e1) : 1;
@@ -500,7 +500,14 @@ bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     };
     // (epilogues with masks / statistics keep more registers live: the 192-row tile runs them without spills)
     const double bias192 = (g.relu_mask != nullptr || g.colstats != nullptr) ? 0.10 : -0.02;
-    if (bm != 192 && bm != 256) bm = fill(192) + bias192 > fill(256) ? 192 : 256;
+    if (bm != 128 && bm != 192 && bm != 256) {
+        bm = fill(192) + bias192 > fill(256) ? 192 : 256;
+        // Short matrices (the encoder side: 6144 rows) give the 192-row tile fewer tiles than CUs: every CU runs `rounds` tiles of
+        // bm rows one after the other, so rounds * bm is the time; the 128-row tile (less operand reuse per MFMA: +10 %) wins when
+        // it spreads the same rows over more CUs.
+        auto serial_rows = [&](int b) { const long tiles = (long)((g.M + b - 1) / b) * tn; return (double)((tiles + 255) / 256) * b; };
+        if (!fp8 && serial_rows(128) * 1.10 < serial_rows(bm)) bm = 128;
+    }
     if (mode == 1 && !fp8) {
         const long tiles = (long)((g.M + bm - 1) / bm) * tn;
         const long ktot = (long)(g.conv == 1 ? g.taps : 1) * g.K;
@@ -515,7 +522,8 @@ bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         return true;
     }
     g_last_tile = bm;
-    if (bm == 192) *rc = f32 ? launch_big1<float, 48, 0>(g, st) : launch_big1<bf16_t, 48, 0>(g, st);
+    if (bm == 128) *rc = f32 ? launch_big1<float, 32, 0>(g, st) : launch_big1<bf16_t, 32, 0>(g, st);
+    else if (bm == 192) *rc = f32 ? launch_big1<float, 48, 0>(g, st) : launch_big1<bf16_t, 48, 0>(g, st);
     else *rc = f32 ? launch_big1<float, 64, 0>(g, st) : launch_big1<bf16_t, 64, 0>(g, st);
     return true;
 }
