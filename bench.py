@@ -99,7 +99,9 @@ class GemmTimer:
             es, cs = (2 if g.dtype == 1 else 4), (2 if g.c_dtype == 1 else 4)
             # algorithmic bytes: every operand element once (conv: the A rows once, not once per tap)
             abytes = (es * (g.M * g.K + g.N * g.K * taps) + cs * g.M * g.N) * float(nb)
-            tile = self._last_tile()      # rows of the block tile the launcher picked: 64 / 128 (gemm.hip), 192 / 256 (gemm_big.hip)
+            # block tile the launcher picked: 64 / 128 = rows of gemm.hip's tile, 192 / 256 = rows of gemm_big.hip's, 130 = its 128-row tile,
+            # 129 = the 16-wave weight-gradient kernel (gemm_big_km.hip)
+            tile = self._last_tile()
             key = ("bf16" if g.dtype == 1 else "f32", "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm", tile)
             flags = ("b" if g.bias else "") + ("r" if g.relu else "") + ("m" if g.relu_mask else "") + ("+" if g.residual else "") + \
                     (f"s{g.colstats_mode}" if g.colstats else "") + ("a" if g.accumulate else "") + ("f" if g.c_dtype == 0 and g.dtype == 1 else "")
@@ -315,13 +317,15 @@ def main():
             gbs = by / (ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            if os.path.exists(tpath):       # HBM bytes per launch of this variant from the PMC passes (tools/summarize_profiles.py)
+                traffic = json.load(open(tpath)).get("by_variant", {}).get("/".join(str(x) for x in key))
             # the roof that binds the dominant kernel's launches on average: algorithmic FLOP per algorithmic byte
             # against the machine balance 2.5 PFLOP/s / 8 TB/s
             hbm_bound = (fl / by) < (PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
             roof = dict(bound="hbm" if hbm_bound else "mfma",
-                        kernel=(f"fs2_gemm_big_kernel<{key[0]}, {key[3]}x256 tile, 16 waves, LDS-DMA> A row-major B row-major" if key[3] >= 192 else
+                        kernel=(f"fs2_gemm_big_kernel<{key[0]}, {128 if key[3] == 130 else key[3]}x256 tile, 16 waves, LDS-DMA> A row-major B row-major"
+                                if key[3] >= 130 else
+                                f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 4 k-groups, LDS-DMA> A k-major B k-major" if key[3] == 129 else
                                 f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}"),
                         achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
                         unit="GB/s" if hbm_bound else "TFLOP/s",

@@ -40,25 +40,42 @@ def pmc(dirname, counter):
 
 
 fetch, write = pmc("pmcb1", "FETCH_SIZE"), pmc("pmcb2", "WRITE_SIZE")
+
+
+def variant(name):
+    """bench.py's variant key (dtype/A layout/B layout/tile id) of a GEMM kernel name, mangled or demangled"""
+    import re
+    if "fs2_gemm_big_km_kernel" in name:
+        return "bf16/km/km/129"
+    m = re.search(r"fs2_gemm_big_kernelI(?:DF16b|f)Li(\d+)E", name) or re.search(r"fs2_gemm_big_kernel<[^,]*, (\d+),", name)
+    if m:
+        return {"32": "bf16/rm/rm/130", "48": "bf16/rm/rm/192", "64": "bf16/rm/rm/256"}.get(m.group(1))
+    m = re.search(r"gemm_kernelI(DF16b|f)(?:DF16b|f)Lb([01])ELb([01])ELi(\d+)E", name)
+    if m:
+        return f"{'bf16' if m.group(1) == 'DF16b' else 'f32'}/{'km' if m.group(2) == '1' else 'rm'}/{'km' if m.group(3) == '1' else 'rm'}/{m.group(4)}"
+    m = re.search(r"gemm_kernel<[^,]*, (true|false), (true|false), (\d+),", name)
+    if m:       # rocprofv3's demangler drops the element types of this one: bf16 in the timed configuration
+        return f"bf16/{'km' if m.group(1) == 'true' else 'rm'}/{'km' if m.group(2) == 'true' else 'rm'}/{m.group(3)}"
+    return None
+
+
 if fetch and write:
-    out = {}
+    out, agg = {}, collections.defaultdict(lambda: [0.0, 0])
     for k in fetch:
-        if "gemm_kernel" not in k or k not in write:
+        if "gemm" not in k or k not in write:
             continue
         n = fetch[k][1]
         # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
         # reads (MI355X_MICROARCH.md, HBM section) -> doubled
         rd = 2.0 * fetch[k][0] * 1024 / n
         wr = write[k][0] * 1024 / write[k][1]
-        out[k] = dict(launches=n, hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
-    dom = max(out.items(), key=lambda kv: kv[1]["launches"] * kv[1]["hbm_bytes_per_launch"]) if out else None
-    res = dict(per_kernel=out, note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); "
-               "separate --pmc passes; bench.py --no-graph --no-overlap --steps 4 --warmup 8")
-    # the bench's dominant variant is the row-major/row-major bf16 kernel with the 128 tile
-    for k, v in out.items():
-        if "Lb0ELb0ELi128" in k or "false, false, 128" in k:
-            if "DF16bDF16b" in k or "__hip_bfloat16" in k or "bf16" in k.lower():
-                res["hbm_bytes_per_launch"] = v["hbm_bytes_per_launch"]
-                res["kernel"] = k
+        out[k] = dict(launches=n, hbm_read_bytes_per_launch=rd, hbm_write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr, variant=variant(k))
+        if variant(k):
+            agg[variant(k)][0] += (rd + wr) * n
+            agg[variant(k)][1] += n
+    res = dict(per_kernel=out, by_variant={k: v[0] / v[1] for k, v in agg.items()},
+               note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); separate --pmc passes; "
+                    "bench.py --no-graph --no-overlap --steps 4 --warmup 8; by_variant = launch-weighted mean over the kernel instances "
+                    "(epilogue variants) that bench.py times under one variant key")
     json.dump(res, open("profiles/gemm_traffic.json", "w"), indent=1)
-    print("wrote profiles/gemm_traffic.json", res.get("kernel"), res.get("hbm_bytes_per_launch"))
+    print("wrote profiles/gemm_traffic.json", {k: round(v / 1e6, 1) for k, v in res["by_variant"].items()}, "MB per launch")

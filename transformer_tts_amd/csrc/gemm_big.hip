@@ -521,7 +521,7 @@ bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         else *rc = f32 ? launch_big1<float, 48, 2>(g, st) : launch_big1<bf16_t, 48, 2>(g, st);
         return true;
     }
-    g_last_tile = bm;
+    g_last_tile = bm == 128 ? 130 : bm;       // 128 is the 128-tile kernel of gemm.hip, 129 the 16-wave weight-gradient kernel
     if (bm == 128) *rc = f32 ? launch_big1<float, 32, 0>(g, st) : launch_big1<bf16_t, 32, 0>(g, st);
     else if (bm == 192) *rc = f32 ? launch_big1<float, 48, 0>(g, st) : launch_big1<bf16_t, 48, 0>(g, st);
     else *rc = f32 ? launch_big1<float, 64, 0>(g, st) : launch_big1<bf16_t, 64, 0>(g, st);
