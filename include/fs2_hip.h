@@ -316,6 +316,12 @@ int fs2_dropout(const void* x, const void* relu_gate, void* out, int dtype, int6
 int fs2_sqnorm(const float* x, int64_t n, float* out, void* stream);
 int fs2_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* gsq,
                   float beta1, float beta2, float eps, float max_norm, void* stream);
+/* the same with some parameter ranges whose GRADIENT is stored as [o][j][i] (what the Conv1d weight-gradient GEMM writes) while the
+ * parameter and its moments are (O,I,k): perm_segments = n_segments x {start, end, O, I, k} (int64, sorted, disjoint, starts
+ * multiples of 4).  Saves the separate permute pass (fs2_permute_add) over every convolution gradient.                         */
+int fs2_adam_step_perm(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* gsq,
+                       float beta1, float beta2, float eps, float max_norm, const int64_t* perm_segments, int n_segments,
+                       void* stream);
 
 /* rng[1] += 1 (one step of the dropout stream). */
 int fs2_rng_advance(uint64_t* rng, void* stream);

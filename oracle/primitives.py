@@ -603,8 +603,13 @@ def sqnorm(x, out):
     out += (_f(x) ** 2).sum().float()
 
 
-def adam_step(p, g, m, v, hyper, gsq, beta1, beta2, eps, max_norm):
-    """clip_grad_norm_ + torch.optim.Adam.step (train_fastspeech2.py:312-315,416)."""
+def adam_step(p, g, m, v, hyper, gsq, beta1, beta2, eps, max_norm, perm=None):
+    """clip_grad_norm_ + torch.optim.Adam.step (train_fastspeech2.py:312-315,416).  perm: rows {start, end, O, I, k} of the arena
+    ranges whose gradient is stored [o][j][i] (the weight-gradient GEMM's layout) instead of the parameter's (O,I,k)."""
+    if perm is not None and perm.numel() > 0:
+        g = g.clone()
+        for start, end, O, I, k in perm.tolist():
+            g[start:end] = g[start:end].view(O, k, I).permute(0, 2, 1).reshape(-1)
     lr, bc1, bc2, gs = (float(h) for h in hyper)
     gmul = gs
     if max_norm > 0 and gsq is not None:

@@ -727,6 +727,54 @@ def test_adam_matches_torch_optimizer(ops):
         close(p, ref.data, f"Adam step {step}", rtol=1e-5, atol=1e-7)
 
 
+def test_adam_with_kernel_layout_conv_gradients(ops):
+    """fs2_adam_step_perm: Conv1d-weight ranges of the arena keep their gradient as [o][j][i] (what the weight-gradient GEMM
+    writes); the update must equal plain Adam on the (O,I,k) gradient, bit for bit, whatever the segment sizes (odd O*I*k, a
+    float4 group running across an o boundary, padding after a segment) -- and optim.ParamArena must expose param.grad in the
+    reference's layout"""
+    shapes = [(7,), (5, 3, 9), (16, 8), (3, 7, 5), (2, 2, 3), (64, 32, 9), (11,)]
+    off, offs = 0, []
+    for sh in shapes:
+        offs.append(off)
+        off += (int(np.prod(sh)) + 3) // 4 * 4
+    n = off
+    p0, m0, v0 = rnd(n, seed=1), 0.1 * rnd(n, seed=2), (0.1 * rnd(n, seed=3)) ** 2
+    g_ref = torch.zeros(n)
+    g_arena = torch.zeros(n)
+    segs = []
+    for sh, o in zip(shapes, offs):
+        gt = rnd(*sh, seed=10 + o)
+        num = gt.numel()
+        g_ref[o:o + num] = gt.reshape(-1)
+        if len(sh) == 3:
+            g_arena[o:o + num] = gt.permute(0, 2, 1).reshape(-1)        # [o][j][i]
+            segs.append([o, o + num, sh[0], sh[1], sh[2]])
+        else:
+            g_arena[o:o + num] = gt.reshape(-1)
+    perm = torch.tensor(segs, dtype=torch.int64)
+    hyper = torch.tensor([1e-3, 1 - 0.9, 1 - 0.98, 1.0])
+    res = []
+    for g, pm in ((g_ref, None), (g_arena, perm)):
+        p, m, v = p0.cuda(), m0.cuda(), v0.cuda()
+        gsq = torch.zeros(1).cuda()
+        ops.sqnorm(g.cuda(), gsq)
+        ops.adam_step(p, g.cuda(), m, v, hyper.cuda(), gsq, 0.9, 0.98, 1e-9, 1.0, perm=pm.cuda() if pm is not None else None)
+        res.append((p.cpu(), m.cpu(), v.cpu()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    po, mo, vo = p0.clone(), m0.clone(), v0.clone()
+    P.adam_step(po, g_arena, mo, vo, hyper, torch.tensor([float((g_ref ** 2).sum())]), 0.9, 0.98, 1e-9, 1.0, perm=perm)
+    close(res[1][0], po, "oracle adam with permuted segments", rtol=1e-4, atol=1e-6)
+    # the arena's views
+    from transformer_tts_amd.optim import ParamArena
+    conv = torch.nn.Conv1d(6, 10, 5).cuda()
+    arena = ParamArena(list(conv.parameters()))
+    w = conv.weight
+    assert w.grad.shape == w.shape and arena.perm.tolist() == [[0, 300, 10, 6, 5]]
+    w._fs2_grad_raw.copy_(torch.arange(300, dtype=torch.float32).view(10, 30))
+    assert torch.equal(w.grad.cpu(), torch.arange(300, dtype=torch.float32).view(10, 5, 6).permute(0, 2, 1))
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_fused_bias_gradients_onehot_and_batched_shadows(ops, dtype):
     """dcolsum outputs of the backward row kernels, the sums-only GEMM epilogue, the one-hot embedding-gradient

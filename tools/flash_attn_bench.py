@@ -64,6 +64,14 @@ def flash_fwd():
     ops.flash_attn_fwd(q, k, v, km, O4, stats, keep, t, alpha, pb, PD, rng, 3)
 
 
+def flash_fwd_pregen():
+    ops.flash_attn_fwd(q, k, v, km, O4, stats, keep, t, alpha, pb, PD, rng, 3, pregenerated=True)
+
+
+def keep_bits():
+    ops.flash_keep_bits(keep, B, H, t, pb, PD, rng, 3)
+
+
 def flash_bwd():
     ops.flash_attn_bwd(q, k, v, km, O4, dO4, stats, keep, aux, dq, dk_, dv, t, alpha, PD)
 
@@ -77,6 +85,9 @@ def flash_bwd_bias():
 
 flops = 2.0 * B * H * t * t * dk
 for name, fn, units in (("strip fwd", strip_fwd, 2), ("strip bwd (+2 bmm)", strip_bwd, 4), ("flash fwd", flash_fwd, 2),
+                        ("flash fwd, bits pre-drawn", flash_fwd_pregen, 2), ("keep-bits generator", keep_bits, 0),
                         ("flash bwd (dQ + dK/dV)", flash_bwd, 7), ("flash bwd + bias sums", flash_bwd_bias, 7)):
+    if PD == 0 and name in ("flash fwd, bits pre-drawn", "keep-bits generator"):
+        continue
     us = timeit(fn)
     print(f"{name:26s} {us:8.1f} us   {units * flops / us * 1e-6:7.1f} TFLOP/s (executed products)")

@@ -241,8 +241,12 @@ def _conv_wgrad(rt, dy, x, conv, pad, bias_done=False):
     O, I, k = w.shape
     gw = grad_of(w)
     with rt.side(dy, x):
+        raw = getattr(w, "_fs2_grad_raw", None)
         if k == 1:
             ops.conv_wgrad(dy, x, 1, 0, gw.view(O, I))
+        elif raw is not None and gw.data_ptr() == raw.data_ptr() and gw.stride() == (k * I, 1, I):
+            # the optimizer's arena keeps this gradient in the GEMM's own [o][j][i] layout (optim.ParamArena): no permute pass
+            ops.conv_wgrad(dy, x, k, pad, raw)
         else:
             scratch = rt.zeros(("wg", O, I, k), (O, k * I), torch.float32, w.device, self_cleaning=True)
             ops.conv_wgrad(dy, x, k, pad, scratch)

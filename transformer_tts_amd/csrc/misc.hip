@@ -492,9 +492,13 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
     const float denom = sqrtf(v) / bc2s + eps;
     p = p - step_size * (m / denom);
 }
+// PERM: some parameter ranges (Conv1d weights, (O,I,k) in the parameter arena) keep their GRADIENT in the layout the weight-gradient
+// GEMM produces, [o][j][i]: the optimizer is the only reader that cares, so it gathers instead of a separate permute pass over
+// every convolution gradient (0.19 ms per step).  segs: sorted, disjoint {start, end, O, I, k} (int64 x 5), starts multiples of 4.
+template <bool PERM>
 __global__ __launch_bounds__(TPB) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
         float* __restrict__ v, int64_t n, const float* __restrict__ hyper, const float* __restrict__ gsq, float b1,
-        float b2, float eps, float max_norm) {
+        float b2, float eps, float max_norm, const int64_t* __restrict__ segs, int nseg) {
     const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gs = hyper[3];
     float gmul = gs;
     if (max_norm > 0.f && gsq != nullptr) {
@@ -505,7 +509,33 @@ __global__ __launch_bounds__(TPB) void adam_k(float* __restrict__ p, const float
     const int64_t nv = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < nv; i += (int64_t)gridDim.x * TPB) {
         float4 pp = reinterpret_cast<float4*>(p)[i], mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 gg;
+        bool gathered = false;
+        if constexpr (PERM) {
+            const int64_t e0 = i << 2;
+            for (int sgi = 0; sgi < nseg; ++sgi) {
+                const int64_t start = segs[5 * sgi];
+                if (e0 < start) break;
+                if (e0 < segs[5 * sgi + 1]) {
+                    const int I = (int)segs[5 * sgi + 3], k = (int)segs[5 * sgi + 4];
+                    const int64_t e = e0 - start;
+                    const int64_t o = e / ((int64_t)I * k);
+                    int rem = (int)(e - o * (int64_t)I * k);
+                    int ii = rem / k, j = rem - ii * k;
+                    const float* gb = g + start + o * (int64_t)I * k;
+                    float t4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {           // (o, ii, j) -> [o][j][ii]; a group of four may run into the next o
+                        t4[c] = (e + c < segs[5 * sgi + 1] - start) ? gb[(int64_t)j * I + ii] : 0.f;
+                        if (++j == k) { j = 0; if (++ii == I) { ii = 0; gb += (int64_t)I * k; } }
+                    }
+                    gg = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                    gathered = true;
+                    break;
+                }
+            }
+        }
+        if (!gathered) gg = reinterpret_cast<const float4*>(g)[i];
         adam1(pp.x, gg.x, mm.x, vv.x, gmul, b1, b2, step_size, bc2s, eps);
         adam1(pp.y, gg.y, mm.y, vv.y, gmul, b1, b2, step_size, bc2s, eps);
         adam1(pp.z, gg.z, mm.z, vv.z, gmul, b1, b2, step_size, bc2s, eps);
@@ -759,12 +789,23 @@ extern "C" int fs2_sqnorm(const float* x, int64_t n, float* out, void* stream) {
     FS2_CHECK_LAUNCH("fs2_sqnorm");
     return FS2_OK;
 }
-extern "C" int fs2_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* gsq,
-                             float beta1, float beta2, float eps, float max_norm, void* stream) {
+extern "C" int fs2_adam_step_perm(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* gsq,
+                                  float beta1, float beta2, float eps, float max_norm, const int64_t* perm_segments, int n_segments,
+                                  void* stream) {
     FS2_REQUIRE(n > 0 && fs2_aligned16(p) && fs2_aligned16(g) && fs2_aligned16(m) && fs2_aligned16(v), "fs2_adam_step: arenas must be 16-byte aligned");
-    hipLaunchKernelGGL(adam_k, dim3(flat_grid(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, hyper, gsq, beta1, beta2, eps, max_norm);
+    FS2_REQUIRE(n_segments >= 0 && (n_segments == 0 || perm_segments != nullptr), "fs2_adam_step_perm: bad segment table");
+    if (n_segments > 0)
+        hipLaunchKernelGGL((adam_k<true>), dim3(flat_grid(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, hyper, gsq, beta1, beta2, eps,
+                           max_norm, perm_segments, n_segments);
+    else
+        hipLaunchKernelGGL((adam_k<false>), dim3(flat_grid(n >> 2)), dim3(TPB), 0, (hipStream_t)stream, p, g, m, v, n, hyper, gsq, beta1, beta2, eps,
+                           max_norm, (const int64_t*)nullptr, 0);
     FS2_CHECK_LAUNCH("fs2_adam_step");
     return FS2_OK;
+}
+extern "C" int fs2_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, const float* gsq,
+                             float beta1, float beta2, float eps, float max_norm, void* stream) {
+    return fs2_adam_step_perm(p, g, m, v, n, hyper, gsq, beta1, beta2, eps, max_norm, nullptr, 0, stream);
 }
 extern "C" int fs2_rng_advance(uint64_t* rng, void* stream) {
     hipLaunchKernelGGL(rng_advance_k, dim3(1), dim3(1), 0, (hipStream_t)stream, rng);

@@ -97,6 +97,7 @@ SIGNATURES = {
     "fs2_l1_bwd": [_P, _I, _P, _I, _L, _P, _P, _I, _P],
     "fs2_sqnorm": [_P, _L, _P, _P],
     "fs2_adam_step": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P],
+    "fs2_adam_step_perm": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P, _I, _P],
     "fs2_rng_advance": [_P, _P],
 }
 
@@ -900,6 +901,12 @@ def sqnorm(x, out):
     _check(lib().fs2_sqnorm(_p(_c(x)), x.numel(), _p(out), _stream()), "fs2_sqnorm")
 
 
-def adam_step(p, g, m, v, hyper, gsq, beta1, beta2, eps, max_norm):
+def adam_step(p, g, m, v, hyper, gsq, beta1, beta2, eps, max_norm, perm=None):
+    """perm: int64 tensor (n_segments, 5) = {start, end, O, I, k} of the ranges whose gradient is stored [o][j][i] (optim.ParamArena)"""
+    if perm is not None and perm.numel() > 0:
+        assert perm.dtype == torch.int64 and perm.is_contiguous() and perm.shape[1] == 5 and perm.device == p.device
+        _check(lib().fs2_adam_step_perm(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(gsq), beta1, beta2, eps, max_norm,
+                                        _p(perm), perm.shape[0], _stream()), "fs2_adam_step_perm")
+        return
     _check(lib().fs2_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _p(gsq), beta1, beta2, eps, max_norm,
                                _stream()), "fs2_adam_step")

@@ -15,7 +15,7 @@ from . import ops
 class ParamArena:
     ALIGN = 4   # elements: keeps every parameter 16-byte aligned for float4 loads
 
-    def __init__(self, params):
+    def __init__(self, params, kernel_layout_grads=True):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no parameters"
         dev = self.params[0].device
@@ -27,12 +27,23 @@ class ParamArena:
         self.numel = off
         self.p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.g = torch.zeros(off, dtype=torch.float32, device=dev)
+        segs = []
         for p, o in zip(self.params, self.offsets):
             view = self.p[o:o + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
-            p._fs2_grad = self.g[o:o + p.numel()].view_as(p)
+            if kernel_layout_grads and p.dim() == 3 and p.shape[2] > 1:
+                # Conv1d weight (O,I,k): its gradient slot holds [o][j][i], the layout the weight-gradient GEMM writes
+                # (p._fs2_grad_raw); param.grad is the (O,I,k) VIEW of it, so every reader sees the reference's layout and only
+                # the fused Adam kernel -- which works on the flat arena -- needs the segment table
+                O, I, k = p.shape
+                p._fs2_grad_raw = self.g[o:o + p.numel()].view(O, k * I)
+                p._fs2_grad = self.g[o:o + p.numel()].view(O, k, I).permute(0, 2, 1)
+                segs.append([o, o + p.numel(), O, I, k])
+            else:
+                p._fs2_grad = self.g[o:o + p.numel()].view_as(p)
             p.grad = p._fs2_grad
+        self.perm = torch.tensor(segs, dtype=torch.int64, device=dev).reshape(-1, 5) if segs else None
         self._index = {id(p): i for i, p in enumerate(self.params)}
 
     def span(self, params):
@@ -96,7 +107,7 @@ class FusedAdam:
         self.gsq.zero_()
         ops.sqnorm(self.arena.g, self.gsq)
         ops.adam_step(self.arena.p, self.arena.g, self.m, self.v, self.hyper, self.gsq, b1, b2, self.eps,
-                      self.max_norm if self.max_norm is not None else 0.0)
+                      self.max_norm if self.max_norm is not None else 0.0, perm=self.arena.perm)
         if self.runtime is not None:
             self.runtime.invalidate()
 
