@@ -644,8 +644,9 @@ def test_length_regulator_and_bucket_embed(ops, dtype):
 
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("p", [0.0, 0.5])
-def test_batchnorm_tanh(ops, dtype, p):
-    M, C = 333, 256
+@pytest.mark.parametrize("C", [256, 512, 80])
+def test_batchnorm_tanh(ops, dtype, p, C):
+    M = 333
     x, dy = rnd(M, C, dtype=dtype, seed=1, scale=2.0) + 0.3, rnd(M, C, dtype=dtype, seed=2)
     gm, bt = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
     out = {}
@@ -661,11 +662,12 @@ def test_batchnorm_tanh(ops, dtype, p):
         red = z(2 * C)
         o.bn_tanh_bwd_reduce(mv(dy), mv(x), mean, rstd, mv(gm), mv(bt), red, p, rng, 31)
         cd = torch.tensor([float(M)], device=dev)
-        dx = o.bn_tanh_bwd_apply(mv(dy), mv(x), mean, rstd, mv(gm), mv(bt), red, 1.0, None, None, p, rng, 31, count_dev=cd)
-        out[dev] = (sums, mean, rstd, rm, rv, nbt.float(), y, red, dx)
+        dgm, dbt = z(C) + 0.25, z(C) - 0.5          # the apply kernel adds the affine gradients (the reduced sums) itself
+        dx = o.bn_tanh_bwd_apply(mv(dy), mv(x), mean, rstd, mv(gm), mv(bt), red, 1.0, dgm, dbt, p, rng, 31, count_dev=cd)
+        out[dev] = (sums, mean, rstd, rm, rv, nbt.float(), y, red, dx, dgm, dbt)
     for i, (a_, b_) in enumerate(zip(out["cuda"], out["cpu"])):
-        close(a_, b_, f"bn output #{i}", rtol=2e-3 if i in (0, 7) else tol(dtype)["rtol"],
-              atol=(5e-2 if i in (0, 7) else tol(dtype, k=2)["atol"]))
+        close(a_, b_, f"bn output #{i}", rtol=2e-3 if i in (0, 7, 9, 10) else tol(dtype)["rtol"],
+              atol=(5e-2 if i in (0, 7, 9, 10) else tol(dtype, k=2)["atol"]))
     # against torch's own BatchNorm1d in training mode (fp32)
     if dtype == torch.float32 and p == 0.0:
         bn = torch.nn.BatchNorm1d(C)

@@ -639,14 +639,18 @@ class PostNetFunction(torch.autograd.Function):
                 red = red_all[li, :2 * C]
                 ops.bn_tanh_bwd_reduce(dh, s["cs"][li], mean, rstd, bn.weight.detach(), bn.bias.detach(), red, p, rng,
                                        mod.sites[li])
-                # affine grads come from the LOCAL sums (as SyncBatchNorm does; the DP gradient average
-                # handles the ranks); colsum over a 1-row matrix is the accumulate-add
-                ops.colsum(red[:C].view(1, C), grad_of(bn.bias))
-                ops.colsum(red[C:].view(1, C), grad_of(bn.weight))
+                # affine grads come from the LOCAL sums (as SyncBatchNorm does; the DP gradient average handles the ranks):
+                # one rank -> the apply kernel adds them itself; several -> added here (colsum over a 1-row matrix is the
+                # accumulate-add) before the sums are exchanged
+                dgamma = dbeta = None
                 if rt.dp is not None:
+                    ops.colsum(red[:C].view(1, C), grad_of(bn.bias))
+                    ops.colsum(red[C:].view(1, C), grad_of(bn.weight))
                     rt.dp.allreduce_sum(red)
+                else:
+                    dgamma, dbeta = grad_of(bn.weight), grad_of(bn.bias)
                 dc = ops.bn_tanh_bwd_apply(dh, s["cs"][li], mean, rstd, bn.weight.detach(), bn.bias.detach(), red, M,
-                                           None, None, p, rng, mod.sites[li], count_dev=count, dcolsum=grad_of(cv.bias))
+                                           dgamma, dbeta, p, rng, mod.sites[li], count_dev=count, dcolsum=grad_of(cv.bias))
                 _conv_wgrad(rt, dc, s["inputs"][li], cv, 4, bias_done=True)
                 if li > 0:
                     dh = ops.conv(dc, rt.w_dgrad(cv.weight), 5, 0)

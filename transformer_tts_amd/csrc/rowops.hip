@@ -884,7 +884,7 @@ __global__ __launch_bounds__(RED_BLOCK) void bn_tanh_bwd_k(const T* __restrict__
         if (dcolsum != nullptr) flush_channel_sums<NG>(a1, dcolsum, C, red);
         if (blockIdx.x == 0 && dgamma != nullptr) {
             // dbeta += sum dz, dgamma += sum dz*xhat (already reduced over rows -- and over ranks -- in red_io)
-            for (int c = threadIdx.x; c < C; c += ROW_BLOCK) {
+            for (int c = threadIdx.x; c < C; c += blockDim.x) {
                 atomicAdd(dbeta + c, red_io[c]);
                 atomicAdd(dgamma + c, red_io[C + c]);
             }
