@@ -5,6 +5,7 @@
 // A block is 4 waves; waves stride over rows, and per-channel reductions over rows (dgamma, dbeta,
 // BatchNorm sums) are kept in registers, combined across the 4 waves in LDS and flushed with one
 // float atomic per channel per block.
+#include <stdlib.h>
 #include "common.cuh"
 
 namespace {
@@ -14,10 +15,12 @@ constexpr int ROW_WAVES = 4;
 constexpr int RED_BLOCK = 1024; // 16 waves (row-reducing kernels)
 constexpr int RED_WAVES = 16;
 static inline int red_grid(int64_t rows) {
-    // every block ends with one contended float atomic per channel: at most 512 blocks, and at least 4 rows per wave
-    // (M = 6144 ran 384 blocks of one row per wave: 19 us for 25 MB, most of it the atomic tail)
+    // every block ends with one contended float atomic per channel: at most 256 blocks, and at least 4 rows per wave
+    // (M = 6144 ran 384 blocks of one row per wave: 19 us for 25 MB, most of it the atomic tail; whole step, A/B on one box:
+    // cap 128: 9.69 ms, 256: 9.33, 512: 9.39, 1024: 9.52)
     int64_t b = (rows + 4 * RED_WAVES - 1) / (4 * RED_WAVES);
-    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+    static const int cap = getenv("FS2_RED_BLOCKS") ? atoi(getenv("FS2_RED_BLOCKS")) : 256;      // (measurement switch)
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 static inline int row_grid(int64_t rows) {
