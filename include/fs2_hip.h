@@ -299,6 +299,18 @@ int fs2_l1_fwd(const void* pred, int pred_dtype, const void* target, int target_
                void* stream);
 int fs2_l1_bwd(const void* pred, int pred_dtype, const void* target, int target_mode, int64_t n, const float* gscale,
                void* dpred, int dpred_dtype, void* stream);
+/* up to 8 L1 terms in one launch each way (the trainer's five nn.L1Loss() terms, train_fastspeech2.py:212-259):
+ * losses[i] += mean |pred_i - target_i| and losses[n_items] += their sum (zeroed by the caller);
+ * backward: dpred_i = gscale[0] * sign(pred_i - target_i) / n_i  (gscale = d(loss)/d(sum of the terms), on the device). */
+typedef struct {
+    const void* pred;       /* n elements, pred_dtype (FS2_F32 / FS2_BF16) */
+    const void* target;     /* target_mode 0: fp32; 1: int64, the target is log(target + 1) */
+    void* dpred;            /* backward only: n elements, dpred_dtype */
+    int64_t n;
+    int32_t pred_dtype, target_mode, dpred_dtype, reserved;
+} FS2L1Item;
+int fs2_l1_multi_fwd(const FS2L1Item* items, int n_items, float* losses, void* stream);
+int fs2_l1_multi_bwd(const FS2L1Item* items, int n_items, const float* gscale, void* stream);
 
 /* Stop-token loss of the autoregressive model: F.binary_cross_entropy_with_logits(x, y, reduction='mean',
  * pos_weight) (train.py:217).  fwd adds the mean to *loss; bwd writes dx = gscale[0] / n * dl/dx. */

@@ -599,6 +599,19 @@ def l1_bwd(pred, target, gscale, dpred_dtype, log1p_int_target=False):
     return (torch.sign(d) * _f(gscale) / pred.numel()).to(dpred_dtype)
 
 
+def l1_multi_fwd(preds, targets, modes, losses):
+    """the same terms, one after the other (train_fastspeech2.py:212-259); losses[-1] = their sum"""
+    for i, (pr, tg, md) in enumerate(zip(preds, targets, modes)):
+        term = (_f(pr) - _f(_l1_target(tg, md))).abs().mean().float()
+        losses[i] += term
+        losses[len(preds)] += term
+    return losses
+
+
+def l1_multi_bwd(preds, targets, modes, gscale, dpred_dtypes):
+    return [l1_bwd(pr, tg, gscale, dt, md) for pr, tg, md, dt in zip(preds, targets, modes, dpred_dtypes)]
+
+
 def sqnorm(x, out):
     out += (_f(x) ** 2).sum().float()
 

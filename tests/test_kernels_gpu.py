@@ -710,6 +710,30 @@ def test_l1_cast_permute_optimizer(ops):
     assert float(res["cuda"][2][:7].abs().sum()) == 0.0
 
 
+def test_l1_multi(ops):
+    """the trainer's L1 terms in one launch each way against the oracle (fp32 and bf16 predictions, an int64 log1p target, odd
+    sizes, unaligned tails) and against nn.L1Loss"""
+    shapes = [(3, 37, 80), (3, 37, 80), (3, 11), (3, 37), (1, 5)]
+    preds = [rnd(*sh, seed=i) for i, sh in enumerate(shapes)]
+    preds[3] = preds[3].to(torch.bfloat16)
+    targets = [rnd(*sh, seed=10 + i) for i, sh in enumerate(shapes)]
+    targets[2] = torch.from_numpy(np.random.default_rng(0).integers(0, 9, size=shapes[2]))
+    modes = (False, False, True, False, False)
+    res = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        pr, tg = [mv(t) for t in preds], [mv(t) for t in targets]
+        losses = torch.zeros(len(pr) + 1, device=dev)
+        o.l1_multi_fwd(pr, tg, modes, losses)
+        d = o.l1_multi_bwd(pr, tg, modes, torch.tensor([0.7], device=dev), [torch.float32, torch.bfloat16, torch.float32, torch.bfloat16, torch.float32])
+        res[dev] = [losses] + d
+    for i, (a, b) in enumerate(zip(res["cuda"], res["cpu"])):
+        close(a, b, f"l1_multi output #{i}", rtol=1e-5 if a.dtype == torch.float32 else 1e-2, atol=1e-6)
+    ref = torch.nn.L1Loss()(preds[0], targets[0])
+    close(res["cuda"][0][0], ref, "vs nn.L1Loss", rtol=1e-5, atol=1e-6)
+    close(res["cuda"][0][-1], res["cuda"][0][:-1].sum(), "sum of the terms", rtol=1e-5, atol=1e-6)
+
+
 def test_adam_matches_torch_optimizer(ops):
     n = 4099
     p0, g1, g2 = rnd(n, seed=1), 3 * rnd(n, seed=2), 0.01 * rnd(n, seed=3)

@@ -692,3 +692,38 @@ class L1LossFunction(torch.autograd.Function):
 
 def l1_loss(pred, target, log1p_int_target=False):
     return L1LossFunction.apply(pred, target, log1p_int_target)
+
+
+class MultiL1LossFunction(torch.autograd.Function):
+    """Several nn.L1Loss() terms and their sum (train_fastspeech2.py:212-259) in one launch each way.  Returns
+    (losses, total): losses[i] = the i-th term (for the log lines; not differentiable), total = their sum (differentiable)."""
+
+    @staticmethod
+    def forward(ctx, modes, *tensors):
+        preds = [t.contiguous() for t in tensors[0::2]]
+        targets = [t.contiguous() for t in tensors[1::2]]
+        out = torch.zeros(len(preds) + 1, dtype=torch.float32, device=preds[0].device)
+        ops.l1_multi_fwd(preds, targets, modes, out)
+        ctx.preds, ctx.targets, ctx.modes = preds, targets, modes
+        losses, total = out[:len(preds)], out[len(preds)]
+        ctx.mark_non_differentiable(losses)
+        return losses, total
+
+    @staticmethod
+    @fp8_bwd
+    def backward(ctx, _dlosses, g):
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        d = ops.l1_multi_bwd(ctx.preds, ctx.targets, ctx.modes, gs, [p.dtype for p in ctx.preds])
+        grads = [None]
+        for dp in d:
+            grads += [dp, None]
+        return tuple(grads)
+
+
+def l1_loss_multi(items):
+    """items: [(pred, target, log1p_int_target), ...] -> (list of the terms, their sum)"""
+    flat = []
+    for pred, target, _ in items:
+        flat += [pred, target]
+    losses, total = MultiL1LossFunction.apply(tuple(bool(m) for _, _, m in items), *flat)
+    return [losses[i] for i in range(len(items))], total

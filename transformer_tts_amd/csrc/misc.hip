@@ -207,6 +207,57 @@ __global__ __launch_bounds__(TPB) void l1_bwd_k(const T* __restrict__ pred, cons
     }
 }
 
+// The loss terms of a step in ONE launch each way (the trainer sums five nn.L1Loss() terms: five forward kernels, five
+// memsets, four adds and five backward kernels of a few microseconds each otherwise).  blockIdx.y = term.
+struct L1Items { FS2L1Item it[8]; };
+template <typename T>
+__device__ __forceinline__ float l1_partial(const T* pred, const void* tgt, int mode, int64_t n) {
+    float acc = 0.f;
+    int64_t done = 0;
+    if constexpr (sizeof(T) == 4) {
+        if (mode == 0 && ((((uintptr_t)pred) | ((uintptr_t)tgt)) & 15) == 0) {
+            const int64_t n4 = n >> 2;
+            const float4* p4 = reinterpret_cast<const float4*>(pred);
+            const float4* t4 = reinterpret_cast<const float4*>(tgt);
+            for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+                const float4 a = p4[i], b = t4[i];
+                acc += (fabsf(a.x - b.x) + fabsf(a.y - b.y)) + (fabsf(a.z - b.z) + fabsf(a.w - b.w));
+            }
+            done = n4 << 2;
+        }
+    }
+    for (int64_t i = done + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+        acc += fabsf(to_f32<T>(pred[i]) - l1_target<T>(tgt, mode, i));
+    return acc;
+}
+__global__ __launch_bounds__(TPB) void l1_multi_fwd_k(const L1Items items, int n_items, float* __restrict__ losses) {
+    __shared__ float lds4[4];
+    const FS2L1Item it = items.it[blockIdx.y];
+    const float acc = it.pred_dtype == FS2_F32 ? l1_partial<float>(reinterpret_cast<const float*>(it.pred), it.target, it.target_mode, it.n)
+                                               : l1_partial<bf16_t>(reinterpret_cast<const bf16_t*>(it.pred), it.target, it.target_mode, it.n);
+    const float s = block_sum(acc, lds4);
+    if (threadIdx.x == 0 && s != 0.f) {
+        atomicAdd(losses + blockIdx.y, s / (float)it.n);
+        atomicAdd(losses + n_items, s / (float)it.n);          // the sum of the terms
+    }
+}
+template <typename T, typename TG>
+__device__ __forceinline__ void l1_grad(const T* pred, const void* tgt, int mode, int64_t n, float g, TG* dpred) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const float df = to_f32<T>(pred[i]) - l1_target<T>(tgt, mode, i);
+        dpred[i] = from_f32<TG>(df > 0.f ? g : (df < 0.f ? -g : 0.f));
+    }
+}
+__global__ __launch_bounds__(TPB) void l1_multi_bwd_k(const L1Items items, const float* __restrict__ gscale) {
+    const FS2L1Item it = items.it[blockIdx.y];
+    const float g = gscale[0] / (float)it.n;
+    const bool pf = it.pred_dtype == FS2_F32, gf = it.dpred_dtype == FS2_F32;
+    if (pf && gf) l1_grad<float, float>((const float*)it.pred, it.target, it.target_mode, it.n, g, (float*)it.dpred);
+    else if (pf) l1_grad<float, bf16_t>((const float*)it.pred, it.target, it.target_mode, it.n, g, (bf16_t*)it.dpred);
+    else if (gf) l1_grad<bf16_t, float>((const bf16_t*)it.pred, it.target, it.target_mode, it.n, g, (float*)it.dpred);
+    else l1_grad<bf16_t, bf16_t>((const bf16_t*)it.pred, it.target, it.target_mode, it.n, g, (bf16_t*)it.dpred);
+}
+
 // ------------------------------------------------------------------ stop-token loss of the autoregressive model
 // F.binary_cross_entropy_with_logits(x, y, reduction='mean', pos_weight=pw) (reference train.py:217):
 //   l = (1 - y) x + (1 + (pw - 1) y) softplus(-x),  softplus(-x) = log1p(exp(-|x|)) + max(-x, 0)
@@ -632,6 +683,36 @@ extern "C" int fs2_l1_bwd(const void* pred, int pred_dtype, const void* target, 
     else if (dpred_dtype == FS2_F32) hipLaunchKernelGGL((l1_bwd_k<bf16_t, float>), grid, block, 0, st, (const bf16_t*)pred, target, target_mode, n, gscale, (float*)dpred);
     else hipLaunchKernelGGL((l1_bwd_k<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)pred, target, target_mode, n, gscale, (bf16_t*)dpred);
     FS2_CHECK_LAUNCH("fs2_l1_bwd");
+    return FS2_OK;
+}
+
+static int l1_items_check(const char* who, const FS2L1Item* items, int n_items, bool bwd, L1Items* out) {
+    FS2_REQUIRE(items != nullptr && n_items > 0 && n_items <= 8, "%s: 1..8 items", who);
+    for (int i = 0; i < n_items; ++i) {
+        const FS2L1Item& it = items[i];
+        FS2_REQUIRE(it.pred && it.target && it.n > 0 && (it.target_mode == 0 || it.target_mode == 1), "%s: bad item %d", who, i);
+        FS2_REQUIRE(it.pred_dtype == FS2_F32 || it.pred_dtype == FS2_BF16, "%s: item %d: pred dtype", who, i);
+        if (bwd) FS2_REQUIRE(it.dpred && (it.dpred_dtype == FS2_F32 || it.dpred_dtype == FS2_BF16), "%s: item %d: dpred", who, i);
+        out->it[i] = it;
+    }
+    return FS2_OK;
+}
+extern "C" int fs2_l1_multi_fwd(const FS2L1Item* items, int n_items, float* losses, void* stream) {
+    L1Items a = {};
+    const int rc = l1_items_check("fs2_l1_multi_fwd", items, n_items, false, &a);
+    if (rc != FS2_OK) return rc;
+    FS2_REQUIRE(losses != nullptr, "fs2_l1_multi_fwd: null losses");
+    hipLaunchKernelGGL(l1_multi_fwd_k, dim3(128, (unsigned)n_items), dim3(TPB), 0, (hipStream_t)stream, a, n_items, losses);
+    FS2_CHECK_LAUNCH("fs2_l1_multi_fwd");
+    return FS2_OK;
+}
+extern "C" int fs2_l1_multi_bwd(const FS2L1Item* items, int n_items, const float* gscale, void* stream) {
+    L1Items a = {};
+    const int rc = l1_items_check("fs2_l1_multi_bwd", items, n_items, true, &a);
+    if (rc != FS2_OK) return rc;
+    FS2_REQUIRE(gscale != nullptr, "fs2_l1_multi_bwd: null gscale");
+    hipLaunchKernelGGL(l1_multi_bwd_k, dim3(512, (unsigned)n_items), dim3(TPB), 0, (hipStream_t)stream, a, gscale);
+    FS2_CHECK_LAUNCH("fs2_l1_multi_bwd");
     return FS2_OK;
 }
 

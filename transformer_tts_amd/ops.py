@@ -23,6 +23,12 @@ class FS2CastDesc(ctypes.Structure):
                 ("I", ctypes.c_int32), ("k", ctypes.c_int32), ("mode", ctypes.c_int32)]
 
 
+class FS2L1Item(ctypes.Structure):
+    _fields_ = [("pred", ctypes.c_void_p), ("target", ctypes.c_void_p), ("dpred", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("pred_dtype", ctypes.c_int32), ("target_mode", ctypes.c_int32), ("dpred_dtype", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class FS2Gemm(ctypes.Structure):
     _fields_ = [
         ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -96,6 +102,8 @@ SIGNATURES = {
     "fs2_l1_fwd": [_P, _I, _P, _I, _L, _P, _P],
     "fs2_l1_bwd": [_P, _I, _P, _I, _L, _P, _P, _I, _P],
     "fs2_sqnorm": [_P, _L, _P, _P],
+    "fs2_l1_multi_fwd": [_P, _I, _P, _P],
+    "fs2_l1_multi_bwd": [_P, _I, _P, _P],
     "fs2_adam_step": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P],
     "fs2_adam_step_perm": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P, _I, _P],
     "fs2_rng_advance": [_P, _P],
@@ -895,6 +903,35 @@ def l1_bwd(pred, target, gscale, dpred_dtype, log1p_int_target=False):
     _check(lib().fs2_l1_bwd(_p(_c(pred)), _dt(pred), _p(_c(target)), int(log1p_int_target), pred.numel(), _p(gscale),
                             _p(dpred), _dt(dpred), _stream()), "fs2_l1_bwd")
     return dpred
+
+
+def _l1_items(preds, targets, modes, dpreds=None):
+    arr = (FS2L1Item * len(preds))()
+    keep = []
+    for i, (it, pr, tg, md) in enumerate(zip(arr, preds, targets, modes)):
+        pr, tg = _c(pr), _c(tg)
+        keep += [pr, tg]
+        assert tg.numel() == pr.numel() and tg.dtype == (torch.int64 if md else torch.float32)
+        it.pred, it.target, it.n, it.pred_dtype, it.target_mode = pr.data_ptr(), tg.data_ptr(), pr.numel(), _dt(pr), int(bool(md))
+        if dpreds is not None:
+            it.dpred, it.dpred_dtype = dpreds[i].data_ptr(), _dt(dpreds[i])
+    return arr, keep
+
+
+def l1_multi_fwd(preds, targets, modes, losses):
+    """losses[i] += mean |pred_i - target_i| (modes[i]: the target is log(int64 target + 1)), losses[len] += their sum; ONE launch"""
+    assert losses.dtype == torch.float32 and losses.numel() == len(preds) + 1 and losses.is_contiguous()
+    arr, keep = _l1_items(preds, targets, modes)
+    _check(lib().fs2_l1_multi_fwd(ctypes.cast(arr, ctypes.c_void_p), len(preds), _p(losses), _stream()), "fs2_l1_multi_fwd")
+    return losses
+
+
+def l1_multi_bwd(preds, targets, modes, gscale, dpred_dtypes):
+    """d(sum of the terms)/d(pred_i) * gscale[0] for every term; ONE launch"""
+    dpreds = [torch.empty(pr.shape, dtype=dt, device=pr.device) for pr, dt in zip(preds, dpred_dtypes)]
+    arr, keep = _l1_items(preds, targets, modes, dpreds)
+    _check(lib().fs2_l1_multi_bwd(ctypes.cast(arr, ctypes.c_void_p), len(preds), _p(gscale), _stream()), "fs2_l1_multi_bwd")
+    return dpreds
 
 
 def sqnorm(x, out):

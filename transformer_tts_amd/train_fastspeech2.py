@@ -27,7 +27,7 @@ import torch.multiprocessing as mp
 from torch.utils.data import DataLoader
 
 from .Models.fastspeech2 import FastSpeech2
-from .Models.functional import l1_loss
+from .Models.functional import l1_loss, l1_loss_multi
 from .optim import FusedAdam
 from .utils import hparams as hp
 from .utils.utils import fill_variables, get_learning_rate, init_weight, load_model, log_config
@@ -75,6 +75,17 @@ def loss_mel(hp, pred, y, channel_wise=False, loss="l1", channel_weight=None):
 def compute_losses(hp, outputs, mel, alignment, f0, energy):
     """The five nn.L1Loss() terms of the reference (:212-259); returns (total, dict of parts)."""
     outputs_prenet, outputs_postnet, log_d_prediction, p_prediction, e_prediction = outputs[:5]
+    if not getattr(hp, "channel_wise", False):      # every term in one launch each way (sum in the reference's order of terms)
+        names, items = ["frame_before"], [(outputs_prenet, mel, False)]
+        if hp.postnet_pred:
+            names.append("frame_after"); items.append((outputs_postnet, mel, False))
+        if hp.pitch_pred:
+            names.append("f0"); items.append((p_prediction, f0, False))
+        if hp.energy_pred:
+            names.append("energy"); items.append((e_prediction, energy, False))
+        names.append("duration"); items.append((log_d_prediction, alignment, True))     # target log(alignment + 1)
+        terms, total = l1_loss_multi(items)
+        return total, dict(zip(names, terms))
     parts = {"frame_before": l1_loss(outputs_prenet, mel)}
     loss = parts["frame_before"]
     if hp.postnet_pred:
