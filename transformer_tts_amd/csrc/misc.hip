@@ -139,9 +139,31 @@ __global__ __launch_bounds__(TPB) void bucket_embed_add_fwd_k(const T* __restric
         const float* __restrict__ Ep, const float* __restrict__ Ee, T* __restrict__ out, int32_t* __restrict__ idx,
         int64_t M, int d) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // nb <= 256 boundaries: every lane keeps four of each table in registers and a row's bucket = the number of boundaries
+    // below its value is four wave ballots -- the binary search cost 2 x 8 dependent loads per row (the same index for sorted
+    // boundaries: torch.bucketize, right=False)
+    const bool in_regs = nb <= 256;
+    float pb[4], eb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int i = 4 * lane + c;
+        pb[c] = (in_regs && i < nb) ? pbins[i] : __builtin_huge_valf();
+        eb[c] = (in_regs && i < nb) ? ebins[i] : __builtin_huge_valf();
+    }
     for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < M; r += (int64_t)gridDim.x * 4) {
-        const int ip = bucketize(pbins, nb, f0[r]);
-        const int ie = bucketize(ebins, nb, en[r]);
+        int ip, ie;
+        if (in_regs) {
+            const float vp = f0[r], ve = en[r];
+            ip = ie = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                ip += __popcll(__ballot(pb[c] < vp));
+                ie += __popcll(__ballot(eb[c] < ve));
+            }
+        } else {
+            ip = bucketize(pbins, nb, f0[r]);
+            ie = bucketize(ebins, nb, en[r]);
+        }
         if (lane == 0) { idx[r] = ip; idx[M + r] = ie; }
         const float* ep = Ep + (int64_t)ip * d;
         const float* ee = Ee + (int64_t)ie * d;
