@@ -117,14 +117,16 @@ def test_eval_forward_after_graphed_steps_sees_the_updated_weights():
     model, hp, _ = product_model("small", amp=True, dropout=0.0, device="cuda")
     opt = FusedAdam(model)
     stepper = GraphedTrainStep(model, opt, hp)
-    text, pos_text = batch[0], batch[2]
+    from transformer_tts_amd.train_fastspeech2 import create_masks
+    text, mel, pos_text, pos_mel, _, _, _, _, f0, energy, align = batch[:11]
+    src_mask, mel_mask = create_masks(pos_text, pos_mel, task="fastspeech2")
 
-    def infer():
+    def infer():        # teacher-forced eval() forward outside the graph (the synthesis branch can refuse all-zero durations)
         model.eval()
         with torch.no_grad():
-            out = model(text[:1, :9], (pos_text[:1, :9] != 0).unsqueeze(-2))
+            out = model(text, src_mask, mel_mask, align, f0, energy)
         model.train()
-        return out[2].float().cpu()          # log-durations: continuous, shape independent of the predicted lengths
+        return out[0].float().cpu()
 
     for i in range(3):      # eager, capture + replay, replay
         stepper(4000 + i, batch)
