@@ -175,6 +175,22 @@ int fs2_ffn_ln_bwd(const void* dy, const void* f2, const void* h, int dtype, con
                    const float* rstd, void* g, float* dgamma, float* dbeta, int64_t M, int d, float p,
                    const uint64_t* rng, uint32_t site, float* dcolsum, void* stream);
 
+/* The FeedForward tail TOGETHER with the residual add and the LayerNorm that follow it in EncoderLayer.forward
+ * (Models/modules.py:85-87, Models/layers.py:40,31, Models/encoder.py:112): one row pass instead of fs2_ffn_ln_* + fs2_add_ln_*.
+ *   forward:  yff = LN1(dropout(f2 + h), site1);  s = r + dropout(yff, site2);  y = LN2(s)     (statistics of both returned)
+ *   backward: dr = ds_down + LN2bwd(dy);  g = d(f2) = d(h) = dropout1'(LN1bwd(dropout2'(dr)));  the four affine gradients and
+ *             dcolsum (+= column sums of g: the bias gradient of the second convolution) accumulate.
+ * The intermediate is rounded to `dtype` where the two-kernel form stores it: same results up to the last place.           */
+int fs2_ffn_tail_fwd(const void* f2, const void* h, int dtype, const float* r, const float* gamma1, const float* beta1,
+                     const float* gamma2, const float* beta2, float* s, void* y, float* mean1, float* rstd1, float* mean2,
+                     float* rstd2, int64_t M, int d, float eps, float p, const uint64_t* rng, uint32_t site1, uint32_t site2,
+                     void* stream);
+int fs2_ffn_tail_bwd(const float* ds_down, const void* dy, int dtype, const float* s, const float* gamma2, const float* mean2,
+                     const float* rstd2, const void* f2, const void* h, const float* gamma1, const float* mean1,
+                     const float* rstd1, float* dr, void* g, float* dgamma2, float* dbeta2, float* dgamma1, float* dbeta1,
+                     float* dcolsum, int64_t M, int d, float p, const uint64_t* rng, uint32_t site1, uint32_t site2,
+                     void* stream);
+
 /* attention() softmax (Models/modules.py:9-19): in place on S [rows = B*H*t][ld = tp >= t]:
  *   P = softmax(mask_keys(S, -1e4));  P_drop = dropout_p(P) (always on).  S already holds QK^T/sqrt(d_k).
  * key_mask [B][t] bytes (0 = padded key).  Columns [t, tp) are written as 0.  p_drop may alias p_out when p == 0.

@@ -326,6 +326,20 @@ def ffn_ln_bwd(dy, f2, h, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, sit
     return (v * ds).to(h.dtype)
 
 
+def ffn_tail_fwd(f2, h, r, gamma1, beta1, gamma2, beta2, eps=1e-5, p=0.0, rng=None, site1=0, site2=0):
+    """Models/modules.py:85-87 then Models/layers.py:40,31: the two steps one after the other"""
+    yff, m1, r1 = ffn_ln_fwd(f2, h, gamma1, beta1, eps, p, rng, site1)
+    s, y, m2, r2 = add_ln_fwd(r, yff, gamma2, beta2, eps, p, rng, site2)
+    return s, y, m1, r1, m2, r2
+
+
+def ffn_tail_bwd(ds_down, dy, s, gamma2, mean2, rstd2, f2, h, gamma1, mean1, rstd1, dgamma2, dbeta2, dgamma1, dbeta1, p=0.0, rng=None,
+                 site1=0, site2=0, dcolsum=None):
+    dr, da = add_ln_bwd(ds_down, dy, s, gamma2, mean2, rstd2, dgamma2, dbeta2, p, rng, site2)
+    g = ffn_ln_bwd(da, f2, h, gamma1, mean1, rstd1, dgamma1, dbeta1, p, rng, site1, dcolsum=dcolsum)
+    return dr, g
+
+
 # ------------------------------------------------------------------------------------------------ attention softmax
 def _strided_index(t):
     """element offsets (relative to the view's first element) of a strided view, as int64 array"""

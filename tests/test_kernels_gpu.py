@@ -710,6 +710,48 @@ def test_l1_cast_permute_optimizer(ops):
     assert float(res["cuda"][2][:7].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("d", [64, 256, 512])
+def test_ffn_tail_fused_equals_two_kernels(ops, dtype, p, d):
+    """fs2_ffn_tail_fwd / _bwd (FeedForward LayerNorm + residual + next LayerNorm in one row pass) against fs2_ffn_ln_* followed by
+    fs2_add_ln_*: the same values up to the last place (the intermediate is rounded where the two-kernel form stores it), and
+    against the oracle's composition within the row-kernel tolerance"""
+    M = 203
+    f2, h, r = rnd(M, d, dtype=dtype, seed=1), rnd(M, d, dtype=dtype, seed=2), rnd(M, d, seed=3)
+    g1, b1, g2, b2 = 1 + 0.1 * rnd(d, seed=4), 0.1 * rnd(d, seed=5), 1 + 0.1 * rnd(d, seed=6), 0.1 * rnd(d, seed=7)
+    dy, dsd = rnd(M, d, dtype=dtype, seed=8), rnd(M, d, seed=9)
+    res = {}
+    for name, o, dev in (("fused", ops, "cuda"), ("two", ops, "cuda"), ("oracle", P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        rng = o.Rng(8, dev)
+        z = lambda: torch.zeros(d, device=dev)
+        dg2, db2, dg1, db1, cs = z(), z(), z(), z(), z()
+        if name == "two":
+            yff, m1, r1 = o.ffn_ln_fwd(mv(f2), mv(h), mv(g1), mv(b1), 1e-5, p, rng, 21)
+            s_, y, m2, r2 = o.add_ln_fwd(mv(r), yff, mv(g2), mv(b2), 1e-5, p, rng, 22)
+            dr, da = o.add_ln_bwd(mv(dsd), mv(dy), s_, mv(g2), m2, r2, dg2, db2, p, rng, 22)
+            g = o.ffn_ln_bwd(da, mv(f2), mv(h), mv(g1), m1, r1, dg1, db1, p, rng, 21, dcolsum=cs)
+        else:
+            s_, y, m1, r1, m2, r2 = o.ffn_tail_fwd(mv(f2), mv(h), mv(r), mv(g1), mv(b1), mv(g2), mv(b2), 1e-5, p, rng, 21, 22)
+            dr, g = o.ffn_tail_bwd(mv(dsd), mv(dy), s_, mv(g2), m2, r2, mv(f2), mv(h), mv(g1), m1, r1, dg2, db2, dg1, db1, p, rng, 21, 22,
+                                   dcolsum=cs)
+        res[name] = [s_, y, m1, r1, m2, r2, dr, g, dg2, db2, dg1, db1, cs]
+    names = ["s", "y", "mean1", "rstd1", "mean2", "rstd2", "dr", "g", "dgamma2", "dbeta2", "dgamma1", "dbeta1", "dcolsum"]
+    for n, a, b in zip(names[:8], res["fused"], res["two"]):      # same arithmetic; hipcc contracts multiply-adds differently in the
+        if a.dtype == torch.float32:                               # two contexts, so fp32 results may differ in the last place
+            close(a, b, f"{n} vs the two-kernel form", rtol=2e-6, atol=2e-6)
+        else:
+            bad = (a.float() - b.float()).abs() > 2.0 ** -7 * b.float().abs().clamp_min(2.0 ** -6)       # at most one bf16 ulp
+            assert not bool(bad.any()), f"{n}: fused differs from the two-kernel form by {(a.float() - b.float()).abs().max().item()}"
+            assert float((a != b).float().mean()) < 2e-3, f"{n}: too many last-place differences"
+    for n, a, b in zip(names[8:], res["fused"][8:], res["two"][8:]):      # per-channel sums: float atomics, order varies
+        close(a, b, n, rtol=1e-4, atol=1e-4)
+    for n, a, b in zip(names, res["fused"], res["oracle"]):
+        k = 30 if a.dim() == 1 and a.numel() == d else 2
+        close(a, b, f"{n} vs oracle", **tol(a.dtype if a.dtype != torch.float32 else dtype, k=k))
+
+
 def test_l1_multi(ops):
     """the trainer's L1 terms in one launch each way against the oracle (fp32 and bf16 predictions, an int64 log1p target, odd
     sizes, unaligned tails) and against nn.L1Loss"""

@@ -354,11 +354,10 @@ class EncoderStackFunction(torch.autograd.Function):
             f1 = ops.conv(h2, rt.w_fwd(ff.f_1.weight), kk, kk // 2, ff.f_1.bias.detach(), relu=True)   # modules.py:83
             f2 = ops.conv(f1, rt.w_fwd(ff.f_2.weight), kk, kk // 2, ff.f_2.bias.detach())              # modules.py:84
             lnf = ff.layer_norm
-            yff, mf, rf = ops.ffn_ln_fwd(f2, h2, lnf.weight.detach(), lnf.bias.detach(), 1e-5, p, rng,
-                                         layer.site_ffn)                                        # modules.py:85-87
             nn_ = enc.layers[i + 1].norm_1 if i + 1 < N else enc.norm
-            x2, hn, mn, rn = ops.add_ln_fwd(x1, yff, nn_.weight.detach(), nn_.bias.detach(), 1e-5, p, rng,
-                                            layer.site_res2)                                    # layers.py:40,31 / encoder.py:112
+            # modules.py:85-87 (LayerNorm of the FFN) and layers.py:40,31 / encoder.py:112 (residual + the next LayerNorm) in one pass
+            x2, hn, mf, rf, mn, rn = ops.ffn_tail_fwd(f2, h2, x1, lnf.weight.detach(), lnf.bias.detach(), nn_.weight.detach(),
+                                                      nn_.bias.detach(), 1e-5, p, rng, layer.site_ffn, layer.site_res2)
             L.update(h=h, qkv=qkv, O=O, x1=x1, h2=h2, m2=m2, r2=r2, f1=f1, f2=f2, mf=mf, rf=rf, x2=x2, mn=mn, rn=rn)
             layers.append(L)
             x, h = x2, hn
@@ -397,12 +396,11 @@ class EncoderStackFunction(torch.autograd.Function):
         for i in reversed(range(N)):
             layer, L = enc.layers[i], layers[i]
             nn_ = enc.layers[i + 1].norm_1 if i + 1 < N else enc.norm
-            dx1, dyff = ops.add_ln_bwd(dx, dh, L["x2"], nn_.weight.detach(), L["mn"], L["rn"], grad_of(nn_.weight),
-                                       grad_of(nn_.bias), p, rng, layer.site_res2)
             ff = layer.ff
             lnf = ff.layer_norm
-            g = ops.ffn_ln_bwd(dyff, L["f2"], L["h2"], lnf.weight.detach(), L["mf"], L["rf"], grad_of(lnf.weight),
-                               grad_of(lnf.bias), p, rng, layer.site_ffn, dcolsum=grad_of(ff.f_2.bias))
+            dx1, g = ops.ffn_tail_bwd(dx, dh, L["x2"], nn_.weight.detach(), L["mn"], L["rn"], L["f2"], L["h2"], lnf.weight.detach(),
+                                      L["mf"], L["rf"], grad_of(nn_.weight), grad_of(nn_.bias), grad_of(lnf.weight), grad_of(lnf.bias),
+                                      p, rng, layer.site_ffn, layer.site_res2, dcolsum=grad_of(ff.f_2.bias))
             kk = ff.f_1.weight.shape[2]
             pad = kk // 2
             _conv_wgrad(rt, g, L["f1"], ff.f_2, pad, bias_done=True)

@@ -369,6 +369,157 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_ln_bwd_k(const T* __restrict__ 
     if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
 }
 
+// ================================================================ FeedForward tail + the residual add and LayerNorm that follow it
+// EncoderLayer.forward after the second convolution (Models/modules.py:85-87, Models/layers.py:40,31 / encoder.py:112):
+//   yff = LN1(dropout1(f2 + h));  s = r + dropout2(yff);  y = LN2(s)
+// = fs2_ffn_ln_fwd followed by fs2_add_ln_fwd without the round trip of yff through HBM (one row pass instead of two).  yff is
+// rounded to the compute dtype exactly where the two-kernel form stores it, so both forms agree to the last place.
+template <typename T> __device__ __forceinline__ float4 round_to(float4 v);
+template <> __device__ __forceinline__ float4 round_to<float>(float4 v) { return v; }
+template <> __device__ __forceinline__ float4 round_to<bf16_t>(float4 v) {
+    return make_float4((float)(bf16_t)v.x, (float)(bf16_t)v.y, (float)(bf16_t)v.z, (float)(bf16_t)v.w);
+}
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void ffn_tail_fwd_k(const T* __restrict__ f2, const T* __restrict__ h,
+        const float* __restrict__ r, const float* __restrict__ gamma1, const float* __restrict__ beta1,
+        const float* __restrict__ gamma2, const float* __restrict__ beta2, float* __restrict__ s, T* __restrict__ y,
+        float* __restrict__ mean1, float* __restrict__ rstd1, float* __restrict__ mean2, float* __restrict__ rstd2, int64_t M, int d,
+        float eps, float p, const uint64_t* rng, uint32_t site1, uint32_t site2) {
+    const DropCtx dc1 = drop_ctx(rng, site1, p), dc2 = drop_ctx(rng, site2, p);
+    float4 g1[NG], b1[NG], g2[NG], b2[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma1, d, lane, g1); row_load<NG, float>(beta1, d, lane, b1);
+        row_load<NG, float>(gamma2, d, lane, g2); row_load<NG, float>(beta2, d, lane, b2);
+    }
+    ROW_LOOP(M) {
+        float4 v[NG], hv[NG], rv[NG];
+        row_load<NG, T>(f2 + row * d, d, lane, v);
+        row_load<NG, T>(h + row * d, d, lane, hv);
+        row_load<NG, float>(r + row * d, d, lane, rv);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g] = add4(v[g], hv[g]);
+            if (dc1.on && GCOL(g) < d) v[g] = mul4(v[g], drop_scale4(dc1, (uint64_t)(row * d + GCOL(g)) >> 2));
+        }
+        float mu, rs;
+        row_stats<NG>(v, d, lane, eps, mu, rs);
+        if (lane == 0) { mean1[row] = mu; rstd1[row] = rs; }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g].x = (v[g].x - mu) * rs * g1[g].x + b1[g].x; v[g].y = (v[g].y - mu) * rs * g1[g].y + b1[g].y;
+            v[g].z = (v[g].z - mu) * rs * g1[g].z + b1[g].z; v[g].w = (v[g].w - mu) * rs * g1[g].w + b1[g].w;
+            v[g] = round_to<T>(v[g]);                        // yff as the two-kernel form stores it
+            if (dc2.on && GCOL(g) < d) v[g] = mul4(v[g], drop_scale4(dc2, (uint64_t)(row * d + GCOL(g)) >> 2));
+            v[g] = (GCOL(g) < d) ? add4(rv[g], v[g]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        row_store<NG, float>(s + row * d, d, lane, v);
+        row_stats<NG>(v, d, lane, eps, mu, rs);
+        if (lane == 0) { mean2[row] = mu; rstd2[row] = rs; }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g].x = (v[g].x - mu) * rs * g2[g].x + b2[g].x; v[g].y = (v[g].y - mu) * rs * g2[g].y + b2[g].y;
+            v[g].z = (v[g].z - mu) * rs * g2[g].z + b2[g].z; v[g].w = (v[g].w - mu) * rs * g2[g].w + b2[g].w;
+        }
+        row_store<NG, T>(y + row * d, d, lane, v);
+    }
+}
+
+// backward of the same: fs2_add_ln_bwd (LN2, residual, dropout2) followed by fs2_ffn_ln_bwd (LN1, dropout1) in one row pass; the
+// gradient handed from one to the other is rounded to the compute dtype where the two-kernel form stores it.
+template <typename T, int NG>
+__global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restrict__ ds_down, const T* __restrict__ dy,
+        const float* __restrict__ s, const float* __restrict__ gamma2, const float* __restrict__ mean2, const float* __restrict__ rstd2,
+        const T* __restrict__ f2, const T* __restrict__ h, const float* __restrict__ gamma1, const float* __restrict__ mean1,
+        const float* __restrict__ rstd1, float* __restrict__ dr, T* __restrict__ gout, float* __restrict__ dgamma2,
+        float* __restrict__ dbeta2, float* __restrict__ dgamma1, float* __restrict__ dbeta1, float* __restrict__ dcolsum, int64_t M,
+        int d, float p, const uint64_t* rng, uint32_t site1, uint32_t site2) {
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
+    const DropCtx dc1 = drop_ctx(rng, site1, p), dc2 = drop_ctx(rng, site2, p);
+    float4 gm2[NG], gm1[NG], ag2[NG], ab2[NG], ag1[NG], ab1[NG], ac[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma2, d, lane, gm2);
+        row_load<NG, float>(gamma1, d, lane, gm1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ag2[g] = ab2[g] = ag1[g] = ab1[g] = ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float invd = 1.f / (float)d;
+    RED_LOOP(M) {
+        // ---- LN2 backward + residual + dropout2'  (add_ln_bwd_k)
+        float4 g_[NG], xv[NG];
+        row_load<NG, T>(dy + row * d, d, lane, g_);
+        row_load<NG, float>(s + row * d, d, lane, xv);
+        float mu = mean2[row], rs = rstd2[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (GCOL(g) < d) {
+                float4 xh = make_float4((xv[g].x - mu) * rs, (xv[g].y - mu) * rs, (xv[g].z - mu) * rs, (xv[g].w - mu) * rs);
+                ag2[g] = add4(ag2[g], mul4(g_[g], xh));
+                ab2[g] = add4(ab2[g], g_[g]);
+                float4 dg = mul4(g_[g], gm2[g]);
+                c1 += sum4(dg);
+                c2 += sum4(mul4(dg, xh));
+                g_[g] = dg;
+                xv[g] = xh;
+            }
+        }
+        c1 = wave_sum(c1) * invd;
+        c2 = wave_sum(c2) * invd;
+        float4 o[NG], dn[NG];
+        if (ds_down != nullptr) row_load<NG, float>(ds_down + row * d, d, lane, dn);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2); o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2);
+            o[g].z = rs * (g_[g].z - c1 - xv[g].z * c2); o[g].w = rs * (g_[g].w - c1 - xv[g].w * c2);
+            if (ds_down != nullptr) o[g] = add4(o[g], dn[g]);
+        }
+        row_store<NG, float>(dr + row * d, d, lane, o);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (dc2.on && GCOL(g) < d) o[g] = mul4(o[g], drop_scale4(dc2, (uint64_t)(row * d + GCOL(g)) >> 2));
+            o[g] = round_to<T>(o[g]);                        // d(yff) as the two-kernel form stores it
+        }
+        // ---- LN1 backward + dropout1'  (ffn_ln_bwd_k with dy = o)
+        float4 fv[NG], hv[NG], ds[NG];
+        row_load<NG, T>(f2 + row * d, d, lane, fv);
+        row_load<NG, T>(h + row * d, d, lane, hv);
+        mu = mean1[row]; rs = rstd1[row];
+        c1 = 0.f; c2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            ds[g] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (GCOL(g) < d) {
+                if (dc1.on) ds[g] = drop_scale4(dc1, (uint64_t)(row * d + GCOL(g)) >> 2);
+                float4 u = mul4(add4(fv[g], hv[g]), ds[g]);
+                float4 xh = make_float4((u.x - mu) * rs, (u.y - mu) * rs, (u.z - mu) * rs, (u.w - mu) * rs);
+                ag1[g] = add4(ag1[g], mul4(o[g], xh));
+                ab1[g] = add4(ab1[g], o[g]);
+                float4 dg = mul4(o[g], gm1[g]);
+                c1 += sum4(dg);
+                c2 += sum4(mul4(dg, xh));
+                o[g] = dg;
+                fv[g] = xh;
+            }
+        }
+        c1 = wave_sum(c1) * invd;
+        c2 = wave_sum(c2) * invd;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            o[g].x = rs * (o[g].x - c1 - fv[g].x * c2) * ds[g].x; o[g].y = rs * (o[g].y - c1 - fv[g].y * c2) * ds[g].y;
+            o[g].z = rs * (o[g].z - c1 - fv[g].z * c2) * ds[g].z; o[g].w = rs * (o[g].w - c1 - fv[g].w * c2) * ds[g].w;
+            ac[g] = add4(ac[g], o[g]);
+        }
+        row_store<NG, T>(gout + row * d, d, lane, o);
+    }
+    flush_channel_sums<NG>(ag2, dgamma2, d, red);
+    flush_channel_sums<NG>(ab2, dbeta2, d, red);
+    flush_channel_sums<NG>(ag1, dgamma1, d, red);
+    flush_channel_sums<NG>(ab1, dbeta1, d, red);
+    if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
+}
+
 // ================================================================ attention softmax (in place) + dropout
 // rows = (b, h, i); S row = base + b*batch_stride + (h*t + i)*tp; keys j < t; pad columns [t,tp) -> 0
 // (tq query rows per head against t keys: tq == t for self-attention; causal: key j of query i is also masked when
@@ -1019,6 +1170,39 @@ extern "C" int fs2_ffn_ln_bwd(const void* dy, const void* f2, const void* h, int
         hipLaunchKernelGGL((ffn_ln_bwd_k<T, NG>), grid, block, 0, st, (const T*)dy, (const T*)f2, (const T*)h, gamma, mean, rstd, (T*)g, dgamma, dbeta, M, d, p, rng, site, dcolsum);
     }); } });
     FS2_CHECK_LAUNCH("fs2_ffn_ln_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_ffn_tail_fwd(const void* f2, const void* h, int dtype, const float* r, const float* gamma1, const float* beta1,
+                                const float* gamma2, const float* beta2, float* s, void* y, float* mean1, float* rstd1, float* mean2,
+                                float* rstd2, int64_t M, int d, float eps, float p, const uint64_t* rng, uint32_t site1, uint32_t site2,
+                                void* stream) {
+    CHECK_ROW("fs2_ffn_tail_fwd", d, 1024); CHECK_DT("fs2_ffn_tail_fwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ffn_tail_fwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((ffn_tail_fwd_k<T, NG>), grid, block, 0, st, (const T*)f2, (const T*)h, r, gamma1, beta1, gamma2, beta2, s, (T*)y, mean1, rstd1, mean2, rstd2, M, d, eps, p, rng, site1, site2);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_ffn_tail_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_ffn_tail_bwd(const float* ds_down, const void* dy, int dtype, const float* s, const float* gamma2, const float* mean2,
+                                const float* rstd2, const void* f2, const void* h, const float* gamma1, const float* mean1,
+                                const float* rstd1, float* dr, void* g, float* dgamma2, float* dbeta2, float* dgamma1, float* dbeta1,
+                                float* dcolsum, int64_t M, int d, float p, const uint64_t* rng, uint32_t site1, uint32_t site2,
+                                void* stream) {
+    CHECK_ROW("fs2_ffn_tail_bwd", d, 1024); CHECK_DT("fs2_ffn_tail_bwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ffn_tail_bwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((ffn_tail_bwd_k<T, NG>), grid, block, 0, st, ds_down, (const T*)dy, s, gamma2, mean2, rstd2, (const T*)f2, (const T*)h, gamma1, mean1, rstd1, dr, (T*)g, dgamma2, dbeta2, dgamma1, dbeta1, dcolsum, M, d, p, rng, site1, site2);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_ffn_tail_bwd");
     return FS2_OK;
 }
 

@@ -102,6 +102,8 @@ SIGNATURES = {
     "fs2_l1_fwd": [_P, _I, _P, _I, _L, _P, _P],
     "fs2_l1_bwd": [_P, _I, _P, _I, _L, _P, _P, _I, _P],
     "fs2_sqnorm": [_P, _L, _P, _P],
+    "fs2_ffn_tail_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _U32, _P],
+    "fs2_ffn_tail_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _U32, _P],
     "fs2_l1_multi_fwd": [_P, _I, _P, _P],
     "fs2_l1_multi_bwd": [_P, _I, _P, _P],
     "fs2_adam_step": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P],
@@ -635,6 +637,33 @@ def ffn_ln_bwd(dy, f2, h, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None, sit
                                 _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, _p(dcolsum), _stream()),
            "fs2_ffn_ln_bwd")
     return g
+
+
+def ffn_tail_fwd(f2, h, r, gamma1, beta1, gamma2, beta2, eps=1e-5, p=0.0, rng=None, site1=0, site2=0):
+    """ffn_ln_fwd followed by add_ln_fwd in one row pass: yff = LN1(dropout(f2 + h, site1)); s = r + dropout(yff, site2);
+    y = LN2(s).  returns s (fp32), y, mean1, rstd1, mean2, rstd2"""
+    d = h.shape[-1]
+    M = h.numel() // d
+    s = torch.empty_like(r)
+    y = torch.empty_like(h)
+    st = [torch.empty(M, dtype=torch.float32, device=h.device) for _ in range(4)]
+    _check(lib().fs2_ffn_tail_fwd(_p(_c(f2)), _p(_c(h)), _dt(h), _p(_c(r)), _p(gamma1), _p(beta1), _p(gamma2), _p(beta2), _p(s), _p(y),
+                                  _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), M, d, eps, p, _rng_ptr(rng, p), site1, site2, _stream()),
+           "fs2_ffn_tail_fwd")
+    return s, y, st[0], st[1], st[2], st[3]
+
+
+def ffn_tail_bwd(ds_down, dy, s, gamma2, mean2, rstd2, f2, h, gamma1, mean1, rstd1, dgamma2, dbeta2, dgamma1, dbeta1, p=0.0, rng=None,
+                 site1=0, site2=0, dcolsum=None):
+    """add_ln_bwd followed by ffn_ln_bwd in one row pass: returns dr (fp32, gradient of the residual r) and g = d(f2) = d(h)"""
+    d = s.shape[-1]
+    M = s.numel() // d
+    dr = torch.empty_like(s)
+    g = torch.empty_like(h)
+    _check(lib().fs2_ffn_tail_bwd(_p(ds_down), _p(_c(dy)), _dt(dy), _p(_c(s)), _p(gamma2), _p(mean2), _p(rstd2), _p(_c(f2)), _p(_c(h)),
+                                  _p(gamma1), _p(mean1), _p(rstd1), _p(dr), _p(g), _p(dgamma2), _p(dbeta2), _p(dgamma1), _p(dbeta1),
+                                  _p(dcolsum), M, d, p, _rng_ptr(rng, p), site1, site2, _stream()), "fs2_ffn_tail_bwd")
+    return dr, g
 
 
 # ------------------------------------------------------------------------------------------------ attention softmax
