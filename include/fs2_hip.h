@@ -316,7 +316,7 @@ int fs2_l1_fwd(const void* pred, int pred_dtype, const void* target, int target_
 int fs2_l1_bwd(const void* pred, int pred_dtype, const void* target, int target_mode, int64_t n, const float* gscale,
                void* dpred, int dpred_dtype, void* stream);
 /* up to 8 L1 terms in one launch each way (the trainer's five nn.L1Loss() terms, train_fastspeech2.py:212-259):
- * losses[i] += mean |pred_i - target_i| and losses[n_items] += their sum (zeroed by the caller);
+ * losses[i] += mean |pred_i - target_i| (zeroed by the caller, who also adds the terms up);
  * backward: dpred_i = gscale[0] * sign(pred_i - target_i) / n_i  (gscale = d(loss)/d(sum of the terms), on the device). */
 typedef struct {
     const void* pred;       /* n elements, pred_dtype (FS2_F32 / FS2_BF16) */

@@ -700,10 +700,10 @@ class MultiL1LossFunction(torch.autograd.Function):
     def forward(ctx, modes, *tensors):
         preds = [t.contiguous() for t in tensors[0::2]]
         targets = [t.contiguous() for t in tensors[1::2]]
-        out = torch.zeros(len(preds) + 1, dtype=torch.float32, device=preds[0].device)
-        ops.l1_multi_fwd(preds, targets, modes, out)
+        losses = torch.zeros(len(preds), dtype=torch.float32, device=preds[0].device)
+        ops.l1_multi_fwd(preds, targets, modes, losses)
         ctx.preds, ctx.targets, ctx.modes = preds, targets, modes
-        losses, total = out[:len(preds)], out[len(preds)]
+        total = losses.sum()
         ctx.mark_non_differentiable(losses)
         return losses, total
 
