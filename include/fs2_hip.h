@@ -286,6 +286,18 @@ int fs2_linear1_fwd(const void* x, int dtype, const float* w, const float* b, co
 int fs2_linear1_bwd(const float* dout, const void* x, int dtype, const float* w, const uint8_t* mask, void* dx,
                     float* dw, float* db, int64_t M, int d, void* stream);
 
+/* The tail of a VariancePredictor in one row pass each way (Models/varianceadaptor.py:226-231):
+ *   forward:  out[m] = mask[m] ? dot(dropout(LN(x[m])), w) + b : 0        (the normalised rows are not stored)
+ *   backward: = fs2_linear1_bwd followed by fs2_layernorm_bwd (relu_mask: x was relu(z), returns dz): dx, and += into dgamma,
+ *             dbeta, dw, db, dcolsum (column sums of dx: the bias gradient of the convolution that produced x).                */
+int fs2_ln_linear1_fwd(const void* x, int dtype, const float* gamma, const float* beta, const float* w, const float* b,
+                       const uint8_t* mask, float* out, float* mean, float* rstd, int64_t M, int d, float eps, float p,
+                       const uint64_t* rng, uint32_t site, void* stream);
+int fs2_ln_linear1_bwd(const float* dout, const void* x, int dtype, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, const float* w, const uint8_t* mask, void* dx, float* dgamma, float* dbeta, float* dw,
+                       float* db, float* dcolsum, int64_t M, int d, float p, const uint64_t* rng, uint32_t site, int relu_mask,
+                       void* stream);
+
 /* BatchNorm1d(batch statistics) + tanh + dropout (Models/postnets.py:71-73).
  *  colstats: x [M][C] -> sums[0..C) += sum, sums[C..2C) += sum of squares (also available fused in fs2_gemm)
  *  finalize: mean/rstd from the (possibly all-reduced) sums and count; running stats updated with

@@ -537,6 +537,21 @@ def linear1_bwd(dout, x, w, mask, dw, db):
     return (g.unsqueeze(-1) * _f(w).reshape(-1)).to(x.dtype)
 
 
+def ln_linear1_fwd(x, gamma, beta, w, b, mask, eps=1e-5, p=0.0, rng=None, site=0):
+    """the tail of a VariancePredictor (Models/varianceadaptor.py:226-231): LayerNorm, dropout, Linear(d -> 1), mask"""
+    n, mean, rstd = layernorm_fwd(x, gamma, beta, x.dtype, eps, p, rng, site)
+    return linear1_fwd(n, w, b, mask), mean, rstd
+
+
+def ln_linear1_bwd(dout, x, gamma, beta, mean, rstd, w, mask, dgamma, dbeta, dw, db, p=0.0, rng=None, site=0, relu_mask=False,
+                   dcolsum=None):
+    shape = x.shape[:-1]
+    n = (_f(x) - mean.reshape(shape).unsqueeze(-1)) * rstd.reshape(shape).unsqueeze(-1) * _f(gamma) + _f(beta)
+    n = (n * drop_scale(tuple(x.shape), p, rng, site)).to(x.dtype)            # what the forward's Linear saw
+    dn = linear1_bwd(dout, n, w, mask, dw, db)
+    return layernorm_bwd(dn, x, gamma, mean, rstd, dgamma, dbeta, p, rng, site, relu_mask=relu_mask, dcolsum=dcolsum)
+
+
 # ------------------------------------------------------------------------------------------------ BatchNorm + tanh
 def colstats(x, sums):
     C = x.shape[-1]

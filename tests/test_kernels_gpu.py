@@ -752,6 +752,41 @@ def test_ffn_tail_fused_equals_two_kernels(ops, dtype, p, d):
         close(a, b, f"{n} vs oracle", **tol(a.dtype if a.dtype != torch.float32 else dtype, k=k))
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("p", [0.0, 0.5])
+@pytest.mark.parametrize("d", [64, 256])
+def test_ln_linear1_fused_equals_two_kernels(ops, dtype, p, d):
+    """fs2_ln_linear1_fwd / _bwd (the tail of a VariancePredictor in one row pass, normalised rows recomputed in the backward)
+    against fs2_layernorm_* + fs2_linear1_*, and against the oracle's composition"""
+    M = 203
+    x = torch.relu(rnd(M, d, dtype=dtype, seed=1))
+    gm, bt, w, b = 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3), 0.3 * rnd(d, seed=4), torch.tensor([0.2])
+    mask = (torch.arange(M) % 7 != 3)
+    dout = rnd(M, seed=5)
+    res = {}
+    for name, o, dev in (("fused", ops, "cuda"), ("two", ops, "cuda"), ("oracle", P, "cpu")):
+        mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+        rng = o.Rng(8, dev)
+        z = lambda *sh: torch.zeros(*sh, device=dev)
+        dg, db_, dw, dbias, cs = z(d), z(d), z(d), z(1), z(d)
+        if name == "two":
+            n, mean, rstd = o.layernorm_fwd(mv(x), mv(gm), mv(bt), dtype, 1e-5, p, rng, 9)
+            out = o.linear1_fwd(n, mv(w), mv(b), mv(mask))
+            dn = o.linear1_bwd(mv(dout), n, mv(w), mv(mask), dw, dbias)
+            dx = o.layernorm_bwd(dn, mv(x), mv(gm), mean, rstd, dg, db_, p, rng, 9, relu_mask=True, dcolsum=cs)
+        else:
+            out, mean, rstd = o.ln_linear1_fwd(mv(x), mv(gm), mv(bt), mv(w), mv(b), mv(mask), 1e-5, p, rng, 9)
+            dx = o.ln_linear1_bwd(mv(dout), mv(x), mv(gm), mv(bt), mean, rstd, mv(w), mv(mask), dg, db_, dw, dbias, p, rng, 9,
+                                  relu_mask=True, dcolsum=cs)
+        res[name] = [out, mean, rstd, dx, dg, db_, dw, dbias, cs]
+    names = ["out", "mean", "rstd", "dx", "dgamma", "dbeta", "dw", "db", "dcolsum"]
+    for other in ("two", "oracle"):
+        for n, a, b_ in zip(names, res["fused"], res[other]):
+            k = 30 if n in ("dgamma", "dbeta", "dw", "db", "dcolsum") else 2
+            close(a, b_, f"{n} vs {other}", **tol(a.dtype if a.dtype != torch.float32 else dtype, k=k))
+    assert torch.all(res["fused"][0].cpu()[~mask] == 0)
+
+
 def test_l1_multi(ops):
     """the trainer's L1 terms in one launch each way against the oracle (fp32 and bf16 predictions, an int64 log1p target, odd
     sizes, unaligned tails) and against nn.L1Loss"""

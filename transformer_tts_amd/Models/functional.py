@@ -487,10 +487,11 @@ class VariancePredictorFunction(torch.autograd.Function):
         n1, m1, r1 = ops.layernorm_fwd(c1, l1.weight.detach(), l1.bias.detach(), T, 1e-5, p, rng, mod.site1)
         c2 = ops.conv(n1, rt.w_fwd(mod.conv2.weight), 3, 1, mod.conv2.bias.detach(), relu=True)
         l2 = mod.layer_norm2
-        n2, m2, r2 = ops.layernorm_fwd(c2, l2.weight.detach(), l2.bias.detach(), T, 1e-5, p, rng, mod.site2)
         lin = mod.linear_layer
-        out = ops.linear1_fwd(n2, lin.weight.detach().view(-1), lin.bias.detach(), km)
-        ctx.mod, ctx.sv = mod, dict(x=x, km=km, c1=c1, n1=n1, m1=m1, r1=r1, c2=c2, n2=n2, m2=m2, r2=r2)
+        # LayerNorm + dropout + Linear(d -> 1) + mask in one row pass; the normalised rows are recomputed in the backward
+        out, m2, r2 = ops.ln_linear1_fwd(c2, l2.weight.detach(), l2.bias.detach(), lin.weight.detach().view(-1), lin.bias.detach(), km,
+                                         1e-5, p, rng, mod.site2)
+        ctx.mod, ctx.sv = mod, dict(x=x, km=km, c1=c1, n1=n1, m1=m1, r1=r1, c2=c2, m2=m2, r2=r2)
         return out
 
     @staticmethod
@@ -500,10 +501,10 @@ class VariancePredictorFunction(torch.autograd.Function):
         rt = mod.rt
         rng, p = rt.rng, mod.dropout
         lin, l1, l2 = mod.linear_layer, mod.layer_norm1, mod.layer_norm2
-        dn2 = ops.linear1_bwd(dout.contiguous(), s["n2"], lin.weight.detach().view(-1), s["km"],
-                              grad_of(lin.weight).view(-1), grad_of(lin.bias))
-        dz2 = ops.layernorm_bwd(dn2, s["c2"], l2.weight.detach(), s["m2"], s["r2"], grad_of(l2.weight),
-                                grad_of(l2.bias), p, rng, mod.site2, relu_mask=True, dcolsum=grad_of(mod.conv2.bias))
+        dz2 = ops.ln_linear1_bwd(dout.contiguous(), s["c2"], l2.weight.detach(), l2.bias.detach(), s["m2"], s["r2"],
+                                 lin.weight.detach().view(-1), s["km"], grad_of(l2.weight), grad_of(l2.bias),
+                                 grad_of(lin.weight).view(-1), grad_of(lin.bias), p, rng, mod.site2, relu_mask=True,
+                                 dcolsum=grad_of(mod.conv2.bias))
         _conv_wgrad(rt, dz2, s["n1"], mod.conv2, 1, bias_done=True)
         dn1 = ops.conv(dz2, rt.w_dgrad(mod.conv2.weight), 3, 1)
         dz1 = ops.layernorm_bwd(dn1, s["c1"], l1.weight.detach(), s["m1"], s["r1"], grad_of(l1.weight),

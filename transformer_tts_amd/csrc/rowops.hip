@@ -901,6 +901,122 @@ __global__ __launch_bounds__(RED_BLOCK) void linear1_bwd_k(const float* __restri
     }
 }
 
+// ================================================================ LayerNorm(+dropout) followed by Linear(d -> 1) + mask
+// The tail of a VariancePredictor (Models/varianceadaptor.py:226-231): out = mask(Linear(dropout(LN(x)))).  = fs2_layernorm_fwd
+// followed by fs2_linear1_fwd without storing the normalised rows (they are recomputed in the backward from x and the row
+// statistics); rounded to T where the two-kernel form stores them.
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void ln_linear1_fwd_k(const T* __restrict__ x, const float* __restrict__ gamma,
+        const float* __restrict__ beta, const float* __restrict__ w, const float* __restrict__ b, const uint8_t* __restrict__ mask,
+        float* __restrict__ out, float* __restrict__ mean, float* __restrict__ rstd, int64_t M, int d, float eps, float p,
+        const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 gm[NG], bt[NG], wv[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm); row_load<NG, float>(beta, d, lane, bt); row_load<NG, float>(w, d, lane, wv);
+    }
+    const float bias = b[0];
+    ROW_LOOP(M) {
+        float4 v[NG];
+        row_load<NG, T>(x + row * d, d, lane, v);
+        float mu, rs;
+        row_stats<NG>(v, d, lane, eps, mu, rs);
+        float sdot = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float4 o;
+            o.x = (v[g].x - mu) * rs * gm[g].x + bt[g].x; o.y = (v[g].y - mu) * rs * gm[g].y + bt[g].y;
+            o.z = (v[g].z - mu) * rs * gm[g].z + bt[g].z; o.w = (v[g].w - mu) * rs * gm[g].w + bt[g].w;
+            if (dc.on && GCOL(g) < d) o = mul4(o, drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+            o = round_to<T>(o);
+            if (GCOL(g) < d) sdot += sum4(mul4(o, wv[g]));
+        }
+        sdot = wave_sum(sdot);
+        if (lane == 0) { out[row] = mask[row] ? sdot + bias : 0.f; mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+// backward of the same: fs2_linear1_bwd followed by fs2_layernorm_bwd (relu_mask: the LayerNorm input was relu(z)) in one row pass
+template <typename T, int NG>
+__global__ __launch_bounds__(RED_BLOCK) void ln_linear1_bwd_k(const float* __restrict__ dout, const T* __restrict__ x,
+        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
+        const float* __restrict__ w, const uint8_t* __restrict__ mask, T* __restrict__ dx, float* __restrict__ dgamma,
+        float* __restrict__ dbeta, float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dcolsum, int64_t M, int d, float p,
+        const uint64_t* rng, uint32_t site, int relu_mask) {
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 gm[NG], bt[NG], wv[NG], ag[NG], ab[NG], ac[NG], aw[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm); row_load<NG, float>(beta, d, lane, bt); row_load<NG, float>(w, d, lane, wv);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = ac[g] = aw[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float invd = 1.f / (float)d;
+    float abias = 0.f;
+    RED_LOOP(M) {
+        const float go = mask[row] ? dout[row] : 0.f;
+        float4 xv[NG], g_[NG];
+        row_load<NG, T>(x + row * d, d, lane, xv);
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+        unsigned pos[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            pos[g] = 0xFu;
+            g_[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (GCOL(g) < d) {
+                float4 ds = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (dc.on) ds = drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2);
+                if (relu_mask)
+                    pos[g] = (xv[g].x > 0.f ? 1u : 0u) | (xv[g].y > 0.f ? 2u : 0u) | (xv[g].z > 0.f ? 4u : 0u) | (xv[g].w > 0.f ? 8u : 0u);
+                float4 xh = make_float4((xv[g].x - mu) * rs, (xv[g].y - mu) * rs, (xv[g].z - mu) * rs, (xv[g].w - mu) * rs);
+                // the forward's normalised row (what the Linear saw), recomputed: weight gradient of the Linear
+                float4 n = make_float4(xh.x * gm[g].x + bt[g].x, xh.y * gm[g].y + bt[g].y, xh.z * gm[g].z + bt[g].z, xh.w * gm[g].w + bt[g].w);
+                n = round_to<T>(mul4(n, ds));
+                aw[g] = add4(aw[g], scale4(n, go));
+                // gradient reaching the LayerNorm output: w * go (rounded as the two-kernel form stores it), through the dropout
+                float4 gy = mul4(round_to<T>(scale4(wv[g], go)), ds);
+                ag[g] = add4(ag[g], mul4(gy, xh));
+                ab[g] = add4(ab[g], gy);
+                float4 dg = mul4(gy, gm[g]);
+                c1 += sum4(dg);
+                c2 += sum4(mul4(dg, xh));
+                g_[g] = dg;
+                xv[g] = xh;
+            }
+        }
+        c1 = wave_sum(c1) * invd;
+        c2 = wave_sum(c2) * invd;
+        float4 o[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2); o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2);
+            o[g].z = rs * (g_[g].z - c1 - xv[g].z * c2); o[g].w = rs * (g_[g].w - c1 - xv[g].w * c2);
+            if (relu_mask) {
+                o[g].x = (pos[g] & 1u) ? o[g].x : 0.f; o[g].y = (pos[g] & 2u) ? o[g].y : 0.f;
+                o[g].z = (pos[g] & 4u) ? o[g].z : 0.f; o[g].w = (pos[g] & 8u) ? o[g].w : 0.f;
+            }
+            ac[g] = add4(ac[g], o[g]);
+        }
+        row_store<NG, T>(dx + row * d, d, lane, o);
+        if (lane == 0) abias += go;
+    }
+    flush_channel_sums<NG>(ag, dgamma, d, red);
+    flush_channel_sums<NG>(ab, dbeta, d, red);
+    flush_channel_sums<NG>(aw, dw, d, red);
+    if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = abias;      // one atomic per block on the single db word
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int wv_ = 0; wv_ < (int)(blockDim.x >> 6); ++wv_) t += red[wv_];
+        atomicAdd(db, t);
+    }
+}
+
 // ================================================================ BatchNorm(batch stats) + tanh + dropout
 template <typename T, int NG>
 __global__ __launch_bounds__(RED_BLOCK) void colstats_k(const T* __restrict__ x, int64_t M, int C, float* __restrict__ sums) {
@@ -1341,6 +1457,37 @@ extern "C" int fs2_linear1_bwd(const float* dout, const void* x, int dtype, cons
         hipLaunchKernelGGL((linear1_bwd_k<T, NG>), grid, block, 0, st, dout, (const T*)x, w, mask, (T*)dx, dw, db, M, d);
     }); } });
     FS2_CHECK_LAUNCH("fs2_linear1_bwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_ln_linear1_fwd(const void* x, int dtype, const float* gamma, const float* beta, const float* w, const float* b,
+                                  const uint8_t* mask, float* out, float* mean, float* rstd, int64_t M, int d, float eps, float p,
+                                  const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_ln_linear1_fwd", d, 1024); CHECK_DT("fs2_ln_linear1_fwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ln_linear1_fwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((ln_linear1_fwd_k<T, NG>), grid, block, 0, st, (const T*)x, gamma, beta, w, b, mask, out, mean, rstd, M, d, eps, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_ln_linear1_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_ln_linear1_bwd(const float* dout, const void* x, int dtype, const float* gamma, const float* beta, const float* mean,
+                                  const float* rstd, const float* w, const uint8_t* mask, void* dx, float* dgamma, float* dbeta, float* dw,
+                                  float* db, float* dcolsum, int64_t M, int d, float p, const uint64_t* rng, uint32_t site, int relu_mask,
+                                  void* stream) {
+    CHECK_ROW("fs2_ln_linear1_bwd", d, 1024); CHECK_DT("fs2_ln_linear1_bwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ln_linear1_bwd: dropout needs rng");
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((ln_linear1_bwd_k<T, NG>), grid, block, 0, st, dout, (const T*)x, gamma, beta, mean, rstd, w, mask, (T*)dx, dgamma, dbeta, dw, db, dcolsum, M, d, p, rng, site, relu_mask);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_ln_linear1_bwd");
     return FS2_OK;
 }
 

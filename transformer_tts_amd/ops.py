@@ -102,6 +102,8 @@ SIGNATURES = {
     "fs2_l1_fwd": [_P, _I, _P, _I, _L, _P, _P],
     "fs2_l1_bwd": [_P, _I, _P, _I, _L, _P, _P, _I, _P],
     "fs2_sqnorm": [_P, _L, _P, _P],
+    "fs2_ln_linear1_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
+    "fs2_ln_linear1_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _I, _P],
     "fs2_ffn_tail_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _U32, _P],
     "fs2_ffn_tail_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _U32, _P],
     "fs2_l1_multi_fwd": [_P, _I, _P, _P],
@@ -876,6 +878,30 @@ def linear1_bwd(dout, x, w, mask, dw, db):
     dx = torch.empty_like(x)
     _check(lib().fs2_linear1_bwd(_p(_c(dout)), _p(_c(x)), _dt(x), _p(_c(w)), _p(_c(mask)), _p(dx), _p(dw), _p(db), M, d,
                                  _stream()), "fs2_linear1_bwd")
+    return dx
+
+
+def ln_linear1_fwd(x, gamma, beta, w, b, mask, eps=1e-5, p=0.0, rng=None, site=0):
+    """layernorm_fwd followed by linear1_fwd in one row pass (the normalised rows are not stored); returns out, mean, rstd"""
+    d = x.shape[-1]
+    M = x.numel() // d
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    _check(lib().fs2_ln_linear1_fwd(_p(_c(x)), _dt(x), _p(gamma), _p(beta), _p(_c(w)), _p(b), _p(_c(mask)), _p(out), _p(mean), _p(rstd),
+                                    M, d, eps, p, _rng_ptr(rng, p), site, _stream()), "fs2_ln_linear1_fwd")
+    return out, mean, rstd
+
+
+def ln_linear1_bwd(dout, x, gamma, beta, mean, rstd, w, mask, dgamma, dbeta, dw, db, p=0.0, rng=None, site=0, relu_mask=False,
+                   dcolsum=None):
+    """linear1_bwd followed by layernorm_bwd in one row pass; returns dx (dtype of x)"""
+    d = x.shape[-1]
+    M = x.numel() // d
+    dx = torch.empty_like(x)
+    _check(lib().fs2_ln_linear1_bwd(_p(_c(dout)), _p(_c(x)), _dt(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(_c(w)), _p(_c(mask)),
+                                    _p(dx), _p(dgamma), _p(dbeta), _p(dw), _p(db), _p(dcolsum), M, d, p, _rng_ptr(rng, p), site,
+                                    int(relu_mask), _stream()), "fs2_ln_linear1_bwd")
     return dx
 
 
