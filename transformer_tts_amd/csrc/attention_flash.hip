@@ -176,7 +176,7 @@ struct FlashArgs {
     // backward
     const bf16_t* dO;                   // rows at dO + b*do_batch + i*do_row + h*head
     int64_t do_row, do_batch;
-    float* aux;                         // (B, H, t, 4) workspace: {-m log2 e, 1/l, delta = rowsum(dO * O), 0}: dQ kernel -> dK/dV kernel
+    float* aux;                         // (B, H, t, 4) workspace: {-m log2 e, 1/l, delta = rowsum(dO * O), kmax bits}: dQ kernel -> dK/dV kernel
     bf16_t *dq, *dk, *dv;               // rows at d? + b*g_batch + i*g_row + h*head
     int64_t g_row, g_batch;
     float *dbq, *dbk, *dbv;             // optional bias gradients of the three projections (H*128 floats each): += column sums of dq / dk / dv
@@ -428,12 +428,18 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
             const float2 st = *reinterpret_cast<const float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2);
             nm2[s] = -st.x * LOG2E;
             linv[s] = 1.f / st.y;
-            if (g == 0) *reinterpret_cast<float4*>(a.aux + (((int64_t)b * a.H + h) * t + qrow) * 4) = make_float4(nm2[s], linv[s], delta[s], 0.f);
         }
     }
     scan_mask<FQ_THREADS>(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
     const int kfull = red[0], kmax = red[1];
     const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
+    // per query for the dK/dV kernel: {-m log2 e, 1/l, delta, kmax of this batch row (as bits: saves that kernel the mask scan)}
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int qrow = q0 + 16 * s;
+        if (qrow < t && g == 0)
+            *reinterpret_cast<float4*>(a.aux + (((int64_t)b * a.H + h) * t + qrow) * 4) = make_float4(nm2[s], linv[s], delta[s], __int_as_float(kmax));
+    }
     const float scale = DROP ? 65536.f / (65536.f - (float)(uint32_t)(a.pdrop * 65536.f + 0.5f)) : 1.f;
     const int qc0 = q0 < t ? q0 : 0, qc1 = q0 + 16 < t ? q0 + 16 : 0;
     const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t) * 4 + g;
@@ -565,7 +571,6 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     unsigned char* qimg = smem;                         // [2][TILE]
     unsigned char* doimg = smem + 2 * TILE;             // [2][TILE]
     unsigned char* auximg = smem + 4 * TILE;            // [2][AUX_BYTES]
-    int* red = reinterpret_cast<int*>(smem + 4 * TILE + 2 * AUX_BYTES);
     const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
     const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
     const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
@@ -575,8 +580,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     const bool kvalid = key < t;
     const int64_t goff = (int64_t)b * a.g_batch + (int64_t)key * a.g_row + (int64_t)h * a.head;
 
-    scan_mask(a.key_mask + (int64_t)b * t, t, nullptr, red, tid);
-    const int kmax = red[1];
+    const int kmax = __float_as_int(a.aux[(((int64_t)b * a.H + h) * t) * 4 + 3]);      // written by the dQ kernel (row 0 always exists)
     if (kmax > 0 && blk * 128 >= kmax) {     // every key of this block is masked: zero probability, zero gradients
         if (kvalid) {
             const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
