@@ -249,17 +249,20 @@ int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_s
  *   q, k, v: rows of one head = 128 contiguous bf16 at  base + b*batch_stride + i*row_stride + h*head_stride  (elements);
  *   o / d_out / dq,dk,dv rows likewise with their own row and batch strides (dq, dk, dv share g_*_stride).           */
 int64_t fs2_flash_attn_keep_words(int B, int H, int t);
+/* {number of leading unmasked keys, last unmasked key + 1} of every batch row: info[B][2].  Optional: pass it as key_info to the
+ * calls below (one scan per stack instead of one per workgroup), or NULL and every workgroup scans its mask row itself. */
+int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, int32_t* info, void* stream);
 int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
-                       const uint8_t* key_mask, void* o_out, int64_t o_row_stride, int64_t o_batch_stride, float* stats,
-                       uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
+                       const uint8_t* key_mask, const int32_t* key_info, void* o_out, int64_t o_row_stride, int64_t o_batch_stride,
+                       float* stats, uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
                        float p, const uint64_t* rng, uint32_t site, void* stream);
 /* the same keep-bits ahead of time (then pass pregenerated = 1 to fs2_flash_attn_fwd, which reads instead of drawing them): a host
  * that knows the shapes of the next layers generates their masks on a side stream while the matrix pipes are busy elsewhere */
 int fs2_flash_attn_keep_bits(uint16_t* keep_bits, int64_t p_batch_stride, int B, int H, int t, int tp, float p, const uint64_t* rng,
                              uint32_t site, void* stream);
 int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
-                       const uint8_t* key_mask, const void* o_saved, int64_t o_row_stride, int64_t o_batch_stride,
-                       const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats,
+                       const uint8_t* key_mask, const int32_t* key_info, const void* o_saved, int64_t o_row_stride,
+                       int64_t o_batch_stride, const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats,
                        const uint16_t* keep_bits, float* aux, void* dq, void* dk, void* dv, int64_t g_row_stride,
                        int64_t g_batch_stride, float* dbias_q, float* dbias_k, float* dbias_v, int B, int H, int t, float alpha,
                        float p, void* stream);

@@ -514,7 +514,11 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
     stats = torch.full((B, H, t, 2), float("nan"), device="cuda")
     p_batch = NL * H * t * tp
     keep = torch.empty(ops.flash_attn_keep_words(B, H, t), dtype=torch.int16, device="cuda") if p > 0 else None
-    ops.flash_attn_fwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), stats, keep, t, dk ** -0.5, p_batch, p, rng, 11)
+    # with dropout: the mask rows scanned once (fs2_flash_attn_mask_info); without: every workgroup scans its own row
+    kinfo = ops.flash_mask_info(km.cuda()) if p > 0 else None
+    if kinfo is not None:
+        assert kinfo.cpu().tolist() == [[n, n] for n in lens]
+    ops.flash_attn_fwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), stats, keep, t, dk ** -0.5, p_batch, p, rng, 11, key_info=kinfo)
     # the oracle composition rounds the scores to bf16 before the softmax (as the unfused reference does in bf16), this path
     # keeps them in fp32: compare against the scale of the output
     err = float((O.float().cpu() - O_ref.float()).abs().max() / O_ref.float().abs().amax().clamp_min(1e-2))
@@ -540,7 +544,7 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
     aux = torch.empty((B, H, t, 4), device="cuda")
     dbias = [torch.full((H * dk,), 0.5, device="cuda") for _ in range(3)]         # accumulated into: += column sums
     ops.flash_attn_bwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), g.permute(0, 2, 1, 3), stats, keep, aux, dq, dk_, dv, t, dk ** -0.5, p,
-                       dbias=dbias)
+                       dbias=dbias, key_info=kinfo)
     for x, j, n in zip(dbias, (0, 2, 1), ("dbias_q", "dbias_k", "dbias_v")):
         # the kernel sums its fp32 accumulators, the comparison sums the bf16 rows it stored: B*t rounding errors of 2^-9 relative
         # (the k column sums are exactly zero in real arithmetic -- sum_k dS = 0 -- so there this noise is all there is)

@@ -307,6 +307,7 @@ class EncoderStackFunction(torch.autograd.Function):
             stats = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
             # dropout keep-bits, one bit per probability (the only (t x t)-sized state of this mode: t*t/8 bytes per head)
             keep = torch.empty((N, ops.flash_attn_keep_words(B, H, t)), dtype=torch.int16, device=dev) if p_att > 0 else None
+            kinfo = ops.flash_mask_info(km)          # first masked key / last unmasked key of every row: one scan for the 3N kernels
         else:
             attn = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
             attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if p_att > 0 else attn
@@ -332,7 +333,7 @@ class EncoderStackFunction(torch.autograd.Function):
                 if pregen and i == 1:
                     rt.side_join()
                 ops.flash_attn_fwd(q, k, v, km, O4, stats[i], keep[i] if keep is not None else None, t, scale, N * H * t * tp, p_att,
-                                   rng, layer.site_attn, pregenerated=pregen and i >= 1)
+                                   rng, layer.site_attn, pregenerated=pregen and i >= 1, key_info=kinfo)
             elif ops.attn_probs_supported(t, dk, T):    # scores stay in LDS (one kernel)
                 S, Pd = attn[:, i], attn_drop[:, i]
                 pv = ops.attn_second_product_supported(dk)
@@ -364,7 +365,7 @@ class EncoderStackFunction(torch.autograd.Function):
 
         ctx.enc, ctx.sv, ctx.layers, ctx.attn, ctx.attn_drop = enc, sv, layers, attn, attn_drop
         ctx.src, ctx.km = src, km
-        ctx.flash, ctx.stats, ctx.keep = flash, (stats if flash else None), (keep if flash else None)
+        ctx.flash, ctx.stats, ctx.keep, ctx.kinfo = flash, (stats if flash else None), (keep if flash else None), (kinfo if flash else None)
         ctx.set_materialize_grads(False)
         attn_out = attn_drop[..., :t] if not flash else torch.empty(0, dtype=T, device=dev)
         ctx.mark_non_differentiable(attn_out)
@@ -424,7 +425,8 @@ class EncoderStackFunction(torch.autograd.Function):
             if flash:                                   # probabilities recomputed from q, k and the row statistics
                 ops.flash_attn_bwd(q, k, v, ctx.km, L["O"].permute(0, 2, 1, 3), dO4, ctx.stats[i],
                                    ctx.keep[i] if ctx.keep is not None else None, aux, dq, dk_, dv, t, scale, p,
-                                   dbias=[grad_of(lin.bias) for lin in (at.q_linear, at.k_linear, at.v_linear)])   # bias sums fused
+                                   dbias=[grad_of(lin.bias) for lin in (at.q_linear, at.k_linear, at.v_linear)],   # bias sums fused
+                                   key_info=ctx.kinfo)
             else:
                 P, Pd = ctx.attn[:, i], ctx.attn_drop[:, i]
                 ops.bmm(Pd, dO4, dv, trans_a=True, trans_b=False)             # dV = Pd^T dO

@@ -164,6 +164,7 @@ struct FlashArgs {
     int64_t row, batch;                 // element strides of q / k / v (one fused projection tensor)
     int head;
     const uint8_t* key_mask;            // (B, t)
+    const int32_t* kinfo;               // optional (B, 2): {kfull, kmax} of every batch row (fs2_flash_attn_mask_info), or nullptr
     bf16_t* O;                          // attention output (written by forward, read by backward), rows at O + b*o_batch + i*o_row + h*head
     int64_t o_row, o_batch;
     float* stats;                       // (B, H, t, 2): {row maximum of the masked scaled scores, sum of exponentials}
@@ -211,6 +212,27 @@ __device__ __forceinline__ void scan_mask(const uint8_t* km_row, int t, unsigned
         }
     }
     __syncthreads();
+}
+
+// the same with kfull / kmax already known (fs2_flash_attn_mask_info ran once for the whole stack): only the LDS copy of the mask
+// row, no atomics and no barrier of its own (the prologue's closing barrier orders the copy before its first reader)
+template <int NT = 512>
+__device__ __forceinline__ void mask_setup(const FlashArgs& a, int b, int t, unsigned char* lmask, int* red, int tid, int& kfull, int& kmax) {
+    if (a.kinfo != nullptr) {
+        const uint8_t* km_row = a.key_mask + (int64_t)b * t;
+        for (int j = tid; j < MASK_BYTES; j += NT) lmask[j] = j < t ? km_row[j] : 0;
+        kfull = a.kinfo[2 * b];
+        kmax = a.kinfo[2 * b + 1];
+    } else {
+        scan_mask<NT>(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
+        kfull = red[0];
+        kmax = red[1];
+    }
+}
+__global__ __launch_bounds__(512) void flash_mask_info_k(const uint8_t* __restrict__ key_mask, int t, int32_t* __restrict__ info) {
+    __shared__ int red[2];
+    scan_mask<512>(key_mask + (int64_t)blockIdx.x * t, t, nullptr, red, threadIdx.x);
+    if (threadIdx.x < 2) info[2 * blockIdx.x + threadIdx.x] = red[threadIdx.x];
 }
 
 // stage one 64-row tile with NW waves: instruction i of wave w covers tile rows 4*(NW i + w) .. +3; lane -> row lane>>4, logical
@@ -301,8 +323,8 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = ld16(rs_q, qrow < t ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
-    scan_mask(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
-    const int kfull = red[0], kmax = red[1];
+    int kfull, kmax;
+    mask_setup<512>(a, b, t, lmask, red, tid, kfull, kmax);
     const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
 
     const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
@@ -430,8 +452,8 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
             linv[s] = 1.f / st.y;
         }
     }
-    scan_mask<FQ_THREADS>(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
-    const int kfull = red[0], kmax = red[1];
+    int kfull, kmax;
+    mask_setup<FQ_THREADS>(a, b, t, lmask, red, tid, kfull, kmax);
     const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
     // per query for the dK/dV kernel: {-m log2 e, 1/l, delta, kmax of this batch row (as bits: saves that kernel the mask scan)}
 #pragma unroll
@@ -735,8 +757,8 @@ int flash_grid(int B, int H, int t) { return 8 * ((B * H + 7) / 8) * ((t + 127) 
 extern "C" int64_t fs2_flash_attn_keep_words(int B, int H, int t) { return (int64_t)B * H * ((t + 63) / 64) * t * 4; }
 
 extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
-                                  const uint8_t* key_mask, void* o_out, int64_t o_row_stride, int64_t o_batch_stride, float* stats,
-                                  uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
+                                  const uint8_t* key_mask, const int32_t* key_info, void* o_out, int64_t o_row_stride, int64_t o_batch_stride,
+                                  float* stats, uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
                                   float p, const uint64_t* rng, uint32_t site, void* stream) {
     const int rc = check_common("fs2_flash_attn_fwd", q, k, v, row_stride, batch_stride, head_stride, B, H, t, p, keep_bits);
     if (rc != FS2_OK) return rc;
@@ -746,7 +768,7 @@ extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, i
     FS2_REQUIRE(p == 0.f || pregenerated || rng != nullptr, "fs2_flash_attn_fwd: dropout needs rng");
     FlashArgs a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.row = row_stride; a.batch = batch_stride; a.head = head_stride;
-    a.key_mask = key_mask; a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.stats = stats; a.keep = keep_bits;
+    a.key_mask = key_mask; a.kinfo = key_info; a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.stats = stats; a.keep = keep_bits;
     a.p_batch = p_batch_stride; a.B = B; a.H = H; a.t = t; a.tp = tp; a.nkt = (t + 63) / 64; a.alpha = alpha; a.pdrop = p; a.rng = rng; a.site = site;
     const int lds = 4 * TILE + MASK_BYTES + 16;
     static bool attr_set = false;
@@ -760,6 +782,13 @@ extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, i
     else if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<1>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(flash_fwd_k<0>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
     FS2_CHECK_LAUNCH("fs2_flash_attn_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, int32_t* info, void* stream) {
+    FS2_REQUIRE(key_mask && info && B > 0 && t > 0 && t <= MASK_BYTES, "fs2_flash_attn_mask_info: bad arguments");
+    hipLaunchKernelGGL(flash_mask_info_k, dim3(B), dim3(512), 0, (hipStream_t)stream, key_mask, t, info);
+    FS2_CHECK_LAUNCH("fs2_flash_attn_mask_info");
     return FS2_OK;
 }
 
@@ -777,7 +806,8 @@ extern "C" int fs2_flash_attn_keep_bits(uint16_t* keep_bits, int64_t p_batch_str
 }
 
 extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
-                                  const uint8_t* key_mask, const void* o_saved, int64_t o_row_stride, int64_t o_batch_stride,
+                                  const uint8_t* key_mask, const int32_t* key_info, const void* o_saved, int64_t o_row_stride,
+                                  int64_t o_batch_stride,
                                   const void* d_out, int64_t do_row_stride, int64_t do_batch_stride, const float* stats,
                                   const uint16_t* keep_bits, float* aux, void* dq, void* dk, void* dv, int64_t g_row_stride,
                                   int64_t g_batch_stride, float* dbias_q, float* dbias_k, float* dbias_v, int B, int H, int t, float alpha,
@@ -793,7 +823,7 @@ extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, i
                 "fs2_flash_attn_bwd: one (batch, head) slice exceeds 2 GiB");
     FlashArgs a = {};
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.row = row_stride; a.batch = batch_stride; a.head = head_stride;
-    a.key_mask = key_mask; a.O = (bf16_t*)const_cast<void*>(o_saved); a.o_row = o_row_stride; a.o_batch = o_batch_stride;
+    a.key_mask = key_mask; a.kinfo = key_info; a.O = (bf16_t*)const_cast<void*>(o_saved); a.o_row = o_row_stride; a.o_batch = o_batch_stride;
     a.stats = const_cast<float*>(stats); a.keep = const_cast<uint16_t*>(keep_bits);
     a.B = B; a.H = H; a.t = t; a.tp = (t + 7) / 8 * 8; a.nkt = (t + 63) / 64; a.alpha = alpha; a.pdrop = p;
     a.dO = (const bf16_t*)d_out; a.do_row = do_row_stride; a.do_batch = do_batch_stride; a.aux = aux;

@@ -77,10 +77,11 @@ SIGNATURES = {
     "fs2_attn_probs_lds_bytes": [_I, _I],
     "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P, _P, _L, _L, _P],
     "fs2_flash_attn_keep_words": [_I, _I, _I],          # returns int64
-    "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _P, _I, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
+    "fs2_flash_attn_mask_info": [_P, _I, _I, _P, _P],
+    "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _I, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
     "fs2_flash_attn_keep_bits": [_P, _L, _I, _I, _I, _I, _F, _P, _U32, _P],
-    "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _F, _F,
-                           _P],
+    "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _F,
+                           _F, _P],
     "fs2_attn_ds_bwd": [_P, _L, _L, _P, _L, _L, _I, _I, _P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _U32, _P, _P, _L, _L, _F, _P],
     "fs2_softmax_bwd": [_P, _L, _P, _L, _I, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_length_regulate_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -733,6 +734,16 @@ def flash_attn_keep_words(B, H, t):
     return int(lib().fs2_flash_attn_keep_words(int(B), int(H), int(t)))
 
 
+def flash_mask_info(key_mask):
+    """(B, 2) int32 {number of leading unmasked keys, last unmasked key + 1} of every row of a (B, t) key mask: computed once per
+    stack and handed to every flash_attn_fwd / _bwd call as key_info"""
+    km = _c(key_mask)
+    B, t = km.shape
+    info = torch.empty((B, 2), dtype=torch.int32, device=km.device)
+    _check(lib().fs2_flash_attn_mask_info(_p(km), B, t, _p(info), _stream()), "fs2_flash_attn_mask_info")
+    return info
+
+
 def flash_keep_bits(keep, B, H, t, p_batch, p, rng, site):
     """draw the dropout keep-bits of one flash_attn_fwd call ahead of time (pass pregenerated=True to that call)"""
     assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t) and p > 0
@@ -740,7 +751,7 @@ def flash_keep_bits(keep, B, H, t, p_batch, p, rng, site):
            "fs2_flash_attn_keep_bits")
 
 
-def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0, rng=None, site=0, pregenerated=False):
+def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0, rng=None, site=0, pregenerated=False, key_info=None):
     """out = dropout_p(softmax(mask_keys(alpha q k^T))) v without the probabilities in HBM; stats (B,H,t,2) fp32 = row maximum
     and sum of exponentials; keep: int16 tensor of flash_attn_keep_words(B,H,t) words receiving the dropout keep-bits (None when
     p == 0).  q, k, v: (B,H,t,128) views of the fused projection; out: (B,H,t,128) view of a (B,t,H,128) tensor; p_batch: batch
@@ -751,12 +762,12 @@ def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0
     assert stats.numel() == B * H * t * 2 and dk == 128
     if p > 0:
         assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t)
-    _check(lib().fs2_flash_attn_fwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(out),
+    _check(lib().fs2_flash_attn_fwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(key_info), _p(out),
                                     out.stride(2), out.stride(0), _p(stats), _p(keep) if p > 0 else None, int(bool(pregenerated)), int(p_batch), B, H, t,
                                     (t + 7) // 8 * 8, float(alpha), p, _rng_ptr(rng, p), site, _stream()), "fs2_flash_attn_fwd")
 
 
-def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv, t, alpha, p=0.0, dbias=None):
+def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv, t, alpha, p=0.0, dbias=None, key_info=None):
     """backward of flash_attn_fwd: dq, dk_, dv (B,H,t,128) views with common strides; keep: the forward's keep-bits; aux:
     (B,H,t,4) fp32 workspace; dbias: optional (dbias_q, dbias_k, dbias_v) fp32 vectors of H*128 that receive += the column sums of
     dq / dk / dv (the projections' bias gradients)."""
@@ -770,7 +781,7 @@ def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv,
         assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t)
     if dbias is not None:
         assert all(x.dtype == torch.float32 and x.is_contiguous() and x.numel() == H * dk for x in dbias)
-    _check(lib().fs2_flash_attn_bwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(out),
+    _check(lib().fs2_flash_attn_bwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(key_info), _p(out),
                                     out.stride(2), out.stride(0), _p(d_out), d_out.stride(2), d_out.stride(0), _p(stats),
                                     _p(keep) if p > 0 else None, _p(aux), _p(dq), _p(dk_), _p(dv), dq.stride(2), dq.stride(0),
                                     *((_p(x) for x in dbias) if dbias is not None else (None, None, None)), B, H, t,
