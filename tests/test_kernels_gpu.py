@@ -860,10 +860,12 @@ def test_adam_with_kernel_layout_conv_gradients(ops):
     perm = torch.tensor(segs, dtype=torch.int64)
     hyper = torch.tensor([1e-3, 1 - 0.9, 1 - 0.98, 1.0])
     res = []
+    # ONE squared norm for both runs: the sum's rounding depends on the element order (and on the arrival order of the blocks'
+    # atomics), and the clip factor derived from it scales every element -- the comparison below is about the gather alone
+    gsq = torch.zeros(1).cuda()
+    ops.sqnorm(g_ref.cuda(), gsq)
     for g, pm in ((g_ref, None), (g_arena, perm)):
         p, m, v = p0.cuda(), m0.cuda(), v0.cuda()
-        gsq = torch.zeros(1).cuda()
-        ops.sqnorm(g.cuda(), gsq)
         ops.adam_step(p, g.cuda(), m, v, hyper.cuda(), gsq, 0.9, 0.98, 1e-9, 1.0, perm=pm.cuda() if pm is not None else None)
         res.append((p.cpu(), m.cpu(), v.cpu()))
     for a, b in zip(*res):

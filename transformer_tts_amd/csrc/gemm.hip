@@ -362,9 +362,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const FS2Gemm p, const int
                         if (cl < WT && n < p.N) {
                             float bias1 = 0.f;
                             if (p.bias != nullptr && cur.split == 0) bias1 = p.bias[n];
-                            for (int rl = 0; rl < WT; ++rl) {
+                            for (int r0 = 0; r0 < WT; ++r0) {
+                                const int rl = (r0 + 4 * cur.split) & (WT - 1);   // splits of one tile walk its rows out of phase
                                 const int m = cur.m0 + wr * WT + rl;
-                                if (m >= p.M) break;
+                                if (m >= p.M) continue;
                                 atomicAdd(reinterpret_cast<float*>(C) + (int64_t)m * p.ldc + n, ew[rl * EPI_LD + cl] * p.alpha + bias1);
                             }
                         }

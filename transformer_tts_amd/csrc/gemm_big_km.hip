@@ -49,7 +49,7 @@ __device__ __forceinline__ bf16x8 km_frag(const unsigned char* img, int o0, int 
 extern thread_local int g_last_tile;     // gemm.hip
 
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
-                                                                  const int nitems) {
+                                                                  const int nitems, const int rot_step) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
     const int lda = (int)p.lda, ldb = (int)p.ldb;
     const int seq = p.seq_len;
 
-    struct Item { int m0, n0, tap, st0, st1; int64_t aoff, boff, coff; };
+    struct Item { int m0, n0, tap, st0, st1, rot; int64_t aoff, boff, coff; };
     auto decode = [&](int j) {
         // item number -> (tile fastest, then k-split, then tap, then batch): neighbours share the reduction range
         Item it;
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
         const int b2 = z % nb2, b1 = z / nb2;
         it.m0 = (tile / tilesN) * TM; it.n0 = (tile % tilesN) * TN;
         it.st0 = sp * per; it.st1 = min(nstk, it.st0 + per);
+        it.rot = (sp * rot_step) & (TM - 1);     // the splits of one tile flush its rows in different orders (below)
         const int c2 = p.conv == 2 ? it.tap : b2;
         it.aoff = b1 * p.sA1 + (p.conv == 2 ? 0 : b2 * p.sA2);
         it.boff = b1 * p.sB1 + (p.conv == 2 ? 0 : b2 * p.sB2);
@@ -210,7 +211,8 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
         float* __restrict__ C = reinterpret_cast<float*>(p.C) + ck.coff;
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
-            const int row = wave * 8 + rr;
+            const int row = (wave * 8 + rr + ck.rot) & (TM - 1);       // rotated per split: the 16-64 workgroups of one tile do not
+                                                                       // pile their atomics onto the same addresses at the same moment (-5 %)
             const int m = ck.m0 + row;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -260,7 +262,8 @@ bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     const long per_x = (nitems + 7) / 8;
     const int grid = 8 * (int)(per_x < 32 ? per_x : 32);
     g_last_tile = 129;          // (measurement aid: the 16-wave weight-gradient kernel)
-    hipLaunchKernelGGL(fs2_gemm_big_km_kernel, dim3(grid), dim3(NT), SMEM, st, g, tilesM, tilesN, splits, (int)nitems);
+    static const int rot_step = getenv("FS2_KM_ROT") ? atoi(getenv("FS2_KM_ROT")) : 4;
+    hipLaunchKernelGGL(fs2_gemm_big_km_kernel, dim3(grid), dim3(NT), SMEM, st, g, tilesM, tilesN, splits, (int)nitems, rot_step);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { fs2_set_error("fs2_gemm(big km): launch failed: %s", hipGetErrorString(e_)); *rc = FS2_ELAUNCH; return true; }
     *rc = FS2_OK;
