@@ -240,9 +240,10 @@ __global__ __launch_bounds__(RED_BLOCK) void add_ln_bwd_k(const float* __restric
     }
     const float invd = 1.f / (float)d;
     RED_LOOP(M) {
-        float4 g_[NG], xv[NG];
+        float4 g_[NG], xv[NG], dn[NG];
         row_load<NG, T>(dy + row * d, d, lane, g_);
         row_load<NG, float>(s + row * d, d, lane, xv);
+        if (ds_down != nullptr) row_load<NG, float>(ds_down + row * d, d, lane, dn);     // requested with the others, used after the reduction
         const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -260,8 +261,7 @@ __global__ __launch_bounds__(RED_BLOCK) void add_ln_bwd_k(const float* __restric
         }
         c1 = wave_sum(c1) * invd;
         c2 = wave_sum(c2) * invd;
-        float4 o[NG], dn[NG];
-        if (ds_down != nullptr) row_load<NG, float>(ds_down + row * d, d, lane, dn);
+        float4 o[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2); o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2);
@@ -447,10 +447,15 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restr
     const float invd = 1.f / (float)d;
     RED_LOOP(M) {
         // ---- LN2 backward + residual + dropout2'  (add_ln_bwd_k)
-        float4 g_[NG], xv[NG];
+        // every operand of the row is requested before the first reduction: one memory round trip per row instead of three
+        float4 g_[NG], xv[NG], dn[NG], fv[NG], hv[NG];
         row_load<NG, T>(dy + row * d, d, lane, g_);
         row_load<NG, float>(s + row * d, d, lane, xv);
+        if (ds_down != nullptr) row_load<NG, float>(ds_down + row * d, d, lane, dn);
+        row_load<NG, T>(f2 + row * d, d, lane, fv);
+        row_load<NG, T>(h + row * d, d, lane, hv);
         float mu = mean2[row], rs = rstd2[row];
+        const float mu1 = mean1[row], rs1 = rstd1[row];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -467,8 +472,7 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restr
         }
         c1 = wave_sum(c1) * invd;
         c2 = wave_sum(c2) * invd;
-        float4 o[NG], dn[NG];
-        if (ds_down != nullptr) row_load<NG, float>(ds_down + row * d, d, lane, dn);
+        float4 o[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2); o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2);
@@ -482,10 +486,8 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restr
             o[g] = round_to<T>(o[g]);                        // d(yff) as the two-kernel form stores it
         }
         // ---- LN1 backward + dropout1'  (ffn_ln_bwd_k with dy = o)
-        float4 fv[NG], hv[NG], ds[NG];
-        row_load<NG, T>(f2 + row * d, d, lane, fv);
-        row_load<NG, T>(h + row * d, d, lane, hv);
-        mu = mean1[row]; rs = rstd1[row];
+        float4 ds[NG];
+        mu = mu1; rs = rs1;
         c1 = 0.f; c2 = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
