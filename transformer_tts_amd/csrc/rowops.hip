@@ -139,9 +139,10 @@ __global__ __launch_bounds__(RED_BLOCK) void layernorm_bwd_k(const TDY* __restri
     }
     const float invd = 1.f / (float)d;
     RED_LOOP(M) {
-        float4 g_[NG], xv[NG];
+        float4 g_[NG], xv[NG], old[NG];
         row_load<NG, TDY>(dy + row * d, d, lane, g_);
         row_load<NG, TX>(x + row * d, d, lane, xv);
+        if (dx_accumulate) row_load<NG, TDX>(dx + row * d, d, lane, old);      // requested with the others, used after the reduction
         const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
         unsigned pos[NG];
@@ -176,8 +177,6 @@ __global__ __launch_bounds__(RED_BLOCK) void layernorm_bwd_k(const TDY* __restri
             ac[g] = add4(ac[g], o[g]);
         }
         if (dx_accumulate) {
-            float4 old[NG];
-            row_load<NG, TDX>(dx + row * d, d, lane, old);
 #pragma unroll
             for (int g = 0; g < NG; ++g) o[g] = add4(o[g], old[g]);
         }
@@ -881,7 +880,8 @@ __global__ __launch_bounds__(RED_BLOCK) void linear1_bwd_k(const float* __restri
     }
     float ab = 0.f;
     RED_LOOP(M) {
-        const float go = mask[row] ? dout[row] : 0.f;
+        const float dout_row = dout[row];             // unconditional: both loads leave together
+        const float go = mask[row] ? dout_row : 0.f;
         float4 v[NG], o[NG];
         row_load<NG, T>(x + row * d, d, lane, v);
 #pragma unroll
@@ -958,7 +958,8 @@ __global__ __launch_bounds__(RED_BLOCK) void ln_linear1_bwd_k(const float* __res
     const float invd = 1.f / (float)d;
     float abias = 0.f;
     RED_LOOP(M) {
-        const float go = mask[row] ? dout[row] : 0.f;
+        const float dout_row = dout[row];             // unconditional: both loads leave together
+        const float go = mask[row] ? dout_row : 0.f;
         float4 xv[NG], g_[NG];
         row_load<NG, T>(x + row * d, d, lane, xv);
         const float mu = mean[row], rs = rstd[row];
