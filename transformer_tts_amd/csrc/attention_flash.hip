@@ -43,6 +43,10 @@ constexpr int AUX_BYTES = 64 * 16;      // dK/dV kernel: {m, 1/l, delta, -} of t
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFF0, 0x00020000);
 }
+// rows of 128 bf16 at a stride of row_stride elements: a 16-byte read that starts past row rows-1 returns zeros
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_rows(const void* p, int rows, int row_stride) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (rows - 1) * row_stride * 2 + 256, 0x00020000);
+}
 __device__ __forceinline__ bf16x8 ld16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
 }
@@ -84,6 +88,28 @@ template <int OFF> __device__ __forceinline__ bf16x8 tr_frag(const FragAddr& fa,
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s16x4*>(fa.tr[ct] + OFF + 16 * 256));
     union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
     u.s.lo = lo; u.s.hi = hi;
+    return u.v;
+}
+// The same through inline assembly, for the phases that run while the next tile's LDS-DMA is in flight: the builtin carries no
+// address information, so hipcc puts an `s_waitcnt vmcnt(0)` in front of the first transposed read that follows a DMA issue (it must
+// assume the DMA writes what the read reads) -- the prefetch then has to land in the middle of the tile it was meant to hide behind.
+// Issue and wait are separate statements so that the reads of fragment d+1 can be in flight while fragment d feeds its MFMA: the
+// wait takes the fragment as an in/out operand, which is what orders the consumer after it.  (LDS operations return in order, so
+// lgkmcnt(2) = "everything but the two reads issued last".)
+struct TrFrag { s16x4 lo, hi; };
+template <int OFF> __device__ __forceinline__ void tr_issue(const FragAddr& fa, int ct, TrFrag& f) {
+    if constexpr (OFF + 4096 < 65536) {
+        asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                     : "=&v"(f.lo), "=&v"(f.hi) : "v"(fa.tr[ct]), "n"(OFF), "n"(OFF + 4096));
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096"
+                     : "=&v"(f.lo), "=&v"(f.hi) : "v"(fa.tr[ct] + OFF));
+    }
+}
+template <int PENDING> __device__ __forceinline__ bf16x8 tr_wait(TrFrag& f) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(PENDING));
+    union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+    u.s.lo = f.lo; u.s.hi = f.hi;
     return u.v;
 }
 // 16 x 16 product tile over the 128 columns: rows r0.. of the LDS image (OFF = image offset + 256 r0) against the register
@@ -238,16 +264,20 @@ __global__ __launch_bounds__(512) void flash_mask_info_k(const uint8_t* __restri
 // stage one 64-row tile with NW waves: instruction i of wave w covers tile rows 4*(NW i + w) .. +3; lane -> row lane>>4, logical
 // chunk (lane&15) ^ f(row); rows >= t use an out-of-range offset (zeros)
 template <int NW = 8>
-__device__ __forceinline__ void stage_tile(const __amdgpu_buffer_rsrc_t rs, unsigned char* dst, int row0, int t, int row_stride,
-                                           int wave, int lane) {
+__device__ __forceinline__ void stage_tile(const __amdgpu_buffer_rsrc_t rs, unsigned char* dst, int row0, int row_stride, int wave,
+                                           unsigned voff0) {
+    __builtin_assume(wave >= 0 && wave < NW);      // the writes stay inside this one image (alias analysis of the LDS reads that follow)
 #pragma unroll
-    for (int i = 0; i < 16 / NW; ++i) {
-        const int r = 4 * (NW * i + wave) + (lane >> 4);
-        const int ch = (lane & 15) ^ img_f(r);
-        const int row = row0 + r;
+    for (int i = 0; i < 16 / NW; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + 1024 * (NW * i + wave)), 16,
-                                                 (int)(row < t ? (unsigned)((row * row_stride + ch * 8) * 2) : OOB), 0, 0, 0);
-    }
+                                                 (int)(voff0 + (unsigned)((row0 + 4 * NW * i) * row_stride * 2)), 0, 0, 0);
+}
+// the lane's share of that: row 4 wave + lane/16 of the first instruction, chunk (lane&15) ^ f(row) -- the later instructions are
+// 4 NW rows further on (same low row bits, same chunk), so ONE per-lane offset serves a whole kernel: the scalar part carries the
+// tile and the instruction.  Rows >= t are cut off by the descriptor (make_rsrc_rows): no per-lane compare, nothing to spill.
+__device__ __forceinline__ unsigned stage_voff(int row_stride, int wave, int lane) {
+    const int r = 4 * wave + (lane >> 4);
+    return (unsigned)((r * row_stride + (((lane & 15) ^ img_f(r)) << 3)) * 2);
 }
 
 __device__ __forceinline__ float and_mask(float v, int msk) { return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & msk); }
@@ -316,10 +346,11 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     int* red = reinterpret_cast<int*>(smem + 4 * TILE + MASK_BYTES);
     const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
     const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
-    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
     const int rowst = (int)a.row;
-    stage_tile(rs_k, kimg, 0, t, rowst, wave, lane);
-    stage_tile(rs_v, vimg, 0, t, rowst, wave, lane);
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc_rows(a.k + hb, t, rowst), rs_v = make_rsrc_rows(a.v + hb, t, rowst);
+    const unsigned voff0 = stage_voff(rowst, wave, lane);
+    stage_tile(rs_k, kimg, 0, rowst, wave, voff0);
+    stage_tile(rs_v, vimg, 0, rowst, wave, voff0);
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = ld16(rs_q, qrow < t ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
@@ -343,8 +374,8 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
         constexpr int KOFF = BUF * TILE, VOFF = 2 * TILE + BUF * TILE;
         unsigned mybits = bits_next;
         if (kt + 1 < nkt) {
-            stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
-            stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), rowst, wave, voff0);
+            stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), rowst, wave, voff0);
             if (DROP == 2) bits_next = keep[(int64_t)(kt + 1) * t * 4];
         }
         if (DROP == 1) {                  // keep-bits of query i16, keys 64kt + 16g .. +15; stashed for the backward kernels
@@ -379,10 +410,16 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
         }
         // ---- O^T += V^T P^T: k-step kp covers the keys of score tiles 2kp, 2kp+1 (in the accumulators' own order)
         const bf16x8 pb0 = pack8(x[0], x[1]), pb1 = pack8(x[2], x[3]);
+        // sixteen V fragments, read one ahead: the reads of fragment n+1 are in flight while fragment n feeds its MFMA
+        TrFrag vf[2];
+        tr_issue<VOFF>(fa, 0, vf[0]);
 #pragma unroll
-        for (int d = 0; d < 8; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VOFF>(fa, d), pb0, oacc[d], 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < 8; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<VOFF + 8192>(fa, d), pb1, oacc[d], 0, 0, 0);
+        for (int n = 0; n < 16; ++n) {
+            if (n + 1 < 8) tr_issue<VOFF>(fa, n + 1, vf[(n + 1) & 1]);
+            else if (n + 1 < 16) tr_issue<VOFF + 8192>(fa, n + 1 - 8, vf[(n + 1) & 1]);
+            const bf16x8 v8 = n + 1 < 16 ? tr_wait<2>(vf[n & 1]) : tr_wait<0>(vf[n & 1]);
+            oacc[n & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v8, n < 8 ? pb0 : pb1, oacc[n & 7], 0, 0, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     for (int kt = 0; kt < nkt; kt += 2) {
@@ -424,12 +461,14 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
     int* red = reinterpret_cast<int*>(smem + 4 * TILE + MASK_BYTES);
     const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
     const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
-    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb);
     const __amdgpu_buffer_rsrc_t rs_do = make_rsrc(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head);
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.O + (int64_t)b * a.o_batch + (int64_t)h * a.head);
     const int rowst = (int)a.row;
-    stage_tile<FQ_WAVES>(rs_k, kimg, 0, t, rowst, wave, lane);
-    stage_tile<FQ_WAVES>(rs_v, vimg, 0, t, rowst, wave, lane);
+    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc_rows(a.k + hb, t, rowst), rs_v = make_rsrc_rows(a.v + hb, t, rowst);
+    const unsigned voff0 = stage_voff(rowst, wave, lane);
+    stage_tile<FQ_WAVES>(rs_k, kimg, 0, rowst, wave, voff0);
+    stage_tile<FQ_WAVES>(rs_v, vimg, 0, rowst, wave, voff0);
 
     bf16x8 qf[2][4], dof[2][4];
     float delta[2], nm2[2] = {0.f, 0.f}, linv[2] = {0.f, 0.f};
@@ -480,8 +519,8 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
         constexpr int KOFF = BUF * TILE, VOFF = 2 * TILE + BUF * TILE;
         const unsigned mybits[2] = {bits_next[0], bits_next[1]};
         if (kt + 1 < nkt) {
-            stage_tile<FQ_WAVES>(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
-            stage_tile<FQ_WAVES>(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), t, rowst, wave, lane);
+            stage_tile<FQ_WAVES>(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), rowst, wave, voff0);
+            stage_tile<FQ_WAVES>(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), rowst, wave, voff0);
             if (DROP) {
                 bits_next[0] = keep[((int64_t)(kt + 1) * t + qc0) * 4];
                 bits_next[1] = keep[((int64_t)(kt + 1) * t + qc1) * 4];
@@ -533,9 +572,12 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
             };
             one(IC<0>{}); one(IC<1>{});
             const bf16x8 dsa = pack8(ds[0][0], ds[0][1]), dsb = pack8(ds[1][0], ds[1][1]);
+            TrFrag kf_[2];                  // K fragments read one ahead of the MFMA pair they feed
+            tr_issue<KOFF + 8192 * kp>(fa, 0, kf_[0]);
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
-                const bf16x8 kfrag = tr_frag<KOFF + 8192 * kp>(fa, d);
+                if (d + 1 < 8) tr_issue<KOFF + 8192 * kp>(fa, d + 1, kf_[(d + 1) & 1]);
+                const bf16x8 kfrag = d + 1 < 8 ? tr_wait<2>(kf_[d & 1]) : tr_wait<0>(kf_[d & 1]);
                 dqacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, dsa, dqacc[0][d], 0, 0, 0);
                 dqacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, dsb, dqacc[1][d], 0, 0, 0);
             }
@@ -595,8 +637,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     unsigned char* auximg = smem + 4 * TILE;            // [2][AUX_BYTES]
     const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
     const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
-    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
-    const __amdgpu_buffer_rsrc_t rs_do = make_rsrc(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head);
+    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
     const __amdgpu_buffer_rsrc_t rs_aux = make_rsrc(a.aux + (((int64_t)b * a.H + h) * t) * 4);
     const int rowst = (int)a.row, dorow = (int)a.do_row;
     const bool kvalid = key < t;
@@ -615,9 +656,12 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
         return;
     }
 
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc_rows(a.q + hb, t, rowst);
+    const __amdgpu_buffer_rsrc_t rs_do = make_rsrc_rows(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head, t, dorow);
+    const unsigned voff_q = stage_voff(rowst, wave, lane), voff_do = stage_voff(dorow, wave, lane);
     auto stage = [&](int qt, int buf) {
-        stage_tile(rs_q, qimg + buf * TILE, 64 * qt, t, rowst, wave, lane);
-        stage_tile(rs_do, doimg + buf * TILE, 64 * qt, t, dorow, wave, lane);
+        stage_tile(rs_q, qimg + buf * TILE, 64 * qt, rowst, wave, voff_q);
+        stage_tile(rs_do, doimg + buf * TILE, 64 * qt, dorow, wave, voff_do);
         if (wave == 0) {
             const int q = 64 * qt + lane;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_aux, (lds_void_t*)(auximg + buf * AUX_BYTES), 16,
