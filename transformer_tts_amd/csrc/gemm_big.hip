@@ -192,6 +192,8 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
         }
     };
 
+    // fp8 operands: the per-tensor de-quantisation factors live on the device (written by fs2_quantize_fp8); read once per launch
+    const float alpha = p.alpha * (p.scale_a != nullptr ? *p.scale_a : 1.f) * (p.scale_b != nullptr ? *p.scale_b : 1.f);
     prep_item(lj);
     issue(0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -253,8 +255,6 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, 
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) bias[4 * j + r] = __uint_as_float(braw[j][r]);
-            // fp8 operands: the per-tensor de-quantisation factors live on the device (written by fs2_quantize_fp8)
-            const float alpha = p.alpha * (p.scale_a != nullptr ? *p.scale_a : 1.f) * (p.scale_b != nullptr ? *p.scale_b : 1.f);
             float cs[STATS ? 16 : 1], cq[SUMSQ ? 16 : 1];
             if constexpr (STATS) {
 #pragma unroll
