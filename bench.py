@@ -255,7 +255,7 @@ def main():
     # so the roofline leg below re-runs a few eager, instrumented steps after the timed region
     # (also with RCCL: the all-reduces are captured into the graph; FS2_GRAPH_DP=0 keeps the multi-rank run eager)
     use_graph = not args.no_graph and ((world == 1 and not force_dp) or os.environ.get('FS2_GRAPH_DP', '1') == '1')
-    graphed = GraphedTrainStep(model, opt, hp) if use_graph else None
+    graphed = GraphedTrainStep(model, opt, hp, eager_fallback=world > 1) if use_graph else None
     run = (lambda st, b: graphed(st, b)) if use_graph else (lambda st, b: train_step(model, opt, st, b, hp))
     step = 1
     warm = max(args.warmup, 2 * POOL) if use_graph else args.warmup      # each shape: 1 eager + 1 capture before replay

@@ -172,6 +172,41 @@ def test_bf16_fast_path_learns_one_batch():
         assert last[i] < 0.7 * first[i], f"{n}: {report}"
 
 
+def test_graph_stepper_falls_back_to_eager_when_capture_fails(monkeypatch, capsys):
+    """bench.py runs the multi-GPU case through GraphedTrainStep(eager_fallback=True): if the runtime refuses to capture the step
+    (simulated here), the stepper reports it once and keeps training with eager launches instead of raising"""
+    from transformer_tts_amd.Models import functional
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd import train_fastspeech2 as T
+    batch = batch_to(CONFIGS["small"]["batch"](), "cuda")
+    functional._site_counter[0] = 9500
+    model, hp, _ = product_model("small", amp=True, dropout=0.0, device="cuda", return_attn=False)
+    opt = FusedAdam(model)
+
+    class Refuses:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            raise RuntimeError("operation not permitted when stream is capturing (simulated)")
+
+        def __exit__(self, *a):
+            return False
+
+    monkeypatch.setattr(torch.cuda, "graph", Refuses)
+    strict = T.GraphedTrainStep(model, opt, hp)
+    strict(4000, batch)
+    with pytest.raises(RuntimeError):
+        strict(4001, batch)
+    stepper = T.GraphedTrainStep(model, opt, hp, eager_fallback=True)
+    p0 = next(model.parameters()).detach().clone()
+    losses = [float(stepper(4002 + i, batch)[0].detach()) for i in range(4)]
+    assert stepper.broken and not stepper.graphs
+    assert "capture failed" in capsys.readouterr().out
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert float((next(model.parameters()).detach() - p0).abs().max()) > 0
+
+
 def _one_rank_group():
     import torch.distributed as dist
     if not dist.is_initialized():

@@ -151,18 +151,23 @@ class GraphedTrainStep:
     Padding is semantically live in this model (BatchNorm statistics and the L1 losses include padded
     positions), so batches are never padded to a common shape -- one graph per (B, L_pad, T_pad)."""
 
-    def __init__(self, model, optimizer, hp, max_graphs=32):
+    def __init__(self, model, optimizer, hp, max_graphs=32, eager_fallback=False):
         assert isinstance(optimizer, FusedAdam)
         self.model, self.optimizer, self.hp = model, optimizer, hp
         self.max_graphs = max_graphs
         self.seen, self.graphs = set(), {}
         self.pool = None
+        # eager_fallback: if a capture raises (e.g. a collective that refuses stream capture on some multi-GPU setup), say so once
+        # and run every later step eagerly instead of dying -- every rank sees the same failure, so the ranks stay in step
+        self.eager_fallback, self.broken = eager_fallback, False
 
     def __call__(self, step, d):
         _set_lr(self.optimizer, step, self.hp)
         tensors = [d[i] for i in (0, 1, 2, 3, 8, 9, 10)]       # text, mel, pos_text, pos_mel, f0, energy, alignment
         key = (tuple(tensors[0].shape), tuple(tensors[1].shape))
         entry = self.graphs.get(key)
+        if self.broken:
+            return train_step(self.model, self.optimizer, step, d, self.hp)
         if entry is None and (key not in self.seen or len(self.graphs) >= self.max_graphs):
             self.seen.add(key)
             return train_step(self.model, self.optimizer, step, d, self.hp)
@@ -179,8 +184,16 @@ class GraphedTrainStep:
             # from ANOTHER thread invalidates the capture in progress.  "thread_local" restricts the unsafe-call check to
             # the capturing thread; work submitted to the capturing stream by the autograd thread is captured either way.
             mode = os.environ.get("FS2_CAPTURE_ERROR_MODE") or ("thread_local" if _dist_alive() else "global")
-            with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
-                loss, parts = step_body(self.model, self.optimizer, self.hp, *static[:4], *static[4:])
+            try:
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
+                    loss, parts = step_body(self.model, self.optimizer, self.hp, *static[:4], *static[4:])
+            except Exception as e:      # noqa: BLE001  (whatever the runtime raises for an operation it cannot capture)
+                if not self.eager_fallback:
+                    raise
+                print(f"GraphedTrainStep: capture failed ({type(e).__name__}: {e}); continuing with eager launches", flush=True)
+                self.broken = True
+                torch.cuda.synchronize()
+                return train_step(self.model, self.optimizer, step, d, self.hp)
             entry = self.graphs[key] = (g, static, loss, parts)
         self.optimizer.host_update()
         g, static, loss, parts = entry
