@@ -148,7 +148,14 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
         const int nst = ck.st1 - ck.st0;
         for (int s = 0; s < nst; ++s) {
             const int buf = s & 1;
-            if (s + 1 < nst) issue(buf ^ 1);      // stage s+1 -> the buffer every wave finished with at the last barrier
+            // stage s+1 -> the buffer every wave finished with at the last barrier.  The vector-memory path of a CU takes ~1000
+            // cycles for the 64 KiB of a stage and a wave BLOCKS at its DMA instructions while the queue is full (shader-clock stamps:
+            // 12-27 % of a workgroup's time); with every wave issuing first, all four waves of a SIMD sat there together and the MFMA
+            // pipe idled.  Half of the waves (two per SIMD) therefore issue their share AFTER their MFMAs: -8...12 % warm, -4...7 % cold on
+            // the stand-alone products (tools/gemm_big_bench.py), 0.5 % inside the training step.
+            const bool issue_first = ((wave >> 2) & 1) != 0;
+            if (issue_first && s + 1 < nst) issue(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
             const unsigned char* la = smem + buf * STAGE;
             const unsigned char* lb = la + OP_BYTES;
             bf16x8 fa[4], fb[4];
@@ -160,6 +167,8 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);         // (or hipcc moves the late issue back up in front of the MFMAs)
+            if (!issue_first && s + 1 < nst) issue(buf ^ 1);
             // own DMA landed, own fragment reads retired; then every wave's
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
