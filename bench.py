@@ -271,15 +271,24 @@ def main():
     t0 = time.perf_counter()
     done = 0
     if args.from_host:      # the shipped trainer's input path: pinned host batches, copied one batch ahead on a second stream
-        from transformer_tts_amd.train_fastspeech2 import DevicePrefetcher
+        from transformer_tts_amd.train_fastspeech2 import STEP_INPUTS, DevicePrefetcher
         host_pool = [tuple(b.cpu().pin_memory() if torch.is_tensor(b) else b for b in bt) for bt in pool]
-        feed = DevicePrefetcher([host_pool[(warm + i) % POOL] for i in range(args.steps)], dev)
+        feed = DevicePrefetcher([host_pool[(warm + i) % POOL] for i in range(args.steps)], dev, indices=STEP_INPUTS)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i, bt in enumerate(feed):
+        _t = {"feed": 0.0, "run": 0.0}
+        _it = iter(feed)
+        for i in range(args.steps):
+            _a = time.perf_counter()
+            bt = next(_it)
+            _b = time.perf_counter()
             run(step, bt)
+            _c = time.perf_counter()
+            _t["feed"] += _b - _a; _t["run"] += _c - _b
             done += frames[(warm + i) % POOL]
             step += 1
+        if os.environ.get("FS2_BENCH_HOST_TIMES"):
+            print("host ms/step: feed %.3f run %.3f" % (_t["feed"] / args.steps * 1e3, _t["run"] / args.steps * 1e3), file=sys.stderr)
     else:
         for i in range(args.steps):
             run(step, pool[(warm + i) % POOL])

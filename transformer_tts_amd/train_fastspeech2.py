@@ -144,6 +144,9 @@ def _dist_alive():
     return dist.is_available() and dist.is_initialized()
 
 
+STEP_INPUTS = (0, 1, 2, 3, 8, 9, 10)      # entries of the collate 16-tuple a FastSpeech2 step reads: text, mel, pos_text, pos_mel, f0, energy, alignment
+
+
 class GraphedTrainStep:
     """train_step with the device work of each batch SHAPE captured once in a hipGraph and replayed:
     the ~600 kernel launches of a step stop costing host time (the step is launch-bound in Python otherwise).
@@ -163,7 +166,7 @@ class GraphedTrainStep:
 
     def __call__(self, step, d):
         _set_lr(self.optimizer, step, self.hp)
-        tensors = [d[i] for i in (0, 1, 2, 3, 8, 9, 10)]       # text, mel, pos_text, pos_mel, f0, energy, alignment
+        tensors = [d[i] for i in STEP_INPUTS]       # text, mel, pos_text, pos_mel, f0, energy, alignment
         key = (tuple(tensors[0].shape), tuple(tensors[1].shape))
         entry = self.graphs.get(key)
         if self.broken:
@@ -211,15 +214,20 @@ class DevicePrefetcher:
     copied host -> device on a separate HIP stream, so the 15.8 MB of a config-2 batch never sit on the compute stream.
     The consumer's stream waits on the copy's event when it takes the batch."""
 
-    def __init__(self, loader, device):
+    def __init__(self, loader, device, indices=None):
         self.loader, self.device = loader, device
         self.stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+        # indices: the batch entries the step reads (None = every tensor).  A host -> device copy call costs ~50 us of host time
+        # and the training thread is busy with the graph launch for the rest of the step, so the calls sit BETWEEN two steps:
+        # the four entries of the 11-tuple that the FastSpeech2 step never touches are left on the host.
+        self.indices = None if indices is None else frozenset(indices)
 
     def _stage(self, d):
         if self.stream is None:
             return d, None
         with torch.cuda.stream(self.stream):
-            out = tuple(x.to(self.device, non_blocking=True) if torch.is_tensor(x) else x for x in d)
+            out = tuple(x.to(self.device, non_blocking=True) if torch.is_tensor(x) and (self.indices is None or i in self.indices) else x
+                        for i, x in enumerate(d))
             ev = torch.cuda.Event()
             ev.record(self.stream)
         return out, ev
@@ -243,7 +251,7 @@ class DevicePrefetcher:
             cur = torch.cuda.current_stream()
             cur.wait_event(ev)
             for x in d:
-                if torch.is_tensor(x):
+                if torch.is_tensor(x) and x.is_cuda:
                     x.record_stream(cur)
         return d
 
@@ -259,7 +267,7 @@ def train_loop(model, optimizer, step, epoch, args, hp, rank, dataloader):
         if stepper is None or stepper.model is not model:
             stepper = optimizer._fs2_graphed = GraphedTrainStep(model, optimizer, hp)
         run = lambda m, o, st, d, h: stepper(st, d)
-    batches = DevicePrefetcher(dataloader, optimizer.arena.p.device) if on_gpu else dataloader
+    batches = DevicePrefetcher(dataloader, optimizer.arena.p.device, indices=STEP_INPUTS) if on_gpu else dataloader
     for d in batches:
         loss, parts, batch_size = run(model, optimizer, step, d, hp)
         if step % log_every == 0:
