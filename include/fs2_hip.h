@@ -249,8 +249,9 @@ int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_s
  *   q, k, v: rows of one head = 128 contiguous bf16 at  base + b*batch_stride + i*row_stride + h*head_stride  (elements);
  *   o / d_out / dq,dk,dv rows likewise with their own row and batch strides (dq, dk, dv share g_*_stride).           */
 int64_t fs2_flash_attn_keep_words(int B, int H, int t);
-/* {number of leading unmasked keys, last unmasked key + 1} of every batch row: info[B][2].  Optional: pass it as key_info to the
- * calls below (one scan per stack instead of one per workgroup), or NULL and every workgroup scans its mask row itself. */
+/* info[B][3]: {number of leading unmasked keys, last unmasked key + 1} of every batch row b, and in info[r][2] the batch row with
+ * the r-th longest unmasked prefix (the kernels start the longest rows first).  Optional: pass it as key_info to the calls below
+ * (one scan per stack instead of one per workgroup), or NULL: every workgroup scans its mask row itself, rows in batch order. */
 int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, int32_t* info, void* stream);
 int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                        const uint8_t* key_mask, const int32_t* key_info, void* o_out, int64_t o_row_stride, int64_t o_batch_stride,

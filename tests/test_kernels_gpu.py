@@ -517,7 +517,10 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
     # with dropout: the mask rows scanned once (fs2_flash_attn_mask_info); without: every workgroup scans its own row
     kinfo = ops.flash_mask_info(km.cuda()) if p > 0 else None
     if kinfo is not None:
-        assert kinfo.cpu().tolist() == [[n, n] for n in lens]
+        ki = kinfo.cpu()
+        assert ki[:, :2].tolist() == [[n, n] for n in lens]
+        order = ki[:, 2].tolist()       # rows ranked by length, longest first, ties in batch order
+        assert order == sorted(range(len(lens)), key=lambda i: (-lens[i], i)), order
     ops.flash_attn_fwd(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), stats, keep, t, dk ** -0.5, p_batch, p, rng, 11, key_info=kinfo)
     # the oracle composition rounds the scores to bf16 before the softmax (as the unfused reference does in bf16), this path
     # keeps them in fp32: compare against the scale of the output

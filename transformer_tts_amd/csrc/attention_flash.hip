@@ -190,7 +190,7 @@ struct FlashArgs {
     int64_t row, batch;                 // element strides of q / k / v (one fused projection tensor)
     int head;
     const uint8_t* key_mask;            // (B, t)
-    const int32_t* kinfo;               // optional (B, 2): {kfull, kmax} of every batch row (fs2_flash_attn_mask_info), or nullptr
+    const int32_t* kinfo;               // optional (B, 3): {kfull, kmax, the batch row of rank b by kmax} (fs2_flash_attn_mask_info), or nullptr
     bf16_t* O;                          // attention output (written by forward, read by backward), rows at O + b*o_batch + i*o_row + h*head
     int64_t o_row, o_batch;
     float* stats;                       // (B, H, t, 2): {row maximum of the masked scaled scores, sum of exponentials}
@@ -220,6 +220,10 @@ __device__ __forceinline__ bool flash_item(const FlashArgs& a, int& blk, int& h,
     blk = slot % nblk;
     h = pair % a.H;
     b = pair / a.H;
+    // Longest sequences first (fs2_flash_attn_mask_info ranks the batch rows by their last unmasked key): a forward / dQ workgroup
+    // costs as many key tiles as its row has, there are 1.5 workgroups per slot at config 2, and in batch order a long row could
+    // start in the second half-round.  The rank list is dealt round-robin to the XCDs like the pairs themselves.
+    if (a.kinfo != nullptr) b = a.kinfo[3 * b + 2];
     return true;
 }
 
@@ -247,8 +251,8 @@ __device__ __forceinline__ void mask_setup(const FlashArgs& a, int b, int t, uns
     if (a.kinfo != nullptr) {
         const uint8_t* km_row = a.key_mask + (int64_t)b * t;
         for (int j = tid; j < MASK_BYTES; j += NT) lmask[j] = j < t ? km_row[j] : 0;
-        kfull = a.kinfo[2 * b];
-        kmax = a.kinfo[2 * b + 1];
+        kfull = a.kinfo[3 * b];
+        kmax = a.kinfo[3 * b + 1];
     } else {
         scan_mask<NT>(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
         kfull = red[0];
@@ -258,7 +262,19 @@ __device__ __forceinline__ void mask_setup(const FlashArgs& a, int b, int t, uns
 __global__ __launch_bounds__(512) void flash_mask_info_k(const uint8_t* __restrict__ key_mask, int t, int32_t* __restrict__ info) {
     __shared__ int red[2];
     scan_mask<512>(key_mask + (int64_t)blockIdx.x * t, t, nullptr, red, threadIdx.x);
-    if (threadIdx.x < 2) info[2 * blockIdx.x + threadIdx.x] = red[threadIdx.x];
+    if (threadIdx.x < 2) info[3 * blockIdx.x + threadIdx.x] = red[threadIdx.x];
+}
+// info[3 r + 2] = the batch row with the r-th largest kmax (ties: lower index first); one thread per row, B comparisons each
+__global__ __launch_bounds__(256) void flash_order_k(int B, int32_t* __restrict__ info) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        const int ki = info[3 * i + 1];
+        int rank = 0;
+        for (int j = 0; j < B; ++j) {
+            const int kj = info[3 * j + 1];
+            rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
+        }
+        info[3 * rank + 2] = i;
+    }
 }
 
 // stage one 64-row tile with NW waves: instruction i of wave w covers tile rows 4*(NW i + w) .. +3; lane -> row lane>>4, logical
@@ -833,6 +849,8 @@ extern "C" int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, i
     FS2_REQUIRE(key_mask && info && B > 0 && t > 0 && t <= MASK_BYTES, "fs2_flash_attn_mask_info: bad arguments");
     hipLaunchKernelGGL(flash_mask_info_k, dim3(B), dim3(512), 0, (hipStream_t)stream, key_mask, t, info);
     FS2_CHECK_LAUNCH("fs2_flash_attn_mask_info");
+    hipLaunchKernelGGL(flash_order_k, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, info);
+    FS2_CHECK_LAUNCH("fs2_flash_attn_mask_info (order)");
     return FS2_OK;
 }
 

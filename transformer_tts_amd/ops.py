@@ -735,11 +735,12 @@ def flash_attn_keep_words(B, H, t):
 
 
 def flash_mask_info(key_mask):
-    """(B, 2) int32 {number of leading unmasked keys, last unmasked key + 1} of every row of a (B, t) key mask: computed once per
-    stack and handed to every flash_attn_fwd / _bwd call as key_info"""
+    """(B, 3) int32: {number of leading unmasked keys, last unmasked key + 1} of every row of a (B, t) key mask and, in column 2,
+    the rows ranked by length (longest first: the order in which the kernels start them); computed once per stack and handed to
+    every flash_attn_fwd / _bwd call as key_info"""
     km = _c(key_mask)
     B, t = km.shape
-    info = torch.empty((B, 2), dtype=torch.int32, device=km.device)
+    info = torch.empty((B, 3), dtype=torch.int32, device=km.device)
     _check(lib().fs2_flash_attn_mask_info(_p(km), B, t, _p(info), _stream()), "fs2_flash_attn_mask_info")
     return info
 
