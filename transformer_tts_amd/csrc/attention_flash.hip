@@ -212,8 +212,9 @@ struct FlashArgs {
 // Work item of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs; the row blocks of one (batch, head) pair -- which
 // stream the same K/V (or Q/dO) tiles -- are given to ONE XCD (one L2), and the pairs go round-robin over the XCDs so that a
 // batch sorted by length does not leave one XCD with all the long sequences.  Grid = 8 * ceil(B H / 8) * nblk.
+template <int BLK = 128>
 __device__ __forceinline__ bool flash_item(const FlashArgs& a, int& blk, int& h, int& b) {
-    const int nblk = (a.t + 127) >> 7;
+    const int nblk = (a.t + BLK - 1) / BLK;
     const int slot = (int)(blockIdx.x >> 3);
     const int pair = (int)(blockIdx.x & 7) + 8 * (slot / nblk);
     if (pair >= a.B * a.H) return false;
@@ -637,16 +638,17 @@ template <int T> __device__ __forceinline__ void row_share4(unsigned bits, unsig
     kb[0] = row_share<4 * T>(bits); kb[1] = row_share<4 * T + 1>(bits); kb[2] = row_share<4 * T + 2>(bits); kb[3] = row_share<4 * T + 3>(bits);
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
+template <bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KB = 16 * NW;          // keys per workgroup: 128 (8 waves, one workgroup per CU) or 64 (4 waves, two per CU)
     int blk, h, b;
-    if (!flash_item(a, blk, h, b)) return;
+    if (!flash_item<KB>(a, blk, h, b)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
     const int t = a.t;
-    const int kb0 = blk * 128 + wave * 16;
+    const int kb0 = blk * KB + wave * 16;
     const int key = kb0 + i16;
     unsigned char* qimg = smem;                         // [2][TILE]
     unsigned char* doimg = smem + 2 * TILE;             // [2][TILE]
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     const int64_t goff = (int64_t)b * a.g_batch + (int64_t)key * a.g_row + (int64_t)h * a.head;
 
     const int kmax = __float_as_int(a.aux[(((int64_t)b * a.H + h) * t) * 4 + 3]);      // written by the dQ kernel (row 0 always exists)
-    if (kmax > 0 && blk * 128 >= kmax) {     // every key of this block is masked: zero probability, zero gradients
+    if (kmax > 0 && blk * KB >= kmax) {     // every key of this block is masked: zero probability, zero gradients
         if (kvalid) {
             const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
 #pragma unroll
@@ -676,8 +678,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     const __amdgpu_buffer_rsrc_t rs_do = make_rsrc_rows(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head, t, dorow);
     const unsigned voff_q = stage_voff(rowst, wave, lane), voff_do = stage_voff(dorow, wave, lane);
     auto stage = [&](int qt, int buf) {
-        stage_tile(rs_q, qimg + buf * TILE, 64 * qt, rowst, wave, voff_q);
-        stage_tile(rs_do, doimg + buf * TILE, 64 * qt, dorow, wave, voff_do);
+        stage_tile<NW>(rs_q, qimg + buf * TILE, 64 * qt, rowst, wave, voff_q);
+        stage_tile<NW>(rs_do, doimg + buf * TILE, 64 * qt, dorow, wave, voff_do);
         if (wave == 0) {
             const int q = 64 * qt + lane;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_aux, (lds_void_t*)(auximg + buf * AUX_BYTES), 16,
@@ -766,8 +768,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkv_k(const FlashArgs a) {
         tile(qt, IC<0>{});
         if (qt + 1 < nqt) tile(qt + 1, IC<1>{});
     }
-    if (a.dbk != nullptr) block_colsum<512>(dkacc, a.alpha, reinterpret_cast<float*>(smem), a.dbk + h * 128, tid, lane);
-    if (a.dbv != nullptr) block_colsum<512>(dvacc, scale, reinterpret_cast<float*>(smem) + 128, a.dbv + h * 128, tid, lane);
+    if (a.dbk != nullptr) block_colsum<64 * NW>(dkacc, a.alpha, reinterpret_cast<float*>(smem), a.dbk + h * 128, tid, lane);
+    if (a.dbv != nullptr) block_colsum<64 * NW>(dvacc, scale, reinterpret_cast<float*>(smem) + 128, a.dbv + h * 128, tid, lane);
     if (kvalid) {
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
@@ -896,17 +898,27 @@ extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, i
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
         attr_set = true;
     }
     const dim3 grid(flash_grid(B, H, t));
+    // dK/dV: 64 keys per workgroup (4 waves, two workgroups per CU; default) or 128 (8 waves, one per CU; FS2_FLASH_DKV_WAVES=8).
+    // Every non-empty key block costs the same (all queries), and at config 2 there are ~2.1 of the 128-key blocks per CU: three
+    // rounds for two rounds' worth of work.  Half-size blocks leave a shorter tail (a lone workgroup on a CU also runs faster than
+    // one of a pair): 149 -> 140 us per decoder layer, at twice the Q / dO staging traffic.
+    static const int kv_waves = getenv("FS2_FLASH_DKV_WAVES") ? atoi(getenv("FS2_FLASH_DKV_WAVES")) : 4;
+    const dim3 grid_kv(kv_waves == 4 ? 8 * ((B * H + 7) / 8) * ((t + 63) / 64) : flash_grid(B, H, t));
     if (p > 0.f) {
         hipLaunchKernelGGL(flash_bwd_dq_k<true>, grid, dim3(FQ_THREADS), lds_q, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(flash_bwd_dkv_k<true>, grid, dim3(512), lds_kv, (hipStream_t)stream, a);
+        if (kv_waves == 4) hipLaunchKernelGGL((flash_bwd_dkv_k<true, 4>), grid_kv, dim3(256), lds_kv, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((flash_bwd_dkv_k<true, 8>), grid_kv, dim3(512), lds_kv, (hipStream_t)stream, a);
     } else {
         hipLaunchKernelGGL(flash_bwd_dq_k<false>, grid, dim3(FQ_THREADS), lds_q, (hipStream_t)stream, a);
-        hipLaunchKernelGGL(flash_bwd_dkv_k<false>, grid, dim3(512), lds_kv, (hipStream_t)stream, a);
+        if (kv_waves == 4) hipLaunchKernelGGL((flash_bwd_dkv_k<false, 4>), grid_kv, dim3(256), lds_kv, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((flash_bwd_dkv_k<false, 8>), grid_kv, dim3(512), lds_kv, (hipStream_t)stream, a);
     }
     FS2_CHECK_LAUNCH("fs2_flash_attn_bwd");
     return FS2_OK;
