@@ -472,6 +472,23 @@ def test_attn_ds_fused_vs_gemm_softmax_bwd(ops, p, t, H, dk):
     assert float(((a - b_).abs() / scale).max()) < 4e-2, float(((a - b_).abs() / scale).max())
 
 
+def test_flash_mask_info_ranks_rows_longest_first(ops):
+    """fs2_flash_attn_mask_info on a batch larger than one block of its ranking kernel: {kfull, kmax} per row (holes in a mask make
+    them differ) and the rank list the flash kernels start their workgroups from"""
+    B, t = 300, 200
+    g = np.random.default_rng(5)
+    lens = g.integers(1, t + 1, size=B)
+    lens[:3] = [t, 1, t]                      # ties and the extremes
+    km = torch.from_numpy(np.arange(t)[None, :] < lens[:, None])
+    km[7, : int(lens[7])] = True
+    if lens[7] > 4:
+        km[7, 2] = False                      # a hole: kfull = 2, kmax = lens[7]
+    info = ops.flash_mask_info(km.cuda()).cpu()
+    kfull = [2 if (i == 7 and lens[7] > 4) else int(n) for i, n in enumerate(lens)]
+    assert info[:, 0].tolist() == kfull and info[:, 1].tolist() == [int(n) for n in lens]
+    assert info[:, 2].tolist() == sorted(range(B), key=lambda i: (-int(lens[i]), i))
+
+
 def _oracle_attention(qkv, dO, km, t, p, seed, site, NL=2, layer=1):
     """attention() forward + backward composed from the oracle's primitives on the fused-qkv layout: O, dqkv."""
     B, _, _, H, dk = qkv.shape
