@@ -224,7 +224,10 @@ def _splitk_plan(M, N, k_total, g, relu_mask, colstats, colsum, alpha):
     if tiles > 160 or stages < 48:
         return 1
     # >= 384 work items keeps fs2_gemm on its 128^2 tile (it switches to 64^2 below that); >= 12 stages per split
-    return int(max(1, min(-(-384 // tiles), stages // 12, 8)))
+    if os.environ.get("FS2_SPLITK_N"):             # (A/B measurements)
+        return int(os.environ["FS2_SPLITK_N"])
+    # (5 splits of the 96-tile encoder convolutions = 480 items for the 512 workgroup slots: 2.5 % faster than 4; 6 drops to the 64^2 tile)
+    return int(max(1, min(-(-448 // tiles), stages // 12, 8)))
 
 
 def _splitk_run(g, M, N, split, out, bias, relu, residual):
