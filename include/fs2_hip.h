@@ -53,7 +53,11 @@ int fs2_abi_version(void);
  *      (zero outside the sequence); batch2 enumerates the taps (use sB2 = 0, sC2 = K_in).
  *  Row strides and the contiguous-dim extents must be multiples of 16 bytes (8 bf16 / 4 f32).
  *  Kb = valid reduction extent of B when it differs from K (0 = K): rows >= Kb of a k-major B read as 0.
- *  accumulate = 1: C is fp32 and results are atomically added (split_k > 1 requires it).
+ *  accumulate = 1: C is fp32 and results are atomically added (split_k > 1 requires accumulate != 0).
+ *  accumulate = 2 (row-major bf16 operands, un-batched, no fused epilogue operand; fp32 C): SLICED split-K -- C is a workspace of
+ *      split_k slices [split][M][ldc] (slice stride sC1 elements); slice s receives the partial sums of the s-th part of the
+ *      reduction with plain stores (nothing is read, nothing has to be zeroed); fs2_splitk_reduce adds the slices up and applies
+ *      bias / ReLU / residual / cast.  split_k is lowered so that no part is empty: read it back with fs2_gemm_last_splits().
  *  colstats != NULL: per-column sum and sum of squares of the stored values are atomically added to
  *      colstats[0..N) and colstats[N..2N)  (BatchNorm batch statistics, Models/postnets.py:58-59).
  */
@@ -94,12 +98,20 @@ int fs2_gemm(const FS2Gemm* g, void* stream);
  * (16-wave LDS-DMA kernel for tall row-major bf16 products, 256 columns wide).  Measurement aid (bench.py groups its
  * per-launch timings by it); FS2_GEMM_BIG=0 in the environment keeps every product on the 4-wave kernel. */
 int fs2_gemm_last_tile(void);
+/* Number of slices the last sliced split-K fs2_gemm call (accumulate = 2) of this thread wrote (<= FS2Gemm.split_k). */
+int fs2_gemm_last_splits(void);
 
 /* Finishing pass of a split-K product whose fused epilogue could not run (few output tiles, long K: the product
  * accumulates fp32 partial sums into `scratch` [M][N], zero on entry, with FS2Gemm.accumulate = 1, split_k > 1):
  *   out[m][n] = act(scratch[m][n] + bias[n]) + residual[m][n]   in out_dtype;   scratch is zero again on return.  */
 int fs2_splitk_finish(float* scratch, int64_t M, int N, const float* bias, const void* residual, int res_dtype,
                       int64_t ldr, int relu, void* out, int out_dtype, int64_t ldc, void* stream);
+
+/* Finishing pass of a SLICED split-K product (FS2Gemm.accumulate = 2):
+ *   out[m][n] = act(sum_{s < nsplit} slices[s * slice_stride + m * ld + n] + bias[n]) + residual[m][n]   in out_dtype.  */
+int fs2_splitk_reduce(const float* slices, int nsplit, int64_t slice_stride, int64_t ld, int64_t M, int N, const float* bias,
+                      const void* residual, int res_dtype, int64_t ldr, int relu, void* out, int out_dtype, int64_t ldc,
+                      void* stream);
 
 /* Weight shadows (fp32 master (O, I, k) as in the reference state_dict -> kernel layout, dtype `dtype`):
  *  mode 0 (forward):  dst[o*dld + j*I + i]       = src[o][i][j]

@@ -175,9 +175,9 @@ def test_gemm_tile_orders_agree(ops):
 
 
 def test_splitk_forward_products(ops):
-    """few output tiles + long reduction: ops.conv / ops.linear run split-K into an fp32 scratch and finish with
-    fs2_splitk_finish (bias / ReLU / residual / cast).  Same results as the oracle, the scratch is left clean, and a
-    second call (scratch reused) gives the same answer."""
+    """few output tiles + long reduction: ops.conv / ops.linear run sliced split-K (FS2Gemm.accumulate = 2: one fp32 workspace
+    slice per split, plain stores) and finish with fs2_splitk_reduce (bias / ReLU / residual / cast).  Same results as the oracle,
+    and a second call (workspace reused, never zeroed) gives bit for bit the same answer."""
     dtype = torch.bfloat16
     B, t, C, N, k = 16, 128, 512, 256, 9
     from transformer_tts_amd import ops as real_ops
@@ -188,11 +188,14 @@ def test_splitk_forward_products(ops):
     for kw in (dict(bias=bias), dict(bias=bias, relu=True), dict(residual=res), dict(bias=bias, residual=res.float(), out_dtype=torch.float32)):
         ref = P.conv(x, w, k, k // 2, **kw)
         cu = {kk: (v.cuda() if torch.is_tensor(v) else v) for kk, v in kw.items()}
+        gots = []
         for _ in range(2):
             got = ops.conv(x.cuda(), w.cuda(), k, k // 2, **cu)
             close(got, ref, f"split-K conv {sorted(kw)}", rtol=2e-2, atol=2e-2)
-    scratch = real_ops._splitk_scratch[(torch.device("cuda", torch.cuda.current_device()), B * t, N)]
-    assert float(scratch.abs().max()) == 0.0, "fs2_splitk_finish must leave the scratch zeroed"
+            gots.append(got)
+            real_ops._splitk_scratch[next(iter(real_ops._splitk_scratch))].fill_(float("nan"))     # the workspace needs no clean state
+        assert torch.equal(gots[0], gots[1])
+    assert real_ops.lib().fs2_gemm_last_splits() > 1
     xl, wl = rnd(1000, 4096, dtype=dtype, seed=5), rnd(128, 4096, dtype=dtype, seed=6, scale=0.05)
     close(ops.linear(xl.cuda(), wl.cuda(), bias[:128].cuda()), P.linear(xl, wl, bias[:128]), "split-K linear", rtol=2e-2, atol=2e-2)
 
@@ -977,16 +980,17 @@ def test_cast_permute_batched_tile_edges(ops, dtype, O, I, k):
     assert torch.equal(res["cuda"][1], w3.flip(2).permute(1, 2, 0).reshape(I, k * O).to(dtype).float())
 
 
-# ------------------------------------------------------------------------------------------------ large-tile GEMM (gemm_big.hip)
+# ------------------------------------------------------------------------------------------------ 16-wave row-major GEMM (gemm_ring.hip)
 @pytest.fixture
 def big_gemm(monkeypatch):
-    """route every eligible product to the 256-wide LDS-DMA kernel (FS2_GEMM_BIG=2), whatever its size"""
+    """route every eligible product to the 256-wide 16-wave LDS-DMA kernel (FS2_GEMM_RING=2), whatever its size"""
     def set_bm(bm):
-        monkeypatch.setenv("FS2_GEMM_BIG", "2")
+        monkeypatch.setenv("FS2_GEMM_RING", "2")
         monkeypatch.setenv("FS2_GEMM_BIG_BM", str(bm))
     yield set_bm
-    monkeypatch.delenv("FS2_GEMM_BIG", raising=False)
+    monkeypatch.delenv("FS2_GEMM_RING", raising=False)
     monkeypatch.delenv("FS2_GEMM_BIG_BM", raising=False)
+    monkeypatch.delenv("FS2_RING_S", raising=False)
 
 
 @pytest.mark.parametrize("bm", [128, 192, 256])
@@ -1013,6 +1017,8 @@ def test_big_gemm_linear_epilogues(ops, big_gemm, bm, M, N, K):
                            out_dtype=torch.float32 if kw.get("out_f32") else None, alpha=kw.get("alpha", 1.0))
             return out, cs, cl
         (a, acs, acl), (b, bcs, bcl) = call(ops, "cuda"), call(P, "cpu")
+        rerouted = bm == 256 and (kw.get("colstats") or (kw.get("relu_mask") and kw.get("residual") == "f32"))   # not compiled for 256 rows (spills)
+        assert ops.lib().fs2_gemm_last_tile() == (130 if bm == 128 else 192 if rerouted else bm)
         close(a, b, f"big linear bm{bm} {kw}", **tol(a.dtype))
         if acs is not None:
             close(acs, bcs, "colstats", rtol=2e-3, atol=2e-2 * M ** 0.5)
@@ -1039,15 +1045,54 @@ def test_big_gemm_conv_geometry(ops, big_gemm, bm, B, t, C, N, taps, pad):
 
 
 def test_big_gemm_is_bit_identical_to_the_128_tile_kernel(ops, monkeypatch):
-    """same k order inside every accumulator: the two kernels must agree bit for bit (44400-row decoder product)"""
+    """same k order inside every accumulator: the two kernels must agree bit for bit (44400-row decoder product); so must the
+    2- and 3-slot rings of the 128-row tile (the counted vmcnt waits are the only difference)"""
     x, w, bias = rnd(44400, 256, dtype=torch.bfloat16, seed=1).cuda(), rnd(512, 256, dtype=torch.bfloat16, seed=2).cuda(), rnd(512, seed=3).cuda()
-    monkeypatch.setenv("FS2_GEMM_BIG", "0")
+    monkeypatch.setenv("FS2_GEMM_RING", "0")
     ref = ops.linear(x, w, bias=bias, relu=True)
-    for bm in ("128", "192", "256"):
-        monkeypatch.setenv("FS2_GEMM_BIG", "2")
+    assert ops.lib().fs2_gemm_last_tile() == 128
+    for bm, ring in (("128", "3"), ("128", "2"), ("192", "2"), ("256", "2")):
+        monkeypatch.setenv("FS2_GEMM_RING", "2")
         monkeypatch.setenv("FS2_GEMM_BIG_BM", bm)
+        monkeypatch.setenv("FS2_RING_S", ring)
         out = ops.linear(x, w, bias=bias, relu=True)
+        assert ops.lib().fs2_gemm_last_tile() == (130 if bm == "128" else int(bm))
         assert torch.equal(out, ref), f"bm {bm}: {(out.float() - ref.float()).abs().max().item()}"
+    monkeypatch.delenv("FS2_RING_S", raising=False)
+
+
+@pytest.mark.parametrize("bm", [128, 192, 256])
+@pytest.mark.parametrize("B,t,C,N,taps,pad,split", [(4, 128, 256, 256, 9, 4, 5), (3, 37, 64, 64, 9, 4, 3), (2, 50, 80, 264, 5, 4, 16), (5, 100, 1024, 256, 1, 0, 4)])
+def test_sliced_split_k(ops, monkeypatch, bm, B, t, C, N, taps, pad, split):
+    """FS2Gemm.accumulate = 2 + fs2_splitk_reduce (gemm_ring.hip): every split stores its fp32 partial tile into its own workspace
+    slice with plain stores (no atomics: the result is bitwise reproducible), the reduce pass adds bias / ReLU / residual; splits that
+    do not divide the slot count, more splits asked for than slots, k tails and conv halos inside a split"""
+    monkeypatch.setenv("FS2_SPLITK_N", str(split))
+    monkeypatch.setenv("FS2_GEMM_BIG_BM", str(bm))
+    dtype = torch.bfloat16
+    x, w = rnd(B, t, C, dtype=dtype, seed=1), rnd(N, taps * C, dtype=dtype, seed=2, scale=(taps * C) ** -0.5)
+    bias, res = rnd(N, seed=3), rnd(B, t, N, seed=4)
+    outs = []
+    for _ in range(2):
+        # (_splitk_plan only splits long reductions onto few tiles: call the runner directly)
+        g = ops.FS2Gemm()
+        x2 = x.cuda().view(B * t, C)
+        wc = w.cuda()
+        g.A, g.B, g.lda, g.ldb = x2.data_ptr(), wc.data_ptr(), C, taps * C
+        g.M, g.N, g.K, g.dtype = B * t, N, C, ops.BF16
+        g.split_k = g.batch1 = g.batch2 = 1
+        g.conv, g.taps, g.pad, g.seq_len = 1, taps, pad, t
+        out = torch.empty(B * t, N, dtype=torch.float32, device="cuda")
+        ops._splitk_run(g, B * t, N, split, out, bias.cuda(), True, res.cuda().view(B * t, N))
+        outs.append(out.view(B, t, N))
+        nslots = taps * ((C + 63) // 64)
+        per = -(-nslots // min(split, nslots))
+        assert ops.lib().fs2_gemm_last_splits() == -(-nslots // per)
+    assert torch.equal(outs[0], outs[1]), "sliced split-K must be bitwise reproducible"
+    b = P.conv(x, w, taps, pad, bias=bias, relu=True, residual=res, out_dtype=torch.float32)
+    close(outs[0], b, f"sliced split-K bm{bm}", **tol(dtype))
+    monkeypatch.delenv("FS2_SPLITK_N", raising=False)
+    monkeypatch.delenv("FS2_GEMM_BIG_BM", raising=False)
 
 
 # ------------------------------------------------------------------------------------------------ autoregressive decoder kernels

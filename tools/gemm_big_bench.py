@@ -96,19 +96,22 @@ def main():
     for name, (fn, fl) in cases.items():
         if only and not any(o in name for o in only):
             continue
-        os.environ["FS2_GEMM_BIG"] = "0"
+        os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"] = "0", "0"
         ref = fn().float()
         t0w, t0c = timeit(fn, False), timeit(fn, True)
-        line = f"{name:40s} old {t0w:7.1f}/{t0c:7.1f} us ({fl / t0c / 1e6:6.0f} TF cold)"
+        line = f"{name:40s} 4-wave {t0w:7.1f}/{t0c:7.1f} us ({fl / t0c / 1e6:6.0f} TF cold)"
         for cfg in cfgs:
-            os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_BM"] = "2", cfg.split(":")[0]
-            os.environ["FS2_GEMM_BIG_ISSUE"] = cfg.split(":")[1] if ":" in cfg else "0"
-            out = fn().float()
-            err = float((out - ref).abs().max())
-            rel = err / float(ref.abs().max())
-            tw, tc = timeit(fn, False), timeit(fn, True)
-            line += f" | big{cfg} {tw:7.1f}/{tc:7.1f} us ({fl / tc / 1e6:6.0f} TF) maxrel {rel:.1e}"
+            os.environ["FS2_GEMM_BIG_BM"] = cfg.split(":")[0]
+            for kern, env in (("big", ("2", "0")), ("ring", ("0", "2"))):      # round-2 large-tile kernel, round-3 ring kernel
+                os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"] = env
+                out = fn().float()
+                err = float((out - ref).abs().max())
+                rel = err / float(ref.abs().max())
+                tw, tc = timeit(fn, False), timeit(fn, True)
+                line += f" | {kern}{cfg} {tw:7.1f}/{tc:7.1f} us ({fl / tc / 1e6:6.0f} TF) maxrel {rel:.1e}"
+        os.environ.pop("FS2_GEMM_BIG_BM", None)
         print(line, flush=True)
+        os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"] = "2", "0"
         if stamps:
             import ctypes
             lib = ops.lib()
@@ -134,7 +137,7 @@ def main():
                     print(f"   bm{cfg} {nm}: blocks {int(act.sum())} stages/block {b[act][:, w, 5].mean():.1f} items {b[act][:, w, 6].mean():.2f} "
                           f"cycles/block {tot.mean():.0f} (max {tot.max():.0f})  issue {sh[0]:.1%} epilogue {sh[1]:.1%} mfma {sh[2]:.1%} "
                           f"dma-wait {sh[3]:.1%} barrier {sh[4]:.1%}", flush=True)
-    os.environ["FS2_GEMM_BIG"] = "1"
+    os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"] = "1", "1"
 
 
 if __name__ == "__main__":

@@ -27,11 +27,14 @@
 #include "common.cuh"
 #include <stdlib.h>
 
+bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc);    // gemm_ring.hip
 bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc);     // gemm_big.hip
 bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc);  // gemm_big_km.hip
 
 thread_local int g_last_tile = 0;     // rows of the block tile of the last fs2_gemm launch of this thread (measurement aid)
+thread_local int g_last_splits = 1;   // slices written by the last sliced split-K launch (accumulate = 2) of this thread
 extern "C" int fs2_gemm_last_tile(void) { return g_last_tile; }
+extern "C" int fs2_gemm_last_splits(void) { return g_last_splits; }
 
 namespace {
 
@@ -657,6 +660,17 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
     FS2_REQUIRE(!(g.split_k > 1 && !g.accumulate), "fs2_gemm: split_k > 1 requires accumulate");
     FS2_REQUIRE(!(g.accumulate && g.c_dtype != FS2_F32), "fs2_gemm: accumulate requires fp32 C");
     FS2_REQUIRE(!(g.accumulate && (g.relu || g.relu_mask || g.residual || g.colstats)), "fs2_gemm: accumulate excludes relu/mask/residual/colstats");
+    FS2_REQUIRE(g.accumulate >= 0 && g.accumulate <= 2, "fs2_gemm: accumulate must be 0, 1 or 2");
+    if (g.accumulate == 2) {      // sliced split-K: the ring kernel only (gemm_ring.hip)
+        FS2_REQUIRE(g.dtype == FS2_BF16 && !g.a_kmajor && !g.b_kmajor && g.conv <= 1 && (long)g.batch1 * g.batch2 == 1 && !g.bias && g.alpha == 1.f &&
+                    g.N % 8 == 0 && g.N <= 2048 && g.sC1 >= (int64_t)g.M * g.ldc && g.sC1 % 4 == 0,
+                    "fs2_gemm: accumulate = 2 (sliced split-K) needs un-batched row-major bf16 operands, no bias / alpha, N %% 8 == 0, N <= 2048 and sC1 >= M * ldc");
+        if (g.conv == 0) { g.taps = 1; g.pad = 0; if (g.seq_len <= 0) g.seq_len = 1; }
+        int rc = FS2_OK;
+        if (fs2_gemm_ring_try(g, (hipStream_t)stream, &rc)) return rc;
+        fs2_set_error("fs2_gemm: accumulate = 2: operand sizes beyond the ring kernel's 32-bit addressing");
+        return FS2_EINVAL;
+    }
     if (g.residual) FS2_REQUIRE(g.ldr % 4 == 0, "fs2_gemm: ldr must be a multiple of 4");
     if (g.relu_mask) FS2_REQUIRE(g.ldm % 4 == 0, "fs2_gemm: ldm must be a multiple of 4");
     if (g.bias) FS2_REQUIRE(fs2_aligned16(g.bias), "fs2_gemm: bias must be 16-byte aligned");
@@ -682,9 +696,9 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
     const long total = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.batch1 * g.batch2 * g.split_k;
     FS2_REQUIRE(total < (1L << 30), "fs2_gemm: too many work items");
     hipStream_t st = (hipStream_t)stream;
-    {   // tall row-major bf16 products: the 256x256 / 16-wave LDS-DMA kernel (gemm_big.hip)
+    {   // tall row-major bf16 products: the 16-wave LDS-DMA kernel (gemm_ring.hip)
         int rc = FS2_OK;
-        if (fs2_gemm_big_try(g, st, &rc)) return rc;      // (sets g_last_tile to 192 / 256)
+        if (fs2_gemm_ring_try(g, st, &rc)) return rc;     // (sets g_last_tile to 130 / 192 / 256)
         if (fs2_gemm_big_km_try(g, st, &rc)) return rc;   // decoder-side weight gradients (g_last_tile 129)
     }
     // tile walk: tall row-major products with 2..8 column tiles of 128 go m-fastest on an XCD-aligned grid (see the

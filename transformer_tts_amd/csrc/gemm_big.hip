@@ -1,5 +1,7 @@
-// Large-tile bf16 MFMA GEMM for gfx950: the tall row-major x row-major products of the decoder side of the model
+// Large-tile MFMA GEMM for gfx950, round-2 form: the tall row-major x row-major products of the decoder side of the model
 // (M = batch * frames ~ 44k rows; linear layers and implicit-GEMM Conv1d, forward and data gradient).
+// Since round 3 the bf16 products run on gemm_ring.hip (same geometry, counted waits, bias in LDS, spill-free epilogues, sliced
+// split-K); this file keeps the ONE-BYTE-OPERAND instances (fp8 e4m3 x e4m3, bf8 e5m2 x fp8 e4m3: hp.fp8, BASELINE configs[4]).
 //
 // Why a second kernel: the 128x128 / 4-wave stage loop of gemm.hip tops out at ~775 TFLOP/s with
 // L2-resident operands; a 256x256 block tile worked on by 16 waves of 64x64 (<= 128 VGPRs, four waves per SIMD, one
@@ -53,13 +55,9 @@ template <int WTM> struct BG {
 __device__ __forceinline__ int fA(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int fB(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 
-unsigned long long* g_big_dbg = nullptr;
-
 }  // namespace
 
 extern thread_local int g_last_tile;     // gemm.hip
-
-extern "C" void fs2_debug_gemm_big_timer(unsigned long long* buf) { g_big_dbg = buf; }
 
 template <typename TC, int WTM, int EPI, bool STAMP, int OPK>
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_kernel(const FS2Gemm p, const int tilesM, const int tilesN, unsigned long long* dbg) {
@@ -440,7 +438,7 @@ int launch_big2(const FS2Gemm& g, hipStream_t st) {
     }
     const long per_xcd = (long)((tilesM + 7) / 8) * tilesN;
     const int grid = 8 * (int)(per_xcd < 32 ? per_xcd : 32);
-    hipLaunchKernelGGL((fs2_gemm_big_kernel<TC, WTM, EPI, STAMP, OPK>), dim3(grid), dim3(NT), lds, st, g, tilesM, tilesN, g_big_dbg);
+    hipLaunchKernelGGL((fs2_gemm_big_kernel<TC, WTM, EPI, STAMP, OPK>), dim3(grid), dim3(NT), lds, st, g, tilesM, tilesN, (unsigned long long*)nullptr);
     FS2_CHECK_LAUNCH("fs2_gemm(big)");
     return FS2_OK;
 }
@@ -449,9 +447,6 @@ template <typename TC, int WTM, int OPK>
 int launch_big1(const FS2Gemm& g, hipStream_t st) {
     const int res = g.residual == nullptr ? 0 : (g.res_dtype == FS2_F32 ? EPI_RES_F32 : EPI_RES_BF16);
     const int epi = (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? (g.colstats_mode == 0 ? EPI_STATS | EPI_SUMSQ : EPI_STATS) : 0);
-    if constexpr (OPK == 0) {
-        if (g_big_dbg != nullptr && epi == 0) return launch_big2<TC, WTM, 0, true, OPK>(g, st);
-    }
     switch (epi) {      // the combinations the model uses; anything else stays on the 128-tile kernel (checked by the caller)
         case 0: return launch_big2<TC, WTM, 0, false, OPK>(g, st);
         case EPI_MASK: return launch_big2<TC, WTM, EPI_MASK, false, OPK>(g, st);
@@ -476,18 +471,11 @@ bool epi_compiled(const FS2Gemm& g) {
 
 }  // namespace
 
-// false: not eligible / not chosen; true: the product was launched on the large-tile kernel and *rc holds the result
+// false: not eligible; true: the product was launched on the large-tile kernel and *rc holds the result (fp8 operands only)
 bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
-    // FS2_GEMM_BIG: 0 never, 1 (default) where the shape heuristic says so, 2 wherever eligible; FS2_GEMM_BIG_BM forces
-    // the row-slab height (128 / 192 / 256).  Read per call so that tests and A/B measurements can switch inside one process.
-    const char* e1 = getenv("FS2_GEMM_BIG");
-    const char* e2 = getenv("FS2_GEMM_BIG_BM");
-    const int mode = e1 ? atoi(e1) : 1;
-    int bm = e2 ? atoi(e2) : 0;
-    if (mode == 0 && !(g.dtype == FS2_FP8 || g.dtype == FS2_BF8_FP8)) return false;
     const bool fp8 = g.dtype == FS2_FP8 || g.dtype == FS2_BF8_FP8;
-    if ((g.dtype != FS2_BF16 && !fp8) || g.a_kmajor || g.b_kmajor || g.accumulate || g.conv > 1) return false;
-    if (fp8 && (g.K % 16 != 0 || g.lda % 16 != 0 || g.ldb % 16 != 0)) return false;
+    if (!fp8 || g.a_kmajor || g.b_kmajor || g.accumulate || g.conv > 1) return false;
+    if (g.K % 16 != 0 || g.lda % 16 != 0 || g.ldb % 16 != 0) return false;
     if ((long)g.batch1 * g.batch2 * g.split_k != 1) return false;
     if (g.N % 8 != 0 || (g.colstats != nullptr && g.N > BIG_COLSTAT_N)) return false;
     if (g.conv == 1 && (g.pad < 0 || g.pad > g.taps)) return false;
@@ -499,37 +487,9 @@ bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         if (g.residual != nullptr && rows * g.ldr * 4 >= 0x7FFFFFF0L) return false;
         if (rows * g.lda * 2 >= 0x7FFFFFF0L || ((long)g.N + 512) * g.ldb * 2 >= 0x7FFFFFF0L) return false;
     }
-    const long tn = (g.N + BN - 1) / BN;
-    auto fill = [&](int b) {       // fraction of the 256 CUs' rounds that carry a tile
-        const long tiles = (long)((g.M + b - 1) / b) * tn;
-        return (double)tiles / (double)(((tiles + 255) / 256) * 256);
-    };
-    // (epilogues with masks / statistics keep more registers live: the 192-row tile runs them without spills)
-    const double bias192 = (g.relu_mask != nullptr || g.colstats != nullptr) ? 0.10 : -0.02;
-    if (bm != 128 && bm != 192 && bm != 256) {
-        bm = fill(192) + bias192 > fill(256) ? 192 : 256;
-        // Short matrices (the encoder side: 6144 rows) give the 192-row tile fewer tiles than CUs: every CU runs `rounds` tiles of
-        // bm rows one after the other, so rounds * bm is the time; the 128-row tile (less operand reuse per MFMA: +10 %) wins when
-        // it spreads the same rows over more CUs.
-        auto serial_rows = [&](int b) { const long tiles = (long)((g.M + b - 1) / b) * tn; return (double)((tiles + 255) / 256) * b; };
-        if (!fp8 && serial_rows(128) * 1.10 < serial_rows(bm)) bm = 128;
-    }
-    if (mode == 1 && !fp8) {
-        const long tiles = (long)((g.M + bm - 1) / bm) * tn;
-        const long ktot = (long)(g.conv == 1 ? g.taps : 1) * g.K;
-        (void)ktot;
-        if (tiles < 128 || g.N < 192) return false;
-    }
     const bool f32 = g.c_dtype == FS2_F32;
-    if (fp8) {          // one-byte operands: the 192-row tile only (keeps the number of kernel instances down)
-        g_last_tile = 192;
-        if (g.dtype == FS2_FP8) *rc = f32 ? launch_big1<float, 48, 1>(g, st) : launch_big1<bf16_t, 48, 1>(g, st);
-        else *rc = f32 ? launch_big1<float, 48, 2>(g, st) : launch_big1<bf16_t, 48, 2>(g, st);
-        return true;
-    }
-    g_last_tile = bm == 128 ? 130 : bm;       // 128 is the 128-tile kernel of gemm.hip, 129 the 16-wave weight-gradient kernel
-    if (bm == 128) *rc = f32 ? launch_big1<float, 32, 0>(g, st) : launch_big1<bf16_t, 32, 0>(g, st);
-    else if (bm == 192) *rc = f32 ? launch_big1<float, 48, 0>(g, st) : launch_big1<bf16_t, 48, 0>(g, st);
-    else *rc = f32 ? launch_big1<float, 64, 0>(g, st) : launch_big1<bf16_t, 64, 0>(g, st);
+    g_last_tile = 192;          // one-byte operands: the 192-row tile only (keeps the number of kernel instances down)
+    if (g.dtype == FS2_FP8) *rc = f32 ? launch_big1<float, 48, 1>(g, st) : launch_big1<bf16_t, 48, 1>(g, st);
+    else *rc = f32 ? launch_big1<float, 48, 2>(g, st) : launch_big1<bf16_t, 48, 2>(g, st);
     return true;
 }

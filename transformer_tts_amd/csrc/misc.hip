@@ -847,6 +847,51 @@ extern "C" int fs2_splitk_finish(float* scratch, int64_t M, int N, const float* 
     return FS2_OK;
 }
 
+// Sliced split-K (fs2_gemm accumulate = 2): out[m][n] = act(sum_s slices[s][m][n] + bias[n]) (+ residual[m][n]).  Plain loads of
+// nsplit fp32 slices (slice stride `sstride` elements, row stride ld): no atomics were involved, nothing to clean.
+template <typename TO>
+__global__ __launch_bounds__(TPB) void splitk_reduce_k(const float* __restrict__ slices, int nsplit, int64_t sstride, int64_t ld, int64_t groups,
+        int N4, const float* __restrict__ bias, const void* __restrict__ residual, int res_dtype, int64_t ldr, int relu,
+        TO* __restrict__ out, int64_t ldc) {
+    for (int64_t gi = (int64_t)blockIdx.x * TPB + threadIdx.x; gi < groups; gi += (int64_t)gridDim.x * TPB) {
+        const int64_t m = gi / N4;
+        const int n = (int)(gi - m * N4) * 4;
+        const float* sp = slices + m * ld + n;
+        float4 v = *reinterpret_cast<const float4*>(sp);
+        for (int s = 1; s < nsplit; ++s) {
+            const float4 w = *reinterpret_cast<const float4*>(sp + s * sstride);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        if (bias != nullptr) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + n);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (residual != nullptr) {
+            float4 r;
+            if (res_dtype == FS2_F32) r = load4<float>(reinterpret_cast<const float*>(residual) + m * ldr + n);
+            else r = load4<bf16_t>(reinterpret_cast<const bf16_t*>(residual) + m * ldr + n);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        store4<TO>(out + m * ldc + n, v);
+    }
+}
+
+extern "C" int fs2_splitk_reduce(const float* slices, int nsplit, int64_t slice_stride, int64_t ld, int64_t M, int N, const float* bias,
+                                 const void* residual, int res_dtype, int64_t ldr, int relu, void* out, int out_dtype, int64_t ldc,
+                                 void* stream) {
+    CHECK_DT("fs2_splitk_reduce", out_dtype);
+    FS2_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0 && ldc >= N && ld % 4 == 0 && ld >= N && (residual == nullptr || (ldr % 4 == 0 && ldr >= N)),
+                "fs2_splitk_reduce: N, ld, ldc, ldr must be multiples of 4");
+    FS2_REQUIRE(nsplit >= 1 && nsplit <= 64 && slice_stride % 4 == 0 && (nsplit == 1 || slice_stride >= M * ld), "fs2_splitk_reduce: bad slice layout");
+    FS2_REQUIRE(fs2_aligned16(slices) && fs2_aligned16(out) && (bias == nullptr || fs2_aligned16(bias)), "fs2_splitk_reduce: 16-byte alignment required");
+    const int64_t groups = M * (N / 4);
+    T_DISPATCH(out_dtype, TO, { hipLaunchKernelGGL((splitk_reduce_k<TO>), dim3(flat_grid(groups)), dim3(TPB), 0, (hipStream_t)stream,
+                                                   slices, nsplit, slice_stride, ld, groups, N / 4, bias, residual, res_dtype, ldr, relu, (TO*)out, ldc); });
+    FS2_CHECK_LAUNCH("fs2_splitk_reduce");
+    return FS2_OK;
+}
+
 extern "C" int fs2_permute_add(float* scratch, float* grad, int O, int I, int k, int rezero, void* stream) {
     FS2_REQUIRE(O > 0 && I > 0 && k > 0, "fs2_permute_add: bad shape");
     const int64_t n = (int64_t)O * I * k;

@@ -53,6 +53,7 @@ _P, _I, _L, _F, _U32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_f
 SIGNATURES = {
     "fs2_gemm": [ctypes.POINTER(FS2Gemm), _P],
     "fs2_gemm_last_tile": [],
+    "fs2_gemm_last_splits": [],
     "fs2_amax": [_P, _I, _L, _P, _P],
     "fs2_quantize_fp8": [_P, _I, _P, _I, _L, _P, _P],
     "fs2_cast_permute": [_P, _P, _I, _I, _I, _L, _I, _I, _P],
@@ -73,6 +74,7 @@ SIGNATURES = {
     "fs2_ffn_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
     "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_splitk_finish": [_P, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
+    "fs2_splitk_reduce": [_P, _I, _L, _L, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
     "fs2_attn_probs_lds_bytes": [_I, _I],
     "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P, _P, _L, _L, _P],
@@ -212,35 +214,37 @@ _splitk_scratch = {}
 
 def _splitk_plan(M, N, k_total, g, relu_mask, colstats, colsum, alpha):
     """split-K factor for a forward / data-gradient product with too few output tiles to fill 256 CUs and a long
-    reduction (config 2: the 6144 x 256 x (9 x 1024) encoder convolutions = 96 tiles of 128^2, which ran as 384 tiles
-    of 64^2 at ~260 TFLOP/s), or 1.  The product then accumulates into an fp32 scratch and fs2_splitk_finish applies
-    bias / ReLU / residual / cast.  FS2_SPLITK_FWD=0 switches it off (A/B measurements)."""
+    reduction (config 2: the 6144 x 256 x (9 x 1024) encoder convolutions: 48 tiles of 128 x 256), or 1.  The product
+    then writes fp32 partial sums into one workspace slice per split (FS2Gemm.accumulate = 2: plain stores, no atomics)
+    and fs2_splitk_reduce adds the slices and applies bias / ReLU / residual / cast.  FS2_SPLITK_FWD=0 switches it off
+    (A/B measurements)."""
     if g.dtype != BF16 or relu_mask is not None or colstats is not None or colsum is not None or alpha != 1.0:
         return 1
-    if os.environ.get("FS2_SPLITK_FWD", "1") == "0" or N % 4 != 0:
+    if os.environ.get("FS2_SPLITK_FWD", "1") == "0" or N % 8 != 0 or N > 2048:
         return 1
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    tiles = ((M + 127) // 128) * ((N + 255) // 256)
     stages = (k_total + 63) // 64
-    if tiles > 160 or stages < 48:
+    if tiles > 96 or stages < 48:
         return 1
-    # >= 384 work items keeps fs2_gemm on its 128^2 tile (it switches to 64^2 below that); >= 12 stages per split
     if os.environ.get("FS2_SPLITK_N"):             # (A/B measurements)
         return int(os.environ["FS2_SPLITK_N"])
-    # (5 splits of the 96-tile encoder convolutions = 480 items for the 512 workgroup slots: 2.5 % faster than 4; 6 drops to the 64^2 tile)
-    return int(max(1, min(-(-448 // tiles), stages // 12, 8)))
+    # about one work item per CU (the kernel picks its row-slab height for the split count), >= 12 stages per split
+    return int(max(1, min(256 // tiles, stages // 12, 16)))
 
 
 def _splitk_run(g, M, N, split, out, bias, relu, residual):
-    key = (out.device, M, N)
-    scratch = _splitk_scratch.get(key)
-    if scratch is None:
-        scratch = _splitk_scratch[key] = torch.zeros((M, N), dtype=torch.float32, device=out.device)
-    g.split_k, g.accumulate = split, 1
-    _epilogue(g, scratch, None, False, None, None, None, 1.0)
+    key = (out.device, M, N, split)
+    slices = _splitk_scratch.get(key)
+    if slices is None:
+        slices = _splitk_scratch[key] = torch.empty((split, M, N), dtype=torch.float32, device=out.device)
+    g.split_k, g.accumulate = split, 2
+    g.sC1 = M * N
+    _epilogue(g, slices[0], None, False, None, None, None, 1.0)
     _gemm_call(g)
-    _check(lib().fs2_splitk_finish(_p(scratch), M, N, _p(bias), _p(residual), _dt(residual) if residual is not None else 0,
-                                   _ld(residual) if residual is not None else 0, int(relu), _p(out), _dt(out), _ld(out),
-                                   _stream()), "fs2_splitk_finish")
+    nsplit = lib().fs2_gemm_last_splits()
+    _check(lib().fs2_splitk_reduce(_p(slices), nsplit, M * N, N, M, N, _p(bias), _p(residual),
+                                   _dt(residual) if residual is not None else 0, _ld(residual) if residual is not None else 0,
+                                   int(relu), _p(out), _dt(out), _ld(out), _stream()), "fs2_splitk_reduce")
     return out
 
 
