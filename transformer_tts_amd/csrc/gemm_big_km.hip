@@ -49,21 +49,28 @@ __device__ __forceinline__ bf16x8 km_frag(const unsigned char* img, int o0, int 
 extern thread_local int g_last_tile;     // gemm.hip
 
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
-                                                                  const int nitems, const int rot_step) {
+                                                                  const int nitems, const int rot_step, const int stream_units) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
     const int g = lane >> 4, i16 = lane & 15;
 
-    // ---- items of this block: XCD group x = blockIdx & 7 owns the contiguous range [x*per_x, (x+1)*per_x) of item numbers,
-    //      its workgroups (slot = blockIdx >> 3) take them round-robin
+    // ---- items of this block.
+    // Uniform k-split (stream_units == 0): XCD group x = blockIdx & 7 owns the contiguous range [x*per_x, (x+1)*per_x) of item
+    //      numbers (tile fastest, then k-split: the workgroups of an XCD run the same reduction rows of different tiles), its
+    //      workgroups (slot = blockIdx >> 3) take them round-robin.
+    // Balanced stream (stream_units = U > 0; for tile counts that no integer split maps onto 256 CUs, e.g. the 144 tiles of an
+    //      encoder convolution's weight gradient: 56 % of the chip for 48 stages): the nbase tiles x nstk stages form one list
+    //      of units (tile-major), workgroup L takes units [L*U, (L+1)*U), U <= nstk: the tail [s0, nstk) of one tile and the head
+    //      [0, r) of the next.  It runs the HEAD FIRST: at step tau every workgroup of the chip is then at reduction stage tau or
+    //      tau + nstk - U -- two k-streams chip-wide, so the operand slabs are shared in L2 exactly as under a uniform split.
     const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const int per_x = (nitems + 7) >> 3;
     const int ibeg = x * per_x, iend = min(nitems, ibeg + per_x);
-    const int have = iend - ibeg;
+    const int have = stream_units > 0 ? 0 : iend - ibeg;
     const int nmine = have > slot ? (have - slot + nslots - 1) / nslots : 0;
-    if (nmine == 0) return;
+    if (stream_units == 0 && nmine == 0) return;
 
     const int tiles = tilesM * tilesN;
     const int taps = p.conv == 2 ? p.batch2 : 1;
@@ -75,16 +82,51 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
     const int seq = p.seq_len;
 
     struct Item { int m0, n0, tap, st0, st1, rot; int64_t aoff, boff, coff; };
+    // balanced stream: the (at most two) parts of this workgroup, head of the second tile first
+    int npart = 0, part_tile[2] = {0, 0}, part_s0[2] = {0, 0}, part_s1[2] = {0, 0};
+    if (stream_units > 0) {
+        const long total = (long)nitems * nstk;               // (nitems = tiles x taps x batch here)
+        // (workgroups b and b + 8 share an XCD: give each XCD a contiguous range of the list -- with the tile order below that is the
+        //  (column tile, tap) tiles of ONE row block of the output, which all read the same columns of A)
+        const int Lw = x * nslots + slot;
+        const long ubeg = (long)Lw * stream_units;
+        if (ubeg >= total) return;
+        const long uend = ubeg + stream_units < total ? ubeg + stream_units : total;
+        const int t0 = (int)(ubeg / nstk), s0 = (int)(ubeg - (long)t0 * nstk);
+        const int n0 = (int)(uend - ubeg);
+        if (s0 + n0 <= nstk) { npart = 1; part_tile[0] = t0; part_s0[0] = s0; part_s1[0] = s0 + n0; }
+        else {
+            npart = 2;
+            part_tile[0] = t0 + 1; part_s0[0] = 0; part_s1[0] = n0 - (nstk - s0);
+            part_tile[1] = t0; part_s0[1] = s0; part_s1[1] = nstk;
+        }
+    }
     auto decode = [&](int j) {
         // item number -> (tile fastest, then k-split, then tap, then batch): neighbours share the reduction range
         Item it;
-        int z = ibeg + j;
-        const int tile = z % tiles; z /= tiles;
-        const int sp = z % splits; z /= splits;
-        it.tap = z % taps; z /= taps;
+        int z, sp;
+        if (stream_units > 0) {
+            const int pi = j == 0 ? 0 : 1;
+            z = part_tile[pi]; sp = (int)blockIdx.x;
+            it.st0 = part_s0[pi]; it.st1 = part_s1[pi];
+        } else {
+            z = ibeg + j;
+            sp = (z / tiles) % splits;
+            it.st0 = sp * per; it.st1 = min(nstk, it.st0 + per);
+            z = (z % tiles) + (z / (tiles * splits)) * tiles;     // drop the split digit: (tile, tap, batch)
+        }
+        int tm, tn;
+        if (stream_units > 0) {      // column tile fastest, then tap, then row block, then batch
+            tn = z % tilesN; z /= tilesN;
+            it.tap = z % taps; z /= taps;
+            tm = z % tilesM; z /= tilesM;
+        } else {
+            const int tile = z % tiles; z /= tiles;
+            it.tap = z % taps; z /= taps;
+            tm = tile / tilesN; tn = tile % tilesN;
+        }
         const int b2 = z % nb2, b1 = z / nb2;
-        it.m0 = (tile / tilesN) * TM; it.n0 = (tile % tilesN) * TN;
-        it.st0 = sp * per; it.st1 = min(nstk, it.st0 + per);
+        it.m0 = tm * TM; it.n0 = tn * TN;
         it.rot = (sp * rot_step) & (TM - 1);     // the splits of one tile flush its rows in different orders (below)
         const int c2 = p.conv == 2 ? it.tap : b2;
         it.aoff = b1 * p.sA1 + (p.conv == 2 ? 0 : b2 * p.sA2);
@@ -135,7 +177,8 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
 
     f32x4 acc[4][4];
 
-    for (int j = slot; j < have; j += nslots) {
+    const int jbeg = stream_units > 0 ? 0 : slot, jend = stream_units > 0 ? npart : have, jstep = stream_units > 0 ? 1 : nslots;
+    for (int j = jbeg; j < jend; j += jstep) {
         ck = decode(j);
         prep(ck);
         lst = ck.st0;
@@ -250,29 +293,43 @@ bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     const long nb = (long)g.batch1 * g.batch2;
     const long base = (long)tilesM * tilesN * nb;             // work items before the k-split
     const int nstk = (g.K + BK - 1) / BK;
-    if (mode == 1 && (g.K < 16384 || base > 96)) return false;   // long reductions onto few output tiles: the decoder side
-    // k-split: about one item per CU, at least 2 stages per split
-    int splits = (int)(256 / base);                           // never more items than CUs: a second round would double the time
+    // uniform k-split: about one item per CU, at least 2 stages per split (never more items than CUs: a second round would double the time)
+    int splits = (int)(256 / base);
     if (splits > nstk / 2) splits = nstk / 2 > 0 ? nstk / 2 : 1;
     if (splits < 1) splits = 1;
     const int per = (nstk + splits - 1) / splits;
     splits = (nstk + per - 1) / per;                          // no empty split
-    const long nitems = base * splits;
+    long nitems = base * splits;
+    // balanced stream (see the kernel): tile counts no integer split maps onto 256 CUs
+    int stream_units = 0;
+    const long total = base * nstk;
+    const bool fits = base <= 256 && nitems >= 208;           // the uniform split fills >= 81 % of the chip in one round
+    if (!fits && total >= 1024 && base < (1L << 20)) {
+        stream_units = (int)((total + 255) / 256);
+        if (stream_units > nstk) stream_units = 0;            // (a workgroup's range may span two tiles, not three)
+    }
+    static const int stream_env = getenv("FS2_KM_STREAM") ? atoi(getenv("FS2_KM_STREAM")) : 1;      // 0: never (A/B measurements)
+    if (!stream_env) stream_units = 0;
+    // long reductions onto few output tiles (the decoder side), or tile sets the balanced stream spreads over the chip (the encoder convolutions)
+    if (mode == 1 && !(g.K >= 16384 && base <= 96) && stream_units == 0) return false;
+    if (stream_units > 0) nitems = base;
     if (nitems >= (1L << 30)) return false;
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_set[16] = {};            // per device (one process per GPU is the deployment; a process driving several still works)
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the weight-gradient kernel");
             *rc = FS2_ELAUNCH;
             return true;
         }
-        attr_set = true;
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     const long per_x = (nitems + 7) / 8;
-    const int grid = 8 * (int)(per_x < 32 ? per_x : 32);
+    const int grid = stream_units > 0 ? 8 * (int)(((total + stream_units - 1) / stream_units + 7) / 8) : 8 * (int)(per_x < 32 ? per_x : 32);
     g_last_tile = 129;          // (measurement aid: the 16-wave weight-gradient kernel)
     static const int rot_step = getenv("FS2_KM_ROT") ? atoi(getenv("FS2_KM_ROT")) : 4;
-    hipLaunchKernelGGL(fs2_gemm_big_km_kernel, dim3(grid), dim3(NT), SMEM, st, g, tilesM, tilesN, splits, (int)nitems, rot_step);
+    hipLaunchKernelGGL(fs2_gemm_big_km_kernel, dim3(grid), dim3(NT), SMEM, st, g, tilesM, tilesN, splits, (int)nitems, rot_step, stream_units);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { fs2_set_error("fs2_gemm(big km): launch failed: %s", hipGetErrorString(e_)); *rc = FS2_ELAUNCH; return true; }
     *rc = FS2_OK;
