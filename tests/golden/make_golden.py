@@ -407,6 +407,59 @@ def run_data():
     print("data ->", path, f"{os.path.getsize(path) / 1024:.0f} KiB", "lbs", [len(b) for b in batches])
 
 
+AR_DATA_CASES = (("r1", 1, False), ("r2", 2, False), ("r3n", 3, True))       # (tag, reduction rate, mean/variance normalised)
+AR_DATA_BATCHES = ([0, 1], [2, 3, 4], [15], [5, 9, 13, 7], [10, 11, 12, 14, 6, 8])
+AR_DATA_MAX_SEQLEN = 320
+
+
+def run_ardata():
+    """SURVEY 8(f) N2 input side: the reference's OWN autoregressive data path (datasets/datasets_transformer.py: TrainDatasets
+    :18-103 with the all-zero go frame and the round-up of mel_length to the reduction rate, collate_fn :335-383 with the sort by mel
+    length, the -5.0 / -0.5 mel pad and the 1.0 stop-token pad, LengthsBatchSampler :431-490, NumBatchSampler :492-522) on the
+    synthetic corpus of configs[0], for reduction rates 1, 2, 3 with and without mean/variance files.  -> ardata.npz"""
+    import tempfile
+    from transformer_tts_amd.datasets.datasets_fastspeech2 import write_synthetic_corpus
+    D = reference_module("datasets_transformer", "datasets/datasets_transformer.py")
+    rhp = D.hp                      # the reference's module-level hparams singleton (utils/__init__.py): attributes set directly
+    names = ("text", "mel", "pos_text", "pos_mel", "text_lengths", "mel_lengths", "stop_token")
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        write_synthetic_corpus(root)
+        rng = np.random.default_rng(7)
+        np.save(os.path.join(root, "mean.npy"), rng.standard_normal(80).astype(np.float32))
+        np.save(os.path.join(root, "var.npy"), rng.uniform(0.5, 2.0, 80).astype(np.float32))
+        for tag, r, norm in AR_DATA_CASES:
+            lf = os.path.join(root, f"lengths_{tag}.npy")
+            for k, v in dict(mel_dim=80, reduction_rate=r, spm_model=None, is_multi_speaker=False, lengths_file=lf,
+                             mean_file=os.path.join(root, "mean.npy") if norm else None,
+                             var_file=os.path.join(root, "var.npy") if norm else None).items():
+                setattr(rhp, k, v)
+            ds = D.TrainDatasets(os.path.join(root, "train.txt"), rhp)
+            out[f"{tag}.n_utt"] = np.int64(len(ds))
+            for bi, idx in enumerate(AR_DATA_BATCHES):
+                tup = D.collate_fn([ds[i] for i in idx])
+                assert len(tup) == 8 and tup[7] is None
+                out[f"{tag}.b{bi}.index"] = np.asarray(idx, np.int64)
+                for k, t in zip(names, tup):
+                    out[f"{tag}.b{bi}.{k}"] = t.numpy()
+                    out[f"{tag}.b{bi}.{k}.dtype"] = np.array(str(t.dtype))
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                lbs = D.LengthsBatchSampler(ds, AR_DATA_MAX_SEQLEN, lf, shuffle=False, shuffle_one_time=False)      # writes the lengths file
+            out[f"{tag}.lengths"] = np.load(lf)
+            bl = list(lbs)
+            out[f"{tag}.lbs.flat"] = np.asarray([i for b in bl for i in b], np.int64)
+            out[f"{tag}.lbs.sizes"] = np.asarray([len(b) for b in bl], np.int64)
+            np.random.seed(5)
+            nbs = D.NumBatchSampler(ds, 3)
+            for ep in range(2):
+                bl = list(nbs)
+                out[f"{tag}.nbs.ep{ep}.flat"] = np.asarray([i for b in bl for i in b], np.int64)
+                out[f"{tag}.nbs.ep{ep}.sizes"] = np.asarray([len(b) for b in bl], np.int64)
+    path = os.path.join(OUT, "ardata.npz")
+    np.savez_compressed(path, **out)
+    print("ardata ->", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def run_init():
     """the reference's ``init_weight`` (utils/utils.py:153-177) applied to the reference model built under
     ``torch.manual_seed(0)`` (the construction draws PyTorch's default initialisations in module order, ``apply`` then
@@ -446,6 +499,8 @@ if __name__ == "__main__":
         run_ar(which)
     elif which == "data":
         run_data()
+    elif which == "ardata":
+        run_ardata()
     elif which == "init":
         run_init()
     else:

@@ -107,3 +107,50 @@ def test_init_weight_equals_the_reference_under_the_same_seed(name):
     assert {k: tuple(v.shape) for k, v in sd.items()} == golden_shapes(g, prefix=f"{name}.")
     for k, v in sd.items():
         np.testing.assert_array_equal(digest(v.float()), g[f"{name}.dig.{k}"], err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------ autoregressive data path (ardata.npz)
+AR_CASES = (("r1", 1, False), ("r2", 2, False), ("r3n", 3, True))       # make_golden.AR_DATA_CASES
+AR_MAX_SEQLEN = 320
+
+
+@pytest.mark.parametrize("tag,r,norm", AR_CASES)
+def test_ar_data_path_equals_the_reference(tmp_path, tag, r, norm):
+    """datasets_transformer.TrainDatasets / collate_fn / samplers against the REFERENCE's own (tests/golden/ardata.npz): the all-zero
+    go frame, mel_length / pos_mel / padding rounded up to the reduction rate, -5.0 (-0.5 when normalised) mel pad, 1.0 stop-token pad,
+    batches sorted by mel length -- 8-tuples bit for bit, the lengths file, the batch lists of both samplers"""
+    from transformer_tts_amd.datasets import datasets_transformer as A
+    g = np.load(os.path.join(GOLDEN, "ardata.npz"))
+    root = str(tmp_path)
+    D.write_synthetic_corpus(root)
+    rng = np.random.default_rng(7)
+    np.save(os.path.join(root, "mean.npy"), rng.standard_normal(80).astype(np.float32))
+    np.save(os.path.join(root, "var.npy"), rng.uniform(0.5, 2.0, 80).astype(np.float32))
+    hp = SimpleNamespace(mel_dim=80, reduction_rate=r, spm_model=None, is_multi_speaker=False,
+                         mean_file=os.path.join(root, "mean.npy") if norm else None, var_file=os.path.join(root, "var.npy") if norm else None)
+    ds = A.TrainDatasets(os.path.join(root, "train.txt"), hp)
+    assert len(ds) == int(g[f"{tag}.n_utt"])
+    collate = A.make_collate_fn(hp)
+    names = ("text", "mel", "pos_text", "pos_mel", "text_lengths", "mel_lengths", "stop_token")
+    bi = 0
+    while f"{tag}.b{bi}.index" in g.files:
+        tup = collate([ds[int(i)] for i in g[f"{tag}.b{bi}.index"]])
+        assert len(tup) == 8 and tup[7] is None
+        for k, t in zip(names, tup):
+            ref = g[f"{tag}.b{bi}.{k}"]
+            assert str(t.dtype) == str(g[f"{tag}.b{bi}.{k}.dtype"]), (k, t.dtype)
+            assert t.shape == ref.shape and np.array_equal(t.numpy(), ref), f"{tag} batch {bi} field {k}"
+        mel = tup[1]
+        assert mel.shape[1] % r == 0 and torch.all(mel[:, 0] == 0), "go frame / reduction-rate padding"
+        bi += 1
+    assert bi == 5
+    lf = os.path.join(root, "lengths_ar.npy")        # (write_synthetic_corpus leaves the FastSpeech2 lengths in lengths.npy)
+    lbs = A.LengthsBatchSampler(ds, AR_MAX_SEQLEN, lf, shuffle=False)
+    assert np.array_equal(np.load(lf), g[f"{tag}.lengths"])
+    flat, sizes = _flat(list(lbs))
+    assert np.array_equal(flat, g[f"{tag}.lbs.flat"]) and np.array_equal(sizes, g[f"{tag}.lbs.sizes"])
+    np.random.seed(5)
+    nbs = A.NumBatchSampler(ds, 3)
+    for ep in range(2):
+        flat, sizes = _flat(list(nbs))
+        assert np.array_equal(flat, g[f"{tag}.nbs.ep{ep}.flat"]) and np.array_equal(sizes, g[f"{tag}.nbs.ep{ep}.sizes"])

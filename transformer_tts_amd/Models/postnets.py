@@ -9,7 +9,6 @@ from .functional import PostNetFunction, Runtime, next_site
 class PostConvNet(nn.Module):
     def __init__(self, hp, num_hidden, mel_dim, reduction_rate, dropout=0.5, prev_version=True, runtime=None):
         super().__init__()
-        assert prev_version or True
         # prev_version=False (Models/transformer.py:92): no `out` Linear; the reference's forward then RETURNS ITS INPUT
         # (postnets.py:76-79) -- see functional_ar.postnet_update_statistics
         assert reduction_rate == 1 or not prev_version

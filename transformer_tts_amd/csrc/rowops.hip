@@ -53,6 +53,29 @@ __device__ __forceinline__ void row_store(T* p, int d, int lane, const float4 (&
     for (int g = 0; g < NG; ++g)
         if (GCOL(g) < d) store4<T>(p + GCOL(g), v[g]);
 }
+// Raw (unconverted) groups of 4 channels: the row-reducing backward kernels request the operands of the NEXT row of a wave before
+// they process the current one (two rows in flight per wave: a wave otherwise sits out one full memory round trip per row, and
+// 16 waves per CU x 5 KB per row did not cover the HBM latency: 3.1 TB/s for the fused FeedForward-tail backward).  The bf16 -> f32
+// conversion happens at the use, so the wait for a row's data sits there and not at the request.
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { typedef float4 type; };
+template <> struct Raw4<bf16_t> { typedef bf16x4 type; };
+template <typename T> __device__ __forceinline__ float4 cvt4(typename Raw4<T>::type v);
+template <> __device__ __forceinline__ float4 cvt4<float>(float4 v) { return v; }
+template <> __device__ __forceinline__ float4 cvt4<bf16_t>(bf16x4 v) { return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]); }
+template <int NG, typename T>
+__device__ __forceinline__ void row_load_raw(const T* p, int d, int lane, typename Raw4<T>::type (&v)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = GCOL(g) < d ? GCOL(g) : 0;          // (columns past the row re-read column 0: no branch around the load; unused)
+        v[g] = *reinterpret_cast<const typename Raw4<T>::type*>(p + c);
+    }
+}
+template <int NG, typename T>
+__device__ __forceinline__ void row_cvt(const typename Raw4<T>::type (&r)[NG], int d, int lane, float4 (&v)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) v[g] = (GCOL(g) < d) ? cvt4<T>(r[g]) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
 __device__ __forceinline__ float sum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -444,17 +467,31 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restr
         for (int g = 0; g < NG; ++g) ag2[g] = ab2[g] = ag1[g] = ab1[g] = ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float invd = 1.f / (float)d;
-    RED_LOOP(M) {
+    // operands of one row, as loaded
+    struct RowOps {
+        typename Raw4<T>::type dy[NG], f2[NG], h[NG];
+        float4 s[NG], dn[NG];
+        float mu2, rs2, mu1, rs1;
+    };
+    const bool has_dn = ds_down != nullptr;
+    auto request = [&](RowOps& o, int64_t row, int lane) __attribute__((always_inline)) {
+        row_load_raw<NG, T>(dy + row * d, d, lane, o.dy);
+        row_load_raw<NG, float>(s + row * d, d, lane, o.s);
+        if (has_dn) row_load_raw<NG, float>(ds_down + row * d, d, lane, o.dn);
+        row_load_raw<NG, T>(f2 + row * d, d, lane, o.f2);
+        row_load_raw<NG, T>(h + row * d, d, lane, o.h);
+        o.mu2 = mean2[row]; o.rs2 = rstd2[row]; o.mu1 = mean1[row]; o.rs1 = rstd1[row];
+    };
+    auto process = [&](const RowOps& in, int64_t row, int lane) __attribute__((always_inline)) {
         // ---- LN2 backward + residual + dropout2'  (add_ln_bwd_k)
-        // every operand of the row is requested before the first reduction: one memory round trip per row instead of three
         float4 g_[NG], xv[NG], dn[NG], fv[NG], hv[NG];
-        row_load<NG, T>(dy + row * d, d, lane, g_);
-        row_load<NG, float>(s + row * d, d, lane, xv);
-        if (ds_down != nullptr) row_load<NG, float>(ds_down + row * d, d, lane, dn);
-        row_load<NG, T>(f2 + row * d, d, lane, fv);
-        row_load<NG, T>(h + row * d, d, lane, hv);
-        float mu = mean2[row], rs = rstd2[row];
-        const float mu1 = mean1[row], rs1 = rstd1[row];
+        row_cvt<NG, T>(in.dy, d, lane, g_);
+        row_cvt<NG, float>(in.s, d, lane, xv);
+        if (has_dn) row_cvt<NG, float>(in.dn, d, lane, dn);
+        row_cvt<NG, T>(in.f2, d, lane, fv);
+        row_cvt<NG, T>(in.h, d, lane, hv);
+        float mu = in.mu2, rs = in.rs2;
+        const float mu1 = in.mu1, rs1 = in.rs1;
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -476,7 +513,7 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restr
         for (int g = 0; g < NG; ++g) {
             o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2); o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2);
             o[g].z = rs * (g_[g].z - c1 - xv[g].z * c2); o[g].w = rs * (g_[g].w - c1 - xv[g].w * c2);
-            if (ds_down != nullptr) o[g] = add4(o[g], dn[g]);
+            if (has_dn) o[g] = add4(o[g], dn[g]);
         }
         row_store<NG, float>(dr + row * d, d, lane, o);
 #pragma unroll
@@ -513,6 +550,24 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restr
             ac[g] = add4(ac[g], o[g]);
         }
         row_store<NG, T>(gout + row * d, d, lane, o);
+    };
+    {
+        // two rows in flight per wave: the operands of row r + stride are requested before row r is processed.  Requests past the
+        // last row are clamped to it (always issued: a load under a branch makes hipcc drain vmcnt at every use) and not processed.
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int64_t stride = (int64_t)gridDim.x * RED_WAVES, last = M - 1;
+        int64_t row = (int64_t)blockIdx.x * RED_WAVES + wave;
+        if (row < M) {
+            RowOps ra, rb;
+            request(ra, row, lane);
+            for (; row < M; row += 2 * stride) {
+                const int64_t r1 = row + stride, r2 = row + 2 * stride;
+                request(rb, r1 < M ? r1 : last, lane);
+                process(ra, row, lane);
+                request(ra, r2 < M ? r2 : last, lane);
+                if (r1 < M) process(rb, r1, lane);
+            }
+        }
     }
     flush_channel_sums<NG>(ag2, dgamma2, d, red);
     flush_channel_sums<NG>(ab2, dbeta2, d, red);

@@ -838,6 +838,7 @@ def bce_logits_fwd(x, y, pos_weight, loss):
 
 
 def bce_logits_bwd(x, y, pos_weight, gscale, dx_dtype):
+    _same_numel(x, y, "bce_logits_bwd")
     dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
     _check(lib().fs2_bce_logits_bwd(_p(_c(x)), _dt(x), _p(_c(y)), x.numel(), float(pos_weight), _p(gscale), _p(dx), _dt(dx),
                                     _stream()), "fs2_bce_logits_bwd")
@@ -966,13 +967,21 @@ def bn_tanh_bwd_apply(dy, x, mean, rstd, gamma, beta, red, count, dgamma, dbeta,
 
 
 # ------------------------------------------------------------------------------------------------ losses / optimizer
+def _same_numel(pred, target, who):
+    """the kernels read `pred.numel()` elements of both operands: a shorter target would be read past its end"""
+    if target.numel() != pred.numel():
+        raise ValueError(f"{who}: prediction {tuple(pred.shape)} and target {tuple(target.shape)} differ in size")
+
+
 def l1_fwd(pred, target, loss, log1p_int_target=False):
     """loss[0] (fp32, zeroed by the caller) += mean |pred - target|"""
+    _same_numel(pred, target, "l1_fwd")
     _check(lib().fs2_l1_fwd(_p(_c(pred)), _dt(pred), _p(_c(target)), int(log1p_int_target), pred.numel(), _p(loss),
                             _stream()), "fs2_l1_fwd")
 
 
 def l1_bwd(pred, target, gscale, dpred_dtype, log1p_int_target=False):
+    _same_numel(pred, target, "l1_bwd")
     dpred = torch.empty(pred.shape, dtype=dpred_dtype, device=pred.device)
     _check(lib().fs2_l1_bwd(_p(_c(pred)), _dt(pred), _p(_c(target)), int(log1p_int_target), pred.numel(), _p(gscale),
                             _p(dpred), _dt(dpred), _stream()), "fs2_l1_bwd")

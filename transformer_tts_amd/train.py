@@ -9,7 +9,9 @@ can be tested step by step against fixtures produced by the reference.  Quirks k
   * the post-net built with prev_version=False returns its input (Models/postnets.py:76-79): outputs_postnet is
     outputs_prenet, both L1 terms are equal and the post-net's parameters never receive a gradient (only its BatchNorm
     running statistics move);
-  * the decoder sees frames 0 .. T-2 (reduction rate r: every r-th frame) and is trained against frames r .. T-1.
+  * the decoder sees frames 0 .. T-2 (reduction rate r: every r-th frame) and is trained against frames r .. T-1; frame 0 is the
+    all-zero go frame ``datasets_transformer.TrainDatasets`` prepends, and T is a multiple of r (its collate_fn pads to one), so
+    the (T - r) / r decoder steps produce exactly the T - r target frames.
 """
 import argparse
 import os
@@ -25,7 +27,7 @@ from .Models.transformer import Transformer
 from .optim import FusedAdam
 from .utils import hparams as hp
 from .utils.utils import fill_variables, get_learning_rate, init_weight, load_model, log_config
-from .datasets import datasets_fastspeech2 as datasets
+from .datasets import datasets_transformer as datasets
 
 DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
@@ -63,6 +65,10 @@ def compute_losses(hp, outputs, mel, stop_token):
         outputs_postnet = outputs_postnet.reshape(b, t * r, c // r)
         outputs_stop_token = outputs_stop_token.reshape(b, t * r)
     target = mel[:, r:, :].contiguous()
+    if outputs_prenet.shape != target.shape or outputs_stop_token.shape != stop_token[:, r:].shape:
+        raise ValueError(f"decoder output {tuple(outputs_prenet.shape)} does not cover the target frames {tuple(target.shape)}: the "
+                         f"padded mel length ({mel.shape[1]}) must be a multiple of hp.reduction_rate ({r}) -- batches must come from "
+                         "datasets_transformer.collate_fn (go frame + round-up), not from the FastSpeech2 reader")
     parts = {"mel": l1_loss(outputs_prenet, target), "post_mel": l1_loss(outputs_postnet, target),
              "token": bce_with_logits(outputs_stop_token, stop_token[:, r:].contiguous(), float(hp.positive_weight))}
     loss = parts["mel"] + parts["post_mel"]
@@ -104,6 +110,7 @@ def train_step(model, optimizer, step, d, hp):
 def train_loop(model, optimizer, step, epoch, hp, dataloader, log_every=1):
     for d in dataloader:
         loss, parts, step = train_step(model, optimizer, step, d, hp)
+        assert not torch.isnan(loss), "loss is nan"          # every iteration, as the reference does (train.py:236)
         if (step - 1) % log_every == 0:
             print(f"step {step - 1}")
             print(f"loss_token = {parts['token'].item()}")
@@ -111,7 +118,6 @@ def train_loop(model, optimizer, step, epoch, hp, dataloader, log_every=1):
             print(f"loss_frame_after = {parts['post_mel'].item()}")
             print(f"loss_total = {loss.item()}")
             print(f"batch size = {d[1].shape[0]}")
-            assert not torch.isnan(loss), "loss is nan"
             sys.stdout.flush()
     if (epoch + 1) >= (hp.max_epoch - 10) or (epoch + 1) % hp.save_per_epoch >= (hp.save_per_epoch - 10) or \
             (epoch + 1) % hp.save_per_epoch == 0:
@@ -139,13 +145,13 @@ def run_training(hp):
     model.train()
     optimizer = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=hp.clip)
     os.makedirs(hp.save_dir, exist_ok=True)
-    dataset_train = datasets.TrainDatasets(hp.train_script, hp, alignment_pred=False, pitch_pred=False, energy_pred=False,
-                                           accent_emb=False)
+    dataset_train = datasets.TrainDatasets(hp.train_script, hp)                    # reference train.py:129-137
+    collate_fn = datasets.make_collate_fn(hp)
     assert (hp.batch_size is None) != (hp.max_seqlen is None)
     if hp.batch_size is not None:
         sampler = datasets.NumBatchSampler(dataset_train, hp.batch_size)
     else:
-        sampler = datasets.LengthsBatchSampler(dataset_train, hp.max_seqlen, hp, hp.lengths_file, shuffle=True, shuffle_one_time=False)
+        sampler = datasets.LengthsBatchSampler(dataset_train, hp.max_seqlen, hp.lengths_file, shuffle=True, shuffle_one_time=False)
     if hp.loaded_epoch is not None:
         start_epoch = hp.loaded_epoch
         print("epoch {} loaded".format(hp.loaded_epoch))
@@ -159,7 +165,7 @@ def run_training(hp):
         start_epoch, step = 0, 1
     for epoch in range(start_epoch, hp.max_epoch):
         dataloader = DataLoader(dataset_train, batch_sampler=sampler, num_workers=int(getattr(hp, "num_workers", 4)),
-                                collate_fn=datasets.collate_fn)
+                                collate_fn=collate_fn)
         start_time = time.time()
         step = train_loop(model, optimizer, step, epoch, hp, dataloader, max(1, int(getattr(hp, "log_every", 1))))
         print("EPOCH {} end".format(epoch + 1))

@@ -265,7 +265,7 @@ def train_loop(model, optimizer, step, epoch, args, hp, rank, dataloader):
     if on_gpu and bool(getattr(hp, "use_graph", True)):
         stepper = getattr(optimizer, "_fs2_graphed", None)
         if stepper is None or stepper.model is not model:
-            stepper = optimizer._fs2_graphed = GraphedTrainStep(model, optimizer, hp)
+            stepper = optimizer._fs2_graphed = GraphedTrainStep(model, optimizer, hp, eager_fallback=_dist_alive())   # (N > 1 capture has never run on hardware: a refusal falls back to eager launches, as in bench.py)
         run = lambda m, o, st, d, h: stepper(st, d)
     batches = DevicePrefetcher(dataloader, optimizer.arena.p.device, indices=STEP_INPUTS) if on_gpu else dataloader
     for d in batches:
