@@ -50,6 +50,10 @@ def bench_hp(amp=True, workload="cfg2", fp8=False, return_attn=False):
     from transformer_tts_amd.utils.utils import fill_variables
     d = dict(_BASE)
     d.update(CONFIGS["bench"]["hp"])
+    if workload == "cfg3":      # BASELINE.json configs[3]: autoregressive Transformer-TTS (encoder-decoder cross-attention + post-net)
+        from golden_configs import _AR
+        d.update(_AR)
+        d.update(dropout_prenet=0.5, dropout_postnet=0.5)      # (reference defaults; the attention dropout follows hp.dropout)
     if workload == "cfg4":      # BASELINE.json configs[4]: d_model 512, 6+6 FFT layers, batch 64 per GPU, fp8 MFMA GEMMs
         d.update(batch_size=64, d_model_encoder=512, n_layer_encoder=6, n_head_encoder=4, d_model_decoder=512, n_layer_decoder=6,
                  n_head_decoder=4)
@@ -96,13 +100,13 @@ class GemmTimer:
             taps = g.taps if g.conv == 1 else 1
             nb = max(1, g.batch1) * max(1, g.batch2)
             flops = 2.0 * g.M * g.N * g.K * taps * nb
-            es, cs = (2 if g.dtype == 1 else 4), (2 if g.c_dtype == 1 else 4)
+            es, cs = {0: 4, 1: 2, 2: 1, 3: 1}[g.dtype], (2 if g.c_dtype == 1 else 4)
             # algorithmic bytes: every operand element once (conv: the A rows once, not once per tap)
             abytes = (es * (g.M * g.K + g.N * g.K * taps) + cs * g.M * g.N) * float(nb)
             # block tile the launcher picked: 64 / 128 = rows of gemm.hip's tile, 192 / 256 = rows of gemm_big.hip's, 130 = its 128-row tile,
             # 129 = the 16-wave weight-gradient kernel (gemm_big_km.hip)
             tile = self._last_tile()
-            key = ("bf16" if g.dtype == 1 else "f32", "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm", tile)
+            key = ({0: "f32", 1: "bf16", 2: "fp8", 3: "bf8xfp8"}[g.dtype], "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm", tile)
             flags = ("b" if g.bias else "") + ("r" if g.relu else "") + ("m" if g.relu_mask else "") + ("+" if g.residual else "") + \
                     (f"s{g.colstats_mode}" if g.colstats else "") + ("a" if g.accumulate else "") + ("f" if g.c_dtype == 0 and g.dtype == 1 else "")
             shape = (g.M, g.N, g.K, taps if g.conv == 1 else (g.batch2 if g.conv == 2 else 1), g.batch1 * g.batch2, g.split_k, flags or "-")
@@ -170,6 +174,122 @@ def cpu_baseline(hp, batch):
                        f"frames): {med:.1f} s per step (min {min(times):.1f}, max {max(times):.1f})")
 
 
+def ar_batch(seed, batch_size, r=1):
+    """(text, mel, pos_text, pos_mel, text_lengths, mel_lengths, stop_token, None) as datasets_transformer.collate_fn hands them to the
+    autoregressive trainer, made from the synthetic FastSpeech2 batch of the same seed: an all-zero go frame in front of every mel,
+    frame counts rounded up to the reduction rate, mel pad -5.0 (no mean/variance files), longest utterance first"""
+    import numpy as np
+    from transformer_tts_amd import synthetic
+    text, mel, pos_text, pos_mel, tl, ml = (x.numpy() for x in synthetic.benchmark_batch(seed, batch_size)[:6])
+    order = np.argsort(-(ml + 1), kind="stable")
+    frames = ml[order] + 1
+    lens = -(-frames // r) * r
+    T = int(-(-int(frames.max()) // r) * r)
+    B = batch_size
+    mel2 = np.full((B, T, mel.shape[2]), -5.0, np.float32)
+    stop = np.ones((B, T), np.float32)
+    pm = np.zeros((B, T), np.int64)
+    for i, b in enumerate(order):
+        n = int(frames[i])
+        mel2[i, 0] = 0.0
+        mel2[i, 1:n] = mel[b, :n - 1]
+        stop[i, :n] = 0.0
+        pm[i, :int(lens[i])] = np.arange(1, int(lens[i]) + 1)
+    t = torch.from_numpy
+    return (t(text[order]), t(mel2), t(pos_text[order]), t(pm), t(tl[order]), t(lens.astype(np.int64)), t(stop), None)
+
+
+def bench_ar(args, hp, dev):
+    """--workload cfg3: BASELINE.json configs[3] (a parity case, reported for completeness: never the headline).  Eager launches
+    (the autoregressive trainer has no graph stepper); a step = reference train.py:156-262 on one resident batch."""
+    from transformer_tts_amd import train as T
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.utils.utils import init_weight
+    T.DEVICE = dev
+    torch.manual_seed(1234)
+    model = T.build_model(hp)
+    model.apply(init_weight)
+    model.train()
+    model = model.to(dev)
+    opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=hp.clip)
+    pool = [tuple(b.to(dev) if torch.is_tensor(b) else b for b in ar_batch(2024 + i, hp.batch_size, hp.reduction_rate)) for i in range(POOL)]
+    frames = [int(b[5].sum()) - b[1].shape[0] for b in pool]            # valid mel frames without the go frames
+    step = 1
+    for i in range(args.warmup):
+        _, _, step = T.train_step(model, opt, step, pool[i % POOL], hp)
+    timer = GemmTimer()
+    timer.calibrate()
+    timer.reserve(2 * 700 * args.steps)
+    timer.install()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(args.steps):
+        _, _, step = T.train_step(model, opt, step, pool[(args.warmup + i) % POOL], hp)
+        done += frames[(args.warmup + i) % POOL]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.remove()
+    return timer, dt, done, int(sum(b[1].shape[0] * b[1].shape[1] for b in pool) / len(pool))
+
+
+def bench_line(args, timer, dt, done, world, warm, use_graph, padded, BATCH, cpu):
+    """the ONE JSON line of the contract (metric, value, roofline of the dominant GEMM variant, cpu_baseline)"""
+    agg = timer.summary()
+    roof = None
+    if agg:
+        key, (fl, ms, cnt, by) = max(agg.items(), key=lambda kv: kv[1][1])
+        tflops = fl / (ms * 1e-3) / 1e12
+        gbs = by / (ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+        if os.path.exists(tpath):       # HBM bytes per launch of this variant from the PMC passes (tools/summarize_profiles.py)
+            traffic = json.load(open(tpath)).get("by_variant", {}).get("/".join(str(x) for x in key))
+        # the roof that binds the dominant kernel's launches on average: algorithmic FLOP per algorithmic byte
+        # against the machine balance 2.5 PFLOP/s / 8 TB/s
+        hbm_bound = (fl / by) < (PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
+        roof = dict(bound="hbm" if hbm_bound else "mfma",
+                    kernel=(f"{'fs2_gemm_ring_kernel' if key[0] == 'bf16' else 'fs2_gemm_big_kernel'}<{key[0]}, {128 if key[3] == 130 else key[3]}x256 tile, 16 waves, LDS-DMA> A row-major B row-major"
+                            if key[3] >= 130 else
+                            f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 4 k-groups, LDS-DMA> A k-major B k-major" if key[3] == 129 else
+                            f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}"),
+                    achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                    unit="GB/s" if hbm_bound else "TFLOP/s",
+                    frac=round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_BF16_TFLOPS), 4), traffic=traffic,
+                    launches=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2), event_pair_overhead_us=round(timer.overhead_ms * 1e3, 2),
+                    algorithmic_bytes_per_launch=round(by / cnt), algorithmic_flops_per_launch=round(fl / cnt),
+                    achieved_tflops=round(tflops, 1), mfma_frac=round(tflops / PEAK_BF16_TFLOPS, 4),
+                    achieved_gbs=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
+                    gemm_ms_per_step=round(sum(v[1] for v in agg.values()) / max(1, (min(args.steps, POOL) if use_graph else args.steps)), 3),
+                    all_variants={"/".join(str(x) for x in k): dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), gbs=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
+                                                     ms=round(v[1], 2), launches=v[2]) for k, v in agg.items()})
+    line = {
+        "metric": ("mel-frames/sec (train step) autoregressive Transformer-TTS d_model=256" if args.workload == "cfg3" else
+                   "mel-frames/sec (train step) FastSpeech2 d_model=256"), "value": round(done / dt, 1),
+        "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
+        "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32" if args.fp32 else ("fp8" if args.fp8 else "bf16"), "data": "synthetic (fed from pinned host memory: PCIe-inclusive)" if args.from_host else "synthetic",
+        "config": {"workload": ("BASELINE.json configs[1]: FastSpeech2 d_model=256, 4+4 FFT layers (H=2, k_enc=9, k_dec=1), "
+                                "80-mel, batch 48/GPU (L_pad<=128, T_pad~925), fwd+bwd+clip+Adam, dropout 0.1/0.5/0.5")
+                   if args.workload == "cfg2" else
+                   ("BASELINE.json configs[3]: autoregressive Transformer-TTS (Models/transformer.py) d_model=256, 4+4 layers (H=2, k_enc=9, "
+                    "k_dec=1), pre-net + encoder-decoder cross-attention + post-net statistics, 80-mel, batch 48 (L_pad<=128, T_pad~926 incl. the "
+                    "go frame), reduction rate 1, fwd+bwd+clip+Adam, dropout 0.1 / pre-net 0.5; a parity case reported for completeness")
+                   if args.workload == "cfg3" else
+                   ("BASELINE.json configs[4]: FastSpeech2 d_model=512, 6+6 FFT layers (H=4, k_enc=9, k_dec=1), 80-mel, batch "
+                    "64/GPU, fwd+bwd+clip+Adam, dropout 0.1/0.5/0.5, " + ("fp8 e4m3/e5m2 operands in the row-major GEMMs"
+                                                                          if args.fp8 else "bf16 operands")),
+                   "global_batch": BATCH * world, "parallelism": f"dp{world}",
+                   "padded_frames_per_step": padded,
+                   "attention": ("scores GEMM -> softmax (causal / rectangular) -> P V GEMM, probabilities in HBM" if args.workload == "cfg3" else
+                                 "hp.return_attn=True: LDS-strip kernels, attention maps written to HBM" if args.return_attn or args.fp32
+                                 else "hp.return_attn=False: flash kernels (no (t x t) tensor in HBM; the loop never reads the maps)"),
+                   "launch": "hipGraph replay per batch shape" if use_graph else "eager"},
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    return line
+
+
 def launch_ranks(n):
     """start n rank processes of this script under torch.distributed.run (a child process; this one never initialises
     the GPU and only relays the exit code)"""
@@ -199,8 +319,9 @@ def main():
     ap.add_argument("--gemm-report", type=str, default=None, help="write per-shape GEMM timings to this file")
     ap.add_argument("--no-overlap", action="store_true", help="(default) keep the weight-gradient GEMMs on the main stream")
     ap.add_argument("--overlap", action="store_true", help="run the weight-gradient GEMMs on a second stream (measured slower: DESIGN.md)")
-    ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2",
-                    help="cfg2 = BASELINE.json configs[1] (the headline, default); cfg4 = configs[4] (d_model 512, 6+6 layers, batch 64/GPU)")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
+                    help="cfg2 = BASELINE.json configs[1] (the headline, default); cfg3 = configs[3] (autoregressive Transformer-TTS, same "
+                         "sizes, eager); cfg4 = configs[4] (d_model 512, 6+6 layers, batch 64/GPU)")
     ap.add_argument("--return-attn", action="store_true",
                     help="hp.return_attn=True: keep the (B,N,H,t,t) attention maps (LDS-strip kernels) instead of the flash kernels")
     ap.add_argument("--from-host", action="store_true",
@@ -235,6 +356,12 @@ def main():
 
     hp = bench_hp(amp=not args.fp32, workload=args.workload, fp8=args.fp8, return_attn=args.return_attn)
     BATCH = hp.batch_size
+    if args.workload == "cfg3":
+        assert world == 1, "configs[3] is a single-GPU parity case"
+        timer, dt, done, padded = bench_ar(args, hp, dev)
+        line = bench_line(args, timer, dt, done, world, args.warmup, False, padded, BATCH, None)
+        print(json.dumps(line), flush=True)
+        return
     torch.manual_seed(1234)
     model = build_model(hp)
     model.apply(init_weight)
@@ -332,55 +459,10 @@ def main():
         dt, done = float(t.item()), float(n.item())
 
     if rank == 0:
-        agg = timer.summary()
-        roof = None
-        if agg:
-            key, (fl, ms, cnt, by) = max(agg.items(), key=lambda kv: kv[1][1])
-            tflops = fl / (ms * 1e-3) / 1e12
-            gbs = by / (ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-            if os.path.exists(tpath):       # HBM bytes per launch of this variant from the PMC passes (tools/summarize_profiles.py)
-                traffic = json.load(open(tpath)).get("by_variant", {}).get("/".join(str(x) for x in key))
-            # the roof that binds the dominant kernel's launches on average: algorithmic FLOP per algorithmic byte
-            # against the machine balance 2.5 PFLOP/s / 8 TB/s
-            hbm_bound = (fl / by) < (PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
-            roof = dict(bound="hbm" if hbm_bound else "mfma",
-                        kernel=(f"fs2_gemm_big_kernel<{key[0]}, {128 if key[3] == 130 else key[3]}x256 tile, 16 waves, LDS-DMA> A row-major B row-major"
-                                if key[3] >= 130 else
-                                f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 4 k-groups, LDS-DMA> A k-major B k-major" if key[3] == 129 else
-                                f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}"),
-                        achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
-                        unit="GB/s" if hbm_bound else "TFLOP/s",
-                        frac=round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_BF16_TFLOPS), 4), traffic=traffic,
-                        launches=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2), event_pair_overhead_us=round(timer.overhead_ms * 1e3, 2),
-                        algorithmic_bytes_per_launch=round(by / cnt), algorithmic_flops_per_launch=round(fl / cnt),
-                        achieved_tflops=round(tflops, 1), mfma_frac=round(tflops / PEAK_BF16_TFLOPS, 4),
-                        achieved_gbs=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
-                        gemm_ms_per_step=round(sum(v[1] for v in agg.values()) / max(1, (min(args.steps, POOL) if use_graph else args.steps)), 3),
-                        all_variants={"/".join(str(x) for x in k): dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), gbs=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
-                                                         ms=round(v[1], 2), launches=v[2]) for k, v in agg.items()})
         cpu = None
         if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             cpu = cpu_baseline(hp, synthetic.benchmark_batch(2024, 48))
-        line = {
-            "metric": "mel-frames/sec (train step) FastSpeech2 d_model=256", "value": round(done / dt, 1),
-            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
-            "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.fp32 else ("fp8" if args.fp8 else "bf16"), "data": "synthetic (fed from pinned host memory: PCIe-inclusive)" if args.from_host else "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: FastSpeech2 d_model=256, 4+4 FFT layers (H=2, k_enc=9, k_dec=1), "
-                                    "80-mel, batch 48/GPU (L_pad<=128, T_pad~925), fwd+bwd+clip+Adam, dropout 0.1/0.5/0.5")
-                       if args.workload == "cfg2" else
-                       ("BASELINE.json configs[4]: FastSpeech2 d_model=512, 6+6 FFT layers (H=4, k_enc=9, k_dec=1), 80-mel, batch "
-                        "64/GPU, fwd+bwd+clip+Adam, dropout 0.1/0.5/0.5, " + ("fp8 e4m3/e5m2 operands in the row-major GEMMs"
-                                                                              if args.fp8 else "bf16 operands")),
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}",
-                       "padded_frames_per_step": int(sum(b[1].shape[0] * b[1].shape[1] for b in pool) / len(pool)),
-                       "attention": ("hp.return_attn=True: LDS-strip kernels, attention maps written to HBM" if args.return_attn or args.fp32
-                                     else "hp.return_attn=False: flash kernels (no (t x t) tensor in HBM; the loop never reads the maps)"),
-                       "launch": "hipGraph replay per batch shape" if use_graph else "eager"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
+        line = bench_line(args, timer, dt, done, world, warm, use_graph, int(sum(b[1].shape[0] * b[1].shape[1] for b in pool) / len(pool)), BATCH, cpu)
         print(json.dumps(line), flush=True)
     if world > 1 or force_dp:
         dist.destroy_process_group()
