@@ -290,6 +290,30 @@ def bench_line(args, timer, dt, done, world, warm, use_graph, padded, BATCH, cpu
     return line
 
 
+def rank_stub(args):
+    """FS2_BENCH_STUB=1: the rank side of `bench.py --gpus N` WITHOUT a GPU -- rendezvous (gloo), the barrier / MAX-over-ranks /
+    SUM-of-frames protocol of the timed region and the one JSON line on rank 0, with a sleep in place of the train steps.  What the
+    CPU test of the launcher glue runs (tests/test_trainer_cpu.py): the first real multi-GPU run must not die in this part."""
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * args.steps * (1 + rank))          # rank r is slower: the MAX must pick the last rank's time
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t, n = torch.tensor([dt], dtype=torch.float64), torch.tensor([1000.0 * args.steps], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": round(float(n) / float(t), 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(float(t) * 1e3 / args.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "frames_all_ranks": float(n), "local_rank": int(os.environ.get("LOCAL_RANK", "-1"))}), flush=True)
+    dist.destroy_process_group()
+
+
 def launch_ranks(n):
     """start n rank processes of this script under torch.distributed.run (a child process; this one never initialises
     the GPU and only relays the exit code)"""
@@ -338,6 +362,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))       # parent: no HIP call has been made in this process
+    if os.environ.get("FS2_BENCH_STUB") == "1":
+        return rank_stub(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -463,6 +489,11 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             cpu = cpu_baseline(hp, synthetic.benchmark_batch(2024, 48))
         line = bench_line(args, timer, dt, done, world, warm, use_graph, int(sum(b[1].shape[0] * b[1].shape[1] for b in pool) / len(pool)), BATCH, cpu)
+        if getattr(opt, "dp", None) is not None:        # the gradient all-reduce schedule of the last eager step (bytes, launched from where)
+            plan = opt.dp.describe_plan()
+            line["config"]["dp_plan"] = {"buckets": [[q["bytes"], q["launched"]] for q in plan],
+                                         "bytes_in_backward": sum(q["bytes"] for q in plan if q["launched"] == "backward"),
+                                         "bytes_total": sum(q["bytes"] for q in plan)}
         print(json.dumps(line), flush=True)
     if world > 1 or force_dp:
         dist.destroy_process_group()

@@ -69,7 +69,10 @@ def _worker(rank, world, port, out_dir):
     opt.dp = DataParallel(model, opt.arena, bucket_bytes=64 << 10)
     batch = CONFIGS["small"]["batch"]()
     loss = _step(T, model, opt, _slice(batch, slice(2 * rank, 2 * rank + 2)), hp)
-    torch.save(dict(p=opt.arena.p.clone(), loss=loss, rm=model.postnet.pre_batchnorm.running_mean.clone()),
+    plan = opt.dp.describe_plan()
+    torch.save(dict(p=opt.arena.p.clone(), loss=loss, rm=model.postnet.pre_batchnorm.running_mean.clone(),
+                    plan=torch.tensor([[q["elements"][0], q["elements"][1], q["bytes"], int(q["launched"] == "backward")] for q in plan]),
+                    numel=opt.arena.numel),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
@@ -82,6 +85,18 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(tmp_path):
     r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
     assert torch.equal(r0["p"], r1["p"]), "ranks diverged"
     assert torch.equal(r0["rm"], r1["rm"]), "SyncBatchNorm running stats diverged"
+    # the gradient all-reduce schedule (DataParallel.describe_plan, what `bench.py --gpus N` prints as config.dp_plan): the same on
+    # both ranks (collectives must be issued in the same order), every arena element reduced exactly once, several buckets launched
+    # from inside the backward (they overlap the rest of it: more than half of the bytes), all of them before finish()'s tail
+    assert torch.equal(r0["plan"], r1["plan"])
+    plan = r0["plan"].tolist()
+    cover = np.zeros(int(r0["numel"]), np.int32)
+    for lo, hi, nbytes, in_bwd in plan:
+        cover[lo:hi] += 1
+        assert nbytes == 4 * (hi - lo)
+    assert cover.min() == 1 and cover.max() == 1
+    assert sum(q[2] for q in plan if q[3]) > 0.5 * 4 * int(r0["numel"])
+    assert sum(q[3] for q in plan) >= 3 and [q[3] for q in plan] == sorted((q[3] for q in plan), reverse=True)
     # single process, whole batch
     T = _setup()
     from helpers import CONFIGS, product_model

@@ -246,3 +246,32 @@ def test_autoregressive_trainer_runs_on_the_reference_data_path(fake_ops, tmp_pa
         from transformer_tts_amd.optim import FusedAdam
         with pytest.raises(ValueError, match="multiple of hp.reduction_rate"):
             T.train_step(model, FusedAdam(model), 1, odd, hp)
+
+
+def test_bench_launcher_glue_runs_two_ranks_without_a_gpu():
+    """`python bench.py --gpus 2` from a plain shell: bench.launch_ranks builds the torch.distributed.run command line, the two rank
+    processes rendezvous over 127.0.0.1, run the barrier / MAX-over-ranks protocol of the timed region and rank 0 prints ONE JSON
+    line.  FS2_BENCH_STUB=1 replaces the GPU work by a sleep (gloo): the launcher glue is what is under test."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, FS2_BENCH_STUB="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["frames_all_ranks"] == 2 * 3000.0 and line["local_rank"] == 0
+    assert line["ms_per_step"] >= 0.9 * 20.0, "the MAX over ranks must report the slower rank's time"
+    # the driver's own form: started under torch.distributed.run, bench.py must not launch a second set of ranks
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1

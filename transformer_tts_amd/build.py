@@ -27,7 +27,7 @@ def _stale(target, deps):
 
 
 def build_library(force=False, verbose=True):
-    headers = [os.path.join(CSRC, "common.cuh"), os.path.join(INCLUDE, "fs2_hip.h")]
+    headers = [os.path.join(CSRC, "fs2_common.h"), os.path.join(INCLUDE, "fs2_hip.h")]
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []

@@ -1,5 +1,5 @@
 // Error reporting and ABI version of libfs2_hip.so.
-#include "common.cuh"
+#include "fs2_common.h"
 
 static thread_local char g_err[512] = "";
 

@@ -13,7 +13,7 @@
 // query row (one 8-byte LDS store into the strip).  Dropout uses the same Philox counters (element offset in P >> 3)
 // as fs2_softmax_fwd, so fs2_softmax_bwd regenerates the masks unchanged.
 #include <stdlib.h>
-#include "common.cuh"
+#include "fs2_common.h"
 
 namespace {
 
@@ -431,10 +431,9 @@ __global__ __launch_bounds__(512, QBT == 32 ? 2 : 1) void attn_strip_k(const Att
 template <int DK, int MODE, int QBT>
 int launch_strip(const AttnArgs& a, int B, hipStream_t st, const char* name) {
     const int lds = QBT * a.sld * 2 + (QBT == 64 ? 2 : 1) * KTile<DK>::BYTES + MASK_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static Fs2PerDevice attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_strip_k<DK, MODE, QBT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-        attr_set = true;
     }
     dim3 grid((a.t + QBT - 1) / QBT, a.H, B);
     hipLaunchKernelGGL((attn_strip_k<DK, MODE, QBT>), grid, dim3(512), lds, st, a);

@@ -29,7 +29,7 @@
 // uniform distribution of the reference comes out), so O, dQ receive nothing from them and their dK, dV rows are zero.
 // Softmax in the exp2 domain: p = exp2(s * (alpha log2 e) - m * (alpha log2 e)) is one fma + v_exp_f32.
 #include <stdlib.h>
-#include "common.cuh"
+#include "fs2_common.h"
 
 namespace {
 
@@ -833,12 +833,11 @@ extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, i
     a.key_mask = key_mask; a.kinfo = key_info; a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.stats = stats; a.keep = keep_bits;
     a.p_batch = p_batch_stride; a.B = B; a.H = H; a.t = t; a.tp = tp; a.nkt = (t + 63) / 64; a.alpha = alpha; a.pdrop = p; a.rng = rng; a.site = site;
     const int lds = 4 * TILE + MASK_BYTES + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static Fs2PerDevice attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     if (p > 0.f && pregenerated) hipLaunchKernelGGL(flash_fwd_k<2>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
     else if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<1>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
@@ -894,15 +893,14 @@ extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, i
     a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.g_row = g_row_stride; a.g_batch = g_batch_stride;
     a.dbq = dbias_q; a.dbk = dbias_k; a.dbv = dbias_v;
     const int lds_q = 4 * TILE + MASK_BYTES + 16, lds_kv = 4 * TILE + 2 * AUX_BYTES + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static Fs2PerDevice attr_set;
+    if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-        attr_set = true;
     }
     const dim3 grid(flash_grid(B, H, t));
     // dK/dV: 64 keys per workgroup (4 waves, two workgroups per CU; default) or 128 (8 waves, one per CU; FS2_FLASH_DKV_WAVES=8).

@@ -1,7 +1,7 @@
 // Per-tensor fp8 quantisation for the fp8 operand mode of fs2_gemm (BASELINE.json configs[4]): OCP e4m3 / e5m2 as gfx950
 // implements them (v_cvt_pk_fp8_f32 / v_cvt_pk_bf8_f32, round to nearest even).  Current scaling with a power-of-two
 // scale: multiplying by it is exact, so the only rounding is the fp8 conversion itself.
-#include "common.cuh"
+#include "fs2_common.h"
 
 namespace {
 

@@ -35,6 +35,20 @@ void fs2_set_error(const char* fmt, ...);
 
 static inline bool fs2_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize (> 64 KiB of dynamic LDS) is a per-DEVICE attribute of a kernel: a launcher remembers
+// per device whether it has been set (one process per GPU is the deployment, but a process that drives several must work too).
+struct Fs2PerDevice {
+    bool done[16] = {};
+    bool need() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 16) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 // ---------------------------------------------------------------- element access by dtype
 template <typename T> struct DType;
 template <> struct DType<float> { static constexpr int code = FS2_F32; };

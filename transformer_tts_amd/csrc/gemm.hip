@@ -24,7 +24,7 @@
 // moved to LDS.  Loads are raw buffer loads: rows outside the matrix / conv halo rows get an out-of-range
 // offset and read as zeros (no branches around loads -- a predicated `if (ok) v = *p` serialises them).
 #include <type_traits>
-#include "common.cuh"
+#include "fs2_common.h"
 #include <stdlib.h>
 
 bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc);    // gemm_ring.hip

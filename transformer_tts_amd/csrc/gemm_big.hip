@@ -28,7 +28,7 @@
 //   * fused epilogue: alpha, bias, ReLU, ReLU mask, residual (fp32 / bf16), fp32 / bf16 output, per-column statistics
 //     (BatchNorm sums or bias-gradient column sums: DPP row reduction over the 16 lanes that share a column group,
 //     LDS accumulators, one global atomic per column per workgroup).
-#include "common.cuh"
+#include "fs2_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -427,14 +427,13 @@ int launch_big2(const FS2Gemm& g, hipStream_t st) {
     typedef BG<WTM> G;
     const int tilesM = (g.M + G::BM - 1) / G::BM, tilesN = (g.N + BN - 1) / BN;
     const int lds = G::SMEM + ((EPI & EPI_STATS) ? 2 * BIG_COLSTAT_N * 4 : 0);
-    static bool attr_set = false;          // > 64 KiB of dynamic LDS must be allowed once per kernel
-    if (!attr_set) {
+    static Fs2PerDevice attr_set;
+    if (attr_set.need()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_kernel<TC, WTM, EPI, STAMP, OPK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM + 2 * BIG_COLSTAT_N * 4) != hipSuccess) {
             fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the large-tile kernel");
             return FS2_ELAUNCH;
         }
-        attr_set = true;
     }
     const long per_xcd = (long)((tilesM + 7) / 8) * tilesN;
     const int grid = 8 * (int)(per_xcd < 32 ? per_xcd : 32);

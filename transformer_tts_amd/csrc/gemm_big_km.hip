@@ -17,7 +17,7 @@
 //     row-contiguous float atomics (256 B per wave-instruction: the full-rate shape);
 //   * persistent workgroups, one per CU; work items (output tile x tap x batch x k-split) numbered so that neighbouring items
 //     share their reduction range (operand slabs hit in L2) and dealt to the 8 XCD groups in contiguous chunks.
-#include "common.cuh"
+#include "fs2_common.h"
 #include <stdlib.h>
 
 namespace {

@@ -23,7 +23,7 @@
 //     every split stores its fp32 partial tile with plain 16-byte stores into its own slice of a workspace; fs2_splitk_reduce sums
 //     the slices and applies bias / ReLU / residual / cast (no float atomics: ~1.3 TB/s chip-wide against ~6 TB/s of plain stores).
 // Results are bit-identical to gemm_big.hip and to the 128-tile kernel of gemm.hip (same MFMA, same k order per accumulator).
-#include "common.cuh"
+#include "fs2_common.h"
 #include <stdlib.h>
 
 namespace {

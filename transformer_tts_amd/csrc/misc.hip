@@ -1,7 +1,7 @@
 // Gather / scatter / scan / reduction / optimizer kernels of the FastSpeech2 path for gfx950:
 // embedding, length regulator (wave scan + gather, segmented-sum backward), bucketize + embedding add,
 // L1 losses, weight-shadow cast/permute, global grad-norm and fused clip + Adam over flat fp32 arenas.
-#include "common.cuh"
+#include "fs2_common.h"
 
 namespace {
 

@@ -6,7 +6,7 @@
 // BatchNorm sums) are kept in registers, combined across the 4 waves in LDS and flushed with one
 // float atomic per channel per block.
 #include <stdlib.h>
-#include "common.cuh"
+#include "fs2_common.h"
 
 namespace {
 

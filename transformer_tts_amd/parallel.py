@@ -13,6 +13,8 @@ import torch.distributed as dist
 
 
 class DataParallel:
+    plan, _plan_now, _in_finish = (), None, False      # (class defaults: tests build instances without __init__)
+
     def __init__(self, model, arena, process_group=None, bucket_bytes=8 << 20):
         assert dist.is_initialized()
         self.pg = process_group
@@ -22,6 +24,9 @@ class DataParallel:
         self.pending = None      # (lo, hi) of adjacent ready ranges not yet launched
         self.works = []
         self.done = []           # launched ranges (for the completeness check in finish())
+        self.plan = []           # the all-reduce schedule of the LAST finished step: (arena lo, hi, "backward" | "finish"), launch order
+        self._plan_now = []
+        self._in_finish = False
         self._count = None
         model.rt.dp = self
         # parameters must start identical on every rank (DDP broadcasts from rank 0 in its constructor)
@@ -33,6 +38,9 @@ class DataParallel:
     def _launch(self, lo, hi):
         self.works.append(dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         self.done.append((lo, hi))
+        if self._plan_now is None:
+            self._plan_now = []
+        self._plan_now.append((lo, hi, "finish" if self._in_finish else "backward"))
 
     def grads_ready(self, module_or_params):
         """The gradients of these parameters are complete (enqueued on the current stream).  The parameters may cover
@@ -65,6 +73,7 @@ class DataParallel:
 
     def finish(self):
         """flush, reduce whatever was never announced, wait; returns world size (Adam divides by it)"""
+        self._in_finish = True
         if self.pending is not None:
             self._launch(*self.pending)
             self.pending = None
@@ -77,7 +86,13 @@ class DataParallel:
         for w in self.works:
             w.wait()
         self.works, self.done = [], []
+        self.plan, self._plan_now, self._in_finish = (self._plan_now or []), [], False
         return self.world
+
+    def describe_plan(self):
+        """the gradient all-reduce schedule of the last step, in launch order: bytes of every bucket and whether it was launched from
+        inside the backward (overlapped with the rest of it) or by finish() (the tail that nothing overlaps)"""
+        return [dict(order=i, bytes=4 * (hi - lo), elements=[int(lo), int(hi)], launched=where) for i, (lo, hi, where) in enumerate(self.plan)]
 
     # ---- SyncBatchNorm statistics (on the compute stream: the next kernel needs them)
     def allreduce_sum(self, t):
