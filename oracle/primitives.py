@@ -31,7 +31,7 @@ class Rng:
 
 
 # ------------------------------------------------------------------------------------------------ Philox dropout
-PHILOX_ROUNDS = 7          # common.cuh PHILOX_ROUNDS
+PHILOX_ROUNDS = 7          # fs2_common.h PHILOX_ROUNDS
 
 
 def _philox4x32(c0, c1, c2, c3, k0, k1):
@@ -48,7 +48,7 @@ def _philox4x32(c0, c1, c2, c3, k0, k1):
 
 
 def drop_scale(shape, p, rng, site, base_index=None):
-    """Per-element factors (0 or 65536/(65536 - thr16)) of the kernels' dropout stream (common.cuh drop_scale8/4) for
+    """Per-element factors (0 or 65536/(65536 - thr16)) of the kernels' dropout stream (fs2_common.h drop_scale8/4) for
     a tensor whose element index (row-major, or ``base_index`` if given as an int64 array of that shape) selects
     the Philox call (index >> 3) and the 16-bit half of its output (word (index & 7) >> 1, half index & 1)."""
     if p <= 0.0:
