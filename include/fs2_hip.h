@@ -248,18 +248,53 @@ int fs2_attn_ds_bwd(const void* d_out, int64_t do_row_stride, int64_t do_batch_s
                     uint32_t site, const void* k, void* dq_out, int64_t dq_row_stride, int64_t dq_batch_stride,
                     float dq_alpha, void* stream);
 
-/* attention() of Models/modules.py:7-21 WITHOUT the probability tensors in HBM (hp.return_attn = False), bf16, d_k = 128,
- * t <= 1024.  Forward: o_out[b][i][h][:] = dropout(softmax(mask_keys(alpha q k^T)))[i][:] v and, per query row,
- * stats[b][h][i] = {maximum of the masked scaled scores, sum of exp(score - maximum)} (fp32 pairs).  With p > 0 it draws the
- * dropout mask from the Philox counters of fs2_attn_probs_fwd (element offset b*p_batch_stride + (h*t + i)*tp + key of the
- * virtual (B,[..],H,t,tp) tensor, so both paths draw the same mask) and stashes it, one bit per probability, in keep_bits
- * (fs2_flash_attn_keep_words(B, H, t) 16-bit words; may be NULL when p == 0).  Backward recomputes the probabilities from
- * q, k and stats, reads the keep-bits and writes dq = alpha dS k, dk = alpha dS^T q, dv = dropout(P)^T d_out; aux is a
- * (B,H,t,4) fp32 workspace it fills itself; dbias_q/k/v (optional, H*128 floats each) receive += the column sums of dq / dk / dv
- * (the bias gradients of the three projections, Models/modules.py:49-51).  Key tiles whose keys are all masked are skipped (their probabilities are
- * exp(-1e4 - max) = 0 in fp32 whenever the row has an unmasked key; a row without one is computed in full).
- *   q, k, v: rows of one head = 128 contiguous bf16 at  base + b*batch_stride + i*row_stride + h*head_stride  (elements);
- *   o / d_out / dq,dk,dv rows likewise with their own row and batch strides (dq, dk, dv share g_*_stride).           */
+/* attention() of Models/modules.py:7-21 WITHOUT the probability tensors in HBM (hp.return_attn = False), bf16, d_k in {64, 96, 128},
+ * up to 16384 keys; self-attention, and the two attentions of the autoregressive decoder (Models/layers.py:108-118 with the masks of
+ * train.py:26-58): `causal` masks key j > query i like a padded key, tq != tk with separate query / key-value strides is the
+ * encoder-decoder attention.
+ *   forward:  o[b][i][h][:] = dropout(softmax(mask(alpha q k^T)))[i][:] v and, per query row, stats[b][h][i] = {maximum of the masked
+ *             scaled scores, sum of exp(score - maximum)} (fp32 pairs).  With p > 0 it draws the dropout mask from the Philox counters of
+ *             fs2_attn_probs_fwd / fs2_softmax_rect_fwd (element offset b*p_batch_stride + (h*tq + i)*tkp + key of the virtual
+ *             (B,[..],H,tq,tkp) tensor: every path draws the same mask) and stashes it, one bit per probability, in keep_bits
+ *             (fs2_flash_attn_keep_words_rect(B, H, tq, tk) 16-bit words; may be NULL when p == 0).
+ *   backward: recomputes the probabilities from q, k and stats, reads the keep-bits and writes dq = alpha dS k, dk = alpha dS^T q,
+ *             dv = dropout(P)^T d_out; aux is a (B,H,tq,4) fp32 workspace it fills itself; dbias_q/k/v (optional, H*dk floats each)
+ *             receive += the column sums of dq / dk / dv (the bias gradients of the projections, Models/modules.py:49-51).
+ * Key tiles whose keys are all masked are skipped (their probabilities are exp(-1e4 - max) = 0 in fp32 whenever the row has an
+ * unmasked key; a row without one is computed in full and gives the reference's uniform distribution).
+ *   q rows of one head = dk contiguous bf16 at  q + b*q_batch_stride + i*q_row_stride + h*head_stride  (elements); k, v rows at
+ *   base + b*kv_batch_stride + j*kv_row_stride + h*head_stride; o / d_out / dq rows (queries) and dk / dv rows (keys) likewise with
+ *   their own row and batch strides.                                                                                              */
+typedef struct FS2FlashAttn {
+    const void *q, *k, *v;
+    int64_t q_row_stride, q_batch_stride, kv_row_stride, kv_batch_stride;
+    int32_t head_stride, dk;
+    const uint8_t* key_mask;  /* (B, tk) bytes, 0 = padded key */
+    const int32_t* key_info;  /* optional (B, 3) from fs2_flash_attn_mask_info, or NULL */
+    void* o;
+    int64_t o_row_stride, o_batch_stride;
+    float* stats;             /* (B, H, tq, 2) */
+    uint16_t* keep_bits;
+    int32_t pregenerated;     /* forward: read keep_bits (written by fs2_flash_attn_keep_bits) instead of drawing them */
+    int32_t causal;
+    int64_t p_batch_stride;
+    int32_t B, H, tq, tk, tkp, reserved0;
+    float alpha, p;
+    const uint64_t* rng;
+    uint32_t site, reserved1;
+    /* backward only */
+    const void* d_out;
+    int64_t do_row_stride, do_batch_stride;
+    float* aux;               /* (B, H, tq, 4) */
+    void *dq, *dk_out, *dv_out;
+    int64_t dq_row_stride, dq_batch_stride, dkv_row_stride, dkv_batch_stride;
+    float *dbias_q, *dbias_k, *dbias_v;
+} FS2FlashAttn;
+int fs2_flash_attention_fwd(const FS2FlashAttn* d, void* stream);
+int fs2_flash_attention_bwd(const FS2FlashAttn* d, void* stream);
+int64_t fs2_flash_attn_keep_words_rect(int B, int H, int tq, int tk);
+/* The round-2 entry points below are the self-attention, d_k = 128 case of the two calls above (q, k, v rows of one fused projection
+ * tensor: common strides; tq = tk = t).                                                                                           */
 int64_t fs2_flash_attn_keep_words(int B, int H, int t);
 /* info[B][3]: {number of leading unmasked keys, last unmasked key + 1} of every batch row b, and in info[r][2] the batch row with
  * the r-th longest unmasked prefix (the kernels start the longest rows first).  Optional: pass it as key_info to the calls below

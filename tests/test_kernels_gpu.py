@@ -520,7 +520,7 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
     fused-qkv layout of the FFT block, ragged key masks, the dropout mask of the strip path (same Philox counters)."""
     dtype, dk, B, NL = torch.bfloat16, 128, 3, 2
     tp = (t + 7) // 8 * 8
-    assert ops.flash_attn_supported(t, dk, dtype) and not ops.flash_attn_supported(1025, dk, dtype)
+    assert ops.flash_attn_supported(t, dk, dtype) and ops.flash_attn_supported(1025, dk, dtype) and not ops.flash_attn_supported(t, 48, dtype)
     lens = [t, max(1, t // 2), max(1, t - 5)]
     km = torch.zeros(B, t, dtype=torch.bool)
     for b, n in enumerate(lens):
@@ -596,6 +596,77 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
         pd_flash = Oe.permute(0, 2, 1, 3)[..., :n].float().cpu()
         big = P_ref[..., :n].float() > 1e-3
         assert torch.equal((pd_flash == 0) & big, (Pd_ref[..., :n].float() == 0) & big)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("tq,tk,dk,causal", [(1025, 1025, 128, False), (1500, 1500, 64, False), (2047, 2047, 96, True), (37, 37, 64, True),
+                                             (65, 65, 128, True), (200, 200, 96, False), (300, 77, 128, False), (130, 925, 96, False),
+                                             (9, 130, 64, False), (1, 1, 128, True)])
+def test_flash_attention_general(ops, p, tq, tk, dk, causal):
+    """fs2_flash_attention_fwd / _bwd (general descriptor): more than 1024 keys (the key-mask row streams through a dynamically sized
+    LDS image), d_k in {64, 96, 128}, the causal (no-peak) self-attention and the rectangular encoder-decoder attention of the
+    autoregressive decoder (Models/layers.py:108-118, masks train.py:26-58) -- against fp32 attention() with the keep-mask the
+    oracle's rectangular softmax draws from the same Philox counters.  Tolerance: 3e-2 of each tensor's scale (bf16 operands)."""
+    dtype, B, H, NL = torch.bfloat16, 2, 2, 2
+    tkp = (tk + 7) // 8 * 8
+    lens = [tk, max(1, tk - 5 if tk > 8 else tk // 2)]
+    km = torch.zeros(B, tk, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        km[b, :n] = True
+    q, dO = rnd(B, tq, H, dk, dtype=dtype, seed=1, scale=1.5), rnd(B, tq, H, dk, dtype=dtype, seed=2)
+    vk = rnd(B, tk, 2, H, dk, dtype=dtype, seed=3, scale=1.5)              # fused [v | k] projection of the key side
+    alpha = dk ** -0.5
+    # ---- reference (fp32, CPU)
+    keepf = torch.ones(B, H, tq, tk)
+    if p > 0:
+        rng = P.Rng(5, "cpu")
+        buf = torch.zeros(B, NL, H, tq, tkp, dtype=dtype)
+        bufd = torch.zeros_like(buf)
+        P.softmax_rect_fwd(buf[:, 1], bufd[:, 1], torch.ones(B, tk, dtype=torch.bool), tk, False, p, rng, 11)
+        thr = int(p * 65536.0 + 0.5)
+        keepf = (bufd[:, 1, ..., :tk].float() != 0).float() * (65536.0 / (65536.0 - thr))
+    qf, kf, vf = (x.float().requires_grad_(True) for x in (q.permute(0, 2, 1, 3), vk[:, :, 1].permute(0, 2, 1, 3), vk[:, :, 0].permute(0, 2, 1, 3)))
+    S = torch.einsum("bhqd,bhkd->bhqk", qf, kf) * alpha
+    vis = km[:, None, None, :].expand(B, H, tq, tk).clone()
+    if causal:
+        vis &= torch.tril(torch.ones(tq, tk, dtype=torch.bool))
+    Sm = S.masked_fill(~vis, -1e4)
+    Pm = torch.softmax(Sm, -1)
+    O_ref = torch.einsum("bhqk,bhkd->bhqd", Pm * keepf, vf)
+    O_ref.backward(dO.permute(0, 2, 1, 3).float())
+    # ---- kernels
+    qc, vkc, g = q.cuda(), vk.cuda(), dO.cuda()
+    q4, v4, k4 = qc.permute(0, 2, 1, 3), vkc[:, :, 0].permute(0, 2, 1, 3), vkc[:, :, 1].permute(0, 2, 1, 3)
+    O = torch.full((B, tq, H, dk), float("nan"), dtype=dtype, device="cuda")
+    stats = torch.full((B, H, tq, 2), float("nan"), device="cuda")
+    keep = torch.empty(ops.flash_attn_keep_words_rect(B, H, tq, tk), dtype=torch.int16, device="cuda") if p > 0 else None
+    rngc = ops.Rng(5, "cuda")
+    p_batch = NL * H * tq * tkp
+    kinfo = ops.flash_mask_info(km.cuda()) if p > 0 else None
+    ops.flash_attention_fwd(q4, k4, v4, km.cuda(), O.permute(0, 2, 1, 3), stats, keep, alpha, p_batch, p, rngc, 11, causal=causal, key_info=kinfo)
+    got = O.permute(0, 2, 1, 3).float().cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - O_ref.detach()).abs().max() / O_ref.detach().abs().amax().clamp_min(1e-2))
+    assert err < 3e-2, ("O", err)
+    close(stats[..., 0].cpu(), Sm.detach().amax(-1), "row maximum", rtol=1e-2, atol=3e-2)
+    close(stats[..., 1].cpu(), torch.exp(Sm.detach() - Sm.detach().amax(-1, keepdim=True)).sum(-1), "sum of exponentials", rtol=2e-2, atol=1e-2)
+    dq = torch.full((B, tq, H, dk), float("nan"), dtype=dtype, device="cuda")
+    dvk = torch.full((B, tk, 2, H, dk), float("nan"), dtype=dtype, device="cuda")
+    aux = torch.empty((B, H, tq, 4), device="cuda")
+    dbias = [torch.full((H * dk,), 0.5, device="cuda") for _ in range(3)]
+    ops.flash_attention_bwd(q4, k4, v4, km.cuda(), O.permute(0, 2, 1, 3), g.permute(0, 2, 1, 3), stats, keep, aux, dq.permute(0, 2, 1, 3),
+                            dvk[:, :, 1].permute(0, 2, 1, 3), dvk[:, :, 0].permute(0, 2, 1, 3), alpha, p, causal=causal, dbias=dbias, key_info=kinfo)
+    for name, a, r in (("dQ", dq.permute(0, 2, 1, 3), qf.grad), ("dK", dvk[:, :, 1].permute(0, 2, 1, 3), kf.grad), ("dV", dvk[:, :, 0].permute(0, 2, 1, 3), vf.grad)):
+        a = a.float().cpu()
+        assert torch.isfinite(a).all(), name
+        # (one key: dS = 0 exactly; what is left is delta = rowsum(dO * bf16(O)) against the fp32 product, ~2^-9 |dO| |V| sqrt(dk))
+        scale = r.abs().amax().clamp_min(1.0 if tk == 1 else 0.05)
+        err = float((a - r).abs().max() / scale)
+        assert err < (1e-1 if tk == 1 else 3e-2), (name, err)
+    for x, rows, n in zip(dbias, (dq, dvk[:, :, 1], dvk[:, :, 0]), ("dbias_q", "dbias_k", "dbias_v")):
+        rows = rows.float()
+        noise = 4.0 * (B * max(tq, tk)) ** 0.5 * 2.0 ** -9 * float(rows.abs().max())
+        close(x.cpu(), rows.sum((0, 1)).reshape(-1).cpu() + 0.5, n, rtol=2e-2, atol=2e-2 + noise)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -1,6 +1,8 @@
-// Flash-style attention for gfx950 (bf16, d_k = 128): attention() of the reference (Models/modules.py:7-21) and its backward
-// WITHOUT the (t x t) probability tensors in HBM -- the mode the trainer runs when the attention maps are not requested
-// (hp.return_attn = False).  Forward keeps per query row the running maximum and the sum of exponentials; backward recomputes
+// Flash-style attention for gfx950 (bf16, d_k = 64 / 96 / 128, any number of keys up to 16384): attention() of the reference
+// (Models/modules.py:7-21) and its backward WITHOUT the (tq x tk) probability tensors in HBM -- the mode the trainer runs when the
+// attention maps are not requested (hp.return_attn = False).  Self-attention of the FastSpeech2 stacks (tq = tk), the masked
+// (no-peak = causal) self-attention and the rectangular encoder-decoder attention of the autoregressive Transformer-TTS decoder
+// (Models/layers.py:108-118, masks of train.py:26-58: a key is masked when it is padding OR lies after the query).  Forward keeps per query row the running maximum and the sum of exponentials; backward recomputes
 // the probabilities from Q, K and those two numbers and regenerates the dropout mask from the same Philox counters as every
 // other kernel of the library (element offset of P[b, h, q, key] in the (B, [layers], H, t, tp) layout, >> 3), so this path and
 // the LDS-strip path (attention.hip) draw IDENTICAL masks and differ only by rounding.
@@ -37,15 +39,16 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 constexpr unsigned OOB = 0x80000000u;
 constexpr int TILE = 64 * 256;          // bytes of one 64-row x 128-column bf16 tile
-constexpr int MASK_BYTES = 1024;
+constexpr int MASK_MAX = 16384;         // longest key sequence: the key-mask row of a batch element lives in LDS (roundup64(tk) + 64 bytes)
 constexpr int AUX_BYTES = 64 * 16;      // dK/dV kernel: {m, 1/l, delta, -} of the 64 queries of a tile
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFF0, 0x00020000);
 }
-// rows of 128 bf16 at a stride of row_stride elements: a 16-byte read that starts past row rows-1 returns zeros
+// rows of DK bf16 at a stride of row_stride elements: a 16-byte read that starts past row rows-1 returns zeros
+template <int DK>
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_rows(const void* p, int rows, int row_stride) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (rows - 1) * row_stride * 2 + 256, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (rows - 1) * row_stride * 2 + 2 * DK, 0x00020000);
 }
 __device__ __forceinline__ bf16x8 ld16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0));
@@ -112,12 +115,12 @@ template <int PENDING> __device__ __forceinline__ bf16x8 tr_wait(TrFrag& f) {
     u.s.lo = f.lo; u.s.hi = f.hi;
     return u.v;
 }
-// 16 x 16 product tile over the 128 columns: rows r0.. of the LDS image (OFF = image offset + 256 r0) against the register
+// 16 x 16 product tile over the DK = 32 KS columns: rows r0.. of the LDS image (OFF = image offset + 256 r0) against the register
 // fragments bf (B operand)
-template <int OFF> __device__ __forceinline__ f32x4 tile128(const FragAddr& fa, const bf16x8 (&bf)[4]) {
+template <int OFF, int KS> __device__ __forceinline__ f32x4 tile128(const FragAddr& fa, const bf16x8 (&bf)[KS]) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<OFF>(fa, ks), bf[ks], acc, 0, 0, 0);
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<OFF>(fa, ks), bf[ks], acc, 0, 0, 0);
     return acc;
 }
 __device__ __forceinline__ bf16x8 pack8(const float (&a)[4], const float (&b)[4]) {
@@ -169,32 +172,34 @@ __device__ __forceinline__ float row16_sum(float v) {
 // bias gradient of a projection = column sums of its gradient rows: acc[d][r] is this lane's value for column 16d + 4g + r of one
 // row (the lane's i16 selects the row); rows of the workgroup are summed through DPP, then LDS, then one global atomic per
 // column per workgroup.  lds: 128 floats nobody else uses any more; NT threads; ends with a barrier-free tail.
-template <int NT>
-__device__ __forceinline__ void block_colsum(const f32x4 (&acc)[8], float factor, float* lds, float* out, int tid, int lane) {
+template <int NT, int DT>
+__device__ __forceinline__ void block_colsum(const f32x4 (&acc)[DT], float factor, float* lds, float* out, int tid, int lane) {
     const int g = lane >> 4, i16 = lane & 15;
-    if (tid < 128) lds[tid] = 0.f;
+    if (tid < 16 * DT) lds[tid] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int d = 0; d < 8; ++d)
+    for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float tot = row16_sum(acc[d][r]);
             if (i16 == 0) atomicAdd(&lds[16 * d + 4 * g + r], tot * factor);
         }
     __syncthreads();
-    if (tid < 128) atomicAdd(out + tid, lds[tid]);
+    if (tid < 16 * DT) atomicAdd(out + tid, lds[tid]);
 }
 
 struct FlashArgs {
-    const bf16_t *q, *k, *v;            // rows of one head: 128 contiguous bf16 at base + b*batch + i*row + h*head
-    int64_t row, batch;                 // element strides of q / k / v (one fused projection tensor)
+    const bf16_t *q, *k, *v;            // rows of one head: DK contiguous bf16 at base + b*batch + i*row + h*head
+    int64_t row, batch;                 // element strides of the QUERY rows (q, and the dq rows are addressed with g_row / g_batch)
+    int64_t kvrow, kvbatch;             // element strides of the KEY / VALUE rows (= row / batch for self-attention on one fused projection)
     int head;
+    int tq, causal, mb;                 // queries (keys: t); causal: key j > query i is masked like a padded key; mb = bytes of the LDS mask row
     const uint8_t* key_mask;            // (B, t)
     const int32_t* kinfo;               // optional (B, 3): {kfull, kmax, the batch row of rank b by kmax} (fs2_flash_attn_mask_info), or nullptr
     bf16_t* O;                          // attention output (written by forward, read by backward), rows at O + b*o_batch + i*o_row + h*head
     int64_t o_row, o_batch;
-    float* stats;                       // (B, H, t, 2): {row maximum of the masked scaled scores, sum of exponentials}
-    uint16_t* keep;                     // (B, H, nkt, t, 4) keep-bits of the dropout: bit j of word [b][h][kt][q][g] = key 64kt + 16g + j
+    float* stats;                       // (B, H, tq, 2): {row maximum of the masked scaled scores, sum of exponentials}
+    uint16_t* keep;                     // (B, H, nkt, tq, 4) keep-bits of the dropout: bit j of word [b][h][kt][q][g] = key 64kt + 16g + j
     int64_t p_batch;                    // batch stride of the virtual P tensor (dropout counters)
     int B, H, t, tp, nkt;
     float alpha, pdrop;
@@ -203,18 +208,18 @@ struct FlashArgs {
     // backward
     const bf16_t* dO;                   // rows at dO + b*do_batch + i*do_row + h*head
     int64_t do_row, do_batch;
-    float* aux;                         // (B, H, t, 4) workspace: {-m log2 e, 1/l, delta = rowsum(dO * O), kmax bits}: dQ kernel -> dK/dV kernel
-    bf16_t *dq, *dk, *dv;               // rows at d? + b*g_batch + i*g_row + h*head
-    int64_t g_row, g_batch;
-    float *dbq, *dbk, *dbv;             // optional bias gradients of the three projections (H*128 floats each): += column sums of dq / dk / dv
+    float* aux;                         // (B, H, tq, 4) workspace: {-m log2 e, 1/l, delta = rowsum(dO * O), kmax bits}: dQ kernel -> dK/dV kernel
+    bf16_t *dq, *dk, *dv;               // rows at dq + b*g_batch + i*g_row + h*head, dk / dv + b*gkv_batch + j*gkv_row + h*head
+    int64_t g_row, g_batch, gkv_row, gkv_batch;
+    float *dbq, *dbk, *dbv;             // optional bias gradients of the three projections (H*DK floats each): += column sums of dq / dk / dv
 };
 
 // Work item of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs; the row blocks of one (batch, head) pair -- which
 // stream the same K/V (or Q/dO) tiles -- are given to ONE XCD (one L2), and the pairs go round-robin over the XCDs so that a
 // batch sorted by length does not leave one XCD with all the long sequences.  Grid = 8 * ceil(B H / 8) * nblk.
 template <int BLK = 128>
-__device__ __forceinline__ bool flash_item(const FlashArgs& a, int& blk, int& h, int& b) {
-    const int nblk = (a.t + BLK - 1) / BLK;
+__device__ __forceinline__ bool flash_item(const FlashArgs& a, const int nrows, int& blk, int& h, int& b) {
+    const int nblk = (nrows + BLK - 1) / BLK;
     const int slot = (int)(blockIdx.x >> 3);
     const int pair = (int)(blockIdx.x & 7) + 8 * (slot / nblk);
     if (pair >= a.B * a.H) return false;
@@ -229,12 +234,12 @@ __device__ __forceinline__ bool flash_item(const FlashArgs& a, int& blk, int& h,
 }
 
 // kfull = number of leading unmasked keys, kmax = last unmasked key + 1 of one batch row (optionally copies the row to LDS,
-// zero padded to MASK_BYTES).  red: two LDS words.  Ends with a barrier.
+// zero padded to mb bytes).  red: two LDS words.  Ends with a barrier.
 template <int NT = 512>
-__device__ __forceinline__ void scan_mask(const uint8_t* km_row, int t, unsigned char* lmask, int* red, int tid) {
+__device__ __forceinline__ void scan_mask(const uint8_t* km_row, int t, int mb, unsigned char* lmask, int* red, int tid) {
     if (tid == 0) { red[0] = t; red[1] = 0; }
     __syncthreads();
-    for (int j = tid; j < MASK_BYTES; j += NT) {
+    for (int j = tid; j < mb; j += NT) {
         const unsigned char mk = j < t ? km_row[j] : 0;
         if (lmask) lmask[j] = mk;
         if (j < t) {
@@ -251,18 +256,18 @@ template <int NT = 512>
 __device__ __forceinline__ void mask_setup(const FlashArgs& a, int b, int t, unsigned char* lmask, int* red, int tid, int& kfull, int& kmax) {
     if (a.kinfo != nullptr) {
         const uint8_t* km_row = a.key_mask + (int64_t)b * t;
-        for (int j = tid; j < MASK_BYTES; j += NT) lmask[j] = j < t ? km_row[j] : 0;
+        for (int j = tid; j < a.mb; j += NT) lmask[j] = j < t ? km_row[j] : 0;
         kfull = a.kinfo[3 * b];
         kmax = a.kinfo[3 * b + 1];
     } else {
-        scan_mask<NT>(a.key_mask + (int64_t)b * t, t, lmask, red, tid);
+        scan_mask<NT>(a.key_mask + (int64_t)b * t, t, a.mb, lmask, red, tid);
         kfull = red[0];
         kmax = red[1];
     }
 }
 __global__ __launch_bounds__(512) void flash_mask_info_k(const uint8_t* __restrict__ key_mask, int t, int32_t* __restrict__ info) {
     __shared__ int red[2];
-    scan_mask<512>(key_mask + (int64_t)blockIdx.x * t, t, nullptr, red, threadIdx.x);
+    scan_mask<512>(key_mask + (int64_t)blockIdx.x * t, t, (t + 63) / 64 * 64, nullptr, red, threadIdx.x);
     if (threadIdx.x < 2) info[3 * blockIdx.x + threadIdx.x] = red[threadIdx.x];
 }
 // info[3 r + 2] = the batch row with the r-th largest kmax (ties: lower index first); one thread per row, B comparisons each
@@ -292,9 +297,13 @@ __device__ __forceinline__ void stage_tile(const __amdgpu_buffer_rsrc_t rs, unsi
 // the lane's share of that: row 4 wave + lane/16 of the first instruction, chunk (lane&15) ^ f(row) -- the later instructions are
 // 4 NW rows further on (same low row bits, same chunk), so ONE per-lane offset serves a whole kernel: the scalar part carries the
 // tile and the instruction.  Rows >= t are cut off by the descriptor (make_rsrc_rows): no per-lane compare, nothing to spill.
+// Heads narrower than 128 columns keep the 256-byte image rows: the chunks past column DK are never read, their lanes fetch
+// nothing (an offset beyond the descriptor: the DMA writes zeros).
+template <int DK>
 __device__ __forceinline__ unsigned stage_voff(int row_stride, int wave, int lane) {
     const int r = 4 * wave + (lane >> 4);
-    return (unsigned)((r * row_stride + (((lane & 15) ^ img_f(r)) << 3)) * 2);
+    const int lc = (lane & 15) ^ img_f(r);
+    return 8 * lc < DK ? (unsigned)((r * row_stride + (lc << 3)) * 2) : OOB;
 }
 
 __device__ __forceinline__ float and_mask(float v, int msk) { return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & msk); }
@@ -304,38 +313,35 @@ __device__ __forceinline__ int keep_mask(unsigned bits, unsigned pos) { return _
 // MFMAs; two independent workgroups per CU).  The forward kernel measured faster as 8 waves x 16 queries (4 waves per SIMD:
 // 55.7 vs 60.6 us per launch averaged over the model's eight attention layers).
 constexpr int FQ_WAVES = 4, FQ_THREADS = 256;
+constexpr int NO_CAUSAL = 0x7FFFFFFF;
 
-// masked (workgroup-uniform): the tile holds masked or non-existent keys -- keys with mask 0 get the raw value whose scaled
-// score is -1e4 (masked_fill), keys >= t get NOKEY.  The MFMA work is common to both cases; only these fix-ups sit under a branch.
-__device__ __forceinline__ void mask_fix(float (&v)[4], unsigned mk, int key0, int t, float masked_raw) {
+// masked (workgroup-uniform): the tile holds masked or non-existent keys -- keys with mask 0, and keys after the query `cq` (causal
+// launches; NO_CAUSAL otherwise), get the raw value whose scaled score is -1e4 (masked_fill), keys >= t get NOKEY.  The MFMA work is
+// common to both cases; only these fix-ups sit under a branch.
+__device__ __forceinline__ void mask_fix(float (&v)[4], unsigned mk, int key0, int t, int cq, float masked_raw) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        v[r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? v[r] : masked_raw;
+        v[r] = (((mk >> (8 * r)) & 0xFFu) != 0 && key0 + r <= cq) ? v[r] : masked_raw;
         v[r] = (key0 + r < t) ? v[r] : NOKEY;
     }
 }
 
 // raw scores S^T of one 64-key tile (image at byte offset KOFF) against the wave's 16 queries: x[T][r] = key 64kt + 16T + 4g + r,
-// query i16.  masked (workgroup-uniform): the tile holds masked or non-existent keys -- keys with mask 0 get the raw value whose
-// scaled score is -1e4 (masked_fill), keys >= t get NOKEY.  The MFMA work is common to both cases, only the element-wise fix-ups
-// sit under the branch (two instantiated copies of a whole step cost ~100 spilled registers in the dQ kernel).
-template <int KOFF>
-__device__ __forceinline__ void score_tiles(const bool masked, const FragAddr& fa, const bf16x8 (&qf)[4], const unsigned char* lmask, int kt,
-                                            int t, float masked_raw, int lane, float (&x)[4][4], float& tmax) {
+// query i16 (cq: this lane's query index in a causal launch).  The MFMA work is common to the masked and the mask-free case, only
+// the element-wise fix-ups sit under the branch (two instantiated copies of a whole step cost ~100 spilled registers in the dQ kernel).
+template <int KOFF, int KS>
+__device__ __forceinline__ void score_tiles(const bool masked, const FragAddr& fa, const bf16x8 (&qf)[KS], const unsigned char* lmask, int kt,
+                                            int t, int cq, float masked_raw, int lane, float (&x)[4][4], float& tmax) {
     const int g = lane >> 4;
     auto one = [&](auto TC) {
         constexpr int T = decltype(TC)::value;
-        const f32x4 s = tile128<KOFF + 4096 * T>(fa, qf);
+        const f32x4 s = tile128<KOFF + 4096 * T, KS>(fa, qf);
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[T][r] = s[r];
         if (masked) {
             const int key0 = 64 * kt + 16 * T + 4 * g;
             const unsigned mk = *reinterpret_cast<const unsigned*>(lmask + key0);        // key0 % 4 == 0; bytes >= t are 0
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                x[T][r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? x[T][r] : masked_raw;
-                x[T][r] = (key0 + r < t) ? x[T][r] : NOKEY;
-            }
+            mask_fix(x[T], mk, key0, t, cq, masked_raw);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, x[T][r]);
@@ -343,46 +349,57 @@ __device__ __forceinline__ void score_tiles(const bool masked, const FragAddr& f
     one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{});
 }
 
+// number of key tiles a block of queries [q_lo, q_hi] has to visit: tiles at or beyond kmax hold masked keys only (probability
+// exp(-1e4 - m) = 0 in fp32 once the row has an unmasked key: kmax > 0); in a causal launch so do the tiles after the block's last
+// query -- provided key 0 is unmasked (kfull > 0), which gives every query a visible key
+__device__ __forceinline__ int key_tiles(const FlashArgs& a, int kfull, int kmax, int q_hi) {
+    int nkt = kmax > 0 ? (kmax + 63) >> 6 : (a.t + 63) >> 6;
+    if (a.causal && kfull > 0) nkt = min(nkt, (q_hi >> 6) + 1);
+    return nkt;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // O = dropout(softmax(mask(alpha Q K^T))) V, stats = {m, l}.  Wave: 16 queries (columns of the transposed score tiles).
 // LDS: K images [2][TILE] at 0, V images [2][TILE] at 2 TILE, key mask, two reduction words.
 // DROP: 0 no dropout; 1 draw the keep-bits (Philox) and stash them; 2 read bits that fs2_flash_attn_keep_bits wrote beforehand
-template <int DROP>
+template <int DROP, int DK>
 __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS = DK / 32, DT = DK / 16;
     int blk, h, b;
-    if (!flash_item(a, blk, h, b)) return;
+    if (!flash_item(a, a.tq, blk, h, b)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int t = a.t;
+    const int t = a.t, tq = a.tq;
     const int qrow = blk * 128 + wave * 16 + i16;
     unsigned char* kimg = smem;                       // [2][TILE]
     unsigned char* vimg = smem + 2 * TILE;            // [2][TILE]
     unsigned char* lmask = smem + 4 * TILE;
-    int* red = reinterpret_cast<int*>(smem + 4 * TILE + MASK_BYTES);
+    int* red = reinterpret_cast<int*>(smem + 4 * TILE + a.mb);
     const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
-    const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
-    const int rowst = (int)a.row;
-    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb), rs_k = make_rsrc_rows(a.k + hb, t, rowst), rs_v = make_rsrc_rows(a.v + hb, t, rowst);
-    const unsigned voff0 = stage_voff(rowst, wave, lane);
-    stage_tile(rs_k, kimg, 0, rowst, wave, voff0);
-    stage_tile(rs_v, vimg, 0, rowst, wave, voff0);
-    bf16x8 qf[4];
+    const int64_t hbq = (int64_t)b * a.batch + (int64_t)h * a.head, hbk = (int64_t)b * a.kvbatch + (int64_t)h * a.head;
+    const int rowst = (int)a.row, kvrow = (int)a.kvrow;
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hbq), rs_k = make_rsrc_rows<DK>(a.k + hbk, t, kvrow), rs_v = make_rsrc_rows<DK>(a.v + hbk, t, kvrow);
+    const unsigned voff0 = stage_voff<DK>(kvrow, wave, lane);
+    stage_tile(rs_k, kimg, 0, kvrow, wave, voff0);
+    stage_tile(rs_v, vimg, 0, kvrow, wave, voff0);
+    bf16x8 qf[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = ld16(rs_q, qrow < t ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = ld16(rs_q, qrow < tq ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
     int kfull, kmax;
     mask_setup<512>(a, b, t, lmask, red, tid, kfull, kmax);
-    const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
+    const int nkt = key_tiles(a, kfull, kmax, min(blk * 128 + 127, tq - 1));
+    const int cq = a.causal ? qrow : NO_CAUSAL;
 
     const DropCtx dc = drop_ctx(a.rng, a.site, a.pdrop);
-    const int64_t prow = (int64_t)b * a.p_batch + ((int64_t)h * t + (qrow < t ? qrow : 0)) * a.tp;
-    uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t + (qrow < t ? qrow : 0)) * 4 + g;
+    const int64_t prow = (int64_t)b * a.p_batch + ((int64_t)h * tq + (qrow < tq ? qrow : 0)) * a.tp;
+    uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * tq + (qrow < tq ? qrow : 0)) * 4 + g;
     const float c2 = a.alpha * LOG2E, masked_raw = MASKED_NAT / a.alpha;
     float m = NOKEY, l = 0.f;            // m: running maximum of the RAW scores
-    f32x4 oacc[8];
+    f32x4 oacc[DT];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < DT; ++d) oacc[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned bits_next = DROP == 2 ? keep[0] : 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -391,24 +408,24 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
         constexpr int KOFF = BUF * TILE, VOFF = 2 * TILE + BUF * TILE;
         unsigned mybits = bits_next;
         if (kt + 1 < nkt) {
-            stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), rowst, wave, voff0);
-            stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), rowst, wave, voff0);
-            if (DROP == 2) bits_next = keep[(int64_t)(kt + 1) * t * 4];
+            stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), kvrow, wave, voff0);
+            stage_tile(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), kvrow, wave, voff0);
+            if (DROP == 2) bits_next = keep[(int64_t)(kt + 1) * tq * 4];
         }
         if (DROP == 1) {                  // keep-bits of query i16, keys 64kt + 16g .. +15; stashed for the backward kernels
             mybits = drop_bits16(dc, (uint64_t)(prow + 64 * kt + 16 * g));
-            if (qrow < t) keep[(int64_t)kt * t * 4] = (uint16_t)mybits;
+            if (qrow < tq) keep[(int64_t)kt * tq * 4] = (uint16_t)mybits;
         }
         float x[4][4];
         float tmax = NOKEY;
-        score_tiles<KOFF>(64 * (kt + 1) > kfull, fa, qf, lmask, kt, t, masked_raw, lane, x, tmax);
+        score_tiles<KOFF, KS>(64 * (kt + 1) > kfull || (a.causal && 64 * (kt + 1) - 1 > blk * 128), fa, qf, lmask, kt, t, cq, masked_raw, lane, x, tmax);
         tmax = xor16_32_max(tmax);
         if (__any(tmax > m)) {           // a new row maximum somewhere in the wave: rescale
             const float m_new = fmaxf(m, tmax);
             const float corr = __builtin_amdgcn_exp2f((m - m_new) * c2);
             l *= corr;
 #pragma unroll
-            for (int d = 0; d < 8; ++d)
+            for (int d = 0; d < DT; ++d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) oacc[d][r] *= corr;
             m = m_new;
@@ -427,15 +444,15 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
         }
         // ---- O^T += V^T P^T: k-step kp covers the keys of score tiles 2kp, 2kp+1 (in the accumulators' own order)
         const bf16x8 pb0 = pack8(x[0], x[1]), pb1 = pack8(x[2], x[3]);
-        // sixteen V fragments, read one ahead: the reads of fragment n+1 are in flight while fragment n feeds its MFMA
+        // 2 DT V fragments, read one ahead: the reads of fragment n+1 are in flight while fragment n feeds its MFMA
         TrFrag vf[2];
         tr_issue<VOFF>(fa, 0, vf[0]);
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            if (n + 1 < 8) tr_issue<VOFF>(fa, n + 1, vf[(n + 1) & 1]);
-            else if (n + 1 < 16) tr_issue<VOFF + 8192>(fa, n + 1 - 8, vf[(n + 1) & 1]);
-            const bf16x8 v8 = n + 1 < 16 ? tr_wait<2>(vf[n & 1]) : tr_wait<0>(vf[n & 1]);
-            oacc[n & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v8, n < 8 ? pb0 : pb1, oacc[n & 7], 0, 0, 0);
+        for (int n = 0; n < 2 * DT; ++n) {
+            if (n + 1 < DT) tr_issue<VOFF>(fa, n + 1, vf[(n + 1) & 1]);
+            else if (n + 1 < 2 * DT) tr_issue<VOFF + 8192>(fa, n + 1 - DT, vf[(n + 1) & 1]);
+            const bf16x8 v8 = n + 1 < 2 * DT ? tr_wait<2>(vf[n & 1]) : tr_wait<0>(vf[n & 1]);
+            oacc[n % DT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v8, n < DT ? pb0 : pb1, oacc[n % DT], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
@@ -444,17 +461,17 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
         if (kt + 1 < nkt) tile(kt + 1, IC<1>{});
     }
     l = xor16_32_sum(l);
-    if (qrow < t) {
+    if (qrow < tq) {
         const float inv = dc.scale / l;             // 1/(1-p) of the kept probabilities, applied once
         bf16_t* orow = a.O + (int64_t)b * a.o_batch + (int64_t)qrow * a.o_row + (int64_t)h * a.head;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {           // oacc[d][r] = O[qrow][16d + 4g + r]
+        for (int d = 0; d < DT; ++d) {          // oacc[d][r] = O[qrow][16d + 4g + r]
             bf16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(oacc[d][r] * inv);
             *reinterpret_cast<bf16x4*>(orow + 16 * d + 4 * g) = o;
         }
-        if (g == 0) *reinterpret_cast<float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2) = make_float2(m * a.alpha, l);
+        if (g == 0) *reinterpret_cast<float2*>(a.stats + (((int64_t)b * a.H + h) * tq + qrow) * 2) = make_float2(m * a.alpha, l);
     }
 }
 
@@ -462,71 +479,75 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
 // Same shape as the forward (4 waves x 32 queries); recomputes S^T and dPd^T = V dO^T per 64-key tile, dS^T = P (dPd keep / (1-p) -
 // delta) (0 at masked keys: masked_fill's backward), dQ^T += K^T dS^T.  Also writes aux = {-m log2 e, 1/l, delta, 0} per query for
 // the dK/dV kernel.
-template <bool DROP>
+template <bool DROP, int DK>
 __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS = DK / 32, DT = DK / 16;
     int blk, h, b;
-    if (!flash_item(a, blk, h, b)) return;
+    if (!flash_item(a, a.tq, blk, h, b)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int t = a.t;
+    const int t = a.t, tq = a.tq;
     const int q0 = blk * 128 + wave * 32 + i16;
     unsigned char* kimg = smem;
     unsigned char* vimg = smem + 2 * TILE;
     unsigned char* lmask = smem + 4 * TILE;
-    int* red = reinterpret_cast<int*>(smem + 4 * TILE + MASK_BYTES);
+    int* red = reinterpret_cast<int*>(smem + 4 * TILE + a.mb);
     const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
-    const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
-    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hb);
+    const int64_t hbq = (int64_t)b * a.batch + (int64_t)h * a.head, hbk = (int64_t)b * a.kvbatch + (int64_t)h * a.head;
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hbq);
     const __amdgpu_buffer_rsrc_t rs_do = make_rsrc(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head);
     const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.O + (int64_t)b * a.o_batch + (int64_t)h * a.head);
-    const int rowst = (int)a.row;
-    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc_rows(a.k + hb, t, rowst), rs_v = make_rsrc_rows(a.v + hb, t, rowst);
-    const unsigned voff0 = stage_voff(rowst, wave, lane);
-    stage_tile<FQ_WAVES>(rs_k, kimg, 0, rowst, wave, voff0);
-    stage_tile<FQ_WAVES>(rs_v, vimg, 0, rowst, wave, voff0);
+    const int rowst = (int)a.row, kvrow = (int)a.kvrow;
+    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc_rows<DK>(a.k + hbk, t, kvrow), rs_v = make_rsrc_rows<DK>(a.v + hbk, t, kvrow);
+    const unsigned voff0 = stage_voff<DK>(kvrow, wave, lane);
+    stage_tile<FQ_WAVES>(rs_k, kimg, 0, kvrow, wave, voff0);
+    stage_tile<FQ_WAVES>(rs_v, vimg, 0, kvrow, wave, voff0);
 
-    bf16x8 qf[2][4], dof[2][4];
+    bf16x8 qf[2][KS], dof[2][KS];
     float delta[2], nm2[2] = {0.f, 0.f}, linv[2] = {0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int qrow = q0 + 16 * s;
         float dl = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qf[s][ks] = ld16(rs_q, qrow < t ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
-            dof[s][ks] = ld16(rs_do, qrow < t ? (unsigned)((qrow * (int)a.do_row + 32 * ks + 8 * g) * 2) : OOB);
-            const bf16x8 of = ld16(rs_o, qrow < t ? (unsigned)((qrow * (int)a.o_row + 32 * ks + 8 * g) * 2) : OOB);
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[s][ks] = ld16(rs_q, qrow < tq ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
+            dof[s][ks] = ld16(rs_do, qrow < tq ? (unsigned)((qrow * (int)a.do_row + 32 * ks + 8 * g) * 2) : OOB);
+            const bf16x8 of = ld16(rs_o, qrow < tq ? (unsigned)((qrow * (int)a.o_row + 32 * ks + 8 * g) * 2) : OOB);
 #pragma unroll
             for (int c = 0; c < 8; ++c) dl += (float)dof[s][ks][c] * (float)of[c];
         }
         delta[s] = xor16_32_sum(dl);
-        if (qrow < t) {
-            const float2 st = *reinterpret_cast<const float2*>(a.stats + (((int64_t)b * a.H + h) * t + qrow) * 2);
+        if (qrow < tq) {
+            const float2 st = *reinterpret_cast<const float2*>(a.stats + (((int64_t)b * a.H + h) * tq + qrow) * 2);
             nm2[s] = -st.x * LOG2E;
             linv[s] = 1.f / st.y;
         }
     }
     int kfull, kmax;
     mask_setup<FQ_THREADS>(a, b, t, lmask, red, tid, kfull, kmax);
-    const int nkt = kmax > 0 ? (kmax + 63) >> 6 : (t + 63) >> 6;
-    // per query for the dK/dV kernel: {-m log2 e, 1/l, delta, kmax of this batch row (as bits: saves that kernel the mask scan)}
+    const int nkt = key_tiles(a, kfull, kmax, min(blk * 128 + 127, tq - 1));
+    // per query for the dK/dV kernel: {-m log2 e, 1/l, delta, kmax of this batch row and "key 0 is unmasked" (as bits: saves that
+    // kernel the mask scan)}
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int qrow = q0 + 16 * s;
-        if (qrow < t && g == 0)
-            *reinterpret_cast<float4*>(a.aux + (((int64_t)b * a.H + h) * t + qrow) * 4) = make_float4(nm2[s], linv[s], delta[s], __int_as_float(kmax));
+        if (qrow < tq && g == 0)
+            *reinterpret_cast<float4*>(a.aux + (((int64_t)b * a.H + h) * tq + qrow) * 4) =
+                make_float4(nm2[s], linv[s], delta[s], __int_as_float(kmax | (kfull > 0 ? 0x40000000 : 0)));
     }
     const float scale = DROP ? 65536.f / (65536.f - (float)(uint32_t)(a.pdrop * 65536.f + 0.5f)) : 1.f;
-    const int qc0 = q0 < t ? q0 : 0, qc1 = q0 + 16 < t ? q0 + 16 : 0;
-    const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * t) * 4 + g;
+    const int qc0 = q0 < tq ? q0 : 0, qc1 = q0 + 16 < tq ? q0 + 16 : 0;
+    const int cq[2] = {a.causal ? q0 : NO_CAUSAL, a.causal ? q0 + 16 : NO_CAUSAL};
+    const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * tq) * 4 + g;
     const float c2 = a.alpha * LOG2E, masked_raw = MASKED_NAT / a.alpha;
-    f32x4 dqacc[2][8];
+    f32x4 dqacc[2][DT];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int d = 0; d < 8; ++d) dqacc[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < DT; ++d) dqacc[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     unsigned bits_next[2] = {0, 0};
     if (DROP) { bits_next[0] = keep[(int64_t)qc0 * 4]; bits_next[1] = keep[(int64_t)qc1 * 4]; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -536,14 +557,14 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
         constexpr int KOFF = BUF * TILE, VOFF = 2 * TILE + BUF * TILE;
         const unsigned mybits[2] = {bits_next[0], bits_next[1]};
         if (kt + 1 < nkt) {
-            stage_tile<FQ_WAVES>(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), rowst, wave, voff0);
-            stage_tile<FQ_WAVES>(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), rowst, wave, voff0);
+            stage_tile<FQ_WAVES>(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), kvrow, wave, voff0);
+            stage_tile<FQ_WAVES>(rs_v, vimg + (BUF ^ 1) * TILE, 64 * (kt + 1), kvrow, wave, voff0);
             if (DROP) {
-                bits_next[0] = keep[((int64_t)(kt + 1) * t + qc0) * 4];
-                bits_next[1] = keep[((int64_t)(kt + 1) * t + qc1) * 4];
+                bits_next[0] = keep[((int64_t)(kt + 1) * tq + qc0) * 4];
+                bits_next[1] = keep[((int64_t)(kt + 1) * tq + qc1) * 4];
             }
         }
-        const bool masked = 64 * (kt + 1) > kfull;
+        const bool masked = 64 * (kt + 1) > kfull || (a.causal && 64 * (kt + 1) - 1 > blk * 128);
         auto pair = [&](auto KPC) {
             constexpr int kp = decltype(KPC)::value;
             float ds[2][2][4];                               // [sub-tile][u][r]
@@ -552,7 +573,7 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
                 __builtin_amdgcn_sched_barrier(0);          // keep the operand reads of later tiles from being hoisted (register pressure)
                 f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, pa = sa, pbb = sa;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8 kfrag = row_frag<KOFF + 4096 * T>(fa, ks);
                     sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[0][ks], sa, 0, 0, 0);
                     sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, qf[1][ks], sb, 0, 0, 0);
@@ -566,8 +587,8 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
                 unsigned mk = 0x01010101u;
                 if (masked) {
                     mk = *reinterpret_cast<const unsigned*>(lmask + key0);
-                    mask_fix(v[0], mk, key0, t, masked_raw);
-                    mask_fix(v[1], mk, key0, t, masked_raw);
+                    mask_fix(v[0], mk, key0, t, cq[0], masked_raw);
+                    mask_fix(v[1], mk, key0, t, cq[1], masked_raw);
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -584,7 +605,8 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ds[s][u][r] = ((mk >> (8 * r)) & 0xFFu) != 0 ? ds[s][u][r] : 0.f;      // masked_fill's backward
+                        for (int r = 0; r < 4; ++r)
+                            ds[s][u][r] = (((mk >> (8 * r)) & 0xFFu) != 0 && key0 + r <= cq[s]) ? ds[s][u][r] : 0.f;      // masked_fill's backward
                 }
             };
             one(IC<0>{}); one(IC<1>{});
@@ -592,9 +614,9 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
             TrFrag kf_[2];                  // K fragments read one ahead of the MFMA pair they feed
             tr_issue<KOFF + 8192 * kp>(fa, 0, kf_[0]);
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                if (d + 1 < 8) tr_issue<KOFF + 8192 * kp>(fa, d + 1, kf_[(d + 1) & 1]);
-                const bf16x8 kfrag = d + 1 < 8 ? tr_wait<2>(kf_[d & 1]) : tr_wait<0>(kf_[d & 1]);
+            for (int d = 0; d < DT; ++d) {
+                if (d + 1 < DT) tr_issue<KOFF + 8192 * kp>(fa, d + 1, kf_[(d + 1) & 1]);
+                const bf16x8 kfrag = d + 1 < DT ? tr_wait<2>(kf_[d & 1]) : tr_wait<0>(kf_[d & 1]);
                 dqacc[0][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, dsa, dqacc[0][d], 0, 0, 0);
                 dqacc[1][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag, dsb, dqacc[1][d], 0, 0, 0);
             }
@@ -607,20 +629,20 @@ __global__ __launch_bounds__(FQ_THREADS, 2) void flash_bwd_dq_k(const FlashArgs 
         if (kt + 1 < nkt) tile(kt + 1, IC<1>{});
     }
     if (a.dbq != nullptr) {               // rows that do not exist hold zeros
-        f32x4 both[8];
+        f32x4 both[DT];
 #pragma unroll
-        for (int d = 0; d < 8; ++d)
+        for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int r = 0; r < 4; ++r) both[d][r] = dqacc[0][d][r] + dqacc[1][d][r];
-        block_colsum<FQ_THREADS>(both, a.alpha, reinterpret_cast<float*>(smem), a.dbq + h * 128, tid, lane);
+        block_colsum<FQ_THREADS, DT>(both, a.alpha, reinterpret_cast<float*>(smem), a.dbq + h * DK, tid, lane);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int qrow = q0 + 16 * s;
-        if (qrow < t) {
+        if (qrow < tq) {
             bf16_t* drow = a.dq + (int64_t)b * a.g_batch + (int64_t)qrow * a.g_row + (int64_t)h * a.head;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
+            for (int d = 0; d < DT; ++d) {
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(dqacc[s][d][r] * a.alpha);
@@ -638,35 +660,38 @@ template <int T> __device__ __forceinline__ void row_share4(unsigned bits, unsig
     kb[0] = row_share<4 * T>(bits); kb[1] = row_share<4 * T + 1>(bits); kb[2] = row_share<4 * T + 2>(bits); kb[3] = row_share<4 * T + 3>(bits);
 }
 
-template <bool DROP, int NW>
+template <bool DROP, int NW, int DK>
 __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int KB = 16 * NW;          // keys per workgroup: 128 (8 waves, one workgroup per CU) or 64 (4 waves, two per CU)
+    constexpr int KS = DK / 32, DT = DK / 16;
+    constexpr int KB = 16 * NW;          // keys per workgroup: 64 (4 waves, two workgroups per CU)
     int blk, h, b;
-    if (!flash_item<KB>(a, blk, h, b)) return;
+    if (!flash_item<KB>(a, a.t, blk, h, b)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i16 = lane & 15;
-    const int t = a.t;
+    const int t = a.t, tq = a.tq;
     const int kb0 = blk * KB + wave * 16;
     const int key = kb0 + i16;
     unsigned char* qimg = smem;                         // [2][TILE]
     unsigned char* doimg = smem + 2 * TILE;             // [2][TILE]
     unsigned char* auximg = smem + 4 * TILE;            // [2][AUX_BYTES]
     const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
-    const int64_t hb = (int64_t)b * a.batch + (int64_t)h * a.head;
-    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(a.k + hb), rs_v = make_rsrc(a.v + hb);
-    const __amdgpu_buffer_rsrc_t rs_aux = make_rsrc(a.aux + (((int64_t)b * a.H + h) * t) * 4);
-    const int rowst = (int)a.row, dorow = (int)a.do_row;
+    const int64_t hbq = (int64_t)b * a.batch + (int64_t)h * a.head, hbk = (int64_t)b * a.kvbatch + (int64_t)h * a.head;
+    const __amdgpu_buffer_rsrc_t rs_k = make_rsrc(a.k + hbk), rs_v = make_rsrc(a.v + hbk);
+    const __amdgpu_buffer_rsrc_t rs_aux = make_rsrc(a.aux + (((int64_t)b * a.H + h) * tq) * 4);
+    const int rowst = (int)a.row, kvrow = (int)a.kvrow, dorow = (int)a.do_row;
     const bool kvalid = key < t;
-    const int64_t goff = (int64_t)b * a.g_batch + (int64_t)key * a.g_row + (int64_t)h * a.head;
+    const int64_t goff = (int64_t)b * a.gkv_batch + (int64_t)key * a.gkv_row + (int64_t)h * a.head;
 
-    const int kmax = __float_as_int(a.aux[(((int64_t)b * a.H + h) * t) * 4 + 3]);      // written by the dQ kernel (row 0 always exists)
+    const int kbits = __float_as_int(a.aux[(((int64_t)b * a.H + h) * tq) * 4 + 3]);      // written by the dQ kernel (query 0 always exists)
+    const int kmax = kbits & 0x3FFFFFFF;
+    const bool key0_visible = (kbits & 0x40000000) != 0;
     if (kmax > 0 && blk * KB >= kmax) {     // every key of this block is masked: zero probability, zero gradients
         if (kvalid) {
             const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
+            for (int d = 0; d < DT; ++d) {
                 *reinterpret_cast<bf16x4*>(a.dv + goff + 16 * d + 4 * g) = z;
                 *reinterpret_cast<bf16x4*>(a.dk + goff + 16 * d + 4 * g) = z;
             }
@@ -674,40 +699,44 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a)
         return;
     }
 
-    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc_rows(a.q + hb, t, rowst);
-    const __amdgpu_buffer_rsrc_t rs_do = make_rsrc_rows(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head, t, dorow);
-    const unsigned voff_q = stage_voff(rowst, wave, lane), voff_do = stage_voff(dorow, wave, lane);
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc_rows<DK>(a.q + hbq, tq, rowst);
+    const __amdgpu_buffer_rsrc_t rs_do = make_rsrc_rows<DK>(a.dO + (int64_t)b * a.do_batch + (int64_t)h * a.head, tq, dorow);
+    const unsigned voff_q = stage_voff<DK>(rowst, wave, lane), voff_do = stage_voff<DK>(dorow, wave, lane);
     auto stage = [&](int qt, int buf) {
         stage_tile<NW>(rs_q, qimg + buf * TILE, 64 * qt, rowst, wave, voff_q);
         stage_tile<NW>(rs_do, doimg + buf * TILE, 64 * qt, dorow, wave, voff_do);
         if (wave == 0) {
             const int q = 64 * qt + lane;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_aux, (lds_void_t*)(auximg + buf * AUX_BYTES), 16,
-                                                     (int)(q < t ? (unsigned)(q * 16) : OOB), 0, 0, 0);
+                                                     (int)(q < tq ? (unsigned)(q * 16) : OOB), 0, 0, 0);
         }
     };
-    const int nqt = (t + 63) >> 6;
-    stage(0, 0);
-    bf16x8 kf[4], vf[4];
+    const int nqt = (tq + 63) >> 6;
+    // causal: the queries before this block's first key do not see it (their probabilities are exactly 0 once key 0 is visible to them)
+    const int qt0 = (a.causal && key0_visible) ? min((blk * KB) >> 6, nqt - 1) : 0;
+    stage(qt0, 0);
+    bf16x8 kf[KS], vf[KS];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = ld16(rs_k, kvalid ? (unsigned)((key * rowst + 32 * ks + 8 * g) * 2) : OOB);
-        vf[ks] = ld16(rs_v, kvalid ? (unsigned)((key * rowst + 32 * ks + 8 * g) * 2) : OOB);
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = ld16(rs_k, kvalid ? (unsigned)((key * kvrow + 32 * ks + 8 * g) * 2) : OOB);
+        vf[ks] = ld16(rs_v, kvalid ? (unsigned)((key * kvrow + 32 * ks + 8 * g) * 2) : OOB);
     }
     const bool on = kvalid && a.key_mask[(int64_t)b * t + (kvalid ? key : 0)] != 0;
     // exp2 argument of this lane's key: s * cl + bl - m log2 e  (masked key: -1e4 log2 e; key that does not exist: NOKEY)
     const float cl = on ? a.alpha * LOG2E : 0.f;
     const float bl = !kvalid ? NOKEY : (on ? 0.f : MASKED_NAT * LOG2E);
     const float ml = on ? 1.f : 0.f;                   // masked_fill's backward
+    const float bl_causal = kvalid ? MASKED_NAT * LOG2E : NOKEY;       // ... of a key that lies after the query (causal launches)
+    const int ckey = a.causal ? key : -1;              // query >= ckey sees this key
     const float scale = DROP ? 65536.f / (65536.f - (float)(uint32_t)(a.pdrop * 65536.f + 0.5f)) : 1.f;
     // keep-bits of the wave's 16 keys for query 64qt + 16(i16>>2) + 4g + (i16&3): element (T, r) = (i16>>2, i16&3) of this
     // lane's row of 16 lanes
     const int qsub = 16 * (i16 >> 2) + 4 * g + (i16 & 3);
-    const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt + (kb0 >> 6)) * t) * 4 + ((kb0 >> 4) & 3);
-    unsigned bits_next = (DROP && qsub < t) ? keep[(int64_t)qsub * 4] : 0;
-    f32x4 dvacc[8], dkacc[8];
+    const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt + (kb0 >> 6)) * tq) * 4 + ((kb0 >> 4) & 3);
+    unsigned bits_next = (DROP && 64 * qt0 + qsub < tq) ? keep[(int64_t)(64 * qt0 + qsub) * 4] : 0;
+    f32x4 dvacc[DT], dkacc[DT];
 #pragma unroll
-    for (int d = 0; d < 8; ++d) { dvacc[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dkacc[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int d = 0; d < DT; ++d) { dvacc[d] = f32x4{0.f, 0.f, 0.f, 0.f}; dkacc[d] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     auto tile = [&](const int qt, auto BUFC) {
@@ -717,31 +746,32 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a)
         if (qt + 1 < nqt) {
             stage(qt + 1, BUF ^ 1);
             const int qq = 64 * (qt + 1) + qsub;
-            if (DROP) bits_next = qq < t ? keep[(int64_t)qq * 4] : 0;
+            if (DROP) bits_next = qq < tq ? keep[(int64_t)qq * 4] : 0;
         }
         const float4* aux = reinterpret_cast<const float4*>(auximg + BUF * AUX_BYTES);
         auto pair = [&](auto KPC) {
             constexpr int kp = decltype(KPC)::value;
             // the transposed fragments of this k-step depend only on the staged tile: their reads are issued BEFORE the score /
-            // element-wise phase, so that the 16 MFMAs below do not run at the pace of one LDS round trip each (the compiler
+            // element-wise phase, so that the 2 DT MFMAs below do not run at the pace of one LDS round trip each (the compiler
             // otherwise keeps a single fragment of lookahead; the kernel has the registers: 2 waves per SIMD)
-            bf16x8 fdo[8], fq[8];
+            bf16x8 fdo[DT], fq[DT];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) fdo[d] = tr_frag<DOFF + 8192 * kp>(fa, d);
+            for (int d = 0; d < DT; ++d) fdo[d] = tr_frag<DOFF + 8192 * kp>(fa, d);
 #pragma unroll
-            for (int d = 0; d < 8; ++d) fq[d] = tr_frag<QOFF + 8192 * kp>(fa, d);
+            for (int d = 0; d < DT; ++d) fq[d] = tr_frag<QOFF + 8192 * kp>(fa, d);
             float pd[2][4], ds[2][4];
             auto one = [&](auto UC) {
                 constexpr int u = decltype(UC)::value, T = 2 * kp + u;
                 __builtin_amdgcn_sched_barrier(0);      // as in dq_tiles
-                const f32x4 s = tile128<QOFF + 4096 * T>(fa, kf);
-                const f32x4 dp = tile128<DOFF + 4096 * T>(fa, vf);
+                const f32x4 s = tile128<QOFF + 4096 * T, KS>(fa, kf);
+                const f32x4 dp = tile128<DOFF + 4096 * T, KS>(fa, vf);
                 unsigned kb[4] = {0, 0, 0, 0};
                 if (DROP) row_share4<T>(mybits, kb);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float4 ax = aux[16 * T + 4 * g + r];                         // {-m log2 e, 1/l, delta, -}; zeros for q >= t
-                    const float pn = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], cl, bl) + ax.x) * ax.y;
+                    const float4 ax = aux[16 * T + 4 * g + r];                         // {-m log2 e, 1/l, delta, -}; zeros for q >= tq
+                    const bool vis = 64 * qt + 16 * T + 4 * g + r >= ckey;             // (always true when the launch is not causal)
+                    const float pn = __builtin_amdgcn_exp2f((vis ? __builtin_fmaf(s[r], cl, bl) : bl_causal) + ax.x) * ax.y;
                     float t1 = dp[r], pk = pn;
                     if (DROP) {
                         const int msk = keep_mask(kb[r], (unsigned)i16);
@@ -749,14 +779,14 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a)
                         pk = and_mask(pn, msk);
                     }
                     pd[u][r] = pk;
-                    ds[u][r] = (pn * ml) * __builtin_fmaf(t1, scale, -ax.z);
+                    ds[u][r] = (pn * (vis ? ml : 0.f)) * __builtin_fmaf(t1, scale, -ax.z);
                 }
             };
             one(IC<0>{}); one(IC<1>{});
             const bf16x8 pdb = pack8(pd[0], pd[1]);
             const bf16x8 dsb = pack8(ds[0], ds[1]);
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
+            for (int d = 0; d < DT; ++d) {
                 dvacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdo[d], pdb, dvacc[d], 0, 0, 0);
                 dkacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[d], dsb, dkacc[d], 0, 0, 0);
             }
@@ -764,15 +794,15 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a)
         pair(IC<0>{}); pair(IC<1>{});
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
-    for (int qt = 0; qt < nqt; qt += 2) {
+    for (int qt = qt0; qt < nqt; qt += 2) {
         tile(qt, IC<0>{});
         if (qt + 1 < nqt) tile(qt + 1, IC<1>{});
     }
-    if (a.dbk != nullptr) block_colsum<64 * NW>(dkacc, a.alpha, reinterpret_cast<float*>(smem), a.dbk + h * 128, tid, lane);
-    if (a.dbv != nullptr) block_colsum<64 * NW>(dvacc, scale, reinterpret_cast<float*>(smem) + 128, a.dbv + h * 128, tid, lane);
+    if (a.dbk != nullptr) block_colsum<64 * NW, DT>(dkacc, a.alpha, reinterpret_cast<float*>(smem), a.dbk + h * DK, tid, lane);
+    if (a.dbv != nullptr) block_colsum<64 * NW, DT>(dvacc, scale, reinterpret_cast<float*>(smem) + 128, a.dbv + h * DK, tid, lane);
     if (kvalid) {
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
+        for (int d = 0; d < DT; ++d) {
             bf16x4 ov, ok;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ov[r] = (bf16_t)(dvacc[d][r] * scale); ok[r] = (bf16_t)(dkacc[d][r] * a.alpha); }
@@ -800,54 +830,136 @@ __global__ __launch_bounds__(256) void flash_keep_bits_k(uint16_t* __restrict__ 
     }
 }
 
-int check_common(const char* who, const void* q, const void* k, const void* v, int64_t row, int64_t batch, int head, int B, int H, int t,
-                 float p, const void* keep_bits) {
-    FS2_REQUIRE(q && k && v, "%s: null argument", who);
-    FS2_REQUIRE(t > 0 && t <= MASK_BYTES, "%s: need 0 < t <= 1024 (t=%d)", who, t);
-    FS2_REQUIRE(B > 0 && H > 0 && (int64_t)B * H * ((t + 127) / 128) < (1 << 28), "%s: bad B/H", who);
-    FS2_REQUIRE(row % 8 == 0 && batch % 8 == 0 && head % 8 == 0, "%s: strides must be multiples of 8 elements", who);
-    FS2_REQUIRE(fs2_aligned16(q) && fs2_aligned16(k) && fs2_aligned16(v), "%s: pointers must be 16-byte aligned", who);
-    FS2_REQUIRE((int64_t)(t + 64) * row * 2 < 0x7FFFFFF0LL, "%s: one (batch, head) slice exceeds 2 GiB", who);
-    FS2_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || keep_bits != nullptr), "%s: dropout needs the keep-bits buffer", who);
+int check_desc(const char* who, const FS2FlashAttn& d, bool backward) {
+    FS2_REQUIRE(d.q && d.k && d.v && d.key_mask && d.o && d.stats, "%s: null argument", who);
+    FS2_REQUIRE(d.dk == 64 || d.dk == 96 || d.dk == 128, "%s: d_k must be 64, 96 or 128 (d_k=%d)", who, d.dk);
+    FS2_REQUIRE(d.tq > 0 && d.tk > 0 && d.tk <= MASK_MAX, "%s: need tq > 0 and 0 < tk <= %d (tq=%d tk=%d)", who, MASK_MAX, d.tq, d.tk);
+    FS2_REQUIRE(d.B > 0 && d.H > 0 && (int64_t)d.B * d.H * ((d.tq + 127) / 128) < (1 << 28) && (int64_t)d.B * d.H * ((d.tk + 63) / 64) < (1 << 28),
+                "%s: bad B/H", who);
+    FS2_REQUIRE(d.q_row_stride % 8 == 0 && d.q_batch_stride % 8 == 0 && d.kv_row_stride % 8 == 0 && d.kv_batch_stride % 8 == 0 && d.head_stride % 8 == 0,
+                "%s: strides must be multiples of 8 elements", who);
+    FS2_REQUIRE(fs2_aligned16(d.q) && fs2_aligned16(d.k) && fs2_aligned16(d.v), "%s: pointers must be 16-byte aligned", who);
+    FS2_REQUIRE((int64_t)(d.tq + 64) * d.q_row_stride * 2 < 0x7FFFFFF0LL && (int64_t)(d.tk + 64) * d.kv_row_stride * 2 < 0x7FFFFFF0LL,
+                "%s: one (batch, head) slice exceeds 2 GiB", who);
+    FS2_REQUIRE(d.p >= 0.f && d.p < 1.f && (d.p == 0.f || d.keep_bits != nullptr), "%s: dropout needs the keep-bits buffer", who);
+    FS2_REQUIRE(d.tkp == (d.tk + 7) / 8 * 8 && d.p_batch_stride % 8 == 0, "%s: need tkp = roundup8(tk) and p_batch_stride %% 8 == 0", who);
+    FS2_REQUIRE(d.o_row_stride % 8 == 0 && d.o_batch_stride % 8 == 0 && fs2_aligned16(d.o), "%s: output rows must be 16-byte aligned", who);
+    if (!backward) FS2_REQUIRE(d.p == 0.f || d.pregenerated || d.rng != nullptr, "%s: dropout needs rng", who);
+    if (backward) {
+        FS2_REQUIRE(d.d_out && d.aux && d.dq && d.dk_out && d.dv_out, "%s: null gradient argument", who);
+        FS2_REQUIRE(d.do_row_stride % 8 == 0 && d.do_batch_stride % 8 == 0 && d.dq_row_stride % 4 == 0 && d.dq_batch_stride % 4 == 0 &&
+                        d.dkv_row_stride % 4 == 0 && d.dkv_batch_stride % 4 == 0, "%s: strides must be multiples of 8 elements (gradients: 4)", who);
+        FS2_REQUIRE(fs2_aligned16(d.d_out) && fs2_aligned16(d.aux) && fs2_aligned16(d.dq) && fs2_aligned16(d.dk_out) && fs2_aligned16(d.dv_out),
+                    "%s: pointers must be 16-byte aligned", who);
+        FS2_REQUIRE((int64_t)(d.tq + 64) * d.do_row_stride * 2 < 0x7FFFFFF0LL && (int64_t)(d.tq + 64) * d.o_row_stride * 2 < 0x7FFFFFF0LL,
+                    "%s: one (batch, head) slice exceeds 2 GiB", who);
+    }
     return FS2_OK;
 }
 
-int flash_grid(int B, int H, int t) { return 8 * ((B * H + 7) / 8) * ((t + 127) / 128); }
-
-}  // namespace
-
-extern "C" int64_t fs2_flash_attn_keep_words(int B, int H, int t) { return (int64_t)B * H * ((t + 63) / 64) * t * 4; }
-
-extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
-                                  const uint8_t* key_mask, const int32_t* key_info, void* o_out, int64_t o_row_stride, int64_t o_batch_stride,
-                                  float* stats, uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
-                                  float p, const uint64_t* rng, uint32_t site, void* stream) {
-    const int rc = check_common("fs2_flash_attn_fwd", q, k, v, row_stride, batch_stride, head_stride, B, H, t, p, keep_bits);
-    if (rc != FS2_OK) return rc;
-    FS2_REQUIRE(key_mask && o_out && stats, "fs2_flash_attn_fwd: null argument");
-    FS2_REQUIRE(tp == (t + 7) / 8 * 8 && p_batch_stride % 8 == 0, "fs2_flash_attn_fwd: need tp = roundup8(t) and p_batch_stride %% 8 == 0");
-    FS2_REQUIRE(o_row_stride % 4 == 0 && o_batch_stride % 4 == 0 && fs2_aligned16(o_out), "fs2_flash_attn_fwd: output rows must be 8-byte aligned");
-    FS2_REQUIRE(p == 0.f || pregenerated || rng != nullptr, "fs2_flash_attn_fwd: dropout needs rng");
+FlashArgs to_args(const FS2FlashAttn& d) {
     FlashArgs a = {};
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.row = row_stride; a.batch = batch_stride; a.head = head_stride;
-    a.key_mask = key_mask; a.kinfo = key_info; a.O = (bf16_t*)o_out; a.o_row = o_row_stride; a.o_batch = o_batch_stride; a.stats = stats; a.keep = keep_bits;
-    a.p_batch = p_batch_stride; a.B = B; a.H = H; a.t = t; a.tp = tp; a.nkt = (t + 63) / 64; a.alpha = alpha; a.pdrop = p; a.rng = rng; a.site = site;
-    const int lds = 4 * TILE + MASK_BYTES + 16;
+    a.q = (const bf16_t*)d.q; a.k = (const bf16_t*)d.k; a.v = (const bf16_t*)d.v;
+    a.row = d.q_row_stride; a.batch = d.q_batch_stride; a.kvrow = d.kv_row_stride; a.kvbatch = d.kv_batch_stride; a.head = d.head_stride;
+    a.tq = d.tq; a.t = d.tk; a.causal = d.causal ? 1 : 0; a.mb = (d.tk + 63) / 64 * 64 + 64;
+    a.key_mask = d.key_mask; a.kinfo = d.key_info; a.O = (bf16_t*)d.o; a.o_row = d.o_row_stride; a.o_batch = d.o_batch_stride;
+    a.stats = d.stats; a.keep = d.keep_bits; a.p_batch = d.p_batch_stride; a.B = d.B; a.H = d.H; a.tp = d.tkp; a.nkt = (d.tk + 63) / 64;
+    a.alpha = d.alpha; a.pdrop = d.p; a.rng = d.rng; a.site = d.site;
+    a.dO = (const bf16_t*)d.d_out; a.do_row = d.do_row_stride; a.do_batch = d.do_batch_stride; a.aux = d.aux;
+    a.dq = (bf16_t*)d.dq; a.dk = (bf16_t*)d.dk_out; a.dv = (bf16_t*)d.dv_out;
+    a.g_row = d.dq_row_stride; a.g_batch = d.dq_batch_stride; a.gkv_row = d.dkv_row_stride; a.gkv_batch = d.dkv_batch_stride;
+    a.dbq = d.dbias_q; a.dbk = d.dbias_k; a.dbv = d.dbias_v;
+    return a;
+}
+
+int flash_grid(int B, int H, int rows, int blk) { return 8 * ((B * H + 7) / 8) * ((rows + blk - 1) / blk); }
+
+template <int DK>
+int launch_fwd(const FlashArgs& a, int drop_mode, hipStream_t st) {
+    const int lds = 4 * TILE + a.mb + 16;
     static Fs2PerDevice attr_set;
     if (attr_set.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<0, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE + MASK_MAX + 128);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<1, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE + MASK_MAX + 128);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_k<2, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE + MASK_MAX + 128);
     }
-    if (p > 0.f && pregenerated) hipLaunchKernelGGL(flash_fwd_k<2>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
-    else if (p > 0.f) hipLaunchKernelGGL(flash_fwd_k<1>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(flash_fwd_k<0>, dim3(flash_grid(B, H, t)), dim3(512), lds, (hipStream_t)stream, a);
+    const dim3 grid(flash_grid(a.B, a.H, a.tq, 128));
+    if (drop_mode == 2) hipLaunchKernelGGL((flash_fwd_k<2, DK>), grid, dim3(512), lds, st, a);
+    else if (drop_mode == 1) hipLaunchKernelGGL((flash_fwd_k<1, DK>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((flash_fwd_k<0, DK>), grid, dim3(512), lds, st, a);
     FS2_CHECK_LAUNCH("fs2_flash_attn_fwd");
     return FS2_OK;
 }
 
+template <int DK>
+int launch_bwd(const FlashArgs& a, hipStream_t st) {
+    const int lds_q = 4 * TILE + a.mb + 16, lds_kv = 4 * TILE + 2 * AUX_BYTES + 16;
+    static Fs2PerDevice attr_set;
+    if (attr_set.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<false, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE + MASK_MAX + 128);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<true, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE + MASK_MAX + 128);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 4, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 4, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+    }
+    // dK/dV: 64 keys per workgroup (4 waves, two workgroups per CU).  Every non-empty key block costs the same (all queries), and at
+    // config 2 there are ~2.1 blocks of 128 keys per CU: three rounds for two rounds' worth of work.  Half-size blocks leave a
+    // shorter tail (a lone workgroup on a CU also runs faster than one of a pair): 149 -> 140 us per decoder layer, at twice the
+    // Q / dO staging traffic (the 8-wave / 128-key form was measured slower and is no longer compiled).
+    const dim3 grid(flash_grid(a.B, a.H, a.tq, 128)), grid_kv(flash_grid(a.B, a.H, a.t, 64));
+    if (a.pdrop > 0.f) {
+        hipLaunchKernelGGL((flash_bwd_dq_k<true, DK>), grid, dim3(FQ_THREADS), lds_q, st, a);
+        hipLaunchKernelGGL((flash_bwd_dkv_k<true, 4, DK>), grid_kv, dim3(256), lds_kv, st, a);
+    } else {
+        hipLaunchKernelGGL((flash_bwd_dq_k<false, DK>), grid, dim3(FQ_THREADS), lds_q, st, a);
+        hipLaunchKernelGGL((flash_bwd_dkv_k<false, 4, DK>), grid_kv, dim3(256), lds_kv, st, a);
+    }
+    FS2_CHECK_LAUNCH("fs2_flash_attn_bwd");
+    return FS2_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t fs2_flash_attn_keep_words(int B, int H, int t) { return (int64_t)B * H * ((t + 63) / 64) * t * 4; }
+extern "C" int64_t fs2_flash_attn_keep_words_rect(int B, int H, int tq, int tk) { return (int64_t)B * H * ((tk + 63) / 64) * tq * 4; }
+
+extern "C" int fs2_flash_attention_fwd(const FS2FlashAttn* dp, void* stream) {
+    FS2_REQUIRE(dp != nullptr, "fs2_flash_attention_fwd: null descriptor");
+    const FS2FlashAttn& d = *dp;
+    const int rc = check_desc("fs2_flash_attention_fwd", d, false);
+    if (rc != FS2_OK) return rc;
+    const FlashArgs a = to_args(d);
+    const int mode = d.p > 0.f ? (d.pregenerated ? 2 : 1) : 0;
+    if (d.dk == 128) return launch_fwd<128>(a, mode, (hipStream_t)stream);
+    if (d.dk == 96) return launch_fwd<96>(a, mode, (hipStream_t)stream);
+    return launch_fwd<64>(a, mode, (hipStream_t)stream);
+}
+
+extern "C" int fs2_flash_attention_bwd(const FS2FlashAttn* dp, void* stream) {
+    FS2_REQUIRE(dp != nullptr, "fs2_flash_attention_bwd: null descriptor");
+    const FS2FlashAttn& d = *dp;
+    const int rc = check_desc("fs2_flash_attention_bwd", d, true);
+    if (rc != FS2_OK) return rc;
+    const FlashArgs a = to_args(d);
+    if (d.dk == 128) return launch_bwd<128>(a, (hipStream_t)stream);
+    if (d.dk == 96) return launch_bwd<96>(a, (hipStream_t)stream);
+    return launch_bwd<64>(a, (hipStream_t)stream);
+}
+
+// ---- the round-2 entry points: self-attention, d_k = 128, q / k / v rows of one fused projection
+extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
+                                  const uint8_t* key_mask, const int32_t* key_info, void* o_out, int64_t o_row_stride, int64_t o_batch_stride,
+                                  float* stats, uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
+                                  float p, const uint64_t* rng, uint32_t site, void* stream) {
+    FS2FlashAttn d = {};
+    d.q = q; d.k = k; d.v = v; d.q_row_stride = d.kv_row_stride = row_stride; d.q_batch_stride = d.kv_batch_stride = batch_stride; d.head_stride = head_stride;
+    d.key_mask = key_mask; d.key_info = key_info; d.o = o_out; d.o_row_stride = o_row_stride; d.o_batch_stride = o_batch_stride; d.stats = stats;
+    d.keep_bits = keep_bits; d.pregenerated = pregenerated; d.p_batch_stride = p_batch_stride; d.B = B; d.H = H; d.tq = d.tk = t; d.tkp = tp; d.dk = 128;
+    d.alpha = alpha; d.p = p; d.rng = rng; d.site = site;
+    return fs2_flash_attention_fwd(&d, stream);
+}
+
 extern "C" int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, int32_t* info, void* stream) {
-    FS2_REQUIRE(key_mask && info && B > 0 && t > 0 && t <= MASK_BYTES, "fs2_flash_attn_mask_info: bad arguments");
+    FS2_REQUIRE(key_mask && info && B > 0 && t > 0 && t <= MASK_MAX, "fs2_flash_attn_mask_info: bad arguments");
     hipLaunchKernelGGL(flash_mask_info_k, dim3(B), dim3(512), 0, (hipStream_t)stream, key_mask, t, info);
     FS2_CHECK_LAUNCH("fs2_flash_attn_mask_info");
     hipLaunchKernelGGL(flash_order_k, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, info);
@@ -858,7 +970,7 @@ extern "C" int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, i
 extern "C" int fs2_flash_attn_keep_bits(uint16_t* keep_bits, int64_t p_batch_stride, int B, int H, int t, int tp, float p, const uint64_t* rng,
                                        uint32_t site, void* stream) {
     FS2_REQUIRE(keep_bits && rng && p > 0.f && p < 1.f, "fs2_flash_attn_keep_bits: need a buffer, rng and 0 < p < 1");
-    FS2_REQUIRE(B > 0 && H > 0 && t > 0 && t <= MASK_BYTES && tp == (t + 7) / 8 * 8 && p_batch_stride % 8 == 0, "fs2_flash_attn_keep_bits: bad shape");
+    FS2_REQUIRE(B > 0 && H > 0 && t > 0 && t <= MASK_MAX && tp == (t + 7) / 8 * 8 && p_batch_stride % 8 == 0, "fs2_flash_attn_keep_bits: bad shape");
     const int nkt = (t + 63) / 64;
     const int64_t n = (int64_t)B * H * nkt * t * 4;
     int64_t blocks = (n + 255) / 256;
@@ -875,49 +987,13 @@ extern "C" int fs2_flash_attn_bwd(const void* q, const void* k, const void* v, i
                                   const uint16_t* keep_bits, float* aux, void* dq, void* dk, void* dv, int64_t g_row_stride,
                                   int64_t g_batch_stride, float* dbias_q, float* dbias_k, float* dbias_v, int B, int H, int t, float alpha,
                                   float p, void* stream) {
-    const int rc = check_common("fs2_flash_attn_bwd", q, k, v, row_stride, batch_stride, head_stride, B, H, t, p, keep_bits);
-    if (rc != FS2_OK) return rc;
-    FS2_REQUIRE(key_mask && o_saved && d_out && stats && aux && dq && dk && dv, "fs2_flash_attn_bwd: null argument");
-    FS2_REQUIRE(o_row_stride % 8 == 0 && o_batch_stride % 8 == 0 && do_row_stride % 8 == 0 && do_batch_stride % 8 == 0 && g_row_stride % 4 == 0 &&
-                    g_batch_stride % 4 == 0, "fs2_flash_attn_bwd: strides must be multiples of 8 elements (gradients: 4)");
-    FS2_REQUIRE(fs2_aligned16(o_saved) && fs2_aligned16(d_out) && fs2_aligned16(aux) && fs2_aligned16(dq) && fs2_aligned16(dk) && fs2_aligned16(dv),
-                "fs2_flash_attn_bwd: pointers must be 16-byte aligned");
-    FS2_REQUIRE((int64_t)(t + 64) * do_row_stride * 2 < 0x7FFFFFF0LL && (int64_t)(t + 64) * o_row_stride * 2 < 0x7FFFFFF0LL,
-                "fs2_flash_attn_bwd: one (batch, head) slice exceeds 2 GiB");
-    FlashArgs a = {};
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.row = row_stride; a.batch = batch_stride; a.head = head_stride;
-    a.key_mask = key_mask; a.kinfo = key_info; a.O = (bf16_t*)const_cast<void*>(o_saved); a.o_row = o_row_stride; a.o_batch = o_batch_stride;
-    a.stats = const_cast<float*>(stats); a.keep = const_cast<uint16_t*>(keep_bits);
-    a.B = B; a.H = H; a.t = t; a.tp = (t + 7) / 8 * 8; a.nkt = (t + 63) / 64; a.alpha = alpha; a.pdrop = p;
-    a.dO = (const bf16_t*)d_out; a.do_row = do_row_stride; a.do_batch = do_batch_stride; a.aux = aux;
-    a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.g_row = g_row_stride; a.g_batch = g_batch_stride;
-    a.dbq = dbias_q; a.dbk = dbias_k; a.dbv = dbias_v;
-    const int lds_q = 4 * TILE + MASK_BYTES + 16, lds_kv = 4 * TILE + 2 * AUX_BYTES + 16;
-    static Fs2PerDevice attr_set;
-    if (attr_set.need()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-    }
-    const dim3 grid(flash_grid(B, H, t));
-    // dK/dV: 64 keys per workgroup (4 waves, two workgroups per CU; default) or 128 (8 waves, one per CU; FS2_FLASH_DKV_WAVES=8).
-    // Every non-empty key block costs the same (all queries), and at config 2 there are ~2.1 of the 128-key blocks per CU: three
-    // rounds for two rounds' worth of work.  Half-size blocks leave a shorter tail (a lone workgroup on a CU also runs faster than
-    // one of a pair): 149 -> 140 us per decoder layer, at twice the Q / dO staging traffic.
-    static const int kv_waves = getenv("FS2_FLASH_DKV_WAVES") ? atoi(getenv("FS2_FLASH_DKV_WAVES")) : 4;
-    const dim3 grid_kv(kv_waves == 4 ? 8 * ((B * H + 7) / 8) * ((t + 63) / 64) : flash_grid(B, H, t));
-    if (p > 0.f) {
-        hipLaunchKernelGGL(flash_bwd_dq_k<true>, grid, dim3(FQ_THREADS), lds_q, (hipStream_t)stream, a);
-        if (kv_waves == 4) hipLaunchKernelGGL((flash_bwd_dkv_k<true, 4>), grid_kv, dim3(256), lds_kv, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((flash_bwd_dkv_k<true, 8>), grid_kv, dim3(512), lds_kv, (hipStream_t)stream, a);
-    } else {
-        hipLaunchKernelGGL(flash_bwd_dq_k<false>, grid, dim3(FQ_THREADS), lds_q, (hipStream_t)stream, a);
-        if (kv_waves == 4) hipLaunchKernelGGL((flash_bwd_dkv_k<false, 4>), grid_kv, dim3(256), lds_kv, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((flash_bwd_dkv_k<false, 8>), grid_kv, dim3(512), lds_kv, (hipStream_t)stream, a);
-    }
-    FS2_CHECK_LAUNCH("fs2_flash_attn_bwd");
-    return FS2_OK;
+    FS2FlashAttn d = {};
+    d.q = q; d.k = k; d.v = v; d.q_row_stride = d.kv_row_stride = row_stride; d.q_batch_stride = d.kv_batch_stride = batch_stride; d.head_stride = head_stride;
+    d.key_mask = key_mask; d.key_info = key_info; d.o = const_cast<void*>(o_saved); d.o_row_stride = o_row_stride; d.o_batch_stride = o_batch_stride;
+    d.stats = const_cast<float*>(stats); d.keep_bits = const_cast<uint16_t*>(keep_bits); d.B = B; d.H = H; d.tq = d.tk = t; d.tkp = (t + 7) / 8 * 8; d.dk = 128;
+    d.alpha = alpha; d.p = p;
+    d.d_out = d_out; d.do_row_stride = do_row_stride; d.do_batch_stride = do_batch_stride; d.aux = aux; d.dq = dq; d.dk_out = dk; d.dv_out = dv;
+    d.dq_row_stride = d.dkv_row_stride = g_row_stride; d.dq_batch_stride = d.dkv_batch_stride = g_batch_stride;
+    d.dbias_q = dbias_q; d.dbias_k = dbias_k; d.dbias_v = dbias_v;
+    return fs2_flash_attention_bwd(&d, stream);
 }

@@ -29,6 +29,23 @@ class FS2L1Item(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class FS2FlashAttn(ctypes.Structure):
+    _fields_ = [("q", ctypes.c_void_p), ("k", ctypes.c_void_p), ("v", ctypes.c_void_p),
+                ("q_row_stride", ctypes.c_int64), ("q_batch_stride", ctypes.c_int64), ("kv_row_stride", ctypes.c_int64),
+                ("kv_batch_stride", ctypes.c_int64), ("head_stride", ctypes.c_int32), ("dk", ctypes.c_int32),
+                ("key_mask", ctypes.c_void_p), ("key_info", ctypes.c_void_p), ("o", ctypes.c_void_p),
+                ("o_row_stride", ctypes.c_int64), ("o_batch_stride", ctypes.c_int64), ("stats", ctypes.c_void_p),
+                ("keep_bits", ctypes.c_void_p), ("pregenerated", ctypes.c_int32), ("causal", ctypes.c_int32),
+                ("p_batch_stride", ctypes.c_int64), ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("tq", ctypes.c_int32),
+                ("tk", ctypes.c_int32), ("tkp", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("alpha", ctypes.c_float),
+                ("p", ctypes.c_float), ("rng", ctypes.c_void_p), ("site", ctypes.c_uint32), ("reserved1", ctypes.c_uint32),
+                ("d_out", ctypes.c_void_p), ("do_row_stride", ctypes.c_int64), ("do_batch_stride", ctypes.c_int64),
+                ("aux", ctypes.c_void_p), ("dq", ctypes.c_void_p), ("dk_out", ctypes.c_void_p), ("dv_out", ctypes.c_void_p),
+                ("dq_row_stride", ctypes.c_int64), ("dq_batch_stride", ctypes.c_int64), ("dkv_row_stride", ctypes.c_int64),
+                ("dkv_batch_stride", ctypes.c_int64), ("dbias_q", ctypes.c_void_p), ("dbias_k", ctypes.c_void_p),
+                ("dbias_v", ctypes.c_void_p)]
+
+
 class FS2Gemm(ctypes.Structure):
     _fields_ = [
         ("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
@@ -79,6 +96,9 @@ SIGNATURES = {
     "fs2_attn_probs_lds_bytes": [_I, _I],
     "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P, _P, _L, _L, _P],
     "fs2_flash_attn_keep_words": [_I, _I, _I],          # returns int64
+    "fs2_flash_attn_keep_words_rect": [_I, _I, _I, _I],  # returns int64
+    "fs2_flash_attention_fwd": [ctypes.POINTER(FS2FlashAttn), _P],
+    "fs2_flash_attention_bwd": [ctypes.POINTER(FS2FlashAttn), _P],
     "fs2_flash_attn_mask_info": [_P, _I, _I, _P, _P],
     "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _I, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
     "fs2_flash_attn_keep_bits": [_P, _L, _I, _I, _I, _I, _F, _P, _U32, _P],
@@ -136,6 +156,7 @@ def lib():
             fn.restype = ctypes.c_int
         l.fs2_last_error.restype = ctypes.c_char_p
         l.fs2_flash_attn_keep_words.restype = ctypes.c_int64
+        l.fs2_flash_attn_keep_words_rect.restype = ctypes.c_int64
         l.fs2_abi_version.restype = ctypes.c_int
         _lib = l
     return _lib
@@ -731,9 +752,68 @@ def attn_ds_bwd(d_out, v, p_saved, ds, t, p=0.0, rng=None, site=0, k=None, dq=No
                                  _stream()), "fs2_attn_ds_bwd")
 
 
+FLASH_MAX_KEYS = 16384
+
+
 def flash_attn_supported(t, dk, dtype):
-    """whether fs2_flash_attn_fwd / _bwd take (t, dk): bf16, d_k = 128, t <= 1024"""
-    return dtype == torch.bfloat16 and dk == 128 and 0 < t <= 1024
+    """whether the flash kernels take (keys t, head size dk): bf16, d_k in {64, 96, 128}, up to 16384 keys"""
+    return dtype == torch.bfloat16 and dk in (64, 96, 128) and 0 < t <= FLASH_MAX_KEYS
+
+
+def flash_attn_keep_words_rect(B, H, tq, tk):
+    """int16 words of the keep-bit stash of one flash_attention_fwd call (one bit per probability): (B, H, ceil(tk/64), tq, 4)"""
+    return int(lib().fs2_flash_attn_keep_words_rect(int(B), int(H), int(tq), int(tk)))
+
+
+def _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p, causal, key_info):
+    B, H, tq, dk = q.shape
+    tk = k.shape[2]
+    assert k.shape == v.shape == (B, H, tk, dk) and k.stride() == v.stride() and q.stride(3) == k.stride(3) == out.stride(3) == 1
+    assert q.stride(1) == k.stride(1) == out.stride(1), "one head stride for q, k, v and the output"
+    assert all(x.dtype == torch.bfloat16 for x in (q, k, v, out)) and stats.dtype == torch.float32 and stats.is_contiguous()
+    assert stats.numel() == B * H * tq * 2 and key_mask.shape == (B, tk) and (not causal or tq == tk)
+    if p > 0:
+        assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words_rect(B, H, tq, tk)
+    d = FS2FlashAttn()
+    d.q, d.k, d.v = _p(q), _p(k), _p(v)
+    d.q_row_stride, d.q_batch_stride, d.kv_row_stride, d.kv_batch_stride = q.stride(2), q.stride(0), k.stride(2), k.stride(0)
+    d.head_stride, d.dk = q.stride(1), dk
+    d.key_mask, d.key_info = _p(_c(key_mask)), _p(key_info)
+    d.o, d.o_row_stride, d.o_batch_stride = _p(out), out.stride(2), out.stride(0)
+    d.stats, d.keep_bits = _p(stats), (_p(keep) if p > 0 else None)
+    d.causal, d.p_batch_stride = int(bool(causal)), int(p_batch)
+    d.B, d.H, d.tq, d.tk, d.tkp = B, H, tq, tk, (tk + 7) // 8 * 8
+    d.alpha, d.p = float(alpha), float(p)
+    return d
+
+
+def flash_attention_fwd(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p=0.0, rng=None, site=0, causal=False, key_info=None,
+                        pregenerated=False):
+    """out = dropout_p(softmax(mask(alpha q k^T))) v without the probabilities in HBM, general form: q (B,H,tq,dk), k / v (B,H,tk,dk)
+    strided views with one head stride, key_mask (B,tk), causal (tq == tk): key j > query i masked like a padded key; stats
+    (B,H,tq,2) fp32; keep: flash_attn_keep_words_rect(B,H,tq,tk) int16 words (None when p == 0); p_batch: batch stride of the virtual
+    (B,[layers],H,tq,tkp) probability tensor (the Philox counters of softmax_rect_fwd / attn_probs_fwd: the same masks)."""
+    d = _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p, causal, key_info)
+    d.rng, d.site, d.pregenerated = _rng_ptr(rng, p), site, int(bool(pregenerated))
+    _check(lib().fs2_flash_attention_fwd(ctypes.byref(d), _stream()), "fs2_flash_attention_fwd")
+
+
+def flash_attention_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv, alpha, p=0.0, causal=False, dbias=None, key_info=None):
+    """backward of flash_attention_fwd: dq (B,H,tq,dk), dk_ / dv (B,H,tk,dk) views; aux: (B,H,tq,4) fp32 workspace; dbias: optional
+    (dbias_q, dbias_k, dbias_v) fp32 vectors of H*dk that receive += the column sums of dq / dk / dv"""
+    B, H, tq, dk = q.shape
+    d = _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, 0, p, causal, key_info)
+    assert d_out.stride(3) == 1 and d_out.stride(1) == q.stride(1) and dq.stride(3) == 1 and dq.stride(1) == q.stride(1)
+    assert dk_.stride() == dv.stride() and dk_.stride(3) == 1 and dk_.stride(1) == q.stride(1) and dk_.shape == k.shape
+    assert all(x.dtype == torch.bfloat16 for x in (d_out, dq, dk_, dv)) and aux.dtype == torch.float32 and aux.is_contiguous()
+    assert aux.numel() == B * H * tq * 4
+    d.d_out, d.do_row_stride, d.do_batch_stride, d.aux = _p(d_out), d_out.stride(2), d_out.stride(0), _p(aux)
+    d.dq, d.dk_out, d.dv_out = _p(dq), _p(dk_), _p(dv)
+    d.dq_row_stride, d.dq_batch_stride, d.dkv_row_stride, d.dkv_batch_stride = dq.stride(2), dq.stride(0), dk_.stride(2), dk_.stride(0)
+    if dbias is not None:
+        assert all(x.dtype == torch.float32 and x.is_contiguous() and x.numel() == H * dk for x in dbias)
+        d.dbias_q, d.dbias_k, d.dbias_v = (_p(x) for x in dbias)
+    _check(lib().fs2_flash_attention_bwd(ctypes.byref(d), _stream()), "fs2_flash_attention_bwd")
 
 
 def flash_attn_keep_words(B, H, t):
@@ -767,7 +847,9 @@ def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0
     B, H, _, dk = q.shape
     assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1 and q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16
     assert out.stride(3) == 1 and out.stride(1) == q.stride(1) and stats.is_contiguous() and stats.dtype == torch.float32
-    assert stats.numel() == B * H * t * 2 and dk == 128
+    assert stats.numel() == B * H * t * 2
+    if dk != 128:       # the round-2 entry point is the d_k = 128 case of the general one
+        return flash_attention_fwd(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p, rng, site, False, key_info, pregenerated)
     if p > 0:
         assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t)
     _check(lib().fs2_flash_attn_fwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(key_info), _p(out),
@@ -780,7 +862,9 @@ def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv,
     (B,H,t,4) fp32 workspace; dbias: optional (dbias_q, dbias_k, dbias_v) fp32 vectors of H*128 that receive += the column sums of
     dq / dk / dv (the projections' bias gradients)."""
     B, H, _, dk = q.shape
-    assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1 and dk == 128
+    assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1
+    if dk != 128:
+        return flash_attention_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv, alpha, p, False, dbias, key_info)
     assert out.stride(3) == 1 and d_out.stride(3) == 1 and out.stride(1) == d_out.stride(1) == q.stride(1)
     assert dq.stride() == dk_.stride() == dv.stride() and dq.stride(3) == 1 and dq.stride(1) == q.stride(1)
     assert all(x.dtype == torch.bfloat16 for x in (q, k, v, out, d_out, dq, dk_, dv))
