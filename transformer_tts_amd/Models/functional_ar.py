@@ -57,21 +57,37 @@ class DecoderStackFunction(torch.autograd.Function):
         h, mean0, rstd0 = ops.layernorm_fwd(x, n1.weight.detach(), n1.bias.detach(), T)
         sv.update(x0=x0, h1=h1, h1d=h1d, h2=h2, x_pe=x, mean0=mean0, rstd0=rstd0)
 
-        attn1 = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
-        attn1_drop = torch.empty_like(attn1) if p_att > 0 else attn1
-        attn2 = torch.empty((B, N, H, t, Lp), dtype=T, device=dev)
-        attn2_drop = torch.empty_like(attn2) if p_att > 0 else attn2
+        # hp.return_attn = False: the maps are not wanted -> flash kernels in their causal (self-attention) and rectangular
+        # (encoder-decoder) modes, no (T x T) / (T x L) tensor in HBM; the Philox counters are those of the (B,N,H,t,tp) layouts
+        # either way, so both modes draw the same dropout masks
+        flash = (not rt.return_attn) and ops.flash_attn_supported(max(t, L), dk, T)
+        if flash:
+            attn1 = attn1_drop = attn2 = attn2_drop = None
+            stats1 = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
+            stats2 = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
+            keep1 = torch.empty((N, ops.flash_attn_keep_words_rect(B, H, t, t)), dtype=torch.int16, device=dev) if p_att > 0 else None
+            keep2 = torch.empty((N, ops.flash_attn_keep_words_rect(B, H, t, L)), dtype=torch.int16, device=dev) if p_att > 0 else None
+            kinfo_trg, kinfo_src = ops.flash_mask_info(trg_km), ops.flash_mask_info(src_km)
+        else:
+            attn1 = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
+            attn1_drop = torch.empty_like(attn1) if p_att > 0 else attn1
+            attn2 = torch.empty((B, N, H, t, Lp), dtype=T, device=dev)
+            attn2_drop = torch.empty_like(attn2) if p_att > 0 else attn2
         layers = []
         for i, layer in enumerate(dec.layers):
             # ---- masked self-attention (layers.py:110-112)
             wf, _, bqkv = rt.qkv(layer.attn_1)
             qkv = ops.linear(h.view(M, d), wf, bqkv)
             q, v, k = _heads(qkv, B, t, 3, H, dk)
-            S, Pd = attn1[:, i], attn1_drop[:, i]
-            ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)
-            ops.softmax_rect_fwd(S, Pd, trg_km, t, True, p_att, rng, layer.site_attn1)
             O = torch.empty((B, t, H, dk), dtype=T, device=dev)
-            ops.bmm(Pd, v, O.permute(0, 2, 1, 3), trans_b=False)
+            if flash:
+                ops.flash_attention_fwd(q, k, v, trg_km, O.permute(0, 2, 1, 3), stats1[i], keep1[i] if keep1 is not None else None, scale,
+                                        N * H * t * tp, p_att, rng, layer.site_attn1, causal=True, key_info=kinfo_trg)
+            else:
+                S, Pd = attn1[:, i], attn1_drop[:, i]
+                ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)
+                ops.softmax_rect_fwd(S, Pd, trg_km, t, True, p_att, rng, layer.site_attn1)
+                ops.bmm(Pd, v, O.permute(0, 2, 1, 3), trans_b=False)
             a = ops.linear(O.view(M, d), rt.w_fwd(layer.attn_1.out.weight), layer.attn_1.out.bias.detach())
             n2 = layer.norm_2
             x1, hq, m2, r2 = ops.add_ln_fwd(x, a.view(B, t, d), n2.weight.detach(), n2.bias.detach(), 1e-5, p, rng, layer.site_res1)
@@ -81,11 +97,15 @@ class DecoderStackFunction(torch.autograd.Function):
             vk = ops.linear(e2, wf2[d:], b2[d:])          # (B*L, 2d): [v | k]
             (qc,) = _heads(q2, B, t, 1, H, dk)
             vc, kc = _heads(vk, B, L, 2, H, dk)
-            S2, Pd2 = attn2[:, i], attn2_drop[:, i]
-            ops.bmm(qc, kc, S2[..., :L], trans_b=True, alpha=scale)
-            ops.softmax_rect_fwd(S2, Pd2, src_km, L, False, p_att, rng, layer.site_attn2)
             O2 = torch.empty((B, t, H, dk), dtype=T, device=dev)
-            ops.bmm(Pd2, vc, O2.permute(0, 2, 1, 3), trans_b=False)
+            if flash:
+                ops.flash_attention_fwd(qc, kc, vc, src_km, O2.permute(0, 2, 1, 3), stats2[i], keep2[i] if keep2 is not None else None, scale,
+                                        N * H * t * Lp, p_att, rng, layer.site_attn2, causal=False, key_info=kinfo_src)
+            else:
+                S2, Pd2 = attn2[:, i], attn2_drop[:, i]
+                ops.bmm(qc, kc, S2[..., :L], trans_b=True, alpha=scale)
+                ops.softmax_rect_fwd(S2, Pd2, src_km, L, False, p_att, rng, layer.site_attn2)
+                ops.bmm(Pd2, vc, O2.permute(0, 2, 1, 3), trans_b=False)
             a2 = ops.linear(O2.view(M, d), rt.w_fwd(layer.attn_2.out.weight), layer.attn_2.out.bias.detach())
             n3 = layer.norm_3
             x2, h3, m3, r3 = ops.add_ln_fwd(x1, a2.view(B, t, d), n3.weight.detach(), n3.bias.detach(), 1e-5, p, rng, layer.site_res2)
@@ -104,9 +124,13 @@ class DecoderStackFunction(torch.autograd.Function):
 
         ctx.dec, ctx.sv, ctx.layers = dec, sv, layers
         ctx.attn = (attn1, attn1_drop, attn2, attn2_drop)
+        ctx.flash = (stats1, stats2, keep1, keep2, kinfo_trg, kinfo_src, trg_km, src_km) if flash else None
         ctx.e2, ctx.dims = e2, (B, t, L, mel_dim)
         ctx.set_materialize_grads(False)
-        a1_out, a2_out = attn1_drop[..., :t], attn2_drop[..., :L]
+        if flash:
+            a1_out, a2_out = torch.empty((B, N, H, 0, 0), dtype=T, device=dev), torch.empty((B, N, H, 0, 0), dtype=T, device=dev)
+        else:
+            a1_out, a2_out = attn1_drop[..., :t], attn2_drop[..., :L]
         ctx.mark_non_differentiable(a1_out, a2_out)
         return h, a1_out, a2_out
 
@@ -132,8 +156,13 @@ class DecoderStackFunction(torch.autograd.Function):
         dh = dh.contiguous()
         dx = None                         # fp32 gradient of the residual stream coming from above
         de = None                         # fp32 gradient of e_outputs, summed over the layers
-        dP = torch.empty((B, H, t, tp), dtype=T, device=dev)
-        dP2 = torch.empty((B, H, t, Lp), dtype=T, device=dev)
+        flash = ctx.flash is not None
+        if flash:
+            stats1, stats2, keep1, keep2, kinfo_trg, kinfo_src, trg_km, src_km = ctx.flash
+            aux = torch.empty((B, H, t, 4), dtype=torch.float32, device=dev)
+        else:
+            dP = torch.empty((B, H, t, tp), dtype=T, device=dev)
+            dP2 = torch.empty((B, H, t, Lp), dtype=T, device=dev)
         for i in reversed(range(N)):
             layer, Lr = dec.layers[i], layers[i]
             nn_ = dec.layers[i + 1].norm_1 if i + 1 < N else dec.norm
@@ -162,17 +191,24 @@ class DecoderStackFunction(torch.autograd.Function):
             dvk = torch.empty((Me, 2 * d), dtype=T, device=dev)
             (dqc,) = _heads(dq2, B, t, 1, H, dk)
             dvc, dkc = _heads(dvk, B, L, 2, H, dk)
-            P2, Pd2 = attn2[:, i], attn2_drop[:, i]
-            ops.bmm(Pd2, dO2, dvc, trans_a=True, trans_b=False)                # dV = Pd^T dO
-            ops.bmm(dO2, vc, dP2[..., :L], trans_b=True)                        # dP = dO V^T
-            ops.softmax_rect_bwd(dP2, P2, L, p_att, rng, layer.site_attn2)      # -> dS (pad columns 0)
-            ops.bmm(dP2, kc, dqc, trans_b=False, alpha=scale)                   # dQ = dS K / sqrt(dk)
-            ops.bmm(dP2, qc, dkc, trans_a=True, trans_b=False, alpha=scale)     # dK = dS^T Q / sqrt(dk)
+            if flash:       # probabilities recomputed from q, k and the row statistics; the three bias gradients are fused
+                ops.flash_attention_bwd(qc, kc, vc, src_km, Lr["O2"].permute(0, 2, 1, 3), dO2, stats2[i], keep2[i] if keep2 is not None else None,
+                                        aux, dqc, dkc, dvc, scale, p_att, causal=False, key_info=kinfo_src,
+                                        dbias=[grad_of(lin.bias) for lin in (at2.q_linear, at2.k_linear, at2.v_linear)])
+            else:
+                P2, Pd2 = attn2[:, i], attn2_drop[:, i]
+                ops.bmm(Pd2, dO2, dvc, trans_a=True, trans_b=False)                # dV = Pd^T dO
+                ops.bmm(dO2, vc, dP2[..., :L], trans_b=True)                        # dP = dO V^T
+                ops.softmax_rect_bwd(dP2, P2, L, p_att, rng, layer.site_attn2)      # -> dS (pad columns 0)
+                ops.bmm(dP2, kc, dqc, trans_b=False, alpha=scale)                   # dQ = dS K / sqrt(dk)
+                ops.bmm(dP2, qc, dkc, trans_a=True, trans_b=False, alpha=scale)     # dK = dS^T Q / sqrt(dk)
             _, wd2, _ = rt.qkv(at2)                                             # (d, 3d): columns [q | v | k]
             with rt.side(dq2, dvk):
-                ops.colsum(dq2, grad_of(at2.q_linear.bias))
+                if not flash:
+                    ops.colsum(dq2, grad_of(at2.q_linear.bias))
                 ops.wgrad(dq2, Lr["hq"].view(M, d), grad_of(at2.q_linear.weight))
-                ops.colsum_blocks(dvk, [grad_of(at2.v_linear.bias), grad_of(at2.k_linear.bias)])
+                if not flash:
+                    ops.colsum_blocks(dvk, [grad_of(at2.v_linear.bias), grad_of(at2.k_linear.bias)])
                 ops.wgrad_batched(dvk, e2, [grad_of(at2.v_linear.weight), grad_of(at2.k_linear.weight)])
             dhq = ops.linear(dq2, wd2[:, :d]).view(B, t, d)
             de = ops.linear(dvk, wd2[:, d:], residual=de, out_dtype=torch.float32)
@@ -186,14 +222,20 @@ class DecoderStackFunction(torch.autograd.Function):
             q, v, k = _heads(Lr["qkv"], B, t, 3, H, dk)
             dqkv = torch.empty((M, 3 * d), dtype=T, device=dev)
             dq, dv, dk_ = _heads(dqkv, B, t, 3, H, dk)
-            P1, Pd1 = attn1[:, i], attn1_drop[:, i]
-            ops.bmm(Pd1, dO, dv, trans_a=True, trans_b=False)
-            ops.bmm(dO, v, dP[..., :t], trans_b=True)
-            ops.softmax_rect_bwd(dP, P1, t, p_att, rng, layer.site_attn1)
-            ops.bmm(dP, k, dq, trans_b=False, alpha=scale)
-            ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale)
+            if flash:
+                ops.flash_attention_bwd(q, k, v, trg_km, Lr["O"].permute(0, 2, 1, 3), dO, stats1[i], keep1[i] if keep1 is not None else None, aux,
+                                        dq, dk_, dv, scale, p_att, causal=True, key_info=kinfo_trg,
+                                        dbias=[grad_of(lin.bias) for lin in (at1.q_linear, at1.k_linear, at1.v_linear)])
+            else:
+                P1, Pd1 = attn1[:, i], attn1_drop[:, i]
+                ops.bmm(Pd1, dO, dv, trans_a=True, trans_b=False)
+                ops.bmm(dO, v, dP[..., :t], trans_b=True)
+                ops.softmax_rect_bwd(dP, P1, t, p_att, rng, layer.site_attn1)
+                ops.bmm(dP, k, dq, trans_b=False, alpha=scale)
+                ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale)
             with rt.side(dqkv):
-                ops.colsum_blocks(dqkv, [grad_of(lin.bias) for lin in (at1.q_linear, at1.v_linear, at1.k_linear)])
+                if not flash:
+                    ops.colsum_blocks(dqkv, [grad_of(lin.bias) for lin in (at1.q_linear, at1.v_linear, at1.k_linear)])
                 ops.wgrad_batched(dqkv, Lr["h"].view(M, d), [grad_of(lin.weight) for lin in (at1.q_linear, at1.v_linear, at1.k_linear)])
             _, wd1, _ = rt.qkv(at1)
             dh = ops.linear(dqkv, wd1).view(B, t, d)
