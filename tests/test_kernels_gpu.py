@@ -1058,9 +1058,11 @@ def big_gemm(monkeypatch):
     """route every eligible product to the 256-wide 16-wave LDS-DMA kernel (FS2_GEMM_RING=2), whatever its size"""
     def set_bm(bm):
         monkeypatch.setenv("FS2_GEMM_RING", "2")
+        monkeypatch.setenv("FS2_GEMM_WS", "0")              # (K = 256 shapes would otherwise go to gemm_ws.hip)
         monkeypatch.setenv("FS2_GEMM_BIG_BM", str(bm))
     yield set_bm
     monkeypatch.delenv("FS2_GEMM_RING", raising=False)
+    monkeypatch.delenv("FS2_GEMM_WS", raising=False)
     monkeypatch.delenv("FS2_GEMM_BIG_BM", raising=False)
     monkeypatch.delenv("FS2_RING_S", raising=False)
 
@@ -1121,6 +1123,7 @@ def test_big_gemm_is_bit_identical_to_the_128_tile_kernel(ops, monkeypatch):
     2- and 3-slot rings of the 128-row tile (the counted vmcnt waits are the only difference)"""
     x, w, bias = rnd(44400, 256, dtype=torch.bfloat16, seed=1).cuda(), rnd(512, 256, dtype=torch.bfloat16, seed=2).cuda(), rnd(512, seed=3).cuda()
     monkeypatch.setenv("FS2_GEMM_RING", "0")
+    monkeypatch.setenv("FS2_GEMM_WS", "0")
     ref = ops.linear(x, w, bias=bias, relu=True)
     assert ops.lib().fs2_gemm_last_tile() == 128
     for bm, ring in (("128", "3"), ("128", "2"), ("192", "2"), ("256", "2")):
@@ -1131,6 +1134,50 @@ def test_big_gemm_is_bit_identical_to_the_128_tile_kernel(ops, monkeypatch):
         assert ops.lib().fs2_gemm_last_tile() == (130 if bm == "128" else int(bm))
         assert torch.equal(out, ref), f"bm {bm}: {(out.float() - ref.float()).abs().max().item()}"
     monkeypatch.delenv("FS2_RING_S", raising=False)
+    monkeypatch.delenv("FS2_GEMM_WS", raising=False)
+
+
+@pytest.mark.parametrize("M,N", [(300, 80), (129, 256), (1000, 1024), (577, 264), (4100, 768)])
+def test_weights_stationary_gemm_epilogues(ops, monkeypatch, M, N):
+    """gemm_ws.hip (K = 256: the weight tile lives in registers, activations stream through an LDS ring, two row halves ping-pong
+    between MFMA and epilogue): every fused epilogue it is compiled for, on ragged shapes (rows not a multiple of the 64-row slab,
+    columns not a multiple of the 256-column tile), against the oracle primitive"""
+    monkeypatch.setenv("FS2_GEMM_WS", "2")
+    dtype, K = torch.bfloat16, 256
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    bias, res, mask = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, dtype=dtype, seed=5)
+    for kw in (dict(), dict(bias=True, relu=True), dict(residual="f32", out_f32=True), dict(residual="bf16", bias=True), dict(relu_mask=True),
+               dict(relu_mask=True, colsum=True), dict(colsum=True), dict(alpha=0.25), dict(bias=True, out_f32=True)):
+        def call(o, dev):
+            mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+            cl = torch.zeros(N, dtype=torch.float32, device=dev) if kw.get("colsum") else None
+            r = None
+            if kw.get("residual"):
+                r = mv(res if kw["residual"] == "f32" else res.to(dtype))
+            out = o.linear(mv(x), mv(w), bias=mv(bias) if kw.get("bias") else None, relu=kw.get("relu", False), residual=r,
+                           relu_mask=mv(mask) if kw.get("relu_mask") else None, colsum=cl,
+                           out_dtype=torch.float32 if kw.get("out_f32") else None, alpha=kw.get("alpha", 1.0))
+            return out, cl
+        (a, acl), (b, bcl) = call(ops, "cuda"), call(P, "cpu")
+        assert ops.lib().fs2_gemm_last_tile() == 131, kw
+        close(a, b, f"ws linear {kw}", **tol(a.dtype))
+        if acl is not None:
+            close(acl, bcl, "colsum", rtol=2e-3, atol=2e-2 * M ** 0.5)
+    monkeypatch.delenv("FS2_GEMM_WS", raising=False)
+
+
+def test_weights_stationary_gemm_is_bit_identical_to_the_tiled_kernels(ops, monkeypatch):
+    """same MFMA, same k order inside every accumulator: the weights-stationary stream, the 16-wave tiled kernel and the 4-wave
+    kernel agree bit for bit on a 44400-row decoder product (and the default routing picks the stream for it)"""
+    x, w, bias = rnd(44400, 256, dtype=torch.bfloat16, seed=1).cuda(), rnd(768, 256, dtype=torch.bfloat16, seed=2).cuda(), rnd(768, seed=3).cuda()
+    outs = {}
+    for name, env in (("4-wave", ("0", "0")), ("tiled", ("0", "2")), ("stream", ("2", "0")), ("default", (None, None))):
+        for k, v in zip(("FS2_GEMM_WS", "FS2_GEMM_RING"), env):
+            monkeypatch.delenv(k, raising=False) if v is None else monkeypatch.setenv(k, v)
+        outs[name] = (ops.linear(x, w, bias=bias, relu=True), ops.lib().fs2_gemm_last_tile())
+    assert outs["4-wave"][1] == 128 and outs["tiled"][1] in (130, 192, 256) and outs["stream"][1] == 131 and outs["default"][1] == 131
+    for name in ("tiled", "stream", "default"):
+        assert torch.equal(outs[name][0], outs["4-wave"][0]), name
 
 
 @pytest.mark.parametrize("bm", [128, 192, 256])

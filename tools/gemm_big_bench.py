@@ -62,6 +62,7 @@ def main():
         "ffn2 plain 44400x256x1024": (lambda: ops.linear(x1024, w_256_1024), 2.0 * M * 256 * 1024),
         "qkv 44400x768x256": (lambda: ops.linear(x256, w_768_256), 2.0 * M * 768 * 256),
         "proj 44400x256x256": (lambda: ops.linear(x256, w_256_256, bias256), 2.0 * M * 256 * 256),
+        "proj-dgrad res-f32 44400x256x256": (lambda: ops.linear(x256, w_256_256, residual=res256, out_dtype=torch.float32), 2.0 * M * 256 * 256),
         "post_conv k5 44400x256x1280": (lambda: ops.conv(xp, wp, 5, 4, bias=bias256), 2.0 * M * 256 * 1280),
         "va_conv k3 44400x256x768": (lambda: ops.conv(xv, wv, 3, 1, bias=bias256, relu=True), 2.0 * M * 256 * 768),
         "enc_conv1 k9 6144x1024x2304": (lambda: ops.conv(xe, we, 9, 4, bias=bias1024, relu=True), 2.0 * 6144 * 1024 * 2304),
@@ -96,14 +97,14 @@ def main():
     for name, (fn, fl) in cases.items():
         if only and not any(o in name for o in only):
             continue
-        os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"] = "0", "0"
+        os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"], os.environ["FS2_GEMM_WS"] = "0", "0", "0"
         ref = fn().float()
         t0w, t0c = timeit(fn, False), timeit(fn, True)
         line = f"{name:40s} 4-wave {t0w:7.1f}/{t0c:7.1f} us ({fl / t0c / 1e6:6.0f} TF cold)"
         for cfg in cfgs:
             os.environ["FS2_GEMM_BIG_BM"] = cfg.split(":")[0]
-            for kern, env in (("big", ("2", "0")), ("ring", ("0", "2"))):      # round-2 large-tile kernel, round-3 ring kernel
-                os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"] = env
+            for kern, env in (("ring", ("0", "2", "0")), ("ws", ("0", "2", "2"))):      # 16-wave tiled kernel, weights-stationary stream (K = 256)
+                os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"], os.environ["FS2_GEMM_WS"] = env
                 out = fn().float()
                 err = float((out - ref).abs().max())
                 rel = err / float(ref.abs().max())
@@ -112,7 +113,7 @@ def main():
         os.environ.pop("FS2_GEMM_BIG_BM", None)
         print(line, flush=True)
         os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"] = "2", "0"
-        if stamps:
+        if False and stamps:
             import ctypes
             lib = ops.lib()
             lib.fs2_debug_gemm_big_timer.argtypes = [ctypes.c_void_p]
@@ -137,7 +138,7 @@ def main():
                     print(f"   bm{cfg} {nm}: blocks {int(act.sum())} stages/block {b[act][:, w, 5].mean():.1f} items {b[act][:, w, 6].mean():.2f} "
                           f"cycles/block {tot.mean():.0f} (max {tot.max():.0f})  issue {sh[0]:.1%} epilogue {sh[1]:.1%} mfma {sh[2]:.1%} "
                           f"dma-wait {sh[3]:.1%} barrier {sh[4]:.1%}", flush=True)
-    os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"] = "1", "1"
+    os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"], os.environ["FS2_GEMM_WS"] = "1", "1", "1"
 
 
 if __name__ == "__main__":

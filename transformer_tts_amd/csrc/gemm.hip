@@ -27,6 +27,7 @@
 #include "fs2_common.h"
 #include <stdlib.h>
 
+bool fs2_gemm_ws_try(const FS2Gemm& g, hipStream_t st, int* rc);      // gemm_ws.hip
 bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc);    // gemm_ring.hip
 bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc);     // gemm_big.hip
 bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc);  // gemm_big_km.hip
@@ -698,6 +699,7 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     {   // tall row-major bf16 products: the 16-wave LDS-DMA kernel (gemm_ring.hip)
         int rc = FS2_OK;
+        if (fs2_gemm_ws_try(g, st, &rc)) return rc;       // tall products with K = 256: weights-stationary stream (g_last_tile 131)
         if (fs2_gemm_ring_try(g, st, &rc)) return rc;     // (sets g_last_tile to 130 / 192 / 256)
         if (fs2_gemm_big_km_try(g, st, &rc)) return rc;   // decoder-side weight gradients (g_last_tile 129)
     }
