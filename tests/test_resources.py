@@ -12,4 +12,4 @@ def test_gemm_kernels_fit_their_register_budget_without_scratch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_resources.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("ok ")]
-    assert len(lines) >= 40, r.stdout      # 2 output types x 3 tile heights x 8 epilogues (minus the two not compiled at 256 rows) + 12 streams
+    assert len(lines) >= 40, r.stdout      # 2 output types x 3 tile heights x 8 epilogues (minus the three not compiled at 256 rows) + 12 streams

@@ -474,7 +474,9 @@ int launch_ring1(const FS2Gemm& g, int splits, hipStream_t st) {
         case EPI_STATS | EPI_SUMSQ:
             if constexpr (WTM < 64) return launch_ring2<TC, WTM, EPI_STATS | EPI_SUMSQ>(g, splits, st);       // (256-row tile: 10-19 spilled registers,
             break;                                                                                            //  fs2_gemm_ring_try picks 192 rows)
-        case EPI_MASK | EPI_STATS: return launch_ring2<TC, WTM, EPI_MASK | EPI_STATS>(g, splits, st);
+        case EPI_MASK | EPI_STATS:
+            if constexpr (WTM < 64) return launch_ring2<TC, WTM, EPI_MASK | EPI_STATS>(g, splits, st);
+            break;
         case EPI_RES_F32: return launch_ring2<TC, WTM, EPI_RES_F32>(g, splits, st);
         case EPI_RES_BF16: return launch_ring2<TC, WTM, EPI_RES_BF16>(g, splits, st);
         case EPI_MASK | EPI_RES_F32:
@@ -540,7 +542,7 @@ bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         auto serial_rows = [&](int b) { const long tiles = (long)((g.M + b - 1) / b) * tn * splits; return (double)((tiles + 255) / 256) * b; };
         if (serial_rows(128) * 1.10 < serial_rows(bm)) bm = 128;
     }
-    if (bm == 256 && (epi == (EPI_STATS | EPI_SUMSQ) || epi == (EPI_MASK | EPI_RES_F32))) bm = 192;      // (not compiled for 256 rows: spills)
+    if (bm == 256 && (epi == (EPI_STATS | EPI_SUMSQ) || epi == (EPI_MASK | EPI_RES_F32) || epi == (EPI_MASK | EPI_STATS))) bm = 192;   // (not compiled for 256 rows: spills)
     if (mode == 1 && !sliced) {
         const long tiles = (long)((g.M + bm - 1) / bm) * tn;
         if (tiles < 128 || g.N < 192) return false;
