@@ -414,6 +414,10 @@ int fs2_adam_step_perm(float* p, const float* g, float* m, float* v, int64_t n, 
                        float beta1, float beta2, float eps, float max_norm, const int64_t* perm_segments, int n_segments,
                        void* stream);
 
+/* Diagnostics (tools/attn_phases.py): shader-clock stamps of the LDS-strip attention kernels are written to `buf` (device memory,
+ * 4 x 64-bit words per workgroup) while it is set; NULL switches the stamps off.  Not used by the product. */
+void fs2_debug_attn_timer(unsigned long long* buf);
+
 /* rng[1] += 1 (one step of the dropout stream). */
 int fs2_rng_advance(uint64_t* rng, void* stream);
 

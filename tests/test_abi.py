@@ -65,3 +65,16 @@ def test_product_has_no_cpu_fallback():
     from transformer_tts_amd import ops
     with pytest.raises(RuntimeError, match="GPU tensors"):
         ops.cast(torch.zeros(4), torch.float32)
+
+
+def test_torch_library_registration_and_fake_tensors():
+    """the fs2:: custom operators exist in the dispatcher with schemas and meta (fake-tensor) implementations: shape propagation
+    works without a GPU (the CUDA implementations are exercised by tests/test_kernels_gpu.py::test_torch_library_ops)"""
+    import transformer_tts_amd.torch_ops  # noqa: F401
+    x, w, b = torch.empty(3, 7, 16, device="meta"), torch.empty(32, 16, device="meta"), torch.empty(32, device="meta")
+    assert torch.ops.fs2.linear(x, w, b, True).shape == (3, 7, 32)
+    assert torch.ops.fs2.conv1d_cl(x, torch.empty(8, 16, 5, device="meta"), None, 2, False).shape == (3, 7, 8)
+    q = torch.empty(2, 4, 9, 64, device="meta")
+    o, st = torch.ops.fs2.flash_attention(q, q, q, torch.empty(2, 9, dtype=torch.bool, device="meta"), True)
+    assert o.shape == (2, 4, 9, 64) and st.shape == (2, 4, 9, 2)
+    assert "fs2::linear" in str(torch.ops.fs2.linear.default._schema)

@@ -1357,3 +1357,47 @@ def test_big_km_wgrad_batched_and_conv(ops, big_km):
         assert ops.lib().fs2_gemm_last_tile() == 129
         b = P.conv_wgrad(dyc, xc, taps, pad, torch.zeros(N, taps * C))
         close(a, b, f"big km conv wgrad taps={taps}", rtol=2e-3, atol=2e-3 * (B * t) ** 0.5)
+
+
+def test_torch_library_ops(ops):
+    """the fs2:: custom operators (transformer_tts_amd/torch_ops.py, torch.library): forward and autograd through the dispatcher on the
+    GPU against plain PyTorch fp32 -- nn.Linear + ReLU, channels-last Conv1d, attention() without dropout (causal and padded keys)."""
+    import transformer_tts_amd.torch_ops  # noqa: F401
+    dtype = torch.bfloat16
+    x = rnd(5, 300, 256, dtype=dtype, seed=1).cuda().requires_grad_(True)
+    w = (rnd(512, 256, dtype=dtype, seed=2) * 256 ** -0.5).cuda().requires_grad_(True)
+    b = rnd(512, seed=3).cuda().requires_grad_(True)
+    y = torch.ops.fs2.linear(x, w, b, True)
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+    yr = torch.relu(xr @ wr.t() + br)
+    close(y.float(), yr, "fs2::linear", **tol(dtype))
+    g = rnd(5, 300, 512, dtype=dtype, seed=4).cuda()
+    y.backward(g)
+    yr.backward(g.float())
+    for a, r, n in ((x.grad, xr.grad, "dx"), (w.grad, wr.grad, "dw"), (b.grad, br.grad, "db")):
+        err = float((a.float() - r).abs().max() / r.abs().max())
+        assert err < 3e-2, (n, err)
+    # Conv1d over time, channels-last
+    xc, wc = rnd(3, 50, 64, dtype=dtype, seed=5).cuda(), (rnd(128, 64, 5, dtype=dtype, seed=6) * 320 ** -0.5).cuda()
+    yc = torch.ops.fs2.conv1d_cl(xc, wc, None, 2, False)
+    ref = torch.nn.functional.conv1d(xc.float().transpose(1, 2), wc.float(), padding=2).transpose(1, 2)
+    close(yc.float(), ref, "fs2::conv1d_cl", **tol(dtype))
+    # attention
+    B, H, t, dk = 2, 2, 130, 64
+    qkv = rnd(B, t, 3, H, dk, dtype=dtype, seed=7, scale=1.5).cuda().requires_grad_(True)
+    q, v, k = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+    km = torch.ones(B, t, dtype=torch.bool, device="cuda")
+    km[1, 100:] = False
+    o, _ = torch.ops.fs2.flash_attention(q, k, v, km, True)
+    qr = qkv.detach().float().requires_grad_(True)
+    q2, v2, k2 = (qr[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+    s = (q2 @ k2.transpose(-1, -2)) * dk ** -0.5
+    vis = km[:, None, None, :] & torch.tril(torch.ones(t, t, dtype=torch.bool, device="cuda"))
+    o_ref = torch.softmax(s.masked_fill(~vis, -1e4), -1) @ v2
+    err = float((o.detach().float() - o_ref.detach()).abs().max() / o_ref.detach().abs().max())
+    assert err < 3e-2, err
+    go = rnd(B, H, t, dk, dtype=dtype, seed=8).cuda()
+    o.backward(go)
+    o_ref.backward(go.float())
+    err = float((qkv.grad.float() - qr.grad).abs().max() / qr.grad.abs().max())
+    assert err < 4e-2, err

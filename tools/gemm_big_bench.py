@@ -1,5 +1,6 @@
-"""Large-tile GEMM kernel (gemm_big.hip) against the 128-tile kernel (gemm.hip) on config-2 product shapes:
-results compared element-wise, both timed warm (back-to-back launches) and cold (1 GiB fill between launches)."""
+"""The 16-wave GEMM kernels (gemm_ring.hip: tiled; gemm_ws.hip: weights-stationary stream for K = 256; gemm_big_km.hip: weight
+gradients) against the 4-wave kernel (gemm.hip) on config-2 product shapes: results compared element-wise, both timed warm
+(back-to-back launches) and cold (1 GiB fill between launches).  Arguments: tile heights (128 / 192 / 256) and name filters."""
 import os
 import sys
 
@@ -41,7 +42,6 @@ def timeit(fn, cold, iters=10):
 
 def main():
     cfgs = [a for a in sys.argv[1:] if a.isdigit() or ":" in a] or ["256"]
-    stamps = "stamps" in sys.argv[1:]
     g = torch.Generator(device=dev).manual_seed(0)
     r = lambda *s: torch.randn(*s, device=dev, generator=g).to(T)
     M = 44400
@@ -81,7 +81,7 @@ def main():
         "conv_wgrad k5 256x(5x256) red 44400": (lambda: ops.conv_wgrad(dyk, xk3, 5, 4, torch.zeros(256, 1280, device=dev)), 2.0 * M * 256 * 1280),
         "conv_wgrad k9 1024x(9x256) red 6144": (lambda: ops.conv_wgrad(dye, xe9, 9, 4, torch.zeros(1024, 2304, device=dev)), 2.0 * 6144 * 1024 * 2304),
     }
-    only = [a for a in sys.argv[1:] if not a.isdigit() and ":" not in a and a != "stamps"]
+    only = [a for a in sys.argv[1:] if not a.isdigit() and ":" not in a]
     for name, (fn, fl) in wcases.items():
         if only and not any(o in name for o in only):
             continue
@@ -113,31 +113,6 @@ def main():
         os.environ.pop("FS2_GEMM_BIG_BM", None)
         print(line, flush=True)
         os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"] = "2", "0"
-        if False and stamps:
-            import ctypes
-            lib = ops.lib()
-            lib.fs2_debug_gemm_big_timer.argtypes = [ctypes.c_void_p]
-            lib.fs2_debug_gemm_big_timer.restype = None
-            for cfg in cfgs:
-                os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_BIG_BM"] = "2", cfg.split(":")[0]
-                os.environ["FS2_GEMM_BIG_ISSUE"] = cfg.split(":")[1] if ":" in cfg else "0"
-                buf = torch.zeros(256 * 2 * 8, dtype=torch.int64, device=dev)
-                lib.fs2_debug_gemm_big_timer(buf.data_ptr())
-                fn()
-                torch.cuda.synchronize()
-                lib.fs2_debug_gemm_big_timer(None)
-                b = buf.view(256, 2, 8).double()
-                act = b[:, 0, 5] > 0
-                if int(act.sum()) == 0:
-                    print("   (no stamps: this launch has a fused epilogue operand; only plain launches are stamped)")
-                    continue
-                for w, nm in ((0, "wave 0"), (1, "wave 15")):
-                    t = b[act][:, w, :5]
-                    tot = t.sum(1)
-                    sh = (t / tot[:, None]).mean(0)
-                    print(f"   bm{cfg} {nm}: blocks {int(act.sum())} stages/block {b[act][:, w, 5].mean():.1f} items {b[act][:, w, 6].mean():.2f} "
-                          f"cycles/block {tot.mean():.0f} (max {tot.max():.0f})  issue {sh[0]:.1%} epilogue {sh[1]:.1%} mfma {sh[2]:.1%} "
-                          f"dma-wait {sh[3]:.1%} barrier {sh[4]:.1%}", flush=True)
     os.environ["FS2_GEMM_BIG"], os.environ["FS2_GEMM_RING"], os.environ["FS2_GEMM_WS"] = "1", "1", "1"
 
 

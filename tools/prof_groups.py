@@ -4,7 +4,8 @@ import glob
 import sys
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-f = sorted(glob.glob("gpurun_out/prof/**/*kernel_stats.csv", recursive=True))[-1]
+import os
+f = max(glob.glob("gpurun_out/prof/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 
 

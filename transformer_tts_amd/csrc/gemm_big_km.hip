@@ -310,8 +310,10 @@ bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     }
     static const int stream_env = getenv("FS2_KM_STREAM") ? atoi(getenv("FS2_KM_STREAM")) : 1;      // 0: never (A/B measurements)
     if (!stream_env) stream_units = 0;
-    // long reductions onto few output tiles (the decoder side), or tile sets the balanced stream spreads over the chip (the encoder convolutions)
-    if (mode == 1 && !(g.K >= 16384 && base <= 96) && stream_units == 0) return false;
+    // every weight gradient of the model with a reduction of >= 2048 rows: the decoder side (44 k rows), the encoder convolutions (balanced
+    // stream) and the encoder's linear layers (6144 rows: 96 items of 2 stages -- as fast as the 4-wave kernel, A/B in the whole step
+    // 8.155 vs 8.16 ms, one kernel family less)
+    if (mode == 1 && nstk < 16) return false;
     if (stream_units > 0) nitems = base;
     if (nitems >= (1L << 30)) return false;
     int dev = 0;

@@ -134,6 +134,7 @@ SIGNATURES = {
     "fs2_adam_step": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P],
     "fs2_adam_step_perm": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P, _I, _P],
     "fs2_rng_advance": [_P, _P],
+    "fs2_debug_attn_timer": [_P],      # diagnostics (returns void)
 }
 
 
@@ -154,6 +155,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int
+        l.fs2_debug_attn_timer.restype = None
         l.fs2_last_error.restype = ctypes.c_char_p
         l.fs2_flash_attn_keep_words.restype = ctypes.c_int64
         l.fs2_flash_attn_keep_words_rect.restype = ctypes.c_int64
