@@ -113,6 +113,23 @@ int fs2_splitk_reduce(const float* slices, int nsplit, int64_t slice_stride, int
                       const void* residual, int res_dtype, int64_t ldr, int relu, void* out, int out_dtype, int64_t ldc,
                       void* stream);
 
+/* Weight gradients without float atomics.  fs2_wgrad_sliced runs the product of an fs2_gemm descriptor with a_kmajor = b_kmajor = 1,
+ * accumulate = 1 (dW += dY^T X, Conv1d taps as conv = 2) but stores the 128 x 128 partial tiles of its k-split with plain stores into
+ * the workspace `ws` (64 KiB per workgroup, ~6 TB/s chip-wide against ~1.3 TB/s of float atomics) and describes them in `part`;
+ * fs2_wgrad_reduce(parts, n) later adds the partial tiles of n such products into their gradients, one launch for all of them (the
+ * trainer reduces once per announced parameter range).  Returns the number of floats of `ws` used, 0 when the product does not run
+ * in that form (the caller then calls fs2_gemm), negative on error.                                                            */
+typedef struct FS2WgradPart {
+    const float* ws;
+    float* dst;
+    int64_t ldc, sC1, sC2;
+    int32_t M, N, tilesM, tilesN, splits, n2, nbatch, block_begin;
+    float alpha;
+    int32_t reserved;
+} FS2WgradPart;
+int64_t fs2_wgrad_sliced(const FS2Gemm* g, float* ws, int64_t ws_floats, FS2WgradPart* part, void* stream);
+int fs2_wgrad_reduce(const FS2WgradPart* parts, int n, void* stream);
+
 /* Weight shadows (fp32 master (O, I, k) as in the reference state_dict -> kernel layout, dtype `dtype`):
  *  mode 0 (forward):  dst[o*dld + j*I + i]       = src[o][i][j]
  *  mode 1 (dgrad):    dst[i*dld + j*O + o]       = src[o][i][k-1-j]

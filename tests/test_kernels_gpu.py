@@ -1359,6 +1359,66 @@ def test_big_km_wgrad_batched_and_conv(ops, big_km):
         close(a, b, f"big km conv wgrad taps={taps}", rtol=2e-3, atol=2e-3 * (B * t) ** 0.5)
 
 
+def test_sliced_weight_gradients(ops, big_km):
+    """fs2_wgrad_sliced / fs2_wgrad_reduce: the partial tiles of the k-split go to a workspace with plain stores and ONE reduce launch
+    adds the tiles of several deferred products (linear, batched q/v/k, Conv1d taps) onto non-zero gradients; against the oracle and
+    against the float-atomics flush of the same kernel"""
+    wg = ops._WG
+    M, d = 2500, 256
+    dy, x = rnd(M, 3 * d, dtype=torch.bfloat16, seed=1), rnd(M, d, dtype=torch.bfloat16, seed=2)
+    dyc, xc = rnd(5, 450, 256, dtype=torch.bfloat16, seed=3), rnd(5, 450, 136, dtype=torch.bfloat16, seed=4)
+    g0 = [rnd(3 * d, d, seed=5), rnd(3 * (d * d + d), seed=6), rnd(256, 3 * 136, seed=7)]
+
+    def run(o, mv, defer):
+        kw = dict(defer=True) if defer else {}
+        outs = [mv(t) for t in g0]
+        o.wgrad(mv(dy), mv(x), outs[0], **kw)
+        blocks = [outs[1][j * (d * d + d):j * (d * d + d) + d * d].view(d, d) for j in range(3)]
+        o.wgrad_batched(mv(dy), mv(x), blocks, **kw)
+        o.conv_wgrad(mv(dyc), mv(xc), 3, 1, outs[2], **kw)
+        return outs
+
+    assert wg.enabled
+    a = run(ops, lambda t: t.cuda(), True)
+    assert len(wg.parts) == 3 and wg.off > 0          # nothing has been added yet
+    assert torch.equal(a[0].cpu(), g0[0])
+    ops.wgrad_flush()
+    assert not wg.parts and wg.off == 0
+    ref = run(P, lambda t: t.clone(), False)
+    for u, v in zip(a, ref):
+        close(u, v, "sliced wgrad", rtol=2e-3, atol=2e-3 * M ** 0.5)
+    # immediate mode, and the atomics flush of the same kernel (different summation order only)
+    b = run(ops, lambda t: t.cuda(), False)
+    assert not wg.parts
+    wg.enabled = False
+    try:
+        c = run(ops, lambda t: t.cuda(), False)
+    finally:
+        wg.enabled = True
+    for u, v, w in zip(a, b, c):
+        assert torch.equal(u, v)
+        close(u, w, "sliced vs atomics", rtol=1e-4, atol=1e-3)
+    # two deferred products into ONE gradient (the mel Linear of the model receives two gradient terms): never in one reduce launch
+    acc = g0[0].cuda()
+    ops.wgrad(dy.cuda(), x.cuda(), acc, defer=True)
+    ops.wgrad(dy.cuda(), x.cuda(), acc, defer=True)
+    assert len(wg.parts) == 1
+    ops.wgrad_flush()
+    close(acc, 2 * a[0] - g0[0].cuda(), "two terms, one gradient", rtol=1e-5, atol=1e-3)
+    # a full workspace: the pending products are reduced first, the new one starts at offset 0
+    keep = wg.FLOATS
+    try:
+        wg.FLOATS = 300 * 128 * 128        # (each of the three products alone fits, no two of them)
+        wg.ws.clear()
+        e = run(ops, lambda t: t.cuda(), True)
+        ops.wgrad_flush()
+    finally:
+        wg.FLOATS = keep
+        wg.ws.clear()
+    for u, v in zip(a, e):
+        assert torch.equal(u, v)
+
+
 def test_torch_library_ops(ops):
     """the fs2:: custom operators (transformer_tts_amd/torch_ops.py, torch.library): forward and autograd through the dispatcher on the
     GPU against plain PyTorch fp32 -- nn.Linear + ReLU, channels-last Conv1d, attention() without dropout (causal and padded keys)."""

@@ -40,6 +40,10 @@ for step in "$@"; do
              FS2_GEMM_MFAST=1 run abmf1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_GEMM_MFAST=0 run abmf0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_GEMM_MFAST=1 run abmf1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline ;;
+    abwg)    FS2_WGRAD_SLICED=0 run abwg0 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_WGRAD_SLICED=1 run abwg1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_WGRAD_SLICED=0 run abwg0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_WGRAD_SLICED=1 run abwg1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline ;;
     ab)      FS2_FUSED_ATTN=0 run ab0 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
              FS2_FUSED_ATTN=1 run ab1 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline
              FS2_FUSED_ATTN=0 run ab0b 400 python bench.py --steps 24 --warmup 8 --no-cpu-baseline

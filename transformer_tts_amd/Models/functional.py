@@ -56,6 +56,12 @@ class Runtime:
             self.rng = ops.Rng(self.seed, device)
         return self.rng
 
+    @property
+    def defer_wgrad(self):
+        """long-reduction weight gradients leave their partial tiles in a workspace; one reduce per announced parameter range adds
+        them to the gradients (ops.wgrad_flush).  Not with the side stream: the workspace is ordered by ONE stream."""
+        return not self.overlap_wgrad
+
     def invalidate(self):
         self.epoch += 1
 
@@ -74,6 +80,7 @@ class Runtime:
 
     def side_join(self):
         """the current stream waits for all side-stream work (call before the gradients are consumed)"""
+        ops.wgrad_flush()
         if self._side_dirty:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_dirty = False
@@ -85,6 +92,8 @@ class Runtime:
         The all-reduce has to follow BOTH this backward's data-gradient stream and the side stream carrying its weight
         gradients; it is launched from the side stream after that stream has picked up the current one, so the
         data-gradient chain never waits for weight-gradient GEMMs (a join here would stall it once per layer)."""
+        if self.defer_wgrad:
+            ops.wgrad_flush()           # the partial tiles of this range's weight gradients: one reduce launch
         if self.dp is None:
             return
         params = list(params)
@@ -243,10 +252,10 @@ def _conv_wgrad(rt, dy, x, conv, pad, bias_done=False):
     with rt.side(dy, x):
         raw = getattr(w, "_fs2_grad_raw", None)
         if k == 1:
-            ops.conv_wgrad(dy, x, 1, 0, gw.view(O, I))
+            ops.conv_wgrad(dy, x, 1, 0, gw.view(O, I), defer=rt.defer_wgrad)
         elif raw is not None and gw.data_ptr() == raw.data_ptr() and gw.stride() == (k * I, 1, I):
             # the optimizer's arena keeps this gradient in the GEMM's own [o][j][i] layout (optim.ParamArena): no permute pass
-            ops.conv_wgrad(dy, x, k, pad, raw)
+            ops.conv_wgrad(dy, x, k, pad, raw, defer=rt.defer_wgrad)
         else:
             scratch = rt.zeros(("wg", O, I, k), (O, k * I), torch.float32, w.device, self_cleaning=True)
             ops.conv_wgrad(dy, x, k, pad, scratch)
@@ -257,7 +266,7 @@ def _conv_wgrad(rt, dy, x, conv, pad, bias_done=False):
 
 def _linear_wgrad(rt, dy2, x2, lin, bias_done=False):
     with rt.side(dy2, x2):
-        ops.wgrad(dy2, x2, grad_of(lin.weight))
+        ops.wgrad(dy2, x2, grad_of(lin.weight), defer=rt.defer_wgrad)
         if not bias_done:
             ops.colsum(dy2, grad_of(lin.bias))
 
@@ -447,7 +456,7 @@ class EncoderStackFunction(torch.autograd.Function):
                 if not flash:
                     ops.colsum_blocks(dqkv2, [grad_of(lin.bias) for lin in (at.q_linear, at.v_linear, at.k_linear)])
                 # the three weight gradients in ONE batched split-K GEMM when they sit at a constant stride (arena)
-                ops.wgrad_batched(dqkv2, h2d, [grad_of(lin.weight) for lin in (at.q_linear, at.v_linear, at.k_linear)])
+                ops.wgrad_batched(dqkv2, h2d, [grad_of(lin.weight) for lin in (at.q_linear, at.v_linear, at.k_linear)], defer=rt.defer_wgrad)
             _, wd, _ = rt.qkv(at)
             dh = ops.linear(dqkv2, wd).view(B, t, d)
             # every gradient of this layer except norm_1's (produced by the next iteration) and the norm that follows the

@@ -206,10 +206,10 @@ class DecoderStackFunction(torch.autograd.Function):
             with rt.side(dq2, dvk):
                 if not flash:
                     ops.colsum(dq2, grad_of(at2.q_linear.bias))
-                ops.wgrad(dq2, Lr["hq"].view(M, d), grad_of(at2.q_linear.weight))
+                ops.wgrad(dq2, Lr["hq"].view(M, d), grad_of(at2.q_linear.weight), defer=rt.defer_wgrad)
                 if not flash:
                     ops.colsum_blocks(dvk, [grad_of(at2.v_linear.bias), grad_of(at2.k_linear.bias)])
-                ops.wgrad_batched(dvk, e2, [grad_of(at2.v_linear.weight), grad_of(at2.k_linear.weight)])
+                ops.wgrad_batched(dvk, e2, [grad_of(at2.v_linear.weight), grad_of(at2.k_linear.weight)], defer=rt.defer_wgrad)
             dhq = ops.linear(dq2, wd2[:, :d]).view(B, t, d)
             de = ops.linear(dvk, wd2[:, d:], residual=de, out_dtype=torch.float32)
             # ---- masked self-attention
@@ -236,7 +236,7 @@ class DecoderStackFunction(torch.autograd.Function):
             with rt.side(dqkv):
                 if not flash:
                     ops.colsum_blocks(dqkv, [grad_of(lin.bias) for lin in (at1.q_linear, at1.v_linear, at1.k_linear)])
-                ops.wgrad_batched(dqkv, Lr["h"].view(M, d), [grad_of(lin.weight) for lin in (at1.q_linear, at1.v_linear, at1.k_linear)])
+                ops.wgrad_batched(dqkv, Lr["h"].view(M, d), [grad_of(lin.weight) for lin in (at1.q_linear, at1.v_linear, at1.k_linear)], defer=rt.defer_wgrad)
             _, wd1, _ = rt.qkv(at1)
             dh = ops.linear(dqkv, wd1).view(B, t, d)
             rt.announce([q_ for name, q_ in layer.named_parameters() if not name.startswith("norm_1.")] + list(nn_.parameters()))

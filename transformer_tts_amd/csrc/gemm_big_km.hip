@@ -49,7 +49,8 @@ __device__ __forceinline__ bf16x8 km_frag(const unsigned char* img, int o0, int 
 extern thread_local int g_last_tile;     // gemm.hip
 
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
-                                                                  const int nitems, const int rot_step, const int stream_units) {
+                                                                  const int nitems, const int rot_step, const int stream_units,
+                                                                  float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,6 +260,15 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ws != nullptr) {
+            // ---- sliced flush (fs2_wgrad_sliced): the 128 x 128 partial tile goes to slice `item` of the workspace with plain
+            //      16-byte stores (64 KiB contiguous per workgroup, ~6 TB/s chip-wide against ~1.3 TB/s of float atomics);
+            //      fs2_wgrad_reduce adds the slices of every tile into the gradient.  Uniform k-split only (item = ibeg + j).
+            float4* dst = reinterpret_cast<float4*>(ws + (int64_t)(ibeg + j) * (TM * TN));
+            const float4* src = reinterpret_cast<const float4*>(red);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[tid + NT * i] = src[tid + NT * i];
+        } else {
         // ---- flush with row-contiguous float atomics (256 B per wave-instruction: the full-rate shape), 8 rows per wave
         float* __restrict__ C = reinterpret_cast<float*>(p.C) + ck.coff;
 #pragma unroll
@@ -273,25 +283,26 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
                 if (m < p.M && n < p.N) atomicAdd(C + (int64_t)m * p.ldc + n, v * p.alpha);
             }
         }
+        }
         // the LDS is free again before the next item's first stage is staged
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
-// false: not eligible / not chosen; true: launched, *rc holds the result
-bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc) {
-    // FS2_GEMM_BIG_KM: 0 never, 1 (default) where the shape heuristic says so, 2 wherever eligible (tests, A/B measurements)
-    const char* e1 = getenv("FS2_GEMM_BIG_KM");
-    const int mode = e1 ? atoi(e1) : 1;
-    if (mode == 0) return false;
+namespace {
+
+struct KmPlan { int tilesM, tilesN, splits, stream_units, grid; long nitems, base; };
+
+// work decomposition of a weight-gradient product, or false when the 16-wave kernel does not take it
+bool km_plan(const FS2Gemm& g, int mode, KmPlan& pl) {
     if (g.dtype != FS2_BF16 || g.c_dtype != FS2_F32 || !g.a_kmajor || !g.b_kmajor || !g.accumulate) return false;
     if (g.conv != 0 && g.conv != 2) return false;
     if (g.bias || g.residual || g.relu_mask || g.colstats || g.relu) return false;
     const long rowsA = (long)g.K + 16, rowsB = (long)(g.Kb > 0 ? g.Kb : g.K) + 64;
     if (rowsA * g.lda * 2 >= 0x7FFFFFF0L || rowsB * g.ldb * 2 >= 0x7FFFFFF0L) return false;
-    const int tilesM = (g.M + TM - 1) / TM, tilesN = (g.N + TN - 1) / TN;
+    pl.tilesM = (g.M + TM - 1) / TM; pl.tilesN = (g.N + TN - 1) / TN;
     const long nb = (long)g.batch1 * g.batch2;
-    const long base = (long)tilesM * tilesN * nb;             // work items before the k-split
+    const long base = (long)pl.tilesM * pl.tilesN * nb;       // output tiles (x taps x batch)
     const int nstk = (g.K + BK - 1) / BK;
     // uniform k-split: about one item per CU, at least 2 stages per split (never more items than CUs: a second round would double the time)
     int splits = (int)(256 / base);
@@ -316,24 +327,134 @@ bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     if (mode == 1 && nstk < 16) return false;
     if (stream_units > 0) nitems = base;
     if (nitems >= (1L << 30)) return false;
+    const long per_x = (nitems + 7) / 8;
+    pl.grid = stream_units > 0 ? 8 * (int)(((total + stream_units - 1) / stream_units + 7) / 8) : 8 * (int)(per_x < 32 ? per_x : 32);
+    pl.splits = splits; pl.stream_units = stream_units; pl.nitems = nitems; pl.base = base;
+    return true;
+}
+
+int km_launch(const FS2Gemm& g, const KmPlan& pl, float* ws, hipStream_t st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr_set[16] = {};            // per device (one process per GPU is the deployment; a process driving several still works)
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the weight-gradient kernel");
-            *rc = FS2_ELAUNCH;
-            return true;
+            return FS2_ELAUNCH;
         }
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
-    const long per_x = (nitems + 7) / 8;
-    const int grid = stream_units > 0 ? 8 * (int)(((total + stream_units - 1) / stream_units + 7) / 8) : 8 * (int)(per_x < 32 ? per_x : 32);
     g_last_tile = 129;          // (measurement aid: the 16-wave weight-gradient kernel)
     static const int rot_step = getenv("FS2_KM_ROT") ? atoi(getenv("FS2_KM_ROT")) : 4;
-    hipLaunchKernelGGL(fs2_gemm_big_km_kernel, dim3(grid), dim3(NT), SMEM, st, g, tilesM, tilesN, splits, (int)nitems, rot_step, stream_units);
+    hipLaunchKernelGGL(fs2_gemm_big_km_kernel, dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
+                       pl.stream_units, ws);
     hipError_t e_ = hipGetLastError();
-    if (e_ != hipSuccess) { fs2_set_error("fs2_gemm(big km): launch failed: %s", hipGetErrorString(e_)); *rc = FS2_ELAUNCH; return true; }
-    *rc = FS2_OK;
+    if (e_ != hipSuccess) { fs2_set_error("fs2_gemm(big km): launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
+    return FS2_OK;
+}
+
+// out[m][n] += alpha * sum_s ws[((y * splits + s) * tiles + tile) * 128 * 128 + ...]: one workgroup per (descriptor, batch item y, tile,
+// block of 8 rows), one float4 per thread, the slices of the k-split read 8 loads deep
+struct ReduceArgs { FS2WgradPart parts[40]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_k(const ReduceArgs a) {
+    int b = blockIdx.x, d = 0;
+    while (d + 1 < a.n && b >= a.parts[d + 1].block_begin) ++d;
+    const FS2WgradPart& p = a.parts[d];
+    b -= p.block_begin;
+    const int chunk = b & 15;
+    b >>= 4;
+    const int tiles = p.tilesM * p.tilesN;
+    const int y = b / tiles, tile = b - y * tiles;
+    const int m0 = (tile / p.tilesN) * TM, n0 = (tile % p.tilesN) * TN;
+    const int tid = threadIdx.x;
+    const int row = chunk * 8 + (tid >> 5), col = (tid & 31) * 4;
+    const int m = m0 + row, n = n0 + col;
+    if (m >= p.M || n >= p.N) return;
+    const int c2 = y % p.n2, b1 = y / p.n2;
+    const float* __restrict__ src = p.ws + ((int64_t)y * p.splits * tiles + tile) * (TM * TN) + row * TN + col;
+    const int64_t sstride = (int64_t)tiles * (TM * TN);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 8 <= p.splits; s += 8) {
+        float4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v.x += w[u].x; v.y += w[u].y; v.z += w[u].z; v.w += w[u].w; }
+    }
+    for (; s < p.splits; ++s) {
+        const float4 w = *reinterpret_cast<const float4*>(src + s * sstride);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    float* o = p.dst + (int64_t)b1 * p.sC1 + (int64_t)c2 * p.sC2 + (int64_t)m * p.ldc + n;
+    if (n + 3 < p.N && ((uintptr_t)o & 15) == 0) {
+        float4 c = *reinterpret_cast<float4*>(o);
+        c.x += v.x * p.alpha; c.y += v.y * p.alpha; c.z += v.z * p.alpha; c.w += v.w * p.alpha;
+        *reinterpret_cast<float4*>(o) = c;
+    } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] += vv[e] * p.alpha;
+    }
+}
+
+}  // namespace
+
+// false: not eligible / not chosen; true: launched, *rc holds the result
+bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc) {
+    // FS2_GEMM_BIG_KM: 0 never, 1 (default) where the shape heuristic says so, 2 wherever eligible (tests, A/B measurements)
+    const char* e1 = getenv("FS2_GEMM_BIG_KM");
+    const int mode = e1 ? atoi(e1) : 1;
+    if (mode == 0) return false;
+    KmPlan pl;
+    if (!km_plan(g, mode, pl)) return false;
+    *rc = km_launch(g, pl, nullptr, st);
     return true;
+}
+
+// Sliced weight gradient: the product of fs2_gemm(a_kmajor = b_kmajor = 1, accumulate = 1) with the partial tiles of the k-split stored
+// with plain stores into `ws` instead of float atomics on C; fs2_wgrad_reduce adds them to C later.  Returns the number of floats of
+// `ws` it used and fills `part` -- or 0 when the product does not run in the uniform k-split form (not eligible, balanced-stream
+// decomposition, workspace too small): the caller then uses fs2_gemm.  Negative: error.
+extern "C" int64_t fs2_wgrad_sliced(const FS2Gemm* gp, float* ws, int64_t ws_floats, FS2WgradPart* part, void* stream) {
+    if (gp == nullptr || ws == nullptr || part == nullptr) { fs2_set_error("fs2_wgrad_sliced: null argument"); return FS2_EINVAL; }
+    FS2Gemm g = *gp;
+    if (g.split_k < 1) g.split_k = 1;
+    if (g.batch1 < 1) g.batch1 = 1;
+    if (g.batch2 < 1) g.batch2 = 1;
+    if (g.conv == 0) { g.taps = 1; g.pad = 0; if (g.seq_len <= 0) g.seq_len = 1; }
+    if (!(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C) || !fs2_aligned16(g.A) || !fs2_aligned16(g.B) || !fs2_aligned16(ws)) return 0;
+    if (g.lda % 8 != 0 || g.ldb % 8 != 0 || g.sA1 % 8 != 0 || g.sA2 % 8 != 0 || g.sB1 % 8 != 0 || g.sB2 % 8 != 0) return 0;
+    if (((g.M + 7) / 8) * 8 > g.lda || ((g.N + 7) / 8) * 8 > g.ldb) return 0;
+    const char* e1 = getenv("FS2_GEMM_BIG_KM");
+    const int mode = e1 ? atoi(e1) : 1;
+    KmPlan pl;
+    if (mode == 0 || !km_plan(g, mode, pl) || pl.stream_units > 0) return 0;
+    const int64_t need = pl.nitems * (int64_t)(TM * TN);
+    if (need > ws_floats || pl.nitems > pl.grid) return 0;          // (one item per workgroup: every slice is written exactly once)
+    const int rc = km_launch(g, pl, ws, (hipStream_t)stream);
+    if (rc != FS2_OK) return rc;
+    const int taps = g.conv == 2 ? g.batch2 : 1, nb2 = g.conv == 2 ? 1 : g.batch2;
+    part->ws = ws; part->dst = (float*)g.C; part->ldc = g.ldc; part->sC1 = g.sC1; part->sC2 = g.sC2;
+    part->M = g.M; part->N = g.N; part->tilesM = pl.tilesM; part->tilesN = pl.tilesN; part->splits = pl.splits;
+    part->n2 = g.conv == 2 ? taps : nb2; part->nbatch = (int)(pl.base / ((long)pl.tilesM * pl.tilesN)); part->alpha = g.alpha; part->block_begin = 0;
+    return need;
+}
+
+extern "C" int fs2_wgrad_reduce(const FS2WgradPart* parts, int n, void* stream) {
+    FS2_REQUIRE(parts != nullptr && n >= 1, "fs2_wgrad_reduce: no parts");
+    for (int i0 = 0; i0 < n; i0 += 40) {
+        ReduceArgs a;
+        a.n = n - i0 < 40 ? n - i0 : 40;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            a.parts[i] = parts[i0 + i];
+            FS2_REQUIRE(a.parts[i].ws && a.parts[i].dst && a.parts[i].splits >= 1 && a.parts[i].tilesM >= 1 && a.parts[i].tilesN >= 1 && a.parts[i].nbatch >= 1 &&
+                            a.parts[i].n2 >= 1, "fs2_wgrad_reduce: bad part %d", i0 + i);
+            a.parts[i].block_begin = blocks;
+            blocks += 16 * a.parts[i].nbatch * a.parts[i].tilesM * a.parts[i].tilesN;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        FS2_CHECK_LAUNCH("fs2_wgrad_reduce");
+    }
+    return FS2_OK;
 }

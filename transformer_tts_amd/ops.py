@@ -92,6 +92,8 @@ SIGNATURES = {
     "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_splitk_finish": [_P, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
     "fs2_splitk_reduce": [_P, _I, _L, _L, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
+    "fs2_wgrad_sliced": [ctypes.POINTER(FS2Gemm), _P, _L, _P, _P],      # returns int64
+    "fs2_wgrad_reduce": [_P, _I, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
     "fs2_attn_probs_lds_bytes": [_I, _I],
     "fs2_attn_probs_fwd": [_P, _P, _L, _L, _I, _I, _P, _P, _P, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P, _P, _L, _L, _P],
@@ -159,6 +161,7 @@ def lib():
         l.fs2_last_error.restype = ctypes.c_char_p
         l.fs2_flash_attn_keep_words.restype = ctypes.c_int64
         l.fs2_flash_attn_keep_words_rect.restype = ctypes.c_int64
+        l.fs2_wgrad_sliced.restype = ctypes.c_int64
         l.fs2_abi_version.restype = ctypes.c_int
         _lib = l
     return _lib
@@ -392,6 +395,79 @@ def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, 
     return out
 
 
+class FS2WgradPart(ctypes.Structure):
+    _fields_ = [("ws", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("sC1", ctypes.c_int64), ("sC2", ctypes.c_int64),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("tilesM", ctypes.c_int32), ("tilesN", ctypes.c_int32),
+                ("splits", ctypes.c_int32), ("n2", ctypes.c_int32), ("nbatch", ctypes.c_int32), ("block_begin", ctypes.c_int32),
+                ("alpha", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
+class _WgradSlices:
+    """Partial tiles of the long-reduction weight gradients (fs2_wgrad_sliced) and the products waiting for their reduce.  One
+    workspace per device, reused from offset 0 after every reduce (the stream is in order), so the same ~64 MiB stay hot."""
+    FLOATS = 48 << 20          # 192 MiB: three products of 256 workgroups each hold 48 MiB
+
+    def __init__(self):
+        self.ws = {}
+        self.off = 0
+        self.parts = []
+        self.keep = []
+        self.spans = []
+        self.device = None
+        self.enabled = os.environ.get("FS2_WGRAD_SLICED", "1") != "0"
+
+    def run(self, g, out, defer, extra_bytes=0):
+        if not self.enabled or not out.is_cuda:
+            return False
+        # two products adding into the same gradient (the mel Linear sees two gradient terms) must not share a reduce launch
+        lo = out.data_ptr()
+        hi = lo + 4 * (sum((n - 1) * st for n, st in zip(out.shape, out.stride())) + 1) + extra_bytes
+        if self.parts and (self.device != out.device or any(lo < b and a < hi for a, b in self.spans)):
+            self.flush()
+        ws = self.ws.get(out.device)
+        if ws is None:
+            ws = self.ws[out.device] = torch.empty(self.FLOATS, dtype=torch.float32, device=out.device)
+        self.device = out.device
+        part = FS2WgradPart()
+        for attempt in range(2):
+            used = lib().fs2_wgrad_sliced(ctypes.byref(g), ws.data_ptr() + 4 * self.off, self.FLOATS - self.off, ctypes.byref(part), _stream())
+            if used < 0:
+                _check(int(used), "fs2_wgrad_sliced")
+            if used > 0 or not self.parts or attempt == 1:
+                break
+            self.flush()           # perhaps the workspace was full: retry from offset 0
+        if used <= 0:
+            return False
+        self.off += int(used)
+        self.parts.append(part)
+        self.keep.append(out)
+        self.spans.append((lo, hi))
+        if not defer or len(self.parts) >= 40:
+            self.flush()
+        return True
+
+    def flush(self):
+        if self.parts:
+            arr = (FS2WgradPart * len(self.parts))(*self.parts)
+            n = len(self.parts)
+            self.parts, self.keep, self.spans, self.off = [], [], [], 0
+            _check(lib().fs2_wgrad_reduce(arr, n, _stream()), "fs2_wgrad_reduce")
+
+
+_WG = _WgradSlices()
+
+
+def wgrad_flush():
+    """add the partial tiles of every deferred weight-gradient product into its gradient (one launch); the models call it once per
+    announced parameter range and at the end of every backward"""
+    _WG.flush()
+
+
+def _wgrad_call(g, out, defer, extra_bytes=0):
+    if not _WG.run(g, out, defer, extra_bytes):
+        _gemm_call(g)
+
+
 def _pick_split(M_out, N_out, K_red, batch):
     """split-K factor of a weight-gradient GEMM: ~384 blocks in all (1-2 per CU; measured optimum 256-384 on the
     config-2 shapes, tools/gemm_bench.py wsplit), at least 6 K-stages of 64 per split, at most 64 splits"""
@@ -401,8 +477,9 @@ def _pick_split(M_out, N_out, K_red, batch):
     return int(max(1, min(want, max(1, ktiles // 6), 64)))
 
 
-def wgrad(dy, x, out, split=None):
-    """out[N,K] (fp32) += dy[M,N]^T @ x[M,K]  (k-major operands, split-K with fp32 atomics)."""
+def wgrad(dy, x, out, split=None, defer=False):
+    """out[N,K] (fp32) += dy[M,N]^T @ x[M,K]  (k-major operands; long reductions: partial tiles + reduce, else split-K with fp32 atomics).
+    defer: the sum into `out` may wait until wgrad_flush()"""
     M, N = dy.shape
     K = x.shape[1]
     assert out.dtype == torch.float32 and out.shape == (N, K)
@@ -414,11 +491,11 @@ def wgrad(dy, x, out, split=None):
     g.split_k = split or _pick_split(N, K, M, 1)
     g.accumulate = 1
     _epilogue(g, out, None, False, None, None, None, 1.0)
-    _gemm_call(g)
+    _wgrad_call(g, out, defer and split is None)
     return out
 
 
-def wgrad_batched(dy, x, outs):
+def wgrad_batched(dy, x, outs, defer=False):
     """outs[j][N,K] (fp32) += dy[:, j*N:(j+1)*N]^T @ x   for the column blocks of one dy (M, len(outs)*N): one launch
     with the blocks as the batch when the outputs sit at a constant address stride, else one launch per block."""
     nb = len(outs)
@@ -430,7 +507,7 @@ def wgrad_batched(dy, x, outs):
         and all(o.dtype == torch.float32 and o.shape == (N, K) and o.is_contiguous() for o in outs)
     if not regular:
         for j, o in enumerate(outs):
-            wgrad(dy[:, j * N:(j + 1) * N], x, o)
+            wgrad(dy[:, j * N:(j + 1) * N], x, o, defer=defer)
         return outs
     g = FS2Gemm()
     g.A, g.B, g.lda, g.ldb = _p(dy), _p(x), _ld(dy), _ld(x)
@@ -441,11 +518,11 @@ def wgrad_batched(dy, x, outs):
     g.split_k = _pick_split(N, K, M, nb)
     g.accumulate = 1
     _epilogue(g, outs[0], None, False, None, None, None, 1.0)
-    _gemm_call(g)
+    _wgrad_call(g, outs[0], defer, step * (nb - 1))
     return outs
 
 
-def conv_wgrad(dy, x, taps, pad, out):
+def conv_wgrad(dy, x, taps, pad, out, defer=False):
     """out[N, taps*C] (fp32) += sum_{b,t} dy[b,t,n] * x[b, t+j-pad, c]   (kernel layout [n][j*C+c])."""
     B, t, N = dy.shape
     C = x.shape[2]
@@ -461,7 +538,7 @@ def conv_wgrad(dy, x, taps, pad, out):
     g.split_k = _pick_split(N, C, B * t, taps)
     g.accumulate = 1
     _epilogue(g, out, None, False, None, None, None, 1.0)
-    _gemm_call(g)
+    _wgrad_call(g, out, defer)
     return out
 
 
