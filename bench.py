@@ -91,31 +91,56 @@ class GemmTimer:
         self._orig = ops._gemm_call
         self._last_tile = ops.lib().fs2_gemm_last_tile
 
-        def timed(g):
-            s = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
-            e = self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
-            s.record()
-            self._orig(g)
-            e.record()
+        def record(g, s, e):
             taps = g.taps if g.conv == 1 else 1
             nb = max(1, g.batch1) * max(1, g.batch2)
             flops = 2.0 * g.M * g.N * g.K * taps * nb
             es, cs = {0: 4, 1: 2, 2: 1, 3: 1}[g.dtype], (2 if g.c_dtype == 1 else 4)
             # algorithmic bytes: every operand element once (conv: the A rows once, not once per tap)
             abytes = (es * (g.M * g.K + g.N * g.K * taps) + cs * g.M * g.N) * float(nb)
-            # block tile the launcher picked: 64 / 128 = rows of gemm.hip's tile, 192 / 256 = rows of gemm_big.hip's, 130 = its 128-row tile,
-            # 129 = the 16-wave weight-gradient kernel (gemm_big_km.hip)
+            # block tile the launcher picked: 64 / 128 = rows of gemm.hip's tile, 130 / 192 / 256 = the 128 / 192 / 256-row tile of
+            # gemm_ring.hip (fp8: gemm_big.hip), 131 = the weights-stationary streaming kernel (gemm_ws.hip), 129 = the 16-wave
+            # weight-gradient kernel (gemm_big_km.hip)
             tile = self._last_tile()
             key = ({0: "f32", 1: "bf16", 2: "fp8", 3: "bf8xfp8"}[g.dtype], "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm", tile)
             flags = ("b" if g.bias else "") + ("r" if g.relu else "") + ("m" if g.relu_mask else "") + ("+" if g.residual else "") + \
                     (f"s{g.colstats_mode}" if g.colstats else "") + ("a" if g.accumulate else "") + ("f" if g.c_dtype == 0 and g.dtype == 1 else "")
             shape = (g.M, g.N, g.K, taps if g.conv == 1 else (g.batch2 if g.conv == 2 else 1), g.batch1 * g.batch2, g.split_k, flags or "-")
             self.records.append((key, flops, s, e, shape, abytes))
+
+        def events():
+            return (self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True),
+                    self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True))
+
+        def timed(g):
+            s, e = events()
+            s.record()
+            self._orig(g)
+            e.record()
+            record(g, s, e)
+
+        def timed_wgrad(g, out, defer, extra_bytes=0):
+            # a weight gradient: the event pair brackets the product kernel; the reduce of its partial tiles (wgrad_reduce_k, one launch
+            # per announced parameter range: ~15 per step, listed in profiles/) runs after the pair
+            s, e = events()
+            ops._gemm_call = self._orig
+            try:
+                s.record()
+                self._orig_wgrad(g, out, True, extra_bytes)
+                e.record()
+            finally:
+                ops._gemm_call = timed
+            if not defer:
+                ops.wgrad_flush()
+            record(g, s, e)
+        self._orig_wgrad = ops._wgrad_call
         ops._gemm_call = timed
+        ops._wgrad_call = timed_wgrad
 
     def remove(self):
         from transformer_tts_amd import ops
         ops._gemm_call = self._orig
+        ops._wgrad_call = self._orig_wgrad
 
     def summary(self):
         agg = {}
@@ -249,9 +274,11 @@ def bench_line(args, timer, dt, done, world, warm, use_graph, padded, BATCH, cpu
         # against the machine balance 2.5 PFLOP/s / 8 TB/s
         hbm_bound = (fl / by) < (PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
         roof = dict(bound="hbm" if hbm_bound else "mfma",
-                    kernel=(f"{'fs2_gemm_ring_kernel' if key[0] == 'bf16' else 'fs2_gemm_big_kernel'}<{key[0]}, {128 if key[3] == 130 else key[3]}x256 tile, 16 waves, LDS-DMA> A row-major B row-major"
+                    kernel=(f"fs2_gemm_ws_kernel<{key[0]}, weights-stationary 256-column tile (K = 256 in registers), activation rows streamed through a 4-deep LDS-DMA ring, 8 waves>"
+                            if key[3] == 131 else
+                            f"{'fs2_gemm_ring_kernel' if key[0] == 'bf16' else 'fs2_gemm_big_kernel'}<{key[0]}, {128 if key[3] == 130 else key[3]}x256 tile, 16 waves, LDS-DMA> A row-major B row-major"
                             if key[3] >= 130 else
-                            f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 4 k-groups, LDS-DMA> A k-major B k-major" if key[3] == 129 else
+                            f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 4 k-groups, LDS-DMA> A k-major B k-major (partial tiles of the k-split to a workspace; wgrad_reduce_k adds them, ~15 launches per step)" if key[3] == 129 else
                             f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}"),
                     achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
                     unit="GB/s" if hbm_bound else "TFLOP/s",

@@ -161,6 +161,17 @@ int fs2_colsum_segmented(const void* x, int dtype, int64_t M, int N, int64_t ldx
  *                      factor fs2_gemm takes as FS2Gemm.scale_a / scale_b.  n is rounded up to 16 internally; dst must hold it. */
 int fs2_amax(const void* src, int src_dtype, int64_t n, float* state, void* stream);
 int fs2_quantize_fp8(const void* src, int src_dtype, void* dst, int bf8, int64_t n, float* state, void* stream);
+/* The same for many bf16 tensors in two launches (the weight shadows of a model, once per optimizer step).  `table` lives in DEVICE
+ * memory; entry i covers blocks [block_begin, block_begin + nblocks) of the grid, nblocks = ceil(n / 32768) (at least 1); the caller
+ * zeroes every state[0] beforehand; dst holds n rounded up to 16 bytes. */
+typedef struct FS2QuantDesc {
+    const void* src;
+    void* dst;
+    float* state;
+    int64_t n;
+    int32_t block_begin, nblocks;
+} FS2QuantDesc;
+int fs2_quantize_fp8_batched(const FS2QuantDesc* table, int n, int total_blocks, int bf8, void* stream);
 
 /* nn.Embedding gather / scatter-add (Models/encoder.py:55,84; Models/varianceadaptor.py:57,62). */
 int fs2_embedding_fwd(const int64_t* ids, const float* table, void* out, int out_dtype, int64_t n, int d, void* stream);

@@ -1288,6 +1288,30 @@ def test_fp8_quantisation_is_bit_exact(ops, bf8, src_dtype):
         assert torch.equal(q.cpu(), qr), f"{int((q.cpu() != qr).sum())} of {n} codes differ (bf8={bf8}, scale={scale})"
 
 
+def test_fp8_batched_weight_quantisation_equals_the_per_tensor_path(ops):
+    """fs2_quantize_fp8_batched (all weight shadows of a model in two launches) against fs2_amax + fs2_quantize_fp8 per tensor: the same
+    codes and the same {amax, 1/scale}, for sizes with ragged tails, a zero tensor and more than one 32768-element chunk"""
+    shapes = [(256, 256), (80, 512), (3, 7), (1024, 2304), (17, 33), (512, 1280)]
+    ws = [rnd(*sh, dtype=torch.bfloat16, seed=i, scale=10.0 ** (i - 3)).cuda() for i, sh in enumerate(shapes)]
+    ws.append(torch.zeros(64, 64, dtype=torch.bfloat16, device="cuda"))
+    ops._FP8_W.clear()
+    ops.fp8_quantize_shadows(ws)
+    for w in ws:
+        if w.numel() < 16:
+            assert w.data_ptr() not in ops._FP8_W
+            continue
+        q, st, n = ops._FP8_W[w.data_ptr()]
+        q2, st2 = ops.quantize_fp8(w, False)
+        assert torch.equal(q, q2) and torch.equal(st, st2), w.shape
+    # a second call re-uses the table and re-quantises in place
+    ws[0].mul_(3.0)
+    ops.fp8_quantize_shadows(ws)
+    q, st, n = ops._FP8_W[ws[0].data_ptr()]
+    q2, st2 = ops.quantize_fp8(ws[0], False)
+    assert torch.equal(q, q2) and torch.equal(st, st2)
+    ops._FP8_W.clear()
+
+
 @pytest.mark.parametrize("M,N,K", [(1500, 256, 256), (2048, 1024, 272), (1111, 264, 1024)])
 def test_fp8_gemm_against_the_dequantised_product(ops, M, N, K):
     """fs2_gemm with fp8 operands (e4m3 x e4m3 forward, e5m2 x e4m3 backward): exact products of the fp8 values summed in fp32,
@@ -1297,7 +1321,7 @@ def test_fp8_gemm_against_the_dequantised_product(ops, M, N, K):
         ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = True, backward
         try:
             out = ops.linear(x.cuda(), w.cuda(), bias=bias.cuda(), relu=not backward, out_dtype=torch.float32)
-            assert ops.lib().fs2_gemm_last_tile() == 192
+            assert ops.lib().fs2_gemm_last_tile() in (130, 192)
         finally:
             ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = False, False
         xq, sx = P.quantize_fp8(x, backward)

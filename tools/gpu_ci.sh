@@ -40,6 +40,12 @@ for step in "$@"; do
              FS2_GEMM_MFAST=1 run abmf1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_GEMM_MFAST=0 run abmf0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_GEMM_MFAST=1 run abmf1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline ;;
+    abring)  FS2_GEMM_RING=1 run abring1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_GEMM_RING=2 run abring2 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_GEMM_WS=2 run abws2 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_GEMM_RING=1 run abring1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_GEMM_RING=2 run abring2b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
+             FS2_GEMM_WS=2 run abws2b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline ;;
     abwg)    FS2_WGRAD_SLICED=0 run abwg0 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_WGRAD_SLICED=1 run abwg1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_WGRAD_SLICED=0 run abwg0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline

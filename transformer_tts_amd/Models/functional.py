@@ -205,6 +205,8 @@ class Runtime:
         ops.cast_permute_batched(self._table, self._table_n, self.dtype)
         for key, ps, val in self._records:
             self.shadows[key] = (tuple(p._version for p in ps) + (self.epoch,), val)
+        if self.fp8 and self.dtype == torch.bfloat16:       # fp8 operand mode: codes + scale of every weight shadow, two launches
+            ops.fp8_quantize_shadows([t for _, _, val in self._records for t in (val if isinstance(val, tuple) else (val,)) if t.dim() == 2])
         self._table_ver = ver
 
     def zeros(self, key, shape, dtype, device, self_cleaning=False):

@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libfs2_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_ring.hip", "gemm_ws.hip", "gemm_big.hip", "gemm_big_km.hip", "fp8.hip", "rowops.hip", "misc.hip", "attention.hip", "attention_flash.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_ring.hip", "gemm_ring_f8.hip", "gemm_ws.hip", "gemm_big.hip", "gemm_big_km.hip", "fp8.hip", "rowops.hip", "misc.hip", "attention.hip", "attention_flash.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC]
 
 
@@ -27,7 +27,7 @@ def _stale(target, deps):
 
 
 def build_library(force=False, verbose=True):
-    headers = [os.path.join(CSRC, "fs2_common.h"), os.path.join(INCLUDE, "fs2_hip.h")]
+    headers = [os.path.join(CSRC, "fs2_common.h"), os.path.join(CSRC, "gemm_ring_impl.h"), os.path.join(INCLUDE, "fs2_hip.h")]
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []

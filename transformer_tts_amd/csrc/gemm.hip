@@ -631,7 +631,8 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
         if (g.conv == 1) FS2_REQUIRE(g.taps >= 1 && g.seq_len > 0, "fs2_gemm: conv=1 needs taps, seq_len");
         if (g.bias) FS2_REQUIRE(fs2_aligned16(g.bias), "fs2_gemm: bias must be 16-byte aligned");
         int rc = FS2_OK;
-        if (fs2_gemm_big_try(g, (hipStream_t)stream, &rc)) return rc;
+        if (fs2_gemm_ring_try(g, (hipStream_t)stream, &rc)) return rc;      // ring kernel, block-scaled 128-deep fp8 MFMA (g_last_tile 130 / 192)
+        if (fs2_gemm_big_try(g, (hipStream_t)stream, &rc)) return rc;       // round-2 kernel, non-scaled fp8 MFMA (FS2_GEMM_F8_RING=0)
         fs2_set_error("fs2_gemm: fp8 operands need a row-major un-batched product with K, lda, ldb multiples of 16, no accumulate / "
                       "split-K, a compiled epilogue combination and 32-bit addressable operands");
         return FS2_EINVAL;

@@ -1,494 +1,7 @@
-// Row-major x row-major bf16 MFMA GEMM for gfx950, 16 waves: the tall products of the model (linear layers and implicit-GEMM
-// Conv1d, forward and data gradient; M = batch * frames rows against N <= 2048 output channels).  Round 3 form of the
-// large-tile kernel (round 2: gemm_big.hip, which keeps the one-byte-operand instances).
-//
-// Geometry (unchanged, it fits the model): BM x 256 block tile, BM = 128 / 192 / 256 chosen per launch, 16 waves of
-// (BM/4) x 64, <= 128 VGPRs (four waves per SIMD), one persistent workgroup per CU walking a flattened stream of k-slots over all
-// its work items; operands swapped on the MFMA (weights as the A operand, weight rows of a wave permuted over its four column
-// tiles) so that a lane holds 16 consecutive output columns of one row: 16-byte stores straight from the accumulators.
-//   * K is consumed in SLOTS of 64 bf16 = 128 B per row; one LDS-DMA wave-instruction (buffer_load_dwordx4 ... lds) covers
-//     8 rows x 128 B: whole cache lines.  (A first round-3 version used 32-deep slots = 16 rows x 64 B per instruction to fit a
-//     5-deep ring: bit-identical and 15-30 % SLOWER -- half-line pieces double the texture-addresser work per byte, exactly the
-//     "fragment-shaped loads" the CDNA4 guide warns about.  Measured, dropped.)
-//   * the LDS holds a RING of S slots: S = 3 for the 128-row tile (48 KiB each), 2 for the 192 / 256-row tiles; 16-byte chunk c of
-//     row r sits at c ^ f(r) (conflict-free ds_read_b128), the swizzle applied on the per-lane SOURCE address of the DMA;
-//   * waits are COUNTED: `s_waitcnt vmcnt(N)` with N = the vector-memory operations this wave has issued since the awaited pieces
-//     (gfx9 retires loads, stores and LDS-DMA in issue order).  The 16-byte stores of an epilogue are therefore not waited for at
-//     the next slot barrier (the round-2 kernel's vmcnt(0) drained them there);
-//   * bias lives in LDS (ds_read_b128 in the epilogue): a plain / bias / ReLU epilogue contains no vector-memory load, so nothing
-//     in the slot stream waits on the in-order queue; mask / residual rows (two of the model's eight product classes) are buffer
-//     loads one row tile ahead inside the epilogue (all row tiles up front cost 24-48 registers: the round-2 instances with a mask
-//     spilled up to 208 B per lane; every instance of this kernel the model uses has zero scratch: tools/check_resources.py);
-//   * sliced split-K for products with few output tiles and a long reduction (the 6144 x 256 x (9 x 1024) encoder convolutions):
-//     every split stores its fp32 partial tile with plain 16-byte stores into its own slice of a workspace; fs2_splitk_reduce sums
-//     the slices and applies bias / ReLU / residual / cast (no float atomics: ~1.3 TB/s chip-wide against ~6 TB/s of plain stores).
-// Results are bit-identical to gemm_big.hip and to the 128-tile kernel of gemm.hip (same MFMA, same k order per accumulator).
-#include "fs2_common.h"
-#include <stdlib.h>
+// Entry of the 16-wave row-major ring kernel (gemm_ring_impl.h): bf16 instances here, the one-byte-operand instances in gemm_ring_f8.hip.
+#include "gemm_ring_impl.h"
 
-namespace {
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-constexpr unsigned OOB = 0x80000000u;
-constexpr int NW = 16, NT = 1024, BN = 256, SK = 64;      // waves, threads, tile columns, k per slot
-constexpr int LDS_MAX = 160 * 1024;
-
-constexpr int EPI_MASK = 1, EPI_RES_F32 = 2, EPI_RES_BF16 = 4, EPI_STATS = 8, EPI_SUMSQ = 16;
-
-template <int WTM> struct RG {
-    static constexpr int MT = WTM / 16, BM = 4 * WTM;
-    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SLOT = A_BYTES + B_BYTES;
-    static constexpr int AQ = BM / 8, BQ = BN / 8;                // LDS-DMA pieces per slot (1 KiB = 8 rows x 128 B each)
-    static constexpr int AI = (AQ + NW - 1) / NW, BI = BQ / NW;   // ... per wave (piece i of wave w covers rows 8*(i*NW + w) .. +7)
-    static constexpr int SMAX = WTM == 32 ? 3 : 2;
-};
-
-// 16-B chunk swizzles: A rows are read 16 consecutive rows per fragment; weight rows 16*(i>>2) + 4*jt + (i&3)
-__device__ __forceinline__ int fA(int r) { return (r >> 1) & 7; }
-__device__ __forceinline__ int fB(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
-
-// wait until at most n of this wave's vector-memory operations are outstanding, and for its LDS reads; then the workgroup barrier
-__device__ __forceinline__ void wait_barrier(int n) {
-#define FS2_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    switch (n) {
-        FS2_W(0) FS2_W(1) FS2_W(2) FS2_W(3) FS2_W(4) FS2_W(5) FS2_W(6) FS2_W(7) FS2_W(8) FS2_W(9) FS2_W(10) FS2_W(11) FS2_W(12)
-        FS2_W(13) FS2_W(14) FS2_W(15) FS2_W(16) FS2_W(17) FS2_W(18) FS2_W(19) FS2_W(20) FS2_W(21) FS2_W(22) FS2_W(23)
-        default: asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    }
-#undef FS2_W
-}
-
-}  // namespace
-
-extern thread_local int g_last_tile;     // gemm.hip
-extern thread_local int g_last_splits;
-
-template <typename TC, int WTM, int EPI>
-__global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
-                                                               const int S, const int stats_off, const int bias_off) {
-    typedef RG<WTM> G;
-    constexpr int MT = G::MT, BM = G::BM, SLOT = G::SLOT;
-    constexpr int ESC = (int)sizeof(TC);
-    constexpr bool HAS_MASK = (EPI & EPI_MASK) != 0, RES_F32 = (EPI & EPI_RES_F32) != 0, RES_BF16 = (EPI & EPI_RES_BF16) != 0;
-    constexpr bool STATS = (EPI & EPI_STATS) != 0, SUMSQ = (EPI & EPI_SUMSQ) != 0;
-    constexpr bool EPI_LOADS = HAS_MASK || RES_F32 || RES_BF16;      // the epilogue issues vector-memory loads of its own
-    constexpr int NSTORES = MT * (ESC == 4 ? 4 : 2);                 // 16-byte stores of one epilogue, per lane
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int g = lane >> 4, i16 = lane & 15;
-
-    // ---- work items of this workgroup: XCD group x = blockIdx & 7 owns the row slabs mt = x (mod 8); its items are numbered
-    //      (slab, k-split, column tile) with the column tile fastest, so the workgroups of one XCD that run at the same time share
-    //      a slab's k-range of A in that XCD's L2; workgroup `slot` of the group takes items slot, slot + nslots, ...
-    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-    const int slabs = tilesM > x ? (tilesM - x + 7) >> 3 : 0;
-    const int items = slabs * tilesN * splits;
-    const int nmine = items > slot ? (items - slot + nslots - 1) / nslots : 0;
-    if (nmine == 0) return;
-    const bool conv = p.conv == 1;
-    const int nkt = (p.K + SK - 1) / SK;
-    const int ntot = (conv ? p.taps : 1) * nkt;                 // slots of a whole reduction
-    const int per = (ntot + splits - 1) / splits;               // slots per split (the host made every split non-empty)
-    const int pad = conv ? p.pad : 0;
-    const int lda = (int)p.lda, ldb = (int)p.ldb;
-    const int ring_bytes = S * SLOT;
-    const bool plain = !conv && (p.K % SK == 0);                // no per-slot validity arithmetic
-    int nst = 0;                                                // slots this workgroup runs through
-    if (splits == 1) nst = nmine * ntot;
-    else
-        for (int j = slot; j < items; j += nslots) {
-            const int sp = (j / tilesN) % splits;
-            nst += min(ntot, sp * per + per) - sp * per;
-        }
-
-    // ---- LDS carve: [ring S x SLOT][column statistics][bias]
-    float* cacc = reinterpret_cast<float*>(smem + stats_off);
-    const float* biasl = reinterpret_cast<const float*>(smem + bias_off);
-    const int ncols = tilesN * BN;
-    if constexpr (STATS) {
-        for (int n = tid; n < (SUMSQ ? 2 : 1) * ncols; n += NT) cacc[n] = 0.f;
-    }
-    const bool has_bias = p.bias != nullptr;                    // without a bias the LDS area is 16 zero floats, read by every lane
-    for (int n = tid; n < (has_bias ? ncols : 16); n += NT)
-        reinterpret_cast<float*>(smem + bias_off)[n] = (has_bias && n < p.N) ? p.bias[n] : 0.f;
-    __syncthreads();        // (no LDS-DMA is in flight yet: the fence's vmcnt(0) costs nothing here)
-
-    // conv: the descriptor base is moved back by `pad` rows so that the scalar slot offset (tap*lda + kb) is never negative
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<const unsigned char*>(p.A) - (int64_t)pad * lda * 2), 0, 0x7FFFFFF0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFF0, 0x00020000);
-
-    // ---- LDS-DMA source coordinates of this lane: piece i of this wave covers tile rows 8*(i*NW + wave) .. +7; the lane fetches
-    //      logical chunk (lane&7) ^ f(row) of row lane>>3 of those (swizzle on the source side)
-    auto dma_row = [&](int i) { return 8 * (i * NW + wave) + (lane >> 3); };
-    auto a_k8 = [&](int i) { return ((lane & 7) ^ fA(dma_row(i))) * 8; };
-    auto b_k8 = [&](int i) { return ((lane & 7) ^ fB(dma_row(i))) * 8; };
-    int pw = G::BI;                                                 // LDS-DMA instructions of this wave per slot (wave-uniform)
-#pragma unroll
-    for (int i = 0; i < G::AI; ++i) pw += (i * NW + wave < G::AQ) ? 1 : 0;
-
-    // ---- load cursor
-    int lj = slot, lsl = 0, lend = 0, ltap = 0, lkb = 0, lleft = nmine, rp_i = 0;
-    unsigned voffA[G::AI], voffB[G::BI];
-    int tA[G::AI];
-    auto prep_item = [&](int j) {
-        const int q = j / (tilesN * splits), rem = j - q * (tilesN * splits);
-        const int sp = rem / tilesN, nt = rem - sp * tilesN;
-        const int m0 = (x + 8 * q) * BM, n0 = nt * BN;
-#pragma unroll
-        for (int i = 0; i < G::AI; ++i) {
-            const int m = m0 + dma_row(i);
-            voffA[i] = (m < p.M) ? (unsigned)((m * lda + a_k8(i)) * 2) : OOB;
-            tA[i] = conv ? (m % p.seq_len) - pad : 0;
-        }
-#pragma unroll
-        for (int i = 0; i < G::BI; ++i) {
-            const int n = n0 + dma_row(i);
-            voffB[i] = (n < p.N) ? (unsigned)((n * ldb + b_k8(i)) * 2) : OOB;
-        }
-        const int s0 = sp * per;
-        lend = min(ntot, s0 + per) - s0;
-        ltap = s0 / nkt;
-        lkb = (s0 - ltap * nkt) * SK;
-    };
-    auto issue = [&]() __attribute__((always_inline)) {
-        const int kb = lkb, tap = ltap;
-        const int sA = (tap * lda + kb) * 2;
-        const int sB = (tap * p.K + kb) * 2;
-        unsigned char* base = smem + rp_i + 1024 * wave;
-#pragma unroll
-        for (int i = 0; i < G::AI; ++i) {
-            if (i * NW + wave < G::AQ) {          // wave-uniform (BM = 192: 24 pieces for 16 waves)
-                bool ok = voffA[i] != OOB;
-                if (!plain) {
-                    ok = ok && (kb + a_k8(i) < p.K);
-                    if (conv) ok = ok && ((unsigned)(tA[i] + tap) < (unsigned)p.seq_len);
-                }
-                // (voffset must be an int expression: an unsigned one makes the host-side instantiation of the kernel template fail
-                //  silently -- no stub, undefined symbol when the library is loaded)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)(ok ? voffA[i] : OOB), sA, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < G::BI; ++i) {
-            bool ok = voffB[i] != OOB;
-            if (!plain) ok = ok && (kb + b_k8(i) < p.K);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + G::A_BYTES + 1024 * NW * i), 16, (int)(ok ? voffB[i] : OOB), sB, 0, 0);
-        }
-        lkb += SK;
-        if (lkb >= p.K) { lkb = 0; ++ltap; }
-        if (++lsl == lend) {
-            lsl = 0;
-            lj += nslots;
-            if (--lleft > 0) prep_item(lj);
-        }
-        rp_i += SLOT;
-        if (rp_i == ring_bytes) rp_i = 0;
-    };
-
-    // ---- fragment read addresses (lane part; A row tile `it` adds it*2048, weight tile jt adds jt*512, ring position rp_c):
-    //      k-step ks (32 k = 64 B) of a row is chunks 4ks .. 4ks+3, lane group g takes chunk 4ks + g (8 elements)
-    int rdA[2], rdB[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int ra = wr * WTM + i16;
-        const int rb = wc * 64 + 16 * (i16 >> 2) + (i16 & 3);
-        const int ch = ks * 4 + g;
-        rdA[ks] = ra * 128 + ((ch ^ fA(ra)) << 4);
-        rdB[ks] = G::A_BYTES + rb * 128 + ((ch ^ fB(rb)) << 4);      // fB does not depend on jt (bits 2,3 of the row)
-    }
-
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- compute cursor
-    int cj = slot, csl = 0, cend = 0, rp_c = 0;
-    int cm0 = 0, cn0 = 0, csp = 0;
-    auto decode_c = [&](int j) {
-        const int q = j / (tilesN * splits), rem = j - q * (tilesN * splits);
-        csp = rem / tilesN;
-        const int nt = rem - csp * tilesN;
-        cm0 = (x + 8 * q) * BM; cn0 = nt * BN;
-        const int s0 = csp * per;
-        cend = min(ntot, s0 + per) - s0;
-    };
-    decode_c(cj);
-
-    const float alpha = p.alpha;
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFF0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)p.relu_mask, 0, p.relu_mask ? 0x7FFFFFF0 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? 0x7FFFFFF0 : 0, 0x00020000);
-
-    // ---- epilogue of the item (cm0, cn0, csp): lane holds C[cm0 + wr*WTM + it*16 + i16][cn0 + wc*64 + 16g + 4jt + r] in acc[it][jt][r]
-    auto epilogue = [&]() __attribute__((always_inline)) {
-        const int mb = cm0 + wr * WTM + i16;
-        const int nb = cn0 + wc * 64 + 16 * g;
-        const bool ok_lo = nb < p.N, ok_hi = nb + 8 < p.N;       // N is a multiple of 8
-        // split-K: slice csp of the fp32 workspace (slice stride sC1 elements)
-        const unsigned offC = (unsigned)((mb * (int)p.ldc + nb) * ESC) + (unsigned)csp * (unsigned)((int)p.sC1 * ESC);
-        float cs[STATS ? 16 : 1], cq[SUMSQ ? 16 : 1];
-        if constexpr (STATS) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { cs[c] = 0.f; if constexpr (SUMSQ) cq[c] = 0.f; }
-        }
-        // operand rows of the first row tile; the rows of tile it+1 are requested before tile it is finished (one tile of lookahead:
-        // all MT tiles up front cost 24-48 registers and spilled in the round-2 kernel)
-        u32x4 mraw[2], rraw[RES_F32 ? 4 : 2];
-        auto fetch = [&](int it) __attribute__((always_inline)) {
-            const bool row_ok = mb + 16 * it < p.M;
-            if constexpr (HAS_MASK) {
-                const unsigned offM = (unsigned)(((mb + 16 * it) * (int)p.ldm + nb) * 2);
-                mraw[0] = __builtin_amdgcn_raw_buffer_load_b128(rsM, (row_ok && ok_lo) ? offM : OOB, 0, 0);
-                mraw[1] = __builtin_amdgcn_raw_buffer_load_b128(rsM, (row_ok && ok_hi) ? offM + 16 : OOB, 0, 0);
-            }
-            if constexpr (RES_F32) {
-                const unsigned offR = (unsigned)(((mb + 16 * it) * (int)p.ldr + nb) * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    rraw[j] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (row_ok && (j < 2 ? ok_lo : ok_hi)) ? offR + 16 * j : OOB, 0, 0);
-            }
-            if constexpr (RES_BF16) {
-                const unsigned offR = (unsigned)(((mb + 16 * it) * (int)p.ldr + nb) * 2);
-                rraw[0] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (row_ok && ok_lo) ? offR : OOB, 0, 0);
-                rraw[1] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (row_ok && ok_hi) ? offR + 16 : OOB, 0, 0);
-            }
-        };
-        // (one tile of lookahead where the registers allow it: the 256-row tile and the mask + fp32-residual form request a tile's rows
-        //  right before they use them instead -- with the lookahead those instances spilled 7-19 registers)
-        constexpr bool LOOK = WTM < 64 && !(HAS_MASK && RES_F32);
-        if constexpr (EPI_LOADS && LOOK) fetch(0);
-#pragma unroll
-        for (int it = 0; it < MT; ++it) {
-            const bool row_ok = mb + 16 * it < p.M;
-            const bool oka = row_ok && ok_lo, okb = row_ok && ok_hi;
-            u32x4 mcur[2], rcur[RES_F32 ? 4 : 2];
-            if constexpr (EPI_LOADS) {
-                if constexpr (!LOOK) fetch(it);
-                mcur[0] = mraw[0]; mcur[1] = mraw[1];
-#pragma unroll
-                for (int j = 0; j < (RES_F32 ? 4 : 2); ++j) rcur[j] = rraw[j];
-                if constexpr (LOOK) { if (it + 1 < MT) fetch(it + 1); }
-            }
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(biasl + (has_bias ? nb + 4 * j : 0));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 4 * j + r;
-                    float t = acc[it][j][r] * alpha + b4[r];
-                    if (p.relu) t = fmaxf(t, 0.f);
-                    if constexpr (HAS_MASK) {
-                        const unsigned w = mcur[c >> 3][(c >> 1) & 3];
-                        const float mk = __uint_as_float((c & 1) ? (w & 0xFFFF0000u) : (w << 16));
-                        t = mk > 0.f ? t : 0.f;
-                    }
-                    if constexpr (RES_F32) t += __uint_as_float(rcur[c >> 2][c & 3]);
-                    if constexpr (RES_BF16) {
-                        const unsigned w = rcur[c >> 3][(c >> 1) & 3];
-                        t += __uint_as_float((c & 1) ? (w & 0xFFFF0000u) : (w << 16));
-                    }
-                    v[c] = t;
-                }
-            }
-            // (the row advance goes into the per-lane offset, not into an SGPR soffset: hipcc pads the "16-byte store, then VALU
-            //  write of its data registers" hazard only for an immediate soffset -- DESIGN.md, "A store hazard found on the way")
-            const unsigned so = (unsigned)(16 * it * (int)p.ldc * ESC);
-            if constexpr (ESC == 4) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4 * j]), __float_as_uint(v[4 * j + 1]), __float_as_uint(v[4 * j + 2]), __float_as_uint(v[4 * j + 3])},
-                                                           rsC, (j < 2 ? oka : okb) ? offC + so + 16 * j : OOB, 0, 0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    union { bf16x8 h; u32x4 u; } o;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) o.h[c] = (bf16_t)v[8 * j + c];
-                    __builtin_amdgcn_raw_buffer_store_b128(o.u, rsC, (j == 0 ? oka : okb) ? offC + so + 16 * j : OOB, 0, 0);
-                    if constexpr (STATS) {      // statistics of the values as stored
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) v[8 * j + c] = (float)o.h[c];
-                    }
-                }
-            }
-            if constexpr (STATS) {
-                if (row_ok) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) { cs[c] += v[c]; if constexpr (SUMSQ) cq[c] += v[c] * v[c]; }
-                }
-            }
-        }
-        if constexpr (STATS) {
-            // the 16 lanes of a DPP row share g (the column group) and hold 16 different rows: four DPP steps leave the row total
-            // in every lane of the row; lane c of the row then adds column c's total to the workgroup's LDS accumulator
-            float mine_s = 0.f, mine_q = 0.f;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                float sv = cs[c];
-                sv += dpp_mov<0xB1>(sv); sv += dpp_mov<0x4E>(sv); sv += dpp_mov<0x124>(sv); sv += dpp_mov<0x128>(sv);
-                mine_s = (i16 == c) ? sv : mine_s;
-                if constexpr (SUMSQ) {
-                    float qv = cq[c];
-                    qv += dpp_mov<0xB1>(qv); qv += dpp_mov<0x4E>(qv); qv += dpp_mov<0x124>(qv); qv += dpp_mov<0x128>(qv);
-                    mine_q = (i16 == c) ? qv : mine_q;
-                }
-            }
-            const int n = nb + i16;
-            if (n < p.N) {
-                atomicAdd(cacc + n, mine_s);
-                if constexpr (SUMSQ) atomicAdd(cacc + ncols + n, mine_q);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-
-    // ---- prologue: S - 1 slots in flight
-    prep_item(lj);
-    const int ahead = S - 1 < nst ? S - 1 : nst;
-    for (int i = 0; i < ahead; ++i) issue();
-
-    // Stores issued by the last epilogue count towards vmcnt like the LDS-DMA pieces; `since_epi` iterations ago this wave issued
-    // NSTORES of them.  They are younger than the piece awaited at iteration t when the epilogue ran in iterations t-W .. t-1, with
-    // W = S - 1 when the slot issue of an item-end iteration precedes its epilogue, S - 2 when it follows it (EPI_LOADS).
-    int since_epi = 1 << 20;
-    constexpr int W_OFF = EPI_LOADS ? 2 : 1;
-
-    for (int t = 0; t < nst; ++t) {
-        const int younger = (S - 2 < nst - 1 - t) ? S - 2 : nst - 1 - t;        // slots issued after slot t so far
-        wait_barrier(younger * pw + (since_epi <= S - W_OFF ? NSTORES : 0));
-        const bool tile_end = (csl + 1 == cend);
-        const bool more = t + S - 1 < nst;
-        // slot t+S-1 -> the ring position every wave finished reading before the barrier it has just passed
-        if (more && !(EPI_LOADS && tile_end)) issue();
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const unsigned char* lb = smem + rp_c;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[MT], fb[4];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(lb + rdA[ks] + i * 2048);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rdB[ks] + j * 512);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]: weights as the A operand
-            }
-        }
-        rp_c += SLOT;
-        if (rp_c == ring_bytes) rp_c = 0;
-        ++since_epi;
-        if (tile_end) {
-            epilogue();
-            since_epi = 1;
-            csl = 0;
-            cj += nslots;
-            if (t + 1 < nst) decode_c(cj);
-            if constexpr (EPI_LOADS) {
-                if (more) issue();
-            }
-        } else {
-            ++csl;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    if constexpr (STATS) {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave's LDS adds are done
-        for (int n = tid; n < p.N; n += NT) {
-            const float a = cacc[n];
-            if (a != 0.f) atomicAdd(p.colstats + n, a);
-            if constexpr (SUMSQ) {
-                const float q = cacc[ncols + n];
-                if (q != 0.f) atomicAdd(p.colstats + p.N + n, q);
-            }
-        }
-    }
-}
-
-namespace {
-
-template <typename TC, int WTM, int EPI>
-int launch_ring2(const FS2Gemm& g, int splits, hipStream_t st) {
-    typedef RG<WTM> G;
-    const int tilesM = (g.M + G::BM - 1) / G::BM, tilesN = (g.N + BN - 1) / BN;
-    const int ncols = tilesN * BN;
-    const int stats_bytes = (EPI & EPI_STATS) ? ((EPI & EPI_SUMSQ) ? 2 : 1) * ncols * 4 : 0;
-    const int bias_bytes = g.bias != nullptr ? ncols * 4 : 64;
-    int S = (LDS_MAX - stats_bytes - bias_bytes) / G::SLOT;
-    if (S > G::SMAX) S = G::SMAX;
-    {   // FS2_RING_S: ring depth override (measurements)
-        static const int s_env = getenv("FS2_RING_S") ? atoi(getenv("FS2_RING_S")) : 0;
-        if (s_env >= 2 && s_env < S) S = s_env;
-    }
-    if (S < 2) { fs2_set_error("fs2_gemm(ring): N=%d leaves no room for the slot ring", g.N); return FS2_EINVAL; }
-    const int stats_off = S * G::SLOT, bias_off = stats_off + stats_bytes;
-    const int lds = bias_off + bias_bytes;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    static bool attr_set[16] = {};            // > 64 KiB of dynamic LDS must be allowed once per kernel and device
-    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_ring_kernel<TC, WTM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_MAX) != hipSuccess) {
-            fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the ring kernel");
-            return FS2_ELAUNCH;
-        }
-        if (dev >= 0 && dev < 16) attr_set[dev] = true;
-    }
-    const long per_xcd = (long)((tilesM + 7) / 8) * tilesN * splits;
-    const int grid = 8 * (int)(per_xcd < 32 ? per_xcd : 32);
-    hipLaunchKernelGGL((fs2_gemm_ring_kernel<TC, WTM, EPI>), dim3(grid), dim3(NT), lds, st, g, tilesM, tilesN, splits, S, stats_off, bias_off);
-    FS2_CHECK_LAUNCH("fs2_gemm(ring)");
-    return FS2_OK;
-}
-
-int epi_code(const FS2Gemm& g) {
-    const int res = g.residual == nullptr ? 0 : (g.res_dtype == FS2_F32 ? EPI_RES_F32 : EPI_RES_BF16);
-    return (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? (g.colstats_mode == 0 ? EPI_STATS | EPI_SUMSQ : EPI_STATS) : 0);
-}
-
-bool epi_compiled(int epi) {
-    return epi == 0 || epi == EPI_MASK || epi == EPI_STATS || epi == (EPI_STATS | EPI_SUMSQ) || epi == (EPI_MASK | EPI_STATS) || epi == EPI_RES_F32 ||
-           epi == EPI_RES_BF16 || epi == (EPI_MASK | EPI_RES_F32);
-}
-
-template <typename TC, int WTM>
-int launch_ring1(const FS2Gemm& g, int splits, hipStream_t st) {
-    switch (epi_code(g)) {      // the combinations the model uses; anything else stays on the older kernels (checked by the caller)
-        case 0: return launch_ring2<TC, WTM, 0>(g, splits, st);
-        case EPI_MASK: return launch_ring2<TC, WTM, EPI_MASK>(g, splits, st);
-        case EPI_STATS: return launch_ring2<TC, WTM, EPI_STATS>(g, splits, st);
-        case EPI_STATS | EPI_SUMSQ:
-            if constexpr (WTM < 64) return launch_ring2<TC, WTM, EPI_STATS | EPI_SUMSQ>(g, splits, st);       // (256-row tile: 10-19 spilled registers,
-            break;                                                                                            //  fs2_gemm_ring_try picks 192 rows)
-        case EPI_MASK | EPI_STATS:
-            if constexpr (WTM < 64) return launch_ring2<TC, WTM, EPI_MASK | EPI_STATS>(g, splits, st);
-            break;
-        case EPI_RES_F32: return launch_ring2<TC, WTM, EPI_RES_F32>(g, splits, st);
-        case EPI_RES_BF16: return launch_ring2<TC, WTM, EPI_RES_BF16>(g, splits, st);
-        case EPI_MASK | EPI_RES_F32:
-            if constexpr (WTM < 64) return launch_ring2<TC, WTM, EPI_MASK | EPI_RES_F32>(g, splits, st);
-            break;
-        default: break;
-    }
-    fs2_set_error("fs2_gemm(ring): epilogue combination not compiled");
-    return FS2_EINVAL;
-}
-
-}  // namespace
+int fs2_gemm_ring_f8_launch(const FS2Gemm& g, int bm, bool f32, hipStream_t st);      // gemm_ring_f8.hip
 
 // false: not eligible / not chosen; true: the product was launched on the ring kernel and *rc holds the result.
 // Split-K form: g.split_k > 1 with g.accumulate == 2 -- C is an fp32 workspace of split_k slices, slice s (stride g.sC1 elements)
@@ -502,7 +15,13 @@ bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     int bm = e2 ? atoi(e2) : 0;
     const bool sliced = g.accumulate == 2;
     if (mode == 0 && !sliced) return false;
-    if (g.dtype != FS2_BF16 || g.a_kmajor || g.b_kmajor || g.conv > 1) return false;
+    const bool f8 = g.dtype == FS2_FP8 || g.dtype == FS2_BF8_FP8;
+    const int es = f8 ? 1 : 2, sk = 128 / es;
+    if ((g.dtype != FS2_BF16 && !f8) || g.a_kmajor || g.b_kmajor || g.conv > 1) return false;
+    if (f8) {       // FS2_GEMM_F8_RING=0: the round-2 kernel (gemm_big.hip, non-scaled fp8 MFMA) for A/B measurements
+        const int f8_env = getenv("FS2_GEMM_F8_RING") ? atoi(getenv("FS2_GEMM_F8_RING")) : 1;      // (read per call: A/B inside one process)
+        if (!f8_env || sliced || g.K % 16 != 0 || g.lda % 16 != 0 || g.ldb % 16 != 0) return false;
+    }
     if (g.accumulate != 0 && !sliced) return false;
     if ((long)g.batch1 * g.batch2 != 1) return false;
     if (!sliced && g.split_k != 1) return false;
@@ -514,7 +33,7 @@ bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     int splits = 1;
     if (sliced) {
         if (epi != 0 || g.bias || g.relu || g.c_dtype != FS2_F32 || g.alpha != 1.f) return false;
-        const int ntot = (g.conv == 1 ? g.taps : 1) * ((g.K + SK - 1) / SK);
+        const int ntot = (g.conv == 1 ? g.taps : 1) * ((g.K + sk - 1) / sk);
         splits = g.split_k < 1 ? 1 : g.split_k;
         if (splits > ntot) splits = ntot;
         const int per = (ntot + splits - 1) / splits;
@@ -527,7 +46,7 @@ bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         if (rows * g.ldc * 4 >= 0x7FFFFFF0L) return false;
         if (g.relu_mask != nullptr && rows * g.ldm * 2 >= 0x7FFFFFF0L) return false;
         if (g.residual != nullptr && rows * g.ldr * 4 >= 0x7FFFFFF0L) return false;
-        if (rows * g.lda * 2 >= 0x7FFFFFF0L || ((long)g.N + 512) * g.ldb * 2 >= 0x7FFFFFF0L) return false;
+        if (rows * g.lda * es >= 0x7FFFFFF0L || ((long)g.N + 512) * g.ldb * es >= 0x7FFFFFF0L) return false;
     }
     const long tn = (g.N + BN - 1) / BN;
     auto fill = [&](int b) {       // fraction of the 256 CUs' rounds that carry a tile
@@ -543,12 +62,14 @@ bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         if (serial_rows(128) * 1.10 < serial_rows(bm)) bm = 128;
     }
     if (bm == 256 && (epi == (EPI_STATS | EPI_SUMSQ) || epi == (EPI_MASK | EPI_RES_F32) || epi == (EPI_MASK | EPI_STATS))) bm = 192;   // (not compiled for 256 rows: spills)
-    if (mode == 1 && !sliced) {
+    const bool f32 = g.c_dtype == FS2_F32;
+    if (f8 && bm == 256) bm = 192;      // (the 32-byte fp8 fragments leave no registers for the 256-row tile's 64 accumulators)
+    if (mode == 1 && !sliced && !f8) {
         const long tiles = (long)((g.M + bm - 1) / bm) * tn;
         if (tiles < 128 || g.N < 192) return false;
     }
-    const bool f32 = g.c_dtype == FS2_F32;
     g_last_tile = bm == 128 ? 130 : bm;       // (measurement aid: 130 / 192 / 256 = rows of the 16-wave row-major tile)
+    if (f8) { *rc = fs2_gemm_ring_f8_launch(g, bm, f32, st); return true; }
     if (bm == 128) *rc = f32 ? launch_ring1<float, 32>(g, splits, st) : launch_ring1<bf16_t, 32>(g, splits, st);
     else if (bm == 192) *rc = f32 ? launch_ring1<float, 48>(g, splits, st) : launch_ring1<bf16_t, 48>(g, splits, st);
     else *rc = f32 ? launch_ring1<float, 64>(g, splits, st) : launch_ring1<bf16_t, 64>(g, splits, st);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_splitk_finish": [_P, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
     "fs2_splitk_reduce": [_P, _I, _L, _L, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
+    "fs2_quantize_fp8_batched": [_P, _I, _I, _I, _P],
     "fs2_wgrad_sliced": [ctypes.POINTER(FS2Gemm), _P, _L, _P, _P],      # returns int64
     "fs2_wgrad_reduce": [_P, _I, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
@@ -323,6 +324,43 @@ def quantize_fp8(x, bf8=False):
     return q[:n].view(x.shape), state
 
 
+class FS2QuantDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("state", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("block_begin", ctypes.c_int32), ("nblocks", ctypes.c_int32)]
+
+
+_FP8_W = {}            # data_ptr of a bf16 weight shadow -> (fp8 codes, state {amax, 1/scale}, numel): filled by fp8_quantize_shadows
+_FP8_W_TABLES = {}
+
+
+def fp8_quantize_shadows(shadows):
+    """e4m3 codes + scale of every weight shadow in `shadows` (contiguous bf16 tensors) in two launches and one memset: what
+    _fp8_operands would otherwise do with two launches per weight and product.  The Runtime calls it after every batched shadow
+    refresh; a shadow rewritten through ops.cast_permute drops out of the cache."""
+    shadows = [t for t in shadows if t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() >= 16]
+    if not shadows:
+        return
+    key = tuple(t.data_ptr() for t in shadows)
+    tab = _FP8_W_TABLES.get(key)
+    if tab is None:
+        dev = shadows[0].device
+        states = torch.zeros((len(shadows), 2), dtype=torch.float32, device=dev)
+        codes = [torch.empty(((t.numel() + 15) // 16 * 16,), dtype=torch.uint8, device=dev) for t in shadows]
+        arr = (FS2QuantDesc * len(shadows))()
+        blocks = 0
+        for i, (d, t, q) in enumerate(zip(arr, shadows, codes)):
+            d.src, d.dst, d.state, d.n = t.data_ptr(), q.data_ptr(), states[i].data_ptr(), t.numel()
+            d.block_begin, d.nblocks = blocks, max(1, -(-t.numel() // 32768))
+            blocks += d.nblocks
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(dev)
+        tab = _FP8_W_TABLES[key] = (table, len(shadows), blocks, states, codes, list(shadows))
+    table, n, blocks, states, codes, keep = tab
+    states.zero_()
+    _check(lib().fs2_quantize_fp8_batched(_p(table), n, blocks, 0, _stream()), "fs2_quantize_fp8_batched")
+    for i, t in enumerate(keep):
+        _FP8_W[t.data_ptr()] = (codes[i][:t.numel()].view(t.shape), states[i], t.numel())
+
+
 def _fp8_eligible(g, M, N, K_total_row, x, w, residual=None, relu_mask=None, stats=False):
     """products the fp8 mode takes: bf16 operands, contiguous rows with K a multiple of 16, N a multiple of 8, enough rows for
     the 16-wave kernel to make sense, and an epilogue combination that kernel is compiled for (gemm_big.hip epi_compiled)"""
@@ -339,7 +377,11 @@ def _fp8_eligible(g, M, N, K_total_row, x, w, residual=None, relu_mask=None, sta
 def _fp8_operands(g, x2, w):
     """quantise both operands of a row-major product and point the descriptor at them"""
     xq, sx = quantize_fp8(x2, bf8=FP8_MODE["backward"])
-    wq, sw = quantize_fp8(w, bf8=False)
+    hit = _FP8_W.get(w.data_ptr())
+    if hit is not None and hit[2] == w.numel() and hit[0].shape == w.shape:
+        wq, sw = hit[0], hit[1]
+    else:
+        wq, sw = quantize_fp8(w, bf8=False)
     g.A, g.B, g.lda, g.ldb = _p(xq), _p(wq), xq.stride(-2), wq.stride(-2)
     g.dtype = BF8_FP8 if FP8_MODE["backward"] else FP8
     g.scale_a, g.scale_b = _p(sx[1:]), _p(sw[1:])
@@ -578,6 +620,10 @@ def cast_permute(src, dst, mode):
     O, I = src.shape[0], src.shape[1]
     k = src.shape[2] if src.dim() == 3 else 1
     _check(lib().fs2_cast_permute(_p(_c(src)), _p(dst), O, I, k, _ld(dst), mode, _dt(dst), _stream()), "fs2_cast_permute")
+    if _FP8_W:
+        base = dst._base if dst._base is not None else dst      # (a view into a fused shadow invalidates the whole shadow)
+        _FP8_W.pop(base.data_ptr(), None)
+        _FP8_W.pop(dst.data_ptr(), None)
     return dst
 
 
