@@ -19,6 +19,7 @@ for step in "$@"; do
     bf16cfg) run bf16cfg 600 python -m pytest tests/test_model_gpu.py -q -m gpu --timeout 400 -p no:cacheprovider -k "benchmark_config" ;;
     smoke)   run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)   run bench 600 python bench.py ;;
+    bench3)  run bench3 500 python bench.py --workload cfg3 --steps 24 --warmup 8 --no-cpu-baseline ;;
     bench4)  run bench4_bf16 500 python bench.py --workload cfg4 --steps 24 --warmup 16 --no-cpu-baseline
              run bench4_fp8 500 python bench.py --workload cfg4 --fp8 --steps 24 --warmup 16 --no-cpu-baseline ;;
     benchq)  run benchq 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report.txt ;;

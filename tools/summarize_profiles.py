@@ -47,6 +47,11 @@ def variant(name):
     import re
     if "fs2_gemm_big_km_kernel" in name:
         return "bf16/km/km/129"
+    if "fs2_gemm_ws_kernel" in name:
+        return "bf16/rm/rm/131"
+    m = re.search(r"fs2_gemm_ring_kernelI(?:DF16b|f)Li(\d+)ELi\d+ELi(\d)E", name) or re.search(r"fs2_gemm_ring_kernel<[^,]*, (\d+), \d+, (\d)>", name)
+    if m:       # (ES = 2: bf16 operands; 1: the fp8 instances, not in the configs[1] step)
+        return {"32": "bf16/rm/rm/130", "48": "bf16/rm/rm/192", "64": "bf16/rm/rm/256"}.get(m.group(1)) if m.group(2) == "2" else None
     m = re.search(r"fs2_gemm_big_kernelI(?:DF16b|f)Li(\d+)E", name) or re.search(r"fs2_gemm_big_kernel<[^,]*, (\d+),", name)
     if m:
         return {"32": "bf16/rm/rm/130", "48": "bf16/rm/rm/192", "64": "bf16/rm/rm/256"}.get(m.group(1))
