@@ -133,19 +133,24 @@ def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, 
                 out_dtype or x.dtype, 1.0, colsum)
 
 
-def wgrad(dy, x, out, split=None):
+def wgrad(dy, x, out, split=None, defer=False):
+    """(defer: the product may leave partial tiles for ops.wgrad_flush(); the restatement adds at once)"""
     out += (_f(dy).t() @ _f(x)).float()
     return out
 
 
-def wgrad_batched(dy, x, outs):
+def wgrad_batched(dy, x, outs, defer=False):
     N = dy.shape[1] // len(outs)
     for j, o in enumerate(outs):
         wgrad(dy[:, j * N:(j + 1) * N], x, o)
     return outs
 
 
-def conv_wgrad(dy, x, taps, pad, out):
+def wgrad_flush():
+    """the sum of deferred weight-gradient partial tiles (ops.wgrad_flush): nothing is deferred here"""
+
+
+def conv_wgrad(dy, x, taps, pad, out, defer=False):
     B, t, N = dy.shape
     out += (_f(dy).reshape(B * t, N).t() @ _unfold(_f(x), taps, pad).reshape(B * t, -1)).float()
     return out
