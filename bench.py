@@ -91,21 +91,25 @@ class GemmTimer:
         self._orig = ops._gemm_call
         self._last_tile = ops.lib().fs2_gemm_last_tile
 
-        def record(g, s, e):
+        def work(g):
             taps = g.taps if g.conv == 1 else 1
             nb = max(1, g.batch1) * max(1, g.batch2)
             flops = 2.0 * g.M * g.N * g.K * taps * nb
             es, cs = {0: 4, 1: 2, 2: 1, 3: 1}[g.dtype], (2 if g.c_dtype == 1 else 4)
             # algorithmic bytes: every operand element once (conv: the A rows once, not once per tap)
             abytes = (es * (g.M * g.K + g.N * g.K * taps) + cs * g.M * g.N) * float(nb)
-            # block tile the launcher picked: 64 / 128 = rows of gemm.hip's tile, 130 / 192 / 256 = the 128 / 192 / 256-row tile of
-            # gemm_ring.hip (fp8: gemm_big.hip), 131 = the weights-stationary streaming kernel (gemm_ws.hip), 129 = the 16-wave
-            # weight-gradient kernel (gemm_big_km.hip)
-            tile = self._last_tile()
-            key = ({0: "f32", 1: "bf16", 2: "fp8", 3: "bf8xfp8"}[g.dtype], "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm", tile)
             flags = ("b" if g.bias else "") + ("r" if g.relu else "") + ("m" if g.relu_mask else "") + ("+" if g.residual else "") + \
                     (f"s{g.colstats_mode}" if g.colstats else "") + ("a" if g.accumulate else "") + ("f" if g.c_dtype == 0 and g.dtype == 1 else "")
             shape = (g.M, g.N, g.K, taps if g.conv == 1 else (g.batch2 if g.conv == 2 else 1), g.batch1 * g.batch2, g.split_k, flags or "-")
+            return flops, abytes, shape
+
+        def record(g, s, e):
+            flops, abytes, shape = work(g)
+            # block tile the launcher picked: 64 / 128 = rows of gemm.hip's tile, 130 / 192 / 256 = the 128 / 192 / 256-row tile of
+            # gemm_ring.hip, 131 = the weights-stationary streaming kernel (gemm_ws.hip), 129 = the 16-wave weight-gradient kernel
+            # (gemm_big_km.hip)
+            tile = self._last_tile()
+            key = ({0: "f32", 1: "bf16", 2: "fp8", 3: "bf8xfp8"}[g.dtype], "km" if g.a_kmajor else "rm", "km" if g.b_kmajor else "rm", tile)
             self.records.append((key, flops, s, e, shape, abytes))
 
         def events():
@@ -119,28 +123,47 @@ class GemmTimer:
             e.record()
             record(g, s, e)
 
-        def timed_wgrad(g, out, defer, extra_bytes=0):
-            # a weight gradient: the event pair brackets the product kernel; the reduce of its partial tiles (wgrad_reduce_k, one launch
-            # per announced parameter range: ~15 per step, listed in profiles/) runs after the pair
+        def timed_wgrad(g, out, defer, extra_bytes=0, keep=()):
+            # a weight gradient launched on its own: the event pair brackets the product kernel; the reduce of its partial tiles
+            # (wgrad_reduce_k) runs after the pair.  Deferred products are only queued here: their group launch is timed below.
+            if defer and ops._WG.group and ops._WG.enabled:
+                self._orig_wgrad(g, out, True, extra_bytes, keep)
+                return
             s, e = events()
             ops._gemm_call = self._orig
             try:
                 s.record()
-                self._orig_wgrad(g, out, True, extra_bytes)
+                self._orig_wgrad(g, out, True, extra_bytes, keep)
                 e.record()
             finally:
                 ops._gemm_call = timed
             if not defer:
                 ops.wgrad_flush()
             record(g, s, e)
+
+        def timed_group(descs, launch):
+            # the weight gradients of one layer in one launch (fs2_wgrad_grouped): one event pair, the group's FLOPs and bytes summed
+            s, e = events()
+            ops._gemm_call = self._orig          # (a group that does not run as one falls back to single launches: not recorded twice)
+            try:
+                s.record()
+                launch()
+                e.record()
+            finally:
+                ops._gemm_call = timed
+            ws = [work(d) for d in descs]
+            shape = (sum(w[2][0] * w[2][1] * w[2][4] for w in ws), len(ws), max(w[2][2] for w in ws), 0, len(ws), 0, "group")
+            self.records.append((("bf16", "km", "km", 129), sum(w[0] for w in ws), s, e, shape, sum(w[1] for w in ws)))
         self._orig_wgrad = ops._wgrad_call
         ops._gemm_call = timed
         ops._wgrad_call = timed_wgrad
+        ops._WG.on_group = timed_group
 
     def remove(self):
         from transformer_tts_amd import ops
         ops._gemm_call = self._orig
         ops._wgrad_call = self._orig_wgrad
+        ops._WG.on_group = None
 
     def summary(self):
         agg = {}
@@ -278,7 +301,7 @@ def bench_line(args, timer, dt, done, world, warm, use_graph, padded, BATCH, cpu
                             if key[3] == 131 else
                             f"{'fs2_gemm_ring_kernel' if key[0] == 'bf16' else 'fs2_gemm_big_kernel'}<{key[0]}, {128 if key[3] == 130 else key[3]}x256 tile, 16 waves, LDS-DMA> A row-major B row-major"
                             if key[3] >= 130 else
-                            f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 4 k-groups, LDS-DMA> A k-major B k-major (partial tiles of the k-split to a workspace; wgrad_reduce_k adds them, ~15 launches per step)" if key[3] == 129 else
+                            f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 4 k-groups, LDS-DMA> A k-major B k-major; a launch = the weight gradients of one layer (fs2_wgrad_grouped, up to 4 products) or one product; partial tiles of the k-split to a workspace, added by wgrad_reduce_k" if key[3] == 129 else
                             f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}"),
                     achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
                     unit="GB/s" if hbm_bound else "TFLOP/s",

@@ -1404,10 +1404,10 @@ def test_sliced_weight_gradients(ops, big_km):
 
     assert wg.enabled
     a = run(ops, lambda t: t.cuda(), True)
-    assert len(wg.parts) == 3 and wg.off > 0          # nothing has been added yet
+    assert len(wg.pending) == 3 and not wg.parts      # deferred products wait for their group launch: nothing has been added yet
     assert torch.equal(a[0].cpu(), g0[0])
     ops.wgrad_flush()
-    assert not wg.parts and wg.off == 0
+    assert not wg.parts and not wg.pending and wg.off == 0
     ref = run(P, lambda t: t.clone(), False)
     for u, v in zip(a, ref):
         close(u, v, "sliced wgrad", rtol=2e-3, atol=2e-3 * M ** 0.5)
@@ -1420,19 +1420,29 @@ def test_sliced_weight_gradients(ops, big_km):
     finally:
         wg.enabled = True
     for u, v, w in zip(a, b, c):
-        assert torch.equal(u, v)
+        close(u, v, "grouped vs immediate", rtol=1e-4, atol=1e-3)
         close(u, w, "sliced vs atomics", rtol=1e-4, atol=1e-3)
     # two deferred products into ONE gradient (the mel Linear of the model receives two gradient terms): never in one reduce launch
     acc = g0[0].cuda()
     ops.wgrad(dy.cuda(), x.cuda(), acc, defer=True)
     ops.wgrad(dy.cuda(), x.cuda(), acc, defer=True)
-    assert len(wg.parts) == 1
+    assert len(wg.pending) == 1 and not wg.parts      # the first term was launched and added before the second was queued
     ops.wgrad_flush()
     close(acc, 2 * a[0] - g0[0].cuda(), "two terms, one gradient", rtol=1e-5, atol=1e-3)
-    # a full workspace: the pending products are reduced first, the new one starts at offset 0
+    # one by one (no grouping): the same partial sums per product, other split counts -> equal up to the summation order
+    wg.group = False
+    try:
+        f = run(ops, lambda t: t.cuda(), True)
+        assert len(wg.parts) == 3 and not wg.pending
+        ops.wgrad_flush()
+    finally:
+        wg.group = True
+    for u, v in zip(a, f):
+        close(u, v, "grouped vs single launches", rtol=1e-4, atol=1e-3)
+    # a small workspace (the group still fits: its k-splits are sized for ~256 items in all)
     keep = wg.FLOATS
     try:
-        wg.FLOATS = 300 * 128 * 128        # (each of the three products alone fits, no two of them)
+        wg.FLOATS = 300 * 128 * 128
         wg.ws.clear()
         e = run(ops, lambda t: t.cuda(), True)
         ops.wgrad_flush()
@@ -1441,6 +1451,16 @@ def test_sliced_weight_gradients(ops, big_km):
         wg.ws.clear()
     for u, v in zip(a, e):
         assert torch.equal(u, v)
+    # a group with a product the grouped launch does not take (144 output tiles: balanced-stream decomposition, float-atomic flush):
+    # every product of the group is then launched on its own
+    dys, xs = rnd(8, 128, 1024, dtype=torch.bfloat16, seed=8), rnd(8, 128, 256, dtype=torch.bfloat16, seed=9)
+    o1, o2 = g0[0].cuda(), torch.zeros(1024, 9 * 256, device="cuda")
+    ops.wgrad(dy.cuda(), x.cuda(), o1, defer=True)
+    ops.conv_wgrad(dys.cuda(), xs.cuda(), 9, 4, o2, defer=True)
+    assert len(wg.pending) == 2
+    ops.wgrad_flush()
+    close(o1, a[0], "fallback: linear", rtol=1e-4, atol=1e-3)
+    close(o2, P.conv_wgrad(dys, xs, 9, 4, torch.zeros(1024, 9 * 256)), "fallback: stream-mode conv", rtol=2e-3, atol=2e-3 * 1024 ** 0.5)
 
 
 def test_torch_library_ops(ops):

@@ -24,6 +24,7 @@ BUDGET = {            # kernel-name prefix -> (source file, max VGPRs, max scrat
     # (weight-gradient kernel: 6 dwords of per-item state are parked in scratch before the stage loop and reloaded for the flush -- no
     #  scratch access inside the loop, checked in the ISA: the 6 stores precede the first v_mfma, the 6 loads follow the last)
     "fs2_gemm_big_km_kernel": ("gemm_big_km.hip", 128, 32),
+    "fs2_gemm_big_km_grouped_kernel": ("gemm_big_km.hip", 128, 32),
 }
 
 

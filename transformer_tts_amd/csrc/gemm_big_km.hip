@@ -48,9 +48,10 @@ __device__ __forceinline__ bf16x8 km_frag(const unsigned char* img, int o0, int 
 
 extern thread_local int g_last_tile;     // gemm.hip
 
-__global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
-                                                                  const int nitems, const int rot_step, const int stream_units,
-                                                                  float* __restrict__ ws) {
+// vblock / vgrid: this workgroup's index in, and the size of, the (virtual) grid of ITS product -- blockIdx / gridDim for a launch of one
+// product, a sub-range of the grid in a grouped launch (fs2_gemm_big_km_grouped_kernel: several products, one launch)
+__device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, const int tilesN, const int splits, const int nitems, const int rot_step,
+                                        const int stream_units, float* __restrict__ ws, const int vblock, const int vgrid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
     //      of units (tile-major), workgroup L takes units [L*U, (L+1)*U), U <= nstk: the tail [s0, nstk) of one tile and the head
     //      [0, r) of the next.  It runs the HEAD FIRST: at step tau every workgroup of the chip is then at reduction stage tau or
     //      tau + nstk - U -- two k-streams chip-wide, so the operand slabs are shared in L2 exactly as under a uniform split.
-    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int x = vblock & 7, slot = vblock >> 3, nslots = vgrid >> 3;
     const int per_x = (nitems + 7) >> 3;
     const int ibeg = x * per_x, iend = min(nitems, ibeg + per_x);
     const int have = stream_units > 0 ? 0 : iend - ibeg;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
         int z, sp;
         if (stream_units > 0) {
             const int pi = j == 0 ? 0 : 1;
-            z = part_tile[pi]; sp = (int)blockIdx.x;
+            z = part_tile[pi]; sp = vblock;
             it.st0 = part_s0[pi]; it.st1 = part_s1[pi];
         } else {
             z = ibeg + j;
@@ -289,6 +290,30 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm 
     }
 }
 
+__global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
+                                                                  const int nitems, const int rot_step, const int stream_units,
+                                                                  float* __restrict__ ws) {
+    km_body(p, tilesM, tilesN, splits, nitems, rot_step, stream_units, ws, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several weight-gradient products in ONE launch (the products of one layer's backward): product d owns the workgroups
+// [wg_begin[d], wg_begin[d+1]) (a multiple of 8 each: the XCD of a workgroup is blockIdx & 7 in both numberings), uniform k-split, partial
+// tiles to ws[d].  One launch ramp, one first-stage latency and one tail for the group instead of one per product, and splits sized for
+// the group's total work (~256 items in all instead of ~256 per product: a third of the partial tiles).
+constexpr int KM_GROUP = 4;
+struct KmGroupArgs {
+    FS2Gemm g[KM_GROUP];
+    float* ws[KM_GROUP];
+    int tilesM[KM_GROUP], tilesN[KM_GROUP], splits[KM_GROUP], nitems[KM_GROUP], wg_begin[KM_GROUP + 1];
+    int n, rot_step;
+};
+__global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_grouped_kernel(const KmGroupArgs a) {
+    int d = 0;
+    while (d + 1 < a.n && (int)blockIdx.x >= a.wg_begin[d + 1]) ++d;
+    km_body(a.g[d], a.tilesM[d], a.tilesN[d], a.splits[d], a.nitems[d], a.rot_step, 0, a.ws[d], (int)blockIdx.x - a.wg_begin[d],
+            a.wg_begin[d + 1] - a.wg_begin[d]);
+}
+
 namespace {
 
 struct KmPlan { int tilesM, tilesN, splits, stream_units, grid; long nitems, base; };
@@ -437,6 +462,93 @@ extern "C" int64_t fs2_wgrad_sliced(const FS2Gemm* gp, float* ws, int64_t ws_flo
     part->ws = ws; part->dst = (float*)g.C; part->ldc = g.ldc; part->sC1 = g.sC1; part->sC2 = g.sC2;
     part->M = g.M; part->N = g.N; part->tilesM = pl.tilesM; part->tilesN = pl.tilesN; part->splits = pl.splits;
     part->n2 = g.conv == 2 ? taps : nb2; part->nbatch = (int)(pl.base / ((long)pl.tilesM * pl.tilesN)); part->alpha = g.alpha; part->block_begin = 0;
+    return need;
+}
+
+namespace {
+// normalised copy of a descriptor + the preconditions of the 16-wave weight-gradient kernel (as fs2_gemm's own checks)
+bool wgrad_desc_ok(const FS2Gemm* gp, FS2Gemm& g) {
+    g = *gp;
+    if (g.split_k < 1) g.split_k = 1;
+    if (g.batch1 < 1) g.batch1 = 1;
+    if (g.batch2 < 1) g.batch2 = 1;
+    if (g.conv == 0) { g.taps = 1; g.pad = 0; if (g.seq_len <= 0) g.seq_len = 1; }
+    if (!(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C) || !fs2_aligned16(g.A) || !fs2_aligned16(g.B)) return false;
+    if (g.lda % 8 != 0 || g.ldb % 8 != 0 || g.sA1 % 8 != 0 || g.sA2 % 8 != 0 || g.sB1 % 8 != 0 || g.sB2 % 8 != 0) return false;
+    if (((g.M + 7) / 8) * 8 > g.lda || ((g.N + 7) / 8) * 8 > g.ldb) return false;
+    return true;
+}
+void fill_part(FS2WgradPart* part, const FS2Gemm& g, const float* ws, int tilesM, int tilesN, int splits, long base) {
+    const int taps = g.conv == 2 ? g.batch2 : 1, nb2 = g.conv == 2 ? 1 : g.batch2;
+    part->ws = ws; part->dst = (float*)g.C; part->ldc = g.ldc; part->sC1 = g.sC1; part->sC2 = g.sC2;
+    part->M = g.M; part->N = g.N; part->tilesM = tilesM; part->tilesN = tilesN; part->splits = splits;
+    part->n2 = g.conv == 2 ? taps : nb2; part->nbatch = (int)(base / ((long)tilesM * tilesN)); part->alpha = g.alpha; part->block_begin = 0;
+}
+}  // namespace
+
+// n (<= 4) products of fs2_wgrad_sliced's kind in ONE launch; parts[i] describes the partial tiles of product i for fs2_wgrad_reduce.
+// Returns the floats of `ws` used, 0 when the group does not run in that form (a product not eligible / balanced-stream decomposition /
+// more than 256 output tiles in all / workspace too small: the caller launches the products one by one), negative on error.
+extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int64_t ws_floats, FS2WgradPart* parts, void* stream) {
+    if (descs == nullptr || ws == nullptr || parts == nullptr || n < 1) { fs2_set_error("fs2_wgrad_grouped: null argument"); return FS2_EINVAL; }
+    if (n > KM_GROUP || !fs2_aligned16(ws)) return 0;
+    const char* e1 = getenv("FS2_GEMM_BIG_KM");
+    const int mode = e1 ? atoi(e1) : 1;
+    if (mode == 0) return 0;
+    KmGroupArgs a;
+    KmPlan pl[KM_GROUP];
+    int nstk[KM_GROUP];
+    long work = 0, tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!wgrad_desc_ok(descs + i, a.g[i]) || !km_plan(a.g[i], mode, pl[i]) || pl[i].stream_units > 0) return 0;
+        nstk[i] = (a.g[i].K + BK - 1) / BK;
+        work += pl[i].base * nstk[i];
+        tiles += pl[i].base;
+    }
+    if (tiles > 224) return 0;
+    // stages per item: the group's work over ~256 workgroups, at least 2; grown until the 8-aligned workgroup ranges fit 256
+    int per = (int)((work + 255) / 256);
+    if (per < 2) per = 2;
+    for (;; ++per) {
+        int wgs = 0;
+        for (int i = 0; i < n; ++i) {
+            int sp = (nstk[i] + per - 1) / per;
+            const int pi = (nstk[i] + sp - 1) / sp;
+            sp = (nstk[i] + pi - 1) / pi;                             // no empty split
+            a.splits[i] = sp;
+            a.nitems[i] = (int)(pl[i].base * sp);
+            a.wg_begin[i] = wgs;
+            wgs += 8 * ((a.nitems[i] + 7) / 8);
+        }
+        a.wg_begin[n] = wgs;
+        if (wgs <= 256) break;
+        if (per > (1 << 20)) return 0;
+    }
+    int64_t need = 0;
+    for (int i = 0; i < n; ++i) {
+        a.ws[i] = ws + need;
+        a.tilesM[i] = pl[i].tilesM; a.tilesN[i] = pl[i].tilesN;
+        need += (int64_t)a.nitems[i] * (TM * TN);
+    }
+    if (need > ws_floats) return 0;
+    for (int i = n; i < KM_GROUP; ++i) { a.g[i] = a.g[0]; a.ws[i] = nullptr; a.tilesM[i] = a.tilesN[i] = a.splits[i] = a.nitems[i] = 0; a.wg_begin[i + 1] = a.wg_begin[n]; }
+    a.n = n;
+    a.rot_step = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_set[16] = {};
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+            fs2_set_error("fs2_wgrad_grouped: cannot raise the dynamic LDS limit of the weight-gradient kernel");
+            return FS2_ELAUNCH;
+        }
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    g_last_tile = 129;
+    hipLaunchKernelGGL(fs2_gemm_big_km_grouped_kernel, dim3(a.wg_begin[n]), dim3(NT), SMEM, (hipStream_t)stream, a);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) { fs2_set_error("fs2_wgrad_grouped: launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
+    for (int i = 0; i < n; ++i) fill_part(parts + i, a.g[i], a.ws[i], pl[i].tilesM, pl[i].tilesN, a.splits[i], pl[i].base);
     return need;
 }
 

@@ -94,6 +94,7 @@ SIGNATURES = {
     "fs2_splitk_reduce": [_P, _I, _L, _L, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
     "fs2_quantize_fp8_batched": [_P, _I, _I, _I, _P],
     "fs2_wgrad_sliced": [ctypes.POINTER(FS2Gemm), _P, _L, _P, _P],      # returns int64
+    "fs2_wgrad_grouped": [_P, _I, _P, _L, _P, _P],      # returns int64
     "fs2_wgrad_reduce": [_P, _I, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
     "fs2_attn_probs_lds_bytes": [_I, _I],
@@ -163,6 +164,7 @@ def lib():
         l.fs2_flash_attn_keep_words.restype = ctypes.c_int64
         l.fs2_flash_attn_keep_words_rect.restype = ctypes.c_int64
         l.fs2_wgrad_sliced.restype = ctypes.c_int64
+        l.fs2_wgrad_grouped.restype = ctypes.c_int64
         l.fs2_abi_version.restype = ctypes.c_int
         _lib = l
     return _lib
@@ -445,8 +447,10 @@ class FS2WgradPart(ctypes.Structure):
 
 
 class _WgradSlices:
-    """Partial tiles of the long-reduction weight gradients (fs2_wgrad_sliced) and the products waiting for their reduce.  One
-    workspace per device, reused from offset 0 after every reduce (the stream is in order), so the same ~64 MiB stay hot."""
+    """Partial tiles of the long-reduction weight gradients (fs2_wgrad_sliced / fs2_wgrad_grouped) and the products waiting for their
+    reduce.  One workspace per device, reused from offset 0 after every reduce (the stream is in order), so the same ~64 MiB stay hot.
+    Deferred products (the models' backward, defer=True) are not even launched at once: up to four of them -- the weight gradients of
+    one layer -- go into ONE launch when wgrad_flush() is called (or a fifth arrives); their operands are kept alive until then."""
     FLOATS = 48 << 20          # 192 MiB: three products of 256 workgroups each hold 48 MiB
 
     def __init__(self):
@@ -455,21 +459,45 @@ class _WgradSlices:
         self.parts = []
         self.keep = []
         self.spans = []
+        self.pending = []      # (descriptor copy, gradient tensor, tensors to keep alive)
         self.device = None
         self.enabled = os.environ.get("FS2_WGRAD_SLICED", "1") != "0"
+        self.group = os.environ.get("FS2_WGRAD_GROUP", "1") != "0"
+        self.on_group = None   # measurement hook: callable(descriptors, launch) that must call launch() once (bench.py)
 
-    def run(self, g, out, defer, extra_bytes=0):
+    def _ws(self, device):
+        ws = self.ws.get(device)
+        if ws is None:
+            ws = self.ws[device] = torch.empty(self.FLOATS, dtype=torch.float32, device=device)
+        return ws
+
+    def run(self, g, out, defer, extra_bytes=0, keep=()):
         if not self.enabled or not out.is_cuda:
             return False
         # two products adding into the same gradient (the mel Linear sees two gradient terms) must not share a reduce launch
         lo = out.data_ptr()
         hi = lo + 4 * (sum((n - 1) * st for n, st in zip(out.shape, out.stride())) + 1) + extra_bytes
-        if self.parts and (self.device != out.device or any(lo < b and a < hi for a, b in self.spans)):
+        if (self.parts or self.pending) and (self.device != out.device or any(lo < b and a < hi for a, b in self.spans)):
             self.flush()
-        ws = self.ws.get(out.device)
-        if ws is None:
-            ws = self.ws[out.device] = torch.empty(self.FLOATS, dtype=torch.float32, device=out.device)
         self.device = out.device
+        if defer and self.group:
+            self.pending.append((FS2Gemm.from_buffer_copy(g), out, keep))
+            self.spans.append((lo, hi))
+            if len(self.pending) >= 4:
+                self._launch_pending()
+            if len(self.parts) >= 36:
+                self.flush()
+            return True
+        if not self._one(g, out):
+            return False
+        self.spans.append((lo, hi))
+        if not defer or len(self.parts) >= 36:
+            self.flush()
+        return True
+
+    def _one(self, g, out):
+        """one product with its partial tiles in the workspace; False: not in that form (the caller uses fs2_gemm)"""
+        ws = self._ws(out.device)
         part = FS2WgradPart()
         for attempt in range(2):
             used = lib().fs2_wgrad_sliced(ctypes.byref(g), ws.data_ptr() + 4 * self.off, self.FLOATS - self.off, ctypes.byref(part), _stream())
@@ -477,23 +505,55 @@ class _WgradSlices:
                 _check(int(used), "fs2_wgrad_sliced")
             if used > 0 or not self.parts or attempt == 1:
                 break
-            self.flush()           # perhaps the workspace was full: retry from offset 0
+            self._reduce()         # perhaps the workspace was full: retry from offset 0
         if used <= 0:
             return False
         self.off += int(used)
         self.parts.append(part)
         self.keep.append(out)
-        self.spans.append((lo, hi))
-        if not defer or len(self.parts) >= 40:
-            self.flush()
         return True
 
-    def flush(self):
+    def _launch_pending(self):
+        pend, self.pending = self.pending, []
+        if not pend:
+            return
+        ws = self._ws(pend[0][1].device)
+        if self.FLOATS - self.off < (20 << 20):
+            self._reduce()
+        n = len(pend)
+        descs = (FS2Gemm * n)(*[p[0] for p in pend])
+        parts = (FS2WgradPart * n)()
+        res = {}
+
+        def launch():
+            res["used"] = lib().fs2_wgrad_grouped(descs, n, ws.data_ptr() + 4 * self.off, self.FLOATS - self.off, parts, _stream())
+        if self.on_group is not None:
+            self.on_group(descs, launch)
+        else:
+            launch()
+        used = res["used"]
+        if used < 0:
+            _check(int(used), "fs2_wgrad_grouped")
+        if used > 0:
+            self.off += int(used)
+            self.parts.extend(parts[i] for i in range(n))
+            self.keep.extend(p[1] for p in pend)
+            return
+        for g, out, _ in pend:                  # not as a group: one by one (partial tiles, or fs2_gemm's own flush)
+            if not self._one(g, out):
+                _gemm_call(g)
+
+    def _reduce(self):
         if self.parts:
             arr = (FS2WgradPart * len(self.parts))(*self.parts)
             n = len(self.parts)
-            self.parts, self.keep, self.spans, self.off = [], [], [], 0
+            self.parts, self.keep, self.off = [], [], 0
             _check(lib().fs2_wgrad_reduce(arr, n, _stream()), "fs2_wgrad_reduce")
+
+    def flush(self):
+        self._launch_pending()
+        self._reduce()
+        self.spans = []
 
 
 _WG = _WgradSlices()
@@ -505,8 +565,8 @@ def wgrad_flush():
     _WG.flush()
 
 
-def _wgrad_call(g, out, defer, extra_bytes=0):
-    if not _WG.run(g, out, defer, extra_bytes):
+def _wgrad_call(g, out, defer, extra_bytes=0, keep=()):
+    if not _WG.run(g, out, defer, extra_bytes, keep):
         _gemm_call(g)
 
 
@@ -533,7 +593,7 @@ def wgrad(dy, x, out, split=None, defer=False):
     g.split_k = split or _pick_split(N, K, M, 1)
     g.accumulate = 1
     _epilogue(g, out, None, False, None, None, None, 1.0)
-    _wgrad_call(g, out, defer and split is None)
+    _wgrad_call(g, out, defer and split is None, keep=(dy, x))
     return out
 
 
@@ -560,7 +620,7 @@ def wgrad_batched(dy, x, outs, defer=False):
     g.split_k = _pick_split(N, K, M, nb)
     g.accumulate = 1
     _epilogue(g, outs[0], None, False, None, None, None, 1.0)
-    _wgrad_call(g, outs[0], defer, step * (nb - 1))
+    _wgrad_call(g, outs[0], defer, step * (nb - 1), keep=(dy, x))
     return outs
 
 
@@ -580,7 +640,7 @@ def conv_wgrad(dy, x, taps, pad, out, defer=False):
     g.split_k = _pick_split(N, C, B * t, taps)
     g.accumulate = 1
     _epilogue(g, out, None, False, None, None, None, 1.0)
-    _wgrad_call(g, out, defer)
+    _wgrad_call(g, out, defer, keep=(dy, x))
     return out
 
 
