@@ -147,11 +147,13 @@ class GemmTimer:
             ops._gemm_call = self._orig          # (a group that does not run as one falls back to single launches: not recorded twice)
             try:
                 s.record()
-                launch()
+                taken = launch()
                 e.record()
             finally:
                 ops._gemm_call = timed
-            ws = [work(d) for d in descs]
+            ws = [work(d) for d, t in zip(descs, taken) if t]
+            if not ws:
+                return
             shape = (sum(w[2][0] * w[2][1] * w[2][4] for w in ws), len(ws), max(w[2][2] for w in ws), 0, len(ws), 0, "group")
             self.records.append((("bf16", "km", "km", 129), sum(w[0] for w in ws), s, e, shape, sum(w[1] for w in ws)))
         self._orig_wgrad = ops._wgrad_call

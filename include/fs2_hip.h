@@ -130,7 +130,8 @@ typedef struct FS2WgradPart {
 int64_t fs2_wgrad_sliced(const FS2Gemm* g, float* ws, int64_t ws_floats, FS2WgradPart* part, void* stream);
 /* n <= 4 such products in ONE launch (the weight gradients of one layer's backward, launched when the last of them is known): one
  * launch ramp / first-stage latency / tail for the group, k-splits sized for the group's total work.  parts[i] describes product i.
- * Returns the floats of `ws` used, or 0 when the group does not run in that form (the caller launches the products one by one). */
+ * Products the group does not take are marked parts[i].splits == 0 (the caller launches those on their own).  Returns the floats of
+ * `ws` used, or 0 when nothing was launched. */
 int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int64_t ws_floats, FS2WgradPart* parts, void* stream);
 int fs2_wgrad_reduce(const FS2WgradPart* parts, int n, void* stream);
 

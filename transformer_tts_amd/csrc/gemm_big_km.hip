@@ -487,8 +487,9 @@ void fill_part(FS2WgradPart* part, const FS2Gemm& g, const float* ws, int tilesM
 }  // namespace
 
 // n (<= 4) products of fs2_wgrad_sliced's kind in ONE launch; parts[i] describes the partial tiles of product i for fs2_wgrad_reduce.
-// Returns the floats of `ws` used, 0 when the group does not run in that form (a product not eligible / balanced-stream decomposition /
-// more than 256 output tiles in all / workspace too small: the caller launches the products one by one), negative on error.
+// Products the grouped launch does not take (not eligible, balanced-stream decomposition, the group already holds 224 output tiles) are
+// left out: parts[i].splits == 0 marks them and the caller launches those on their own.  Returns the floats of `ws` used, 0 when
+// nothing was launched (no product taken / workspace too small), negative on error.
 extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int64_t ws_floats, FS2WgradPart* parts, void* stream) {
     if (descs == nullptr || ws == nullptr || parts == nullptr || n < 1) { fs2_set_error("fs2_wgrad_grouped: null argument"); return FS2_EINVAL; }
     if (n > KM_GROUP || !fs2_aligned16(ws)) return 0;
@@ -497,21 +498,25 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
     if (mode == 0) return 0;
     KmGroupArgs a;
     KmPlan pl[KM_GROUP];
-    int nstk[KM_GROUP];
+    int nstk[KM_GROUP], src[KM_GROUP];       // src[k]: index in descs of the k-th product the group takes
     long work = 0, tiles = 0;
+    int m = 0;
     for (int i = 0; i < n; ++i) {
-        if (!wgrad_desc_ok(descs + i, a.g[i]) || !km_plan(a.g[i], mode, pl[i]) || pl[i].stream_units > 0) return 0;
-        nstk[i] = (a.g[i].K + BK - 1) / BK;
-        work += pl[i].base * nstk[i];
-        tiles += pl[i].base;
+        parts[i].splits = 0;                 // "not taken" until proven otherwise
+        if (!wgrad_desc_ok(descs + i, a.g[m]) || !km_plan(a.g[m], mode, pl[m]) || pl[m].stream_units > 0) continue;
+        if (tiles + pl[m].base > 224) continue;
+        nstk[m] = (a.g[m].K + BK - 1) / BK;
+        work += pl[m].base * nstk[m];
+        tiles += pl[m].base;
+        src[m++] = i;
     }
-    if (tiles > 224) return 0;
+    if (m == 0) return 0;
     // stages per item: the group's work over ~256 workgroups, at least 2; grown until the 8-aligned workgroup ranges fit 256
     int per = (int)((work + 255) / 256);
     if (per < 2) per = 2;
     for (;; ++per) {
         int wgs = 0;
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < m; ++i) {
             int sp = (nstk[i] + per - 1) / per;
             const int pi = (nstk[i] + sp - 1) / sp;
             sp = (nstk[i] + pi - 1) / pi;                             // no empty split
@@ -520,19 +525,19 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
             a.wg_begin[i] = wgs;
             wgs += 8 * ((a.nitems[i] + 7) / 8);
         }
-        a.wg_begin[n] = wgs;
+        a.wg_begin[m] = wgs;
         if (wgs <= 256) break;
         if (per > (1 << 20)) return 0;
     }
     int64_t need = 0;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < m; ++i) {
         a.ws[i] = ws + need;
         a.tilesM[i] = pl[i].tilesM; a.tilesN[i] = pl[i].tilesN;
         need += (int64_t)a.nitems[i] * (TM * TN);
     }
     if (need > ws_floats) return 0;
-    for (int i = n; i < KM_GROUP; ++i) { a.g[i] = a.g[0]; a.ws[i] = nullptr; a.tilesM[i] = a.tilesN[i] = a.splits[i] = a.nitems[i] = 0; a.wg_begin[i + 1] = a.wg_begin[n]; }
-    a.n = n;
+    for (int i = m; i < KM_GROUP; ++i) { a.g[i] = a.g[0]; a.ws[i] = nullptr; a.tilesM[i] = a.tilesN[i] = a.splits[i] = a.nitems[i] = 0; a.wg_begin[i + 1] = a.wg_begin[m]; }
+    a.n = m;
     a.rot_step = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -545,10 +550,10 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     g_last_tile = 129;
-    hipLaunchKernelGGL(fs2_gemm_big_km_grouped_kernel, dim3(a.wg_begin[n]), dim3(NT), SMEM, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(fs2_gemm_big_km_grouped_kernel, dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { fs2_set_error("fs2_wgrad_grouped: launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
-    for (int i = 0; i < n; ++i) fill_part(parts + i, a.g[i], a.ws[i], pl[i].tilesM, pl[i].tilesN, a.splits[i], pl[i].base);
+    for (int i = 0; i < m; ++i) fill_part(parts + src[i], a.g[i], a.ws[i], pl[i].tilesM, pl[i].tilesN, a.splits[i], pl[i].base);
     return need;
 }
 

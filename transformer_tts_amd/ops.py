@@ -527,6 +527,7 @@ class _WgradSlices:
 
         def launch():
             res["used"] = lib().fs2_wgrad_grouped(descs, n, ws.data_ptr() + 4 * self.off, self.FLOATS - self.off, parts, _stream())
+            return [res["used"] > 0 and parts[i].splits > 0 for i in range(n)]      # the products the launch took
         if self.on_group is not None:
             self.on_group(descs, launch)
         else:
@@ -534,13 +535,13 @@ class _WgradSlices:
         used = res["used"]
         if used < 0:
             _check(int(used), "fs2_wgrad_grouped")
+        taken = [used > 0 and parts[i].splits > 0 for i in range(n)]
         if used > 0:
             self.off += int(used)
-            self.parts.extend(parts[i] for i in range(n))
-            self.keep.extend(p[1] for p in pend)
-            return
-        for g, out, _ in pend:                  # not as a group: one by one (partial tiles, or fs2_gemm's own flush)
-            if not self._one(g, out):
+            self.parts.extend(parts[i] for i in range(n) if taken[i])
+            self.keep.extend(p[1] for i, p in enumerate(pend) if taken[i])
+        for i, (g, out, _) in enumerate(pend):  # not in the group: on its own (partial tiles, or fs2_gemm's own flush)
+            if not taken[i] and not self._one(g, out):
                 _gemm_call(g)
 
     def _reduce(self):
