@@ -91,6 +91,16 @@ typedef struct FS2Gemm {
      * DEVICE scalars multiplied into alpha -- the de-quantisation factors fs2_quantize_fp8 wrote for A and B (NULL = 1). */
     const float* scale_a;
     const float* scale_b;
+    /* fp8 copy of the OUTPUT written by the epilogue (the 16-wave ring kernel with fp8 operands and a bf16 C; otherwise must be NULL):
+     * q8[m][n] (ld = ldc, one byte per element) = fp8(C[m][n] as stored * scale), scale = the power of two fs2_quantize_fp8 would derive
+     * from q8_prev[0] -- a SPECULATION: the amax this tensor had one training step ago.  The epilogue also reduces max |C| into
+     * q8_state[0] (zeroed by the caller).  fs2_quantize_fp8_repair then writes q8_state[1] and re-quantises from C only if the true amax
+     * asks for another scale: the codes equal fs2_amax + fs2_quantize_fp8 of C, always, without a pass over C in the common case. */
+    void* q8;
+    float* q8_state;
+    const float* q8_prev;
+    int32_t q8_bf8;      /* 0: e4m3, 1: e5m2 */
+    int32_t q8_reserved;
 } FS2Gemm;
 
 int fs2_gemm(const FS2Gemm* g, void* stream);
@@ -166,6 +176,8 @@ int fs2_colsum_segmented(const void* x, int dtype, int64_t M, int N, int64_t ldx
  *                      factor fs2_gemm takes as FS2Gemm.scale_a / scale_b.  n is rounded up to 16 internally; dst must hold it. */
 int fs2_amax(const void* src, int src_dtype, int64_t n, float* state, void* stream);
 int fs2_quantize_fp8(const void* src, int src_dtype, void* dst, int bf8, int64_t n, float* state, void* stream);
+/* Second half of FS2Gemm.q8: state[1] = 1/scale(state[0]); if scale(state[0]) != scale(prev[0]) quantise src again into dst. */
+int fs2_quantize_fp8_repair(const void* src, int src_dtype, void* dst, int bf8, int64_t n, float* state, const float* prev, void* stream);
 /* The same for many bf16 tensors in two launches (the weight shadows of a model, once per optimizer step).  `table` lives in DEVICE
  * memory; entry i covers blocks [block_begin, block_begin + nblocks) of the grid, nblocks = ceil(n / 32768) (at least 1); the caller
  * zeroes every state[0] beforehand; dst holds n rounded up to 16 bytes. */

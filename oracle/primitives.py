@@ -105,7 +105,7 @@ def _epi(v, bias, relu, residual, relu_mask, colstats, out, out_dtype, alpha=1.0
     return r
 
 
-def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, out_dtype=None,
+def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, out_dtype=None, q8_out=False,
            alpha=1.0, colsum=None):
     """nn.Linear: Models/modules.py:32-41,49-51,68; Models/encoder.py:57; Models/postnets.py:43,67."""
     return _epi(_f(x) @ _f(w).t(), bias, relu, residual, relu_mask, colstats, out, out_dtype or x.dtype, alpha, colsum)
@@ -125,7 +125,7 @@ def _unfold(x, taps, pad):
     return torch.cat(cols, dim=2)
 
 
-def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None,
+def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, q8_out=False,
          out_dtype=None, colsum=None):
     """nn.Conv1d over time (Models/modules.py:76-84; varianceadaptor.py:203-209; postnets.py:28-39,71-75)
     in channels-last form; w is the kernel-layout shadow [n][j*C + c] = weight[n][c][j]."""

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/fs2_hip.h but not exported by {path}"
     table = set(ops.SIGNATURES) | {"fs2_last_error", "fs2_abi_version"}
     assert table == set(names), f"ops.SIGNATURES out of sync with the header: {table ^ set(names)}"
-    assert ops.lib().fs2_abi_version() == 8
+    assert ops.lib().fs2_abi_version() == 9
 
 
 def test_argument_errors_are_reported_not_crashed():

@@ -1288,6 +1288,42 @@ def test_fp8_quantisation_is_bit_exact(ops, bf8, src_dtype):
         assert torch.equal(q.cpu(), qr), f"{int((q.cpu() != qr).sum())} of {n} codes differ (bf8={bf8}, scale={scale})"
 
 
+@pytest.mark.parametrize("backward", [False, True])
+def test_fp8_copy_written_by_the_gemm_epilogue_is_current_scaling(ops, backward):
+    """FS2Gemm.q8: the fp8 ring kernel writes the fp8 copy of its bf16 output with the scale of LAST step's amax and reduces the new
+    amax; fs2_quantize_fp8_repair re-quantises only when the binade moved.  Codes and {amax, 1/scale} must equal fs2_amax +
+    fs2_quantize_fp8 of the output in every case: first step (no history), history that matches, history off by 2^7 either way."""
+    M, N, K = 3000, 1024, 512
+    x = rnd(M, K, dtype=torch.bfloat16, seed=1).cuda()
+    w = (rnd(N, K, dtype=torch.bfloat16, seed=2) * K ** -0.5).cuda()
+    bias, mask, cs = rnd(N, seed=3).cuda(), rnd(M, N, dtype=torch.bfloat16, seed=4).cuda(), torch.zeros(N, device="cuda")
+    ops._FP8_STATES["buf"] = ops._FP8_STATES["prev"] = None
+    ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = True, backward
+    try:
+        for step, factor in enumerate((1.0, 1.0, 1.0, 128.0, 1.0 / 128.0)):
+            ops.fp8_begin_step(torch.device("cuda"))
+            xs = (x * factor).to(torch.bfloat16)
+            if backward:
+                out = ops.linear(xs, w, relu_mask=mask, colsum=cs.zero_(), q8_out=True)
+            else:
+                out = ops.linear(xs, w, bias, relu=True, q8_out=True)
+            assert ops.lib().fs2_gemm_last_tile() == 130
+            q, st, bf8 = out._fs2_q8
+            assert bf8 == backward
+            q_ref, st_ref = ops.quantize_fp8(out, backward)
+            assert torch.equal(st, st_ref), (step, st, st_ref)
+            assert torch.equal(q, q_ref), (step, int((q != q_ref).sum()))
+            # the consumer picks the copy up: same result as quantising the activation itself
+            w2 = (rnd(256, N, dtype=torch.bfloat16, seed=5) * N ** -0.5).cuda()
+            y = ops.linear(out, w2)
+            del out._fs2_q8
+            y_ref = ops.linear(out, w2)
+            assert torch.equal(y, y_ref)
+    finally:
+        ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = False, False
+        ops._FP8_STATES["buf"] = ops._FP8_STATES["prev"] = None
+
+
 def test_fp8_batched_weight_quantisation_equals_the_per_tensor_path(ops):
     """fs2_quantize_fp8_batched (all weight shadows of a model in two launches) against fs2_amax + fs2_quantize_fp8 per tensor: the same
     codes and the same {amax, 1/scale}, for sizes with ragged tails, a zero tensor and more than one 32768-element chunk"""

@@ -457,6 +457,41 @@ def test_config4_model_fp8_vs_oracle():
     assert float((res[True][3] - res[False][3]).abs().mean()) > 1e-4, "fp8 mode produced the bf16 result: it did not run"
 
 
+def test_fp8_copies_from_the_epilogues_change_nothing():
+    """the FFN activations whose fp8 copy is written by the producing GEMM's epilogue (FS2Gemm.q8, speculative scale + repair) against
+    the two-pass quantisation of the same tensors over three steps (history: none, then set).  The codes are bit-identical
+    (tests/test_kernels_gpu.py checks that on the kernels); here the whole step agrees to the noise of its float-atomic reductions
+    (BatchNorm statistics, bias sums), orders of magnitude below the fp8 rounding itself"""
+    from transformer_tts_amd import ops, synthetic
+    from transformer_tts_amd.train_fastspeech2 import build_model
+    batch = batch_to(synthetic.make_batch(92, 12, l_range=(40, 81), dur_range=(2, 7), vocab=152), "cuda")
+    res = {}
+    for fused in (True, False):
+        ops.FP8_FUSED_OUT = fused
+        ops._FP8_STATES["buf"] = ops._FP8_STATES["prev"] = None
+        try:
+            hp = _config4_hp(2, 12, True)
+            torch.manual_seed(7)
+            model = build_model(hp)
+            model.postnet.dropout = 0.0
+            model = model.cuda().train()
+            runs = []
+            for step in range(3):
+                for p in model.parameters():
+                    p.grad = None
+                out, total, parts = fwd_bwd(model, hp, batch)
+                runs.append((total.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+            res[fused] = runs
+        finally:
+            ops.FP8_MODE["on"] = False
+            ops.FP8_FUSED_OUT = True
+    for (la, ga), (lb, gb) in zip(res[True], res[False]):
+        assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)
+        num = sum(float((ga[k].double() - gb[k].double()).pow(2).sum()) for k in ga)
+        den = sum(float(gb[k].double().pow(2).sum()) for k in ga)
+        assert (num / den) ** 0.5 <= 1e-3, (num / den) ** 0.5
+
+
 def test_config4_full_size_fp8_step_properties():
     """BASELINE.json configs[4] at full size (d_model 512, 6+6 layers, batch 64, reference dropout): one fp8 train step and
     one bf16 train step from the same weights -- finite losses that agree within the fp8 tolerance, parameters that moved"""

@@ -363,7 +363,7 @@ class EncoderStackFunction(torch.autograd.Function):
                                             layer.site_res1)                                    # layers.py:33-35
             ff = layer.ff
             kk = ff.f_1.weight.shape[2]
-            f1 = ops.conv(h2, rt.w_fwd(ff.f_1.weight), kk, kk // 2, ff.f_1.bias.detach(), relu=True)   # modules.py:83
+            f1 = ops.conv(h2, rt.w_fwd(ff.f_1.weight), kk, kk // 2, ff.f_1.bias.detach(), relu=True, q8_out=rt.fp8)   # modules.py:83
             f2 = ops.conv(f1, rt.w_fwd(ff.f_2.weight), kk, kk // 2, ff.f_2.bias.detach())              # modules.py:84
             lnf = ff.layer_norm
             nn_ = enc.layers[i + 1].norm_1 if i + 1 < N else enc.norm
@@ -416,7 +416,7 @@ class EncoderStackFunction(torch.autograd.Function):
             kk = ff.f_1.weight.shape[2]
             pad = kk // 2
             _conv_wgrad(rt, g, L["f1"], ff.f_2, pad, bias_done=True)
-            dz1 = ops.conv(g, rt.w_dgrad(ff.f_2.weight), kk, kk - 1 - pad, relu_mask=L["f1"], colsum=grad_of(ff.f_1.bias))
+            dz1 = ops.conv(g, rt.w_dgrad(ff.f_2.weight), kk, kk - 1 - pad, relu_mask=L["f1"], colsum=grad_of(ff.f_1.bias), q8_out=rt.fp8)
             _conv_wgrad(rt, dz1, L["h2"], ff.f_1, pad, bias_done=True)
             dh2 = ops.conv(dz1, rt.w_dgrad(ff.f_1.weight), kk, kk - 1 - pad, residual=g)
             n2 = layer.norm_2

@@ -49,24 +49,22 @@ __global__ __launch_bounds__(TPB) void amax_k(const T* __restrict__ x, int64_t n
     }
 }
 
-// scale = 2^k with amax * 2^k < 2^LOG2MAX: k = LOG2MAX - 1 - exponent(amax)   (amax in [2^e, 2^(e+1)))
-__device__ __forceinline__ float pow2_scale(float amax, int log2max, float* inv) {
-    if (!(amax > 0.f) || !(amax < 3.0e38f)) { *inv = 1.f; return 1.f; }
-    int e = (int)((__float_as_uint(amax) >> 23) & 0xFFu) - 127;
-    if (e < -126) e = -126;                       // subnormal amax
-    int k = log2max - 1 - e;
-    k = k > 126 ? 126 : (k < -126 ? -126 : k);
-    *inv = __uint_as_float((unsigned)(127 - k) << 23);
-    return __uint_as_float((unsigned)(127 + k) << 23);
-}
+__device__ __forceinline__ float pow2_scale(float amax, int log2max, float* inv) { return fs2_pow2_scale(amax, log2max, inv); }
 
-template <typename T, bool BF8>
-__global__ __launch_bounds__(TPB) void quant_k(const T* __restrict__ x, unsigned* __restrict__ dst, int64_t n, float* __restrict__ state) {
+// REPAIR: the codes in dst were written by a producer (FS2Gemm.q8) with the scale of prev[0]; nothing to do but 1/scale when the true
+// amax state[0] gives the same scale
+template <typename T, bool BF8, bool REPAIR = false>
+__global__ __launch_bounds__(TPB) void quant_k(const T* __restrict__ x, unsigned* __restrict__ dst, int64_t n, float* __restrict__ state,
+                                               const float* __restrict__ prev = nullptr) {
     constexpr int LOG2MAX = BF8 ? 15 : 8;        // e5m2: max 57344 >= 2^15; e4m3: max 448 >= 2^8
     constexpr float FMAX = BF8 ? 57344.f : 448.f;
     float inv;
     const float scale = pow2_scale(state[0], LOG2MAX, &inv);
     if (blockIdx.x == 0 && threadIdx.x == 0) state[1] = inv;
+    if constexpr (REPAIR) {
+        float inv_spec;
+        if (pow2_scale(prev[0], LOG2MAX, &inv_spec) == scale) return;
+    }
     // 16 source elements -> one 16-byte store of fp8 codes per iteration (two or four 16-byte loads)
     constexpr int VN = Vec16<T>::N;
     const int64_t n16 = n >> 4;
@@ -202,13 +200,24 @@ extern "C" int fs2_quantize_fp8(const void* src, int src_dtype, void* dst, int b
     FS2_REQUIRE(fs2_aligned16(src) && fs2_aligned16(dst), "fs2_quantize_fp8: src and dst must be 16-byte aligned");
     dim3 grid(flat_grid((n + 15) >> 4)), block(TPB);
     if (src_dtype == FS2_F32) {
-        if (bf8) hipLaunchKernelGGL((quant_k<float, true>), grid, block, 0, st, (const float*)src, (unsigned*)dst, n, state);
-        else hipLaunchKernelGGL((quant_k<float, false>), grid, block, 0, st, (const float*)src, (unsigned*)dst, n, state);
+        if (bf8) hipLaunchKernelGGL((quant_k<float, true>), grid, block, 0, st, (const float*)src, (unsigned*)dst, n, state, (const float*)nullptr);
+        else hipLaunchKernelGGL((quant_k<float, false>), grid, block, 0, st, (const float*)src, (unsigned*)dst, n, state, (const float*)nullptr);
     } else {
-        if (bf8) hipLaunchKernelGGL((quant_k<bf16_t, true>), grid, block, 0, st, (const bf16_t*)src, (unsigned*)dst, n, state);
-        else hipLaunchKernelGGL((quant_k<bf16_t, false>), grid, block, 0, st, (const bf16_t*)src, (unsigned*)dst, n, state);
+        if (bf8) hipLaunchKernelGGL((quant_k<bf16_t, true>), grid, block, 0, st, (const bf16_t*)src, (unsigned*)dst, n, state, (const float*)nullptr);
+        else hipLaunchKernelGGL((quant_k<bf16_t, false>), grid, block, 0, st, (const bf16_t*)src, (unsigned*)dst, n, state, (const float*)nullptr);
     }
     FS2_CHECK_LAUNCH("fs2_quantize_fp8");
+    return FS2_OK;
+}
+
+extern "C" int fs2_quantize_fp8_repair(const void* src, int src_dtype, void* dst, int bf8, int64_t n, float* state, const float* prev, void* stream) {
+    FS2_REQUIRE(src_dtype == FS2_BF16, "fs2_quantize_fp8_repair: bf16 sources only (dtype %d)", src_dtype);
+    FS2_REQUIRE(n > 0 && src && dst && state && prev, "fs2_quantize_fp8_repair: bad arguments");
+    FS2_REQUIRE(fs2_aligned16(src) && fs2_aligned16(dst), "fs2_quantize_fp8_repair: src and dst must be 16-byte aligned");
+    dim3 grid(flat_grid((n + 15) >> 4, 512)), block(TPB);      // (a no-op in the common case: few workgroups)
+    if (bf8) hipLaunchKernelGGL((quant_k<bf16_t, true, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)src, (unsigned*)dst, n, state, prev);
+    else hipLaunchKernelGGL((quant_k<bf16_t, false, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)src, (unsigned*)dst, n, state, prev);
+    FS2_CHECK_LAUNCH("fs2_quantize_fp8_repair");
     return FS2_OK;
 }
 

@@ -91,6 +91,18 @@ template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
 __device__ __forceinline__ float lane_value(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
+// fp8 per-tensor scale: 2^k with amax * 2^k < 2^LOG2MAX (k = LOG2MAX - 1 - exponent(amax)); LOG2MAX = 8 for e4m3 (max 448), 15 for
+// e5m2 (max 57344); *inv = 2^-k
+__device__ __forceinline__ float fs2_pow2_scale(float amax, int log2max, float* inv) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) { *inv = 1.f; return 1.f; }
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xFFu) - 127;
+    if (e < -126) e = -126;                       // subnormal amax
+    int k = log2max - 1 - e;
+    k = k > 126 ? 126 : (k < -126 ? -126 : k);
+    *inv = __uint_as_float((unsigned)(127 - k) << 23);
+    return __uint_as_float((unsigned)(127 + k) << 23);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]

@@ -632,12 +632,14 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
         if (g.bias) FS2_REQUIRE(fs2_aligned16(g.bias), "fs2_gemm: bias must be 16-byte aligned");
         int rc = FS2_OK;
         if (fs2_gemm_ring_try(g, (hipStream_t)stream, &rc)) return rc;      // ring kernel, block-scaled 128-deep fp8 MFMA (g_last_tile 130 / 192)
+        FS2_REQUIRE(g.q8 == nullptr, "fs2_gemm: FS2Gemm.q8 needs the fp8 ring kernel (bf16 C, contiguous rows, N %% 16 == 0)");
         if (fs2_gemm_big_try(g, (hipStream_t)stream, &rc)) return rc;       // round-2 kernel, non-scaled fp8 MFMA (FS2_GEMM_F8_RING=0)
         fs2_set_error("fs2_gemm: fp8 operands need a row-major un-batched product with K, lda, ldb multiples of 16, no accumulate / "
                       "split-K, a compiled epilogue combination and 32-bit addressable operands");
         return FS2_EINVAL;
     }
     FS2_REQUIRE(g.dtype == FS2_F32 || g.dtype == FS2_BF16, "fs2_gemm: bad dtype %d", g.dtype);
+    FS2_REQUIRE(g.q8 == nullptr, "fs2_gemm: FS2Gemm.q8 (fp8 copy of C) exists for fp8 operands only");
     FS2_REQUIRE(g.c_dtype == FS2_F32 || g.c_dtype == g.dtype, "fs2_gemm: c_dtype must be f32 or the operand dtype");
     FS2_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "fs2_gemm: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
     if (g.split_k < 1) g.split_k = 1;

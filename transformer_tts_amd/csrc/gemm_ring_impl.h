@@ -36,7 +36,7 @@ constexpr unsigned OOB = 0x80000000u;
 constexpr int NW = 16, NT = 1024, BN = 256;               // waves, threads, tile columns (k per slot: 128 B = 64 bf16 or 128 fp8)
 constexpr int LDS_MAX = 160 * 1024;
 
-constexpr int EPI_MASK = 1, EPI_RES_F32 = 2, EPI_RES_BF16 = 4, EPI_STATS = 8, EPI_SUMSQ = 16;
+constexpr int EPI_MASK = 1, EPI_RES_F32 = 2, EPI_RES_BF16 = 4, EPI_STATS = 8, EPI_SUMSQ = 16, EPI_Q8 = 32;
 
 template <int WTM> struct RG {
     static constexpr int MT = WTM / 16, BM = 4 * WTM;
@@ -78,8 +78,9 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     constexpr int ESC = (int)sizeof(TC);
     constexpr bool HAS_MASK = (EPI & EPI_MASK) != 0, RES_F32 = (EPI & EPI_RES_F32) != 0, RES_BF16 = (EPI & EPI_RES_BF16) != 0;
     constexpr bool STATS = (EPI & EPI_STATS) != 0, SUMSQ = (EPI & EPI_SUMSQ) != 0;
+    constexpr bool Q8 = (EPI & EPI_Q8) != 0;          // the epilogue also writes an fp8 copy of C (FS2Gemm.q8; bf16 C only)
     constexpr bool EPI_LOADS = HAS_MASK || RES_F32 || RES_BF16;      // the epilogue issues vector-memory loads of its own
-    constexpr int NSTORES = MT * (ESC == 4 ? 4 : 2);                 // 16-byte stores of one epilogue, per lane
+    constexpr int NSTORES = MT * ((ESC == 4 ? 4 : 2) + (Q8 ? 1 : 0));  // 16-byte stores of one epilogue, per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,6 +234,16 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)p.relu_mask, 0, p.relu_mask ? 0x7FFFFFF0 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? 0x7FFFFFF0 : 0, 0x00020000);
+    // fp8 copy of C: speculative scale (the amax of this tensor one step ago), amax of the values as stored for the repair launch
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(Q8 ? p.q8 : nullptr, 0, Q8 ? 0x7FFFFFF0 : 0, 0x00020000);
+    typedef __attribute__((ext_vector_type(2))) unsigned short us16x2;
+    float qscale = 1.f, qfmax = 448.f;
+    us16x2 qmax_pk = {0, 0};
+    if constexpr (Q8) {
+        float inv;
+        qscale = fs2_pow2_scale(p.q8_prev[0], p.q8_bf8 ? 15 : 8, &inv);
+        qfmax = p.q8_bf8 ? 57344.f : 448.f;
+    }
 
     // ---- epilogue of the item (cm0, cn0, csp): lane holds C[cm0 + wr*WTM + it*16 + i16][cn0 + wc*64 + 16g + 4jt + r] in acc[it][jt][r]
     auto epilogue = [&]() __attribute__((always_inline)) {
@@ -315,16 +326,42 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4 * j]), __float_as_uint(v[4 * j + 1]), __float_as_uint(v[4 * j + 2]), __float_as_uint(v[4 * j + 3])},
                                                            rsC, (j < 2 ? oka : okb) ? offC + so + 16 * j : OOB, 0, 0);
             } else {
+                u32x4 q8w;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     union { bf16x8 h; u32x4 u; } o;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) o.h[c] = (bf16_t)v[8 * j + c];
                     __builtin_amdgcn_raw_buffer_store_b128(o.u, rsC, (j == 0 ? oka : okb) ? offC + so + 16 * j : OOB, 0, 0);
-                    if constexpr (STATS) {      // statistics of the values as stored
+                    if constexpr (STATS || Q8) {      // statistics / fp8 codes of the values as stored
 #pragma unroll
                         for (int c = 0; c < 8; ++c) v[8 * j + c] = (float)o.h[c];
                     }
+                    if constexpr (Q8) {
+                        // amax of the stored bf16 values on their packed bit patterns (non-negative bf16 order like their 15-bit codes)
+                        if (j == 0 ? oka : okb) {
+#pragma unroll
+                            for (int k4 = 0; k4 < 4; ++k4) {
+                                union { unsigned u; us16x2 h; } m;
+                                m.u = o.u[k4] & 0x7FFF7FFFu;
+                                qmax_pk = __builtin_elementwise_max(qmax_pk, m.h);
+                            }
+                        }
+                        int w0 = 0, w1 = 0;
+                        auto cv = [&](int c) { return fminf(fmaxf(v[8 * j + c] * qscale, -qfmax), qfmax); };
+                        if (p.q8_bf8) {
+                            w0 = __builtin_amdgcn_cvt_pk_bf8_f32(cv(0), cv(1), w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(cv(2), cv(3), w0, true);
+                            w1 = __builtin_amdgcn_cvt_pk_bf8_f32(cv(4), cv(5), w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(cv(6), cv(7), w1, true);
+                        } else {
+                            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cv(0), cv(1), w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(cv(2), cv(3), w0, true);
+                            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cv(4), cv(5), w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(cv(6), cv(7), w1, true);
+                        }
+                        q8w[2 * j] = (unsigned)w0; q8w[2 * j + 1] = (unsigned)w1;
+                    }
+                }
+                if constexpr (Q8) {       // 16 codes = the lane's 16 consecutive columns of this row (N is a multiple of 16 here)
+                    const unsigned offQ = (unsigned)((mb + 16 * it) * (int)p.ldc + nb);
+                    __builtin_amdgcn_raw_buffer_store_b128(q8w, rsQ, oka ? offQ : OOB, 0, 0);
                 }
             }
             if constexpr (STATS) {
@@ -441,6 +478,21 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (Q8) {       // one atomic per workgroup on the tensor's amax word (16 floats of LDS behind the bias area)
+        float* q8wm = reinterpret_cast<float*>(smem + bias_off + (has_bias ? ncols * 4 : 64));
+        const unsigned short mb16 = qmax_pk[0] > qmax_pk[1] ? qmax_pk[0] : qmax_pk[1];
+        float qamax = __uint_as_float((unsigned)mb16 << 16);
+        if (!(qamax == qamax)) qamax = 0.f;                      // (a NaN in the tensor does not define its range)
+        qamax = wave_max(qamax);
+        if (lane == 0) q8wm[wave] = qamax;
+        __syncthreads();
+        if (tid == 0) {
+            float b = q8wm[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) b = fmaxf(b, q8wm[w]);
+            if (b > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.q8_state), __float_as_uint(b));
+        }
+    }
     if constexpr (STATS) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave's LDS adds are done
         for (int n = tid; n < p.N; n += NT) {
@@ -463,7 +515,7 @@ int launch_ring2(const FS2Gemm& g, int splits, hipStream_t st) {
     const int ncols = tilesN * BN;
     const int stats_bytes = (EPI & EPI_STATS) ? ((EPI & EPI_SUMSQ) ? 2 : 1) * ncols * 4 : 0;
     const int bias_bytes = g.bias != nullptr ? ncols * 4 : 64;
-    int S = (LDS_MAX - stats_bytes - bias_bytes) / G::SLOT;
+    int S = (LDS_MAX - stats_bytes - bias_bytes - 64) / G::SLOT;
     if (S > G::SMAX) S = G::SMAX;
     {   // FS2_RING_S: ring depth override (measurements)
         static const int s_env = getenv("FS2_RING_S") ? atoi(getenv("FS2_RING_S")) : 0;
@@ -471,7 +523,7 @@ int launch_ring2(const FS2Gemm& g, int splits, hipStream_t st) {
     }
     if (S < 2) { fs2_set_error("fs2_gemm(ring): N=%d leaves no room for the slot ring", g.N); return FS2_EINVAL; }
     const int stats_off = S * G::SLOT, bias_off = stats_off + stats_bytes;
-    const int lds = bias_off + bias_bytes;
+    const int lds = bias_off + bias_bytes + ((EPI & EPI_Q8) ? 64 : 0);
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr_set[16] = {};            // > 64 KiB of dynamic LDS must be allowed once per kernel and device
@@ -492,10 +544,11 @@ int launch_ring2(const FS2Gemm& g, int splits, hipStream_t st) {
 
 int epi_code(const FS2Gemm& g) {
     const int res = g.residual == nullptr ? 0 : (g.res_dtype == FS2_F32 ? EPI_RES_F32 : EPI_RES_BF16);
-    return (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? (g.colstats_mode == 0 ? EPI_STATS | EPI_SUMSQ : EPI_STATS) : 0);
+    return (g.relu_mask ? EPI_MASK : 0) | res | (g.colstats ? (g.colstats_mode == 0 ? EPI_STATS | EPI_SUMSQ : EPI_STATS) : 0) | (g.q8 ? EPI_Q8 : 0);
 }
 
 bool epi_compiled(int epi) {
+    if (epi == EPI_Q8 || epi == (EPI_MASK | EPI_STATS | EPI_Q8)) return true;       // (fp8 operands + bf16 C only: checked by the caller)
     return epi == 0 || epi == EPI_MASK || epi == EPI_STATS || epi == (EPI_STATS | EPI_SUMSQ) || epi == (EPI_MASK | EPI_STATS) || epi == EPI_RES_F32 ||
            epi == EPI_RES_BF16 || epi == (EPI_MASK | EPI_RES_F32);
 }
@@ -522,6 +575,12 @@ int launch_ring1(const FS2Gemm& g, int splits, hipStream_t st) {
         case EPI_RES_BF16: return launch_ring2<TC, WTM, EPI_RES_BF16, ES>(g, splits, st);
         case EPI_MASK | EPI_RES_F32:
             if constexpr (WTM < 64 && (ES == 2 || WTM == 32)) return launch_ring2<TC, WTM, EPI_MASK | EPI_RES_F32, ES>(g, splits, st);
+            break;
+        case EPI_Q8:
+            if constexpr (ES == 1 && sizeof(TC) == 2 && WTM == 32) return launch_ring2<TC, WTM, EPI_Q8, ES>(g, splits, st);     // (192 rows: 16 B of scratch)
+            break;
+        case EPI_MASK | EPI_STATS | EPI_Q8:
+            if constexpr (ES == 1 && sizeof(TC) == 2 && WTM == 32) return launch_ring2<TC, WTM, EPI_MASK | EPI_STATS | EPI_Q8, ES>(g, splits, st);
             break;
         default: break;
     }

@@ -62,6 +62,8 @@ class FS2Gemm(ctypes.Structure):
         ("seq_len", ctypes.c_int32), ("alpha", ctypes.c_float), ("colstats_mode", ctypes.c_int32),
         ("tile_order", ctypes.c_int32),
         ("scale_a", ctypes.c_void_p), ("scale_b", ctypes.c_void_p),
+        ("q8", ctypes.c_void_p), ("q8_state", ctypes.c_void_p), ("q8_prev", ctypes.c_void_p), ("q8_bf8", ctypes.c_int32),
+        ("q8_reserved", ctypes.c_int32),
     ]
 
 
@@ -92,6 +94,7 @@ SIGNATURES = {
     "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_splitk_finish": [_P, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
     "fs2_splitk_reduce": [_P, _I, _L, _L, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
+    "fs2_quantize_fp8_repair": [_P, _I, _P, _I, _L, _P, _P, _P],
     "fs2_quantize_fp8_batched": [_P, _I, _I, _I, _P],
     "fs2_wgrad_sliced": [ctypes.POINTER(FS2Gemm), _P, _L, _P, _P],      # returns int64
     "fs2_wgrad_grouped": [_P, _I, _P, _L, _P, _P],      # returns int64
@@ -293,25 +296,31 @@ class fp8_backward:
         FP8_MODE["backward"] = self.prev
 
 
-_FP8_STATES = {"buf": None, "idx": 0}
+_FP8_STATES = {"buf": None, "prev": None, "idx": 0}
 
 
 def fp8_begin_step(device, slots=4096):
-    """one zero-fill for all {amax, 1/scale} pairs of a training step (instead of one tiny fill per quantised tensor)"""
+    """one zero-fill for all {amax, 1/scale} pairs of a training step (instead of one tiny fill per quantised tensor).  The states of
+    the step before are kept in a second buffer (copied, so that both buffers keep their addresses inside a captured graph): the k-th
+    quantisation of a step is the same call site as the k-th of the previous one, and its old amax is the speculation of the
+    producers that write the fp8 copy of their output themselves (FS2Gemm.q8)."""
     buf = _FP8_STATES["buf"]
     if buf is None or buf.device != device:
-        buf = _FP8_STATES["buf"] = torch.zeros((slots, 2), dtype=torch.float32, device=device)
+        _FP8_STATES["buf"] = torch.zeros((slots, 2), dtype=torch.float32, device=device)
+        _FP8_STATES["prev"] = torch.zeros((slots, 2), dtype=torch.float32, device=device)
     else:
+        _FP8_STATES["prev"].copy_(buf)
         buf.zero_()
     _FP8_STATES["idx"] = 0
 
 
-def _fp8_state(device):
-    buf, i = _FP8_STATES["buf"], _FP8_STATES["idx"]
+def _fp8_state(device, with_prev=False):
+    buf, prev, i = _FP8_STATES["buf"], _FP8_STATES["prev"], _FP8_STATES["idx"]
     if buf is None or buf.device != device or i >= buf.shape[0]:
-        return torch.zeros(2, dtype=torch.float32, device=device)
+        st = torch.zeros(2, dtype=torch.float32, device=device)
+        return (st, None) if with_prev else st
     _FP8_STATES["idx"] = i + 1
-    return buf[i]
+    return (buf[i], prev[i]) if with_prev else buf[i]
 
 
 def quantize_fp8(x, bf8=False):
@@ -376,9 +385,38 @@ def _fp8_eligible(g, M, N, K_total_row, x, w, residual=None, relu_mask=None, sta
     return True
 
 
-def _fp8_operands(g, x2, w):
-    """quantise both operands of a row-major product and point the descriptor at them"""
-    xq, sx = quantize_fp8(x2, bf8=FP8_MODE["backward"])
+FP8_FUSED_OUT = os.environ.get("FS2_FP8_Q8", "1") != "0"     # producers write the fp8 copy of their output (FS2Gemm.q8)
+
+
+def _fp8_q8_request(g, out2, relu_mask, colstats, colsum, residual):
+    """ask the product described by g (fp8 operands already set) to write the fp8 copy of its bf16 output `out2` as well; returns the
+    handle the consumer picks up (out._fs2_q8) or None when the epilogue / shape has no such form"""
+    M, N = out2.shape
+    if not FP8_FUSED_OUT or out2.dtype != torch.bfloat16 or N % 16 != 0 or out2.stride(0) != N or out2.stride(1) != 1 or residual is not None:
+        return None
+    if colstats is not None or (relu_mask is None) != (colsum is None):       # plain (bias / ReLU) or mask + column sums
+        return None
+    state, prev = _fp8_state(out2.device, with_prev=True)
+    if prev is None:
+        return None
+    q = torch.empty((M * N + 15) // 16 * 16, dtype=torch.uint8, device=out2.device)
+    bf8 = bool(FP8_MODE["backward"])
+    g.q8, g.q8_state, g.q8_prev, g.q8_bf8 = _p(q), _p(state), _p(prev), int(bf8)
+    return (q, state, prev, bf8, M * N)
+
+
+def _fp8_q8_finish(handle, out2):
+    q, state, prev, bf8, n = handle
+    _check(lib().fs2_quantize_fp8_repair(_p(out2), BF16, _p(q), int(bf8), n, _p(state), _p(prev), _stream()), "fs2_quantize_fp8_repair")
+    return (q[:n].view(out2.shape), state, bf8)
+
+
+def _fp8_operands(g, x2, w, pre=None):
+    """quantise both operands of a row-major product and point the descriptor at them (pre: the fp8 copy the producer of x2 wrote)"""
+    if pre is not None and pre[2] == bool(FP8_MODE["backward"]) and pre[0].numel() == x2.numel():
+        xq, sx = pre[0].view(x2.shape), pre[1]
+    else:
+        xq, sx = quantize_fp8(x2, bf8=FP8_MODE["backward"])
     hit = _FP8_W.get(w.data_ptr())
     if hit is not None and hit[2] == w.numel() and hit[0].shape == w.shape:
         wq, sw = hit[0], hit[1]
@@ -391,8 +429,9 @@ def _fp8_operands(g, x2, w):
 
 
 def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None, out_dtype=None,
-           alpha=1.0, colsum=None):
-    """out[M,N] = alpha * x[M,K] @ w[N,K]^T (+bias)(ReLU)(*mask>0)(+residual).  x, w: same dtype (f32 | bf16)."""
+           alpha=1.0, colsum=None, q8_out=False):
+    """out[M,N] = alpha * x[M,K] @ w[N,K]^T (+bias)(ReLU)(*mask>0)(+residual).  x, w: same dtype (f32 | bf16).
+    q8_out (fp8 operand mode only): the output feeds another row-major product -- let the epilogue write its fp8 copy (out._fs2_q8)."""
     M, K = x.shape
     N = w.shape[0]
     if out is None:
@@ -404,15 +443,19 @@ def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=
     split = _splitk_plan(M, N, K, g, relu_mask, colstats, colsum, alpha)
     if split > 1:
         return _splitk_run(g, M, N, split, out, bias, relu, residual)
-    keep = _fp8_operands(g, x, w) if _fp8_eligible(g, M, N, K, x, w, residual, relu_mask, colstats is not None or colsum is not None) else None
+    keep = _fp8_operands(g, x, w, getattr(x, "_fs2_q8", None)) \
+        if _fp8_eligible(g, M, N, K, x, w, residual, relu_mask, colstats is not None or colsum is not None) else None
     _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha, colsum)
+    handle = _fp8_q8_request(g, out, relu_mask, colstats, colsum, residual) if (q8_out and keep is not None and alpha == 1.0) else None
     _gemm_call(g)
+    if handle is not None:
+        out._fs2_q8 = _fp8_q8_finish(handle, out)
     del keep
     return out
 
 
 def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, colstats=None, out=None,
-         out_dtype=None, colsum=None):
+         out_dtype=None, colsum=None, q8_out=False):
     """Conv1d over time as implicit GEMM: x (B,t,C) channels-last, w (N, taps*C) [n][j*C + c];
     out[b,t,n] = sum_{j,c} x[b, t+j-pad, c] * w[n, j*C+c]  (zero outside the sequence)."""
     B, t, C = x.shape
@@ -432,9 +475,13 @@ def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, 
     if split > 1:
         _splitk_run(g, B * t, N, split, o2, bias, relu, r2)
         return out
-    keep = _fp8_operands(g, x2, w) if _fp8_eligible(g, B * t, N, C, x2, w, residual, relu_mask, colstats is not None or colsum is not None) else None
+    keep = _fp8_operands(g, x2, w, getattr(x, "_fs2_q8", None)) \
+        if _fp8_eligible(g, B * t, N, C, x2, w, residual, relu_mask, colstats is not None or colsum is not None) else None
     _epilogue(g, o2, bias, relu, r2, m2, colstats, 1.0, colsum)
+    handle = _fp8_q8_request(g, o2, m2, colstats, colsum, r2) if (q8_out and keep is not None) else None
     _gemm_call(g)
+    if handle is not None:
+        out._fs2_q8 = _fp8_q8_finish(handle, o2)
     del keep
     return out
 
