@@ -176,7 +176,11 @@ int fs2_colsum_segmented(const void* x, int dtype, int64_t M, int N, int64_t ldx
  *                      factor fs2_gemm takes as FS2Gemm.scale_a / scale_b.  n is rounded up to 16 internally; dst must hold it. */
 int fs2_amax(const void* src, int src_dtype, int64_t n, float* state, void* stream);
 int fs2_quantize_fp8(const void* src, int src_dtype, void* dst, int bf8, int64_t n, float* state, void* stream);
-/* Second half of FS2Gemm.q8: state[1] = 1/scale(state[0]); if scale(state[0]) != scale(prev[0]) quantise src again into dst. */
+/* The same for the row kernels that produce a GEMM operand: the NEXT fs2_add_ln_fwd (y), fs2_add_ln_bwd (da), fs2_ffn_tail_fwd (y) or
+ * fs2_ffn_tail_bwd (g) launch of this host thread with a bf16 output also writes its fp8 copy q8[row * d + col] (scale speculated
+ * from prev[0], amax into state[0]; rows must be a multiple of 4 columns long, which these kernels require anyway). */
+int fs2_q8_next(void* q8, float* state, const float* prev, int bf8);
+/* Second half of FS2Gemm.q8 / fs2_q8_next: state[1] = 1/scale(state[0]); if scale(state[0]) != scale(prev[0]) quantise src again into dst. */
 int fs2_quantize_fp8_repair(const void* src, int src_dtype, void* dst, int bf8, int64_t n, float* state, const float* prev, void* stream);
 /* The same for many bf16 tensors in two launches (the weight shadows of a model, once per optimizer step).  `table` lives in DEVICE
  * memory; entry i covers blocks [block_begin, block_begin + nblocks) of the grid, nblocks = ceil(n / 32768) (at least 1); the caller

@@ -146,6 +146,11 @@ def wgrad_batched(dy, x, outs, defer=False):
     return outs
 
 
+def view2d(x, M, d):
+    """ops.view2d (a view that keeps a producer's fp8 copy attached): a plain view here"""
+    return x.view(M, d)
+
+
 def wgrad_flush():
     """the sum of deferred weight-gradient partial tiles (ops.wgrad_flush): nothing is deferred here"""
 

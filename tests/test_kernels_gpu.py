@@ -1301,7 +1301,7 @@ def test_fp8_copy_written_by_the_gemm_epilogue_is_current_scaling(ops, backward)
     ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = True, backward
     try:
         for step, factor in enumerate((1.0, 1.0, 1.0, 128.0, 1.0 / 128.0)):
-            ops.fp8_begin_step(torch.device("cuda"))
+            ops.fp8_begin_step(x.device)
             xs = (x * factor).to(torch.bfloat16)
             if backward:
                 out = ops.linear(xs, w, relu_mask=mask, colsum=cs.zero_(), q8_out=True)
@@ -1319,6 +1319,50 @@ def test_fp8_copy_written_by_the_gemm_epilogue_is_current_scaling(ops, backward)
             del out._fs2_q8
             y_ref = ops.linear(out, w2)
             assert torch.equal(y, y_ref)
+    finally:
+        ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = False, False
+        ops._FP8_STATES["buf"] = ops._FP8_STATES["prev"] = None
+
+
+def test_fp8_copy_written_by_the_row_kernels_is_current_scaling(ops):
+    """fs2_q8_next: the four LayerNorm-family kernels whose bf16 output is a GEMM operand (add_ln fwd / bwd, FFN tail fwd / bwd) write
+    its fp8 copy themselves (e4m3 forward, e5m2 backward); codes and state equal the two-pass quantisation of the stored output for a
+    first step, a matching history and a history in another binade"""
+    M, d = 3000, 512
+    dev = torch.device("cuda", torch.cuda.current_device())
+    r, a = rnd(M, d, seed=1).cuda(), rnd(M, d, dtype=torch.bfloat16, seed=2).cuda()
+    f2, h = rnd(M, d, dtype=torch.bfloat16, seed=3).cuda(), rnd(M, d, dtype=torch.bfloat16, seed=4).cuda()
+    gam, bet = (1 + 0.1 * rnd(d, seed=5)).cuda(), (0.1 * rnd(d, seed=6)).cuda()
+    rng = ops.Rng(7, dev)
+    ops._FP8_STATES["buf"] = ops._FP8_STATES["prev"] = None
+    ops.FP8_MODE["on"] = True
+    try:
+        for step, factor in enumerate((1.0, 1.0, 64.0, 1.0 / 64.0)):
+            ops.fp8_begin_step(dev)
+            rs, as_ = r * factor, (a * factor).to(torch.bfloat16)
+            outs = []
+            ops.FP8_MODE["backward"] = False
+            s1, y1, mean, rstd = ops.add_ln_fwd(rs, as_, gam * factor, bet, p=0.1, rng=rng, site=3)
+            outs.append((y1, False))
+            s2, y2, m1, r1, m2, r2 = ops.ffn_tail_fwd(f2, h, rs, gam, bet, gam * factor, bet, p=0.1, rng=rng, site1=4, site2=5)
+            outs.append((y2, False))
+            ops.FP8_MODE["backward"] = True
+            dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
+            dr, da = ops.add_ln_bwd(None, as_, s1, gam, mean, rstd, dg, db, p=0.1, rng=rng, site=3)
+            outs.append((da, True))
+            dg2, db2, dg1, db1 = (torch.zeros(d, device=dev) for _ in range(4))
+            dr2, g = ops.ffn_tail_bwd(None, as_, s2, gam, m2, r2, f2, h, gam, m1, r1, dg2, db2, dg1, db1, p=0.1, rng=rng, site1=4, site2=5)
+            outs.append((g, True))
+            for y, bf8 in outs:
+                q, st, fmt = y._fs2_q8
+                assert fmt == bf8
+                q_ref, st_ref = ops.quantize_fp8(y, bf8)
+                assert torch.equal(st, st_ref), (step, bf8, st, st_ref)
+                assert torch.equal(q, q_ref), (step, bf8, int((q != q_ref).sum()))
+            y3 = y1.view(3, 1000, d)                  # (a plain view drops the attribute; the models use ops.view2d)
+            assert not hasattr(y3, "_fs2_q8")
+            y3._fs2_q8 = y1._fs2_q8
+            assert ops.view2d(y3, M, d)._fs2_q8[0].shape == (M, d)
     finally:
         ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = False, False
         ops._FP8_STATES["buf"] = ops._FP8_STATES["prev"] = None

@@ -335,7 +335,7 @@ class EncoderStackFunction(torch.autograd.Function):
         for i, layer in enumerate(enc.layers):
             L = {}
             wf, _, bqkv = rt.qkv(layer.attn)
-            qkv = ops.linear(h.view(M, d), wf, bqkv)                                             # modules.py:49-51
+            qkv = ops.linear(ops.view2d(h, M, d), wf, bqkv)                                             # modules.py:49-51
             q5 = qkv.view(B, t, 3, H, dk)
             q, v, k = (q5[:, :, j].permute(0, 2, 1, 3) for j in range(3))                        # (B,H,t,dk) views
             O = torch.empty((B, t, H, dk), dtype=T, device=dev)
@@ -423,7 +423,7 @@ class EncoderStackFunction(torch.autograd.Function):
             at = layer.attn
             dx, da = ops.add_ln_bwd(dx1, dh2, L["x1"], n2.weight.detach(), L["m2"], L["r2"], grad_of(n2.weight),
                                     grad_of(n2.bias), p, rng, layer.site_res1, dcolsum=grad_of(at.out.bias))
-            da2 = da.view(M, d)
+            da2 = ops.view2d(da, M, d)
             _linear_wgrad(rt, da2, L["O"].view(M, d), at.out, bias_done=True)
             dO = ops.linear(da2, rt.w_dgrad(at.out.weight))
             dO4 = dO.view(B, t, H, dk).permute(0, 2, 1, 3)

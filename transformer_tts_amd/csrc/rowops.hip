@@ -53,6 +53,53 @@ __device__ __forceinline__ void row_store(T* p, int d, int lane, const float4 (&
     for (int g = 0; g < NG; ++g)
         if (GCOL(g) < d) store4<T>(p + GCOL(g), v[g]);
 }
+// ---- fp8 copy of a kernel's bf16 row output, written by the kernel itself (fs2_q8_next: the launch behind it): codes with the scale
+//      of the amax this tensor had one step ago, the new amax reduced per thread -> workgroup -> one atomic (fs2_quantize_fp8_repair
+//      re-quantises when the binade moved: the codes equal fs2_amax + fs2_quantize_fp8 of the stored tensor, always)
+struct Q8Arg { unsigned char* q; float* state; const float* prev; int bf8; };
+struct Q8Run { float scale, fmax, amax; };
+__device__ __forceinline__ Q8Run q8_begin(const Q8Arg& qa) {
+    Q8Run r = {1.f, 448.f, 0.f};
+    if (qa.q != nullptr) {
+        float inv;
+        r.scale = fs2_pow2_scale(qa.prev[0], qa.bf8 ? 15 : 8, &inv);
+        r.fmax = qa.bf8 ? 57344.f : 448.f;
+    }
+    return r;
+}
+template <int NG>
+__device__ __forceinline__ void row_store_q8(const Q8Arg& qa, Q8Run& r, int64_t rowoff, int d, int lane, const float4 (&v)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (GCOL(g) < d) {
+            const float e[4] = {(float)(bf16_t)v[g].x, (float)(bf16_t)v[g].y, (float)(bf16_t)v[g].z, (float)(bf16_t)v[g].w};   // as stored
+            float c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = __uint_as_float(__float_as_uint(e[k]) & 0x7FFFFFFFu);
+                r.amax = (a == a) ? fmaxf(r.amax, a) : r.amax;
+                c[k] = fminf(fmaxf(e[k] * r.scale, -r.fmax), r.fmax);
+            }
+            int w = 0;
+            if (qa.bf8) { w = __builtin_amdgcn_cvt_pk_bf8_f32(c[0], c[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(c[2], c[3], w, true); }
+            else { w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true); }
+            *reinterpret_cast<int*>(qa.q + rowoff + GCOL(g)) = w;
+        }
+    }
+}
+// one atomic per workgroup; `slots` = LDS floats the caller can spare (>= blockDim / 64), every thread of the block calls it
+__device__ __forceinline__ void q8_finish(const Q8Arg& qa, const Q8Run& r, float* slots) {
+    if (qa.q == nullptr) return;
+    const float m = wave_max(r.amax);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = slots[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) b = fmaxf(b, slots[w]);
+        if (b > 0.f) atomicMax(reinterpret_cast<unsigned*>(qa.state), __float_as_uint(b));
+    }
+}
 // Raw (unconverted) groups of 4 channels: the row-reducing backward kernels request the operands of the NEXT row of a wave before
 // they process the current one (two rows in flight per wave: a wave otherwise sits out one full memory round trip per row, and
 // 16 waves per CU x 5 KB per row did not cover the HBM latency: 3.1 TB/s for the fused FeedForward-tail backward).  The bf16 -> f32
@@ -215,8 +262,10 @@ template <typename T, int NG>
 __global__ __launch_bounds__(ROW_BLOCK) void add_ln_fwd_k(const float* __restrict__ r, const T* __restrict__ a,
         float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
         float* __restrict__ mean, float* __restrict__ rstd, int64_t M, int d, float eps, float p, const uint64_t* rng,
-        uint32_t site) {
+        uint32_t site, const Q8Arg qa) {
+    __shared__ float q8s[ROW_BLOCK / 64];
     const DropCtx dc = drop_ctx(rng, site, p);
+    Q8Run qr = q8_begin(qa);
     float4 gm[NG], bt[NG];
     {
         const int lane = threadIdx.x & 63;
@@ -241,8 +290,10 @@ __global__ __launch_bounds__(ROW_BLOCK) void add_ln_fwd_k(const float* __restric
             v[g].z = (v[g].z - mu) * rs * gm[g].z + bt[g].z; v[g].w = (v[g].w - mu) * rs * gm[g].w + bt[g].w;
         }
         row_store<NG, T>(y + row * d, d, lane, v);
+        if (qa.q != nullptr) row_store_q8<NG>(qa, qr, row * d, d, lane, v);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
+    q8_finish(qa, qr, q8s);
 }
 
 template <typename T, int NG>
@@ -250,9 +301,10 @@ __global__ __launch_bounds__(RED_BLOCK) void add_ln_bwd_k(const float* __restric
         const float* __restrict__ s, const float* __restrict__ gamma, const float* __restrict__ mean,
         const float* __restrict__ rstd, float* __restrict__ dr, T* __restrict__ da, float* __restrict__ dgamma,
         float* __restrict__ dbeta, int64_t M, int d, float p, const uint64_t* rng, uint32_t site,
-        float* __restrict__ dcolsum) {
+        float* __restrict__ dcolsum, const Q8Arg qa) {
     __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
     const DropCtx dc = drop_ctx(rng, site, p);
+    Q8Run qr = q8_begin(qa);
     float4 gm[NG], ag[NG], ab[NG], ac[NG];
     {
         const int lane = threadIdx.x & 63;
@@ -298,10 +350,12 @@ __global__ __launch_bounds__(RED_BLOCK) void add_ln_bwd_k(const float* __restric
             ac[g] = add4(ac[g], o[g]);
         }
         row_store<NG, T>(da + row * d, d, lane, o);
+        if (qa.q != nullptr) row_store_q8<NG>(qa, qr, row * d, d, lane, o);
     }
     flush_channel_sums<NG>(ag, dgamma, d, red);
     flush_channel_sums<NG>(ab, dbeta, d, red);
     if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
+    q8_finish(qa, qr, red);
 }
 
 // ================================================================ y = LN(dropout(f2 + h))
@@ -406,8 +460,10 @@ __global__ __launch_bounds__(ROW_BLOCK) void ffn_tail_fwd_k(const T* __restrict_
         const float* __restrict__ r, const float* __restrict__ gamma1, const float* __restrict__ beta1,
         const float* __restrict__ gamma2, const float* __restrict__ beta2, float* __restrict__ s, T* __restrict__ y,
         float* __restrict__ mean1, float* __restrict__ rstd1, float* __restrict__ mean2, float* __restrict__ rstd2, int64_t M, int d,
-        float eps, float p, const uint64_t* rng, uint32_t site1, uint32_t site2) {
+        float eps, float p, const uint64_t* rng, uint32_t site1, uint32_t site2, const Q8Arg qa) {
+    __shared__ float q8s[ROW_BLOCK / 64];
     const DropCtx dc1 = drop_ctx(rng, site1, p), dc2 = drop_ctx(rng, site2, p);
+    Q8Run qr = q8_begin(qa);
     float4 g1[NG], b1[NG], g2[NG], b2[NG];
     {
         const int lane = threadIdx.x & 63;
@@ -444,7 +500,9 @@ __global__ __launch_bounds__(ROW_BLOCK) void ffn_tail_fwd_k(const T* __restrict_
             v[g].z = (v[g].z - mu) * rs * g2[g].z + b2[g].z; v[g].w = (v[g].w - mu) * rs * g2[g].w + b2[g].w;
         }
         row_store<NG, T>(y + row * d, d, lane, v);
+        if (qa.q != nullptr) row_store_q8<NG>(qa, qr, row * d, d, lane, v);
     }
+    q8_finish(qa, qr, q8s);
 }
 
 // backward of the same: fs2_add_ln_bwd (LN2, residual, dropout2) followed by fs2_ffn_ln_bwd (LN1, dropout1) in one row pass; the
@@ -455,9 +513,10 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restr
         const T* __restrict__ f2, const T* __restrict__ h, const float* __restrict__ gamma1, const float* __restrict__ mean1,
         const float* __restrict__ rstd1, float* __restrict__ dr, T* __restrict__ gout, float* __restrict__ dgamma2,
         float* __restrict__ dbeta2, float* __restrict__ dgamma1, float* __restrict__ dbeta1, float* __restrict__ dcolsum, int64_t M,
-        int d, float p, const uint64_t* rng, uint32_t site1, uint32_t site2) {
+        int d, float p, const uint64_t* rng, uint32_t site1, uint32_t site2, const Q8Arg qa) {
     __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
     const DropCtx dc1 = drop_ctx(rng, site1, p), dc2 = drop_ctx(rng, site2, p);
+    Q8Run qr = q8_begin(qa);
     float4 gm2[NG], gm1[NG], ag2[NG], ab2[NG], ag1[NG], ab1[NG], ac[NG];
     {
         const int lane = threadIdx.x & 63;
@@ -550,6 +609,7 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restr
             ac[g] = add4(ac[g], o[g]);
         }
         row_store<NG, T>(gout + row * d, d, lane, o);
+        if (qa.q != nullptr) row_store_q8<NG>(qa, qr, row * d, d, lane, o);
     };
     {
         // two rows in flight per wave: the operands of row r + stride are requested before row r is processed.  Requests past the
@@ -574,6 +634,7 @@ __global__ __launch_bounds__(RED_BLOCK) void ffn_tail_bwd_k(const float* __restr
     flush_channel_sums<NG>(ag1, dgamma1, d, red);
     flush_channel_sums<NG>(ab1, dbeta1, d, red);
     if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
+    q8_finish(qa, qr, red);
 }
 
 // ================================================================ attention softmax (in place) + dropout
@@ -1235,6 +1296,24 @@ __global__ __launch_bounds__(RED_BLOCK) void bn_tanh_bwd_k(const T* __restrict__
     FS2_REQUIRE((d) > 0 && (d) % 4 == 0 && (d) <= (maxd), "%s: row length %d must be a multiple of 4 and <= %d", name, (int)(d), (int)(maxd))
 #define CHECK_DT(name, dt) FS2_REQUIRE((dt) == FS2_F32 || (dt) == FS2_BF16, "%s: bad dtype %d", name, (int)(dt))
 
+// ---- one-shot request (per host thread): the next fs2_add_ln_fwd / fs2_add_ln_bwd / fs2_ffn_tail_fwd / fs2_ffn_tail_bwd launch also writes
+//      the fp8 copy of its bf16 row output (y / da / y / g)
+namespace {
+thread_local Q8Arg g_q8_next = {nullptr, nullptr, nullptr, 0};
+Q8Arg take_q8(int dtype) {
+    Q8Arg a = g_q8_next;
+    g_q8_next = Q8Arg{nullptr, nullptr, nullptr, 0};
+    if (dtype != FS2_BF16) a.q = nullptr;
+    return a;
+}
+}  // namespace
+extern "C" int fs2_q8_next(void* q8, float* state, const float* prev, int bf8) {
+    FS2_REQUIRE(q8 != nullptr && state != nullptr && prev != nullptr, "fs2_q8_next: null argument");
+    FS2_REQUIRE((reinterpret_cast<uintptr_t>(q8) & 3u) == 0, "fs2_q8_next: q8 must be 4-byte aligned");
+    g_q8_next = Q8Arg{reinterpret_cast<unsigned char*>(q8), state, prev, bf8 ? 1 : 0};
+    return FS2_OK;
+}
+
 extern "C" int fs2_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                                  float* mean, float* rstd, int64_t M, int d, float eps, float p, const uint64_t* rng,
                                  uint32_t site, void* stream) {
@@ -1291,12 +1370,13 @@ extern "C" int fs2_add_ln_fwd(const float* r, const void* a, int dtype, float* s
                               void* y, float* mean, float* rstd, int64_t M, int d, float eps, float p,
                               const uint64_t* rng, uint32_t site, void* stream) {
     CHECK_ROW("fs2_add_ln_fwd", d, 1024); CHECK_DT("fs2_add_ln_fwd", dtype);
+    const Q8Arg qa = take_q8(dtype);
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_add_ln_fwd: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid(M)), block(ROW_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((add_ln_fwd_k<T, NG>), grid, block, 0, st, r, (const T*)a, s, gamma, beta, (T*)y, mean, rstd, M, d, eps, p, rng, site);
+        hipLaunchKernelGGL((add_ln_fwd_k<T, NG>), grid, block, 0, st, r, (const T*)a, s, gamma, beta, (T*)y, mean, rstd, M, d, eps, p, rng, site, qa);
     }); } });
     FS2_CHECK_LAUNCH("fs2_add_ln_fwd");
     return FS2_OK;
@@ -1306,12 +1386,13 @@ extern "C" int fs2_add_ln_bwd(const float* ds_down, const void* dy, int dtype, c
                               const float* mean, const float* rstd, float* dr, void* da, float* dgamma, float* dbeta,
                               int64_t M, int d, float p, const uint64_t* rng, uint32_t site, float* dcolsum, void* stream) {
     CHECK_ROW("fs2_add_ln_bwd", d, 1024); CHECK_DT("fs2_add_ln_bwd", dtype);
+    const Q8Arg qa = take_q8(dtype);
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_add_ln_bwd: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((add_ln_bwd_k<T, NG>), grid, block, 0, st, ds_down, (const T*)dy, s, gamma, mean, rstd, dr, (T*)da, dgamma, dbeta, M, d, p, rng, site, dcolsum);
+        hipLaunchKernelGGL((add_ln_bwd_k<T, NG>), grid, block, 0, st, ds_down, (const T*)dy, s, gamma, mean, rstd, dr, (T*)da, dgamma, dbeta, M, d, p, rng, site, dcolsum, qa);
     }); } });
     FS2_CHECK_LAUNCH("fs2_add_ln_bwd");
     return FS2_OK;
@@ -1352,12 +1433,13 @@ extern "C" int fs2_ffn_tail_fwd(const void* f2, const void* h, int dtype, const 
                                 float* rstd2, int64_t M, int d, float eps, float p, const uint64_t* rng, uint32_t site1, uint32_t site2,
                                 void* stream) {
     CHECK_ROW("fs2_ffn_tail_fwd", d, 1024); CHECK_DT("fs2_ffn_tail_fwd", dtype);
+    const Q8Arg qa = take_q8(dtype);
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ffn_tail_fwd: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(row_grid(M)), block(ROW_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((ffn_tail_fwd_k<T, NG>), grid, block, 0, st, (const T*)f2, (const T*)h, r, gamma1, beta1, gamma2, beta2, s, (T*)y, mean1, rstd1, mean2, rstd2, M, d, eps, p, rng, site1, site2);
+        hipLaunchKernelGGL((ffn_tail_fwd_k<T, NG>), grid, block, 0, st, (const T*)f2, (const T*)h, r, gamma1, beta1, gamma2, beta2, s, (T*)y, mean1, rstd1, mean2, rstd2, M, d, eps, p, rng, site1, site2, qa);
     }); } });
     FS2_CHECK_LAUNCH("fs2_ffn_tail_fwd");
     return FS2_OK;
@@ -1369,12 +1451,13 @@ extern "C" int fs2_ffn_tail_bwd(const float* ds_down, const void* dy, int dtype,
                                 float* dcolsum, int64_t M, int d, float p, const uint64_t* rng, uint32_t site1, uint32_t site2,
                                 void* stream) {
     CHECK_ROW("fs2_ffn_tail_bwd", d, 1024); CHECK_DT("fs2_ffn_tail_bwd", dtype);
+    const Q8Arg qa = take_q8(dtype);
     FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ffn_tail_bwd: dropout needs rng");
     if (M <= 0) return FS2_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(red_grid(M)), block(RED_BLOCK);
     NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
-        hipLaunchKernelGGL((ffn_tail_bwd_k<T, NG>), grid, block, 0, st, ds_down, (const T*)dy, s, gamma2, mean2, rstd2, (const T*)f2, (const T*)h, gamma1, mean1, rstd1, dr, (T*)g, dgamma2, dbeta2, dgamma1, dbeta1, dcolsum, M, d, p, rng, site1, site2);
+        hipLaunchKernelGGL((ffn_tail_bwd_k<T, NG>), grid, block, 0, st, ds_down, (const T*)dy, s, gamma2, mean2, rstd2, (const T*)f2, (const T*)h, gamma1, mean1, rstd1, dr, (T*)g, dgamma2, dbeta2, dgamma1, dbeta1, dcolsum, M, d, p, rng, site1, site2, qa);
     }); } });
     FS2_CHECK_LAUNCH("fs2_ffn_tail_bwd");
     return FS2_OK;

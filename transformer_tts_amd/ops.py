@@ -94,6 +94,7 @@ SIGNATURES = {
     "fs2_ffn_ln_bwd": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_splitk_finish": [_P, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
     "fs2_splitk_reduce": [_P, _I, _L, _L, _L, _I, _P, _P, _I, _L, _I, _P, _I, _L, _P],
+    "fs2_q8_next": [_P, _P, _P, _I],
     "fs2_quantize_fp8_repair": [_P, _I, _P, _I, _L, _P, _P, _P],
     "fs2_quantize_fp8_batched": [_P, _I, _I, _I, _P],
     "fs2_wgrad_sliced": [ctypes.POINTER(FS2Gemm), _P, _L, _P, _P],      # returns int64
@@ -409,6 +410,39 @@ def _fp8_q8_finish(handle, out2):
     q, state, prev, bf8, n = handle
     _check(lib().fs2_quantize_fp8_repair(_p(out2), BF16, _p(q), int(bf8), n, _p(state), _p(prev), _stream()), "fs2_quantize_fp8_repair")
     return (q[:n].view(out2.shape), state, bf8)
+
+
+class _RowQ8:
+    """fp8 copy of the bf16 row output `y` of one of the four LayerNorm-family kernels that produce GEMM operands, written by the kernel
+    itself: `with _RowQ8(y) as r: <launch>` arms fs2_q8_next before the launch and runs the repair launch behind it"""
+
+    def __init__(self, y):
+        self.y, self.handle = y, None
+        if FP8_MODE["on"] and FP8_FUSED_OUT and y.is_cuda and y.dtype == torch.bfloat16 and y.is_contiguous() and y.numel() >= 1024 * 64:
+            state, prev = _fp8_state(y.device, with_prev=True)
+            if prev is not None:
+                n = y.numel()
+                q = torch.empty((n + 15) // 16 * 16, dtype=torch.uint8, device=y.device)
+                self.handle = (q, state, prev, bool(FP8_MODE["backward"]), n)
+
+    def __enter__(self):
+        if self.handle is not None:
+            q, state, prev, bf8, n = self.handle
+            _check(lib().fs2_q8_next(_p(q), _p(state), _p(prev), int(bf8)), "fs2_q8_next")
+        return self
+
+    def __exit__(self, *exc):
+        if self.handle is not None and exc[0] is None:
+            self.y._fs2_q8 = _fp8_q8_finish(self.handle, self.y)
+
+
+def view2d(x, M, d):
+    """x.view(M, d) that keeps the fp8 copy a producer attached to x (a plain .view() makes a new tensor object)"""
+    y = x.view(M, d)
+    pre = getattr(x, "_fs2_q8", None)
+    if pre is not None:
+        y._fs2_q8 = (pre[0].view(M, d), pre[1], pre[2])
+    return y
 
 
 def _fp8_operands(g, x2, w, pre=None):
@@ -865,8 +899,9 @@ def add_ln_fwd(r, a, gamma, beta, eps=1e-5, p=0.0, rng=None, site=0):
     y = torch.empty_like(a)
     mean = torch.empty(M, dtype=torch.float32, device=r.device)
     rstd = torch.empty(M, dtype=torch.float32, device=r.device)
-    _check(lib().fs2_add_ln_fwd(_p(_c(r)), _p(_c(a)), _dt(a), _p(s), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d,
-                                eps, p, _rng_ptr(rng, p), site, _stream()), "fs2_add_ln_fwd")
+    with _RowQ8(y):
+        _check(lib().fs2_add_ln_fwd(_p(_c(r)), _p(_c(a)), _dt(a), _p(s), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, d,
+                                    eps, p, _rng_ptr(rng, p), site, _stream()), "fs2_add_ln_fwd")
     return s, y, mean, rstd
 
 
@@ -876,9 +911,10 @@ def add_ln_bwd(ds_down, dy, s, gamma, mean, rstd, dgamma, dbeta, p=0.0, rng=None
     M = s.numel() // d
     dr = torch.empty_like(s)
     da = torch.empty_like(dy)
-    _check(lib().fs2_add_ln_bwd(_p(ds_down), _p(_c(dy)), _dt(dy), _p(_c(s)), _p(gamma), _p(mean), _p(rstd), _p(dr),
-                                _p(da), _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, _p(dcolsum), _stream()),
-           "fs2_add_ln_bwd")
+    with _RowQ8(da):
+        _check(lib().fs2_add_ln_bwd(_p(ds_down), _p(_c(dy)), _dt(dy), _p(_c(s)), _p(gamma), _p(mean), _p(rstd), _p(dr),
+                                    _p(da), _p(dgamma), _p(dbeta), M, d, p, _rng_ptr(rng, p), site, _p(dcolsum), _stream()),
+               "fs2_add_ln_bwd")
     return dr, da
 
 
@@ -911,9 +947,10 @@ def ffn_tail_fwd(f2, h, r, gamma1, beta1, gamma2, beta2, eps=1e-5, p=0.0, rng=No
     s = torch.empty_like(r)
     y = torch.empty_like(h)
     st = [torch.empty(M, dtype=torch.float32, device=h.device) for _ in range(4)]
-    _check(lib().fs2_ffn_tail_fwd(_p(_c(f2)), _p(_c(h)), _dt(h), _p(_c(r)), _p(gamma1), _p(beta1), _p(gamma2), _p(beta2), _p(s), _p(y),
-                                  _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), M, d, eps, p, _rng_ptr(rng, p), site1, site2, _stream()),
-           "fs2_ffn_tail_fwd")
+    with _RowQ8(y):
+        _check(lib().fs2_ffn_tail_fwd(_p(_c(f2)), _p(_c(h)), _dt(h), _p(_c(r)), _p(gamma1), _p(beta1), _p(gamma2), _p(beta2), _p(s), _p(y),
+                                      _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), M, d, eps, p, _rng_ptr(rng, p), site1, site2, _stream()),
+               "fs2_ffn_tail_fwd")
     return s, y, st[0], st[1], st[2], st[3]
 
 
@@ -924,9 +961,10 @@ def ffn_tail_bwd(ds_down, dy, s, gamma2, mean2, rstd2, f2, h, gamma1, mean1, rst
     M = s.numel() // d
     dr = torch.empty_like(s)
     g = torch.empty_like(h)
-    _check(lib().fs2_ffn_tail_bwd(_p(ds_down), _p(_c(dy)), _dt(dy), _p(_c(s)), _p(gamma2), _p(mean2), _p(rstd2), _p(_c(f2)), _p(_c(h)),
-                                  _p(gamma1), _p(mean1), _p(rstd1), _p(dr), _p(g), _p(dgamma2), _p(dbeta2), _p(dgamma1), _p(dbeta1),
-                                  _p(dcolsum), M, d, p, _rng_ptr(rng, p), site1, site2, _stream()), "fs2_ffn_tail_bwd")
+    with _RowQ8(g):
+        _check(lib().fs2_ffn_tail_bwd(_p(ds_down), _p(_c(dy)), _dt(dy), _p(_c(s)), _p(gamma2), _p(mean2), _p(rstd2), _p(_c(f2)), _p(_c(h)),
+                                      _p(gamma1), _p(mean1), _p(rstd1), _p(dr), _p(g), _p(dgamma2), _p(dbeta2), _p(dgamma1), _p(dbeta1),
+                                      _p(dcolsum), M, d, p, _rng_ptr(rng, p), site1, site2, _stream()), "fs2_ffn_tail_bwd")
     return dr, g
 
 
