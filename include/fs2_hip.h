@@ -136,8 +136,15 @@ typedef struct FS2WgradPart {
     int32_t M, N, tilesM, tilesN, splits, n2, nbatch, block_begin;
     float alpha;
     int32_t reserved;
+    const float* scale_a;      /* fp8 operands: device de-quantisation factors multiplied into alpha (NULL = 1) */
+    const float* scale_b;
 } FS2WgradPart;
 int64_t fs2_wgrad_sliced(const FS2Gemm* g, float* ws, int64_t ws_floats, FS2WgradPart* part, void* stream);
+/* fp8 operands (dtype FS2_BF8_FP8: A = dY in e5m2, B = X in e4m3, one byte per element, lda / ldb multiples of 16, FS2Gemm.scale_a / scale_b)
+ * are taken by fs2_wgrad_sliced / fs2_wgrad_grouped only.  fs2_wgrad_plan tells beforehand how a product would run: 0 the 16-wave kernel
+ * does not take it, 1 uniform k-split (partial tiles), 2 balanced stream or more than 256 output tiles -- bf16: through fs2_gemm (fs2_wgrad_sliced returns 0); fp8:
+ * fs2_wgrad_sliced launches it with the float-atomic flush, returns 1 and sets part->splits = 0 (complete, nothing to reduce). */
+int fs2_wgrad_plan(const FS2Gemm* g);
 /* n <= 4 such products in ONE launch (the weight gradients of one layer's backward, launched when the last of them is known): one
  * launch ramp / first-stage latency / tail for the group, k-splits sized for the group's total work.  parts[i] describes product i.
  * Products the group does not take are marked parts[i].splits == 0 (the caller launches those on their own).  Returns the floats of

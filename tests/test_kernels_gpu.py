@@ -1368,6 +1368,57 @@ def test_fp8_copy_written_by_the_row_kernels_is_current_scaling(ops):
         ops._FP8_STATES["buf"] = ops._FP8_STATES["prev"] = None
 
 
+def test_fp8_weight_gradients_against_the_dequantised_product(ops, big_km):
+    """fp8 weight gradients (gemm_big_km.hip, ES = 1: dY in e5m2 x X in e4m3, ds_read_b64_tr_b8 fragments, v_mfma_f32_16x16x32_bf8_fp8):
+    exact products of the fp8 values summed in fp32 and scaled by the two de-quantisation factors -- linear, the batched q/v/k form and
+    Conv1d taps, launched on their own and as a deferred group, accumulating onto a non-zero gradient"""
+    M, d = 2560, 256
+    dy = rnd(M, 3 * d, dtype=torch.bfloat16, seed=1).cuda()
+    x = rnd(M, d, dtype=torch.bfloat16, seed=2, scale=3.0).cuda()
+    dyc, xc = rnd(5, 448, 256, dtype=torch.bfloat16, seed=3).cuda(), rnd(5, 448, 144, dtype=torch.bfloat16, seed=4).cuda()
+    g0 = [rnd(3 * d, d, seed=5), rnd(3 * (d * d + d), seed=6), rnd(256, 3 * 144, seed=7)]
+
+    def attach(t, bf8):
+        q, st = ops.quantize_fp8(t, bf8)
+        t._fs2_q8 = (q, st, bf8)
+        return P.dequantize_fp8(q.cpu(), st.cpu(), bf8)
+
+    ddy, dx, ddyc, dxc = attach(dy, True), attach(x, False), attach(dyc, True), attach(xc, False)
+    ref0 = g0[0].double() + ddy.t() @ dx
+    ref1 = [g0[1][j * (d * d + d):j * (d * d + d) + d * d].view(d, d).double() + ddy[:, j * d:(j + 1) * d].t() @ dx for j in range(3)]
+    ref2 = P.conv_wgrad(ddyc.float(), dxc.float(), 3, 1, g0[2].clone())
+    ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = True, True
+    try:
+        for defer in (False, True):
+            outs = [t.cuda() for t in g0]
+            kw = dict(defer=True) if defer else {}
+            ops.wgrad(dy, x, outs[0], **kw)
+            blocks = [outs[1][j * (d * d + d):j * (d * d + d) + d * d].view(d, d) for j in range(3)]
+            ops.wgrad_batched(dy, x, blocks, **kw)
+            ops.conv_wgrad(dyc, xc, 3, 1, outs[2], **kw)
+            if defer:
+                descs = [p[0] for p in ops._WG.pending]
+                assert len(descs) == 3
+                ops.wgrad_flush()
+            close(outs[0], ref0.float(), f"fp8 wgrad defer={defer}", rtol=2e-5, atol=2e-5 * M ** 0.5 * 30)
+            for b, r in zip(blocks, ref1):
+                close(b, r.float(), f"fp8 batched wgrad defer={defer}", rtol=2e-5, atol=2e-5 * M ** 0.5 * 30)
+            close(outs[2], ref2, f"fp8 conv wgrad defer={defer}", rtol=2e-3, atol=2e-3 * 2240 ** 0.5)
+        # 144 output tiles: balanced-stream decomposition, float-atomic flush with the scales read on the device
+        dys, xs = rnd(8, 128, 1024, dtype=torch.bfloat16, seed=8).cuda(), rnd(8, 128, 256, dtype=torch.bfloat16, seed=9).cuda()
+        dd, dxs = attach(dys, True), attach(xs, False)
+        o2 = torch.zeros(1024, 9 * 256, device="cuda")
+        ops.conv_wgrad(dys, xs, 9, 4, o2, defer=True)
+        ops.wgrad_flush()
+        close(o2, P.conv_wgrad(dd.float(), dxs.float(), 9, 4, torch.zeros(1024, 9 * 256)), "fp8 stream-mode conv wgrad", rtol=2e-3, atol=2e-3 * 1024 ** 0.5)
+        assert float((o2.cpu() - P.conv_wgrad(dys.cpu(), xs.cpu(), 9, 4, torch.zeros(1024, 9 * 256))).abs().max()) > 1e-3
+        # and it is the fp8 kernel that ran: the result differs from the bf16 product of the unquantised operands
+        full = g0[0].double() + dy.cpu().double().t() @ x.cpu().double()
+        assert float((outs[0].cpu().double() - full).abs().max()) > 1e-3
+    finally:
+        ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = False, False
+
+
 def test_fp8_batched_weight_quantisation_equals_the_per_tensor_path(ops):
     """fs2_quantize_fp8_batched (all weight shadows of a model in two launches) against fs2_amax + fs2_quantize_fp8 per tensor: the same
     codes and the same {amax, 1/scale}, for sizes with ragged tails, a zero tensor and more than one 32768-element chunk"""

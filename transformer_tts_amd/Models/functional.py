@@ -424,7 +424,7 @@ class EncoderStackFunction(torch.autograd.Function):
             dx, da = ops.add_ln_bwd(dx1, dh2, L["x1"], n2.weight.detach(), L["m2"], L["r2"], grad_of(n2.weight),
                                     grad_of(n2.bias), p, rng, layer.site_res1, dcolsum=grad_of(at.out.bias))
             da2 = ops.view2d(da, M, d)
-            _linear_wgrad(rt, da2, L["O"].view(M, d), at.out, bias_done=True)
+            _linear_wgrad(rt, da2, ops.view2d(L["O"], M, d), at.out, bias_done=True)
             dO = ops.linear(da2, rt.w_dgrad(at.out.weight))
             dO4 = dO.view(B, t, H, dk).permute(0, 2, 1, 3)
             qkv = L["qkv"]
@@ -452,7 +452,7 @@ class EncoderStackFunction(torch.autograd.Function):
                     ops.softmax_bwd(dP, P, t, p, rng, layer.site_attn)        # -> dS (pad columns 0)
                     ops.bmm(dP, k, dq, trans_b=False, alpha=scale)            # dQ = dS K / sqrt(dk)
                 ops.bmm(dP, q, dk_, trans_a=True, trans_b=False, alpha=scale) # dK = dS^T Q / sqrt(dk)
-            dqkv2, h2d = dqkv.view(M, 3 * d), L["h"].view(M, d)
+            dqkv2, h2d = dqkv.view(M, 3 * d), ops.view2d(L["h"], M, d)
             # bias gradients of q/v/k: ONE pass over dqkv, straight into the three gradient vectors (constant stride in the arena)
             with rt.side(dqkv2):
                 if not flash:

@@ -44,12 +44,31 @@ __device__ __forceinline__ bf16x8 km_frag(const unsigned char* img, int o0, int 
     return u.v;
 }
 
+// one-byte operands: image rows of 128 B, 16-byte chunk c of row r at c ^ ((r >> 1) & 7); ds_read_b64_tr_b8 hands lane i of a 16-lane group
+// column i of an 8-row x 16-column byte block (lane 2q + p of the group supplies the address of row q, columns 8p .. 8p+7 -- measured,
+// tools/probes/tr8_probe.hip): the 8 k-values lane (column i16, k-group g) needs for v_mfma_f32_16x16x32_bf8_fp8.  Conflict-free: the
+// 32 lanes of a half read 16 rows x 16 B of one logical chunk = 16 different (row parity, swizzled chunk) pairs x 2 halves.
+typedef __attribute__((ext_vector_type(2))) int i32x2_t;
+typedef __attribute__((address_space(3))) i32x2_t lds_i32x2;
+__device__ __forceinline__ int km_f8(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ long km_frag8(const unsigned char* img, int o0, int r0k, int lane) {
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 1, pp = i16 & 1;
+    const int r0 = r0k + 8 * g + q;
+    const i32x2_t v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_i32x2*)(img + r0 * 128 + (((o0 >> 4) ^ km_f8(r0)) << 4) + 8 * pp));
+    union { i32x2_t v; long l; } u;
+    u.v = v;
+    return u.l;
+}
+
 }  // namespace
 
 extern thread_local int g_last_tile;     // gemm.hip
 
 // vblock / vgrid: this workgroup's index in, and the size of, the (virtual) grid of ITS product -- blockIdx / gridDim for a launch of one
 // product, a sub-range of the grid in a grouped launch (fs2_gemm_big_km_grouped_kernel: several products, one launch)
+// ES: bytes per operand element -- 2: bf16; 1: fp8 (A = dY in e5m2, B = X in e4m3: the copies the data-gradient / forward products of the
+// fp8 operand mode already hold; half the staged and LDS-read bytes per multiply-add on a kernel that is bound by exactly those)
+template <int ES>
 __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, const int tilesN, const int splits, const int nitems, const int rot_step,
                                         const int stream_units, float* __restrict__ ws, const int vblock, const int vgrid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -139,18 +158,20 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
 
     // ---- LDS-DMA: instruction i of this wave covers image rows 4*(i*NW + wave) .. +3 of A (i = 0,1) and of B (i = 0,1);
     //      the lane fetches logical chunk (lane&15) ^ f(row) of row lane>>4 of those
-    auto dma_row = [&](int i) { return 4 * (i * NW + wave) + (lane >> 4); };
-    auto dma_col = [&](int i) { return ((lane & 15) ^ km_f(dma_row(i))) * 8; };
+    //      (fp8: ONE instruction per operand, image rows 8*wave .. +7 of 128 B, chunk (lane&7) ^ f8(row) of row lane>>3)
+    constexpr int NI = ES == 2 ? 2 : 1, OPB = BK * 128 * ES;
+    auto dma_row = [&](int i) { return ES == 2 ? 4 * (i * NW + wave) + (lane >> 4) : 8 * wave + (lane >> 3); };
+    auto dma_col = [&](int i) { return ES == 2 ? ((lane & 15) ^ km_f(dma_row(i))) * 8 : ((lane & 7) ^ km_f8(dma_row(i))) * 16; };
 
     __amdgpu_buffer_rsrc_t rsA, rsB;
     bool colA[2], colB[2];
     Item ck;
     int lst = 0;                          // next stage to stage
     auto prep = [&](const Item& k) {
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const bf16_t*>(p.A) + k.aoff), 0, 0x7FFFFFF0, 0x00020000);
-        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const bf16_t*>(p.B) + k.boff), 0, 0x7FFFFFF0, 0x00020000);
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.A) + k.aoff * ES), 0, 0x7FFFFFF0, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.B) + k.boff * ES), 0, 0x7FFFFFF0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             colA[i] = k.m0 + dma_col(i) < p.M;
             colB[i] = k.n0 + dma_col(i) < p.N;
         }
@@ -160,19 +181,19 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
         const int shiftB = p.conv == 2 ? ck.tap - p.pad : 0;
         unsigned char* base = smem + buf * STAGE + 1024 * wave;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int kk = kb + dma_row(i);
             const bool ok = colA[i] && kk < p.K;
-            const unsigned off = (unsigned)((kk * lda + ck.m0 + dma_col(i)) * 2);
+            const unsigned off = (unsigned)((kk * lda + ck.m0 + dma_col(i)) * ES);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)(ok ? off : OOB), 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int kk = kb + dma_row(i);
             bool ok = colB[i] && kk < Kb;
             if (p.conv == 2) { const int tt = (kk % seq) + shiftB; ok = ok && tt >= 0 && tt < seq; }
-            const unsigned off = (unsigned)(((kk + shiftB) * ldb + ck.n0 + dma_col(i)) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + OP_BYTES + 1024 * NW * i), 16, (int)(ok ? off : OOB), 0, 0, 0);
+            const unsigned off = (unsigned)(((kk + shiftB) * ldb + ck.n0 + dma_col(i)) * ES);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + OPB + 1024 * NW * i), 16, (int)(ok ? off : OOB), 0, 0, 0);
         }
         ++lst;
     };
@@ -202,16 +223,28 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
             if (issue_first && s + 1 < nst) issue(buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             const unsigned char* la = smem + buf * STAGE;
-            const unsigned char* lb = la + OP_BYTES;
-            bf16x8 fa[4], fb[4];
+            const unsigned char* lb = la + OPB;
+            if constexpr (ES == 2) {
+                bf16x8 fa[4], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = km_frag(la, wr * 64 + i * 16, 32 * kg, lane);
+                for (int i = 0; i < 4; ++i) fa[i] = km_frag(la, wr * 64 + i * 16, 32 * kg, lane);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) fb[jj] = km_frag(lb, wc * 64 + jj * 16, 32 * kg, lane);
+                for (int jj = 0; jj < 4; ++jj) fb[jj] = km_frag(lb, wc * 64 + jj * 16, 32 * kg, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+            } else {
+                long fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = km_frag8(la, wr * 64 + i * 16, 32 * kg, lane);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) fb[jj] = km_frag8(lb, wc * 64 + jj * 16, 32 * kg, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);         // (or hipcc moves the late issue back up in front of the MFMAs)
             if (!issue_first && s + 1 < nst) issue(buf ^ 1);
             // own DMA landed, own fragment reads retired; then every wave's
@@ -272,6 +305,8 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
         } else {
         // ---- flush with row-contiguous float atomics (256 B per wave-instruction: the full-rate shape), 8 rows per wave
         float* __restrict__ C = reinterpret_cast<float*>(p.C) + ck.coff;
+        // (fp8 operands: the two de-quantisation factors are device scalars)
+        const float alpha_eff = ES == 1 ? p.alpha * (p.scale_a != nullptr ? *p.scale_a : 1.f) * (p.scale_b != nullptr ? *p.scale_b : 1.f) : p.alpha;
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int row = (wave * 8 + rr + ck.rot) & (TM - 1);       // rotated per split: the 16-64 workgroups of one tile do not
@@ -281,7 +316,7 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
             for (int h = 0; h < 2; ++h) {
                 const int n = ck.n0 + h * 64 + lane;
                 const float v = red[row * TN + h * 64 + lane];
-                if (m < p.M && n < p.N) atomicAdd(C + (int64_t)m * p.ldc + n, v * p.alpha);
+                if (m < p.M && n < p.N) atomicAdd(C + (int64_t)m * p.ldc + n, v * alpha_eff);
             }
         }
         }
@@ -290,10 +325,11 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     }
 }
 
+template <int ES>
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
                                                                   const int nitems, const int rot_step, const int stream_units,
                                                                   float* __restrict__ ws) {
-    km_body(p, tilesM, tilesN, splits, nitems, rot_step, stream_units, ws, (int)blockIdx.x, (int)gridDim.x);
+    km_body<ES>(p, tilesM, tilesN, splits, nitems, rot_step, stream_units, ws, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Several weight-gradient products in ONE launch (the products of one layer's backward): product d owns the workgroups
@@ -307,10 +343,11 @@ struct KmGroupArgs {
     int tilesM[KM_GROUP], tilesN[KM_GROUP], splits[KM_GROUP], nitems[KM_GROUP], wg_begin[KM_GROUP + 1];
     int n, rot_step;
 };
+template <int ES>
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_grouped_kernel(const KmGroupArgs a) {
     int d = 0;
     while (d + 1 < a.n && (int)blockIdx.x >= a.wg_begin[d + 1]) ++d;
-    km_body(a.g[d], a.tilesM[d], a.tilesN[d], a.splits[d], a.nitems[d], a.rot_step, 0, a.ws[d], (int)blockIdx.x - a.wg_begin[d],
+    km_body<ES>(a.g[d], a.tilesM[d], a.tilesN[d], a.splits[d], a.nitems[d], a.rot_step, 0, a.ws[d], (int)blockIdx.x - a.wg_begin[d],
             a.wg_begin[d + 1] - a.wg_begin[d]);
 }
 
@@ -319,8 +356,9 @@ namespace {
 struct KmPlan { int tilesM, tilesN, splits, stream_units, grid; long nitems, base; };
 
 // work decomposition of a weight-gradient product, or false when the 16-wave kernel does not take it
-bool km_plan(const FS2Gemm& g, int mode, KmPlan& pl) {
-    if (g.dtype != FS2_BF16 || g.c_dtype != FS2_F32 || !g.a_kmajor || !g.b_kmajor || !g.accumulate) return false;
+bool km_plan(const FS2Gemm& g, int mode, KmPlan& pl, bool allow_f8 = false) {
+    const bool f8 = allow_f8 && g.dtype == FS2_BF8_FP8;      // (A = dY in e5m2, B = X in e4m3; fs2_wgrad_sliced / fs2_wgrad_grouped only)
+    if ((g.dtype != FS2_BF16 && !f8) || g.c_dtype != FS2_F32 || !g.a_kmajor || !g.b_kmajor || !g.accumulate) return false;
     if (g.conv != 0 && g.conv != 2) return false;
     if (g.bias || g.residual || g.relu_mask || g.colstats || g.relu) return false;
     const long rowsA = (long)g.K + 16, rowsB = (long)(g.Kb > 0 ? g.Kb : g.K) + 64;
@@ -363,7 +401,8 @@ int km_launch(const FS2Gemm& g, const KmPlan& pl, float* ws, hipStream_t st) {
     (void)hipGetDevice(&dev);
     static bool attr_set[16] = {};            // per device (one process per GPU is the deployment; a process driving several still works)
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the weight-gradient kernel");
             return FS2_ELAUNCH;
         }
@@ -371,8 +410,12 @@ int km_launch(const FS2Gemm& g, const KmPlan& pl, float* ws, hipStream_t st) {
     }
     g_last_tile = 129;          // (measurement aid: the 16-wave weight-gradient kernel)
     static const int rot_step = getenv("FS2_KM_ROT") ? atoi(getenv("FS2_KM_ROT")) : 4;
-    hipLaunchKernelGGL(fs2_gemm_big_km_kernel, dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
-                       pl.stream_units, ws);
+    if (g.dtype == FS2_BF16)
+        hipLaunchKernelGGL(fs2_gemm_big_km_kernel<2>, dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
+                           pl.stream_units, ws);
+    else
+        hipLaunchKernelGGL(fs2_gemm_big_km_kernel<1>, dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
+                           pl.stream_units, ws);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { fs2_set_error("fs2_gemm(big km): launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
     return FS2_OK;
@@ -411,14 +454,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const ReduceArgs a) {
         const float4 w = *reinterpret_cast<const float4*>(src + s * sstride);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
     }
+    const float alpha = p.alpha * (p.scale_a != nullptr ? *p.scale_a : 1.f) * (p.scale_b != nullptr ? *p.scale_b : 1.f);    // (fp8 operands)
     float* o = p.dst + (int64_t)b1 * p.sC1 + (int64_t)c2 * p.sC2 + (int64_t)m * p.ldc + n;
     if (n + 3 < p.N && ((uintptr_t)o & 15) == 0) {
         float4 c = *reinterpret_cast<float4*>(o);
-        c.x += v.x * p.alpha; c.y += v.y * p.alpha; c.z += v.z * p.alpha; c.w += v.w * p.alpha;
+        c.x += v.x * alpha; c.y += v.y * alpha; c.z += v.z * alpha; c.w += v.w * alpha;
         *reinterpret_cast<float4*>(o) = c;
     } else {
         const float vv[4] = {v.x, v.y, v.z, v.w};
-        for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] += vv[e] * p.alpha;
+        for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] += vv[e] * alpha;
     }
 }
 
@@ -436,35 +480,6 @@ bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     return true;
 }
 
-// Sliced weight gradient: the product of fs2_gemm(a_kmajor = b_kmajor = 1, accumulate = 1) with the partial tiles of the k-split stored
-// with plain stores into `ws` instead of float atomics on C; fs2_wgrad_reduce adds them to C later.  Returns the number of floats of
-// `ws` it used and fills `part` -- or 0 when the product does not run in the uniform k-split form (not eligible, balanced-stream
-// decomposition, workspace too small): the caller then uses fs2_gemm.  Negative: error.
-extern "C" int64_t fs2_wgrad_sliced(const FS2Gemm* gp, float* ws, int64_t ws_floats, FS2WgradPart* part, void* stream) {
-    if (gp == nullptr || ws == nullptr || part == nullptr) { fs2_set_error("fs2_wgrad_sliced: null argument"); return FS2_EINVAL; }
-    FS2Gemm g = *gp;
-    if (g.split_k < 1) g.split_k = 1;
-    if (g.batch1 < 1) g.batch1 = 1;
-    if (g.batch2 < 1) g.batch2 = 1;
-    if (g.conv == 0) { g.taps = 1; g.pad = 0; if (g.seq_len <= 0) g.seq_len = 1; }
-    if (!(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C) || !fs2_aligned16(g.A) || !fs2_aligned16(g.B) || !fs2_aligned16(ws)) return 0;
-    if (g.lda % 8 != 0 || g.ldb % 8 != 0 || g.sA1 % 8 != 0 || g.sA2 % 8 != 0 || g.sB1 % 8 != 0 || g.sB2 % 8 != 0) return 0;
-    if (((g.M + 7) / 8) * 8 > g.lda || ((g.N + 7) / 8) * 8 > g.ldb) return 0;
-    const char* e1 = getenv("FS2_GEMM_BIG_KM");
-    const int mode = e1 ? atoi(e1) : 1;
-    KmPlan pl;
-    if (mode == 0 || !km_plan(g, mode, pl) || pl.stream_units > 0) return 0;
-    const int64_t need = pl.nitems * (int64_t)(TM * TN);
-    if (need > ws_floats || pl.nitems > pl.grid) return 0;          // (one item per workgroup: every slice is written exactly once)
-    const int rc = km_launch(g, pl, ws, (hipStream_t)stream);
-    if (rc != FS2_OK) return rc;
-    const int taps = g.conv == 2 ? g.batch2 : 1, nb2 = g.conv == 2 ? 1 : g.batch2;
-    part->ws = ws; part->dst = (float*)g.C; part->ldc = g.ldc; part->sC1 = g.sC1; part->sC2 = g.sC2;
-    part->M = g.M; part->N = g.N; part->tilesM = pl.tilesM; part->tilesN = pl.tilesN; part->splits = pl.splits;
-    part->n2 = g.conv == 2 ? taps : nb2; part->nbatch = (int)(pl.base / ((long)pl.tilesM * pl.tilesN)); part->alpha = g.alpha; part->block_begin = 0;
-    return need;
-}
-
 namespace {
 // normalised copy of a descriptor + the preconditions of the 16-wave weight-gradient kernel (as fs2_gemm's own checks)
 bool wgrad_desc_ok(const FS2Gemm* gp, FS2Gemm& g) {
@@ -474,8 +489,9 @@ bool wgrad_desc_ok(const FS2Gemm* gp, FS2Gemm& g) {
     if (g.batch2 < 1) g.batch2 = 1;
     if (g.conv == 0) { g.taps = 1; g.pad = 0; if (g.seq_len <= 0) g.seq_len = 1; }
     if (!(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C) || !fs2_aligned16(g.A) || !fs2_aligned16(g.B)) return false;
-    if (g.lda % 8 != 0 || g.ldb % 8 != 0 || g.sA1 % 8 != 0 || g.sA2 % 8 != 0 || g.sB1 % 8 != 0 || g.sB2 % 8 != 0) return false;
-    if (((g.M + 7) / 8) * 8 > g.lda || ((g.N + 7) / 8) * 8 > g.ldb) return false;
+    const int al = g.dtype == FS2_BF8_FP8 ? 16 : 8;       // 16-byte chunks
+    if (g.lda % al != 0 || g.ldb % al != 0 || g.sA1 % al != 0 || g.sA2 % al != 0 || g.sB1 % al != 0 || g.sB2 % al != 0) return false;
+    if (((g.M + al - 1) / al) * al > g.lda || ((g.N + al - 1) / al) * al > g.ldb) return false;
     return true;
 }
 void fill_part(FS2WgradPart* part, const FS2Gemm& g, const float* ws, int tilesM, int tilesN, int splits, long base) {
@@ -483,8 +499,52 @@ void fill_part(FS2WgradPart* part, const FS2Gemm& g, const float* ws, int tilesM
     part->ws = ws; part->dst = (float*)g.C; part->ldc = g.ldc; part->sC1 = g.sC1; part->sC2 = g.sC2;
     part->M = g.M; part->N = g.N; part->tilesM = tilesM; part->tilesN = tilesN; part->splits = splits;
     part->n2 = g.conv == 2 ? taps : nb2; part->nbatch = (int)(base / ((long)tilesM * tilesN)); part->alpha = g.alpha; part->block_begin = 0;
+    part->scale_a = g.dtype == FS2_BF8_FP8 ? g.scale_a : nullptr;
+    part->scale_b = g.dtype == FS2_BF8_FP8 ? g.scale_b : nullptr;
 }
 }  // namespace
+
+// Sliced weight gradient: the product of fs2_gemm(a_kmajor = b_kmajor = 1, accumulate = 1) with the partial tiles of the k-split stored
+// with plain stores into `ws` instead of float atomics on C; fs2_wgrad_reduce adds them to C later.  Returns the number of floats of
+// `ws` it used and fills `part` -- or 0 when the product does not run in the uniform k-split form (not eligible, balanced-stream
+// decomposition, workspace too small): the caller then uses fs2_gemm.  Negative: error.
+extern "C" int64_t fs2_wgrad_sliced(const FS2Gemm* gp, float* ws, int64_t ws_floats, FS2WgradPart* part, void* stream) {
+    if (gp == nullptr || ws == nullptr || part == nullptr) { fs2_set_error("fs2_wgrad_sliced: null argument"); return FS2_EINVAL; }
+    FS2Gemm g;
+    if (!wgrad_desc_ok(gp, g) || !fs2_aligned16(ws)) return 0;
+    const char* e1 = getenv("FS2_GEMM_BIG_KM");
+    const int mode = e1 ? atoi(e1) : 1;
+    KmPlan pl;
+    if (mode == 0 || !km_plan(g, mode, pl, true)) return 0;
+    if (pl.stream_units > 0 || pl.nitems > pl.grid) {
+        // balanced stream, or more items than workgroups (> 256 output tiles): float-atomic flush straight into the gradient.  bf16
+        // operands take that road through fs2_gemm; fp8 operands (which fs2_gemm does not accept k-major) are launched here: the
+        // product is complete on return, nothing to reduce
+        if (g.dtype != FS2_BF8_FP8) return 0;
+        const int rc = km_launch(g, pl, nullptr, (hipStream_t)stream);
+        if (rc != FS2_OK) return rc;
+        part->splits = 0;
+        return 1;
+    }
+    const int64_t need = pl.nitems * (int64_t)(TM * TN);
+    if (need > ws_floats || pl.nitems > pl.grid) return 0;          // (one item per workgroup: every slice is written exactly once)
+    const int rc = km_launch(g, pl, ws, (hipStream_t)stream);
+    if (rc != FS2_OK) return rc;
+    fill_part(part, g, ws, pl.tilesM, pl.tilesN, pl.splits, pl.base);
+    return need;
+}
+
+// How fs2_wgrad_sliced / fs2_wgrad_grouped would run the product: 0 not at all (fs2_gemm's own kernels), 1 uniform k-split with partial
+// tiles (the only form that takes fp8 operands), 2 balanced stream (bf16, float-atomic flush through fs2_gemm)
+extern "C" int fs2_wgrad_plan(const FS2Gemm* gp) {
+    FS2Gemm g;
+    if (gp == nullptr || !wgrad_desc_ok(gp, g)) return 0;
+    const char* e1 = getenv("FS2_GEMM_BIG_KM");
+    const int mode = e1 ? atoi(e1) : 1;
+    KmPlan pl;
+    if (mode == 0 || !km_plan(g, mode, pl, true)) return 0;
+    return (pl.stream_units > 0 || pl.nitems > pl.grid) ? 2 : 1;
+}
 
 // n (<= 4) products of fs2_wgrad_sliced's kind in ONE launch; parts[i] describes the partial tiles of product i for fs2_wgrad_reduce.
 // Products the grouped launch does not take (not eligible, balanced-stream decomposition, the group already holds 224 output tiles) are
@@ -503,7 +563,8 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
     int m = 0;
     for (int i = 0; i < n; ++i) {
         parts[i].splits = 0;                 // "not taken" until proven otherwise
-        if (!wgrad_desc_ok(descs + i, a.g[m]) || !km_plan(a.g[m], mode, pl[m]) || pl[m].stream_units > 0) continue;
+        if (!wgrad_desc_ok(descs + i, a.g[m]) || !km_plan(a.g[m], mode, pl[m], true) || pl[m].stream_units > 0) continue;
+        if (m > 0 && a.g[m].dtype != a.g[0].dtype) continue;            // (one operand format per launch)
         if (tiles + pl[m].base > 224) continue;
         nstk[m] = (a.g[m].K + BK - 1) / BK;
         work += pl[m].base * nstk[m];
@@ -543,14 +604,16 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
     (void)hipGetDevice(&dev);
     static bool attr_set[16] = {};
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             fs2_set_error("fs2_wgrad_grouped: cannot raise the dynamic LDS limit of the weight-gradient kernel");
             return FS2_ELAUNCH;
         }
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     g_last_tile = 129;
-    hipLaunchKernelGGL(fs2_gemm_big_km_grouped_kernel, dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
+    if (a.g[0].dtype == FS2_BF16) hipLaunchKernelGGL(fs2_gemm_big_km_grouped_kernel<2>, dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(fs2_gemm_big_km_grouped_kernel<1>, dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { fs2_set_error("fs2_wgrad_grouped: launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
     for (int i = 0; i < m; ++i) fill_part(parts + src[i], a.g[i], a.ws[i], pl[i].tilesM, pl[i].tilesN, a.splits[i], pl[i].base);

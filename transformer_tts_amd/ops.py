@@ -98,6 +98,7 @@ SIGNATURES = {
     "fs2_quantize_fp8_repair": [_P, _I, _P, _I, _L, _P, _P, _P],
     "fs2_quantize_fp8_batched": [_P, _I, _I, _I, _P],
     "fs2_wgrad_sliced": [ctypes.POINTER(FS2Gemm), _P, _L, _P, _P],      # returns int64
+    "fs2_wgrad_plan": [ctypes.POINTER(FS2Gemm)],
     "fs2_wgrad_grouped": [_P, _I, _P, _L, _P, _P],      # returns int64
     "fs2_wgrad_reduce": [_P, _I, _P],
     "fs2_softmax_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _L, _F, _P, _U32, _P],
@@ -387,6 +388,24 @@ def _fp8_eligible(g, M, N, K_total_row, x, w, residual=None, relu_mask=None, sta
 
 
 FP8_FUSED_OUT = os.environ.get("FS2_FP8_Q8", "1") != "0"     # producers write the fp8 copy of their output (FS2Gemm.q8)
+FP8_WGRAD = os.environ.get("FS2_FP8_WGRAD", "1") != "0"      # weight gradients multiply the fp8 copies of dY (e5m2) and X (e4m3)
+
+
+def _wgrad_fp8(g, dy, x):
+    """the descriptor of a weight-gradient product with its operands swapped for their fp8 copies -- when the fp8 mode is on, both
+    tensors carry one (dY in e5m2 from the data-gradient product or its producer, X in e4m3 from the forward) and the product runs in
+    the uniform k-split form (fs2_wgrad_plan); else None"""
+    if not (FP8_MODE["on"] and FP8_WGRAD) or dy is None or x is None:
+        return None
+    a, b = getattr(dy, "_fs2_q8", None), getattr(x, "_fs2_q8", None)
+    if a is None or b is None or not a[2] or b[2] or a[0].numel() != dy.numel() or b[0].numel() != x.numel():
+        return None
+    g2 = FS2Gemm.from_buffer_copy(g)
+    g2.A, g2.B, g2.dtype = _p(a[0]), _p(b[0]), BF8_FP8
+    g2.scale_a, g2.scale_b = _p(a[1][1:]), _p(b[1][1:])
+    if lib().fs2_wgrad_plan(ctypes.byref(g2)) == 0:       # (1: uniform k-split, partial tiles; 2: balanced stream, atomic flush)
+        return None
+    return g2, (a, b)
 
 
 def _fp8_q8_request(g, out2, relu_mask, colstats, colsum, residual):
@@ -451,6 +470,11 @@ def _fp8_operands(g, x2, w, pre=None):
         xq, sx = pre[0].view(x2.shape), pre[1]
     else:
         xq, sx = quantize_fp8(x2, bf8=FP8_MODE["backward"])
+        if FP8_WGRAD:       # the weight gradient of this layer multiplies the same tensor: keep the copy with it (and with its base)
+            x2._fs2_q8 = (xq, sx, bool(FP8_MODE["backward"]))
+            base = x2._base
+            if base is not None and base.numel() == x2.numel() and base.is_contiguous():
+                base._fs2_q8 = (xq.view(base.shape), sx, bool(FP8_MODE["backward"]))
     hit = _FP8_W.get(w.data_ptr())
     if hit is not None and hit[2] == w.numel() and hit[0].shape == w.shape:
         wq, sw = hit[0], hit[1]
@@ -524,7 +548,7 @@ class FS2WgradPart(ctypes.Structure):
     _fields_ = [("ws", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("sC1", ctypes.c_int64), ("sC2", ctypes.c_int64),
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("tilesM", ctypes.c_int32), ("tilesN", ctypes.c_int32),
                 ("splits", ctypes.c_int32), ("n2", ctypes.c_int32), ("nbatch", ctypes.c_int32), ("block_begin", ctypes.c_int32),
-                ("alpha", ctypes.c_float), ("reserved", ctypes.c_int32)]
+                ("alpha", ctypes.c_float), ("reserved", ctypes.c_int32), ("scale_a", ctypes.c_void_p), ("scale_b", ctypes.c_void_p)]
 
 
 class _WgradSlices:
@@ -562,14 +586,15 @@ class _WgradSlices:
             self.flush()
         self.device = out.device
         if defer and self.group:
-            self.pending.append((FS2Gemm.from_buffer_copy(g), out, keep))
+            self.pending.append((FS2Gemm.from_buffer_copy(g), out, keep))      # (the fp8 copies of the operands are looked up at launch)
             self.spans.append((lo, hi))
             if len(self.pending) >= 4:
                 self._launch_pending()
             if len(self.parts) >= 36:
                 self.flush()
             return True
-        if not self._one(g, out):
+        f8 = _wgrad_fp8(g, *keep) if len(keep) == 2 else None
+        if not self._one(f8[0] if f8 else g, out):
             return False
         self.spans.append((lo, hi))
         if not defer or len(self.parts) >= 36:
@@ -589,9 +614,10 @@ class _WgradSlices:
             self._reduce()         # perhaps the workspace was full: retry from offset 0
         if used <= 0:
             return False
-        self.off += int(used)
-        self.parts.append(part)
-        self.keep.append(out)
+        if part.splits > 0:             # (0: an fp8 product in the balanced-stream form, already added with float atomics)
+            self.off += int(used)
+            self.parts.append(part)
+            self.keep.append(out)
         return True
 
     def _launch_pending(self):
@@ -602,6 +628,8 @@ class _WgradSlices:
         if self.FLOATS - self.off < (20 << 20):
             self._reduce()
         n = len(pend)
+        f8 = [(_wgrad_fp8(p[0], *p[2]) if len(p[2]) == 2 else None) for p in pend]      # fp8 copies that exist by now (kept alive via pend)
+        pend = [((f[0] if f else p[0]), p[1], p[2] + ((f[1],) if f else ())) for p, f in zip(pend, f8)]
         descs = (FS2Gemm * n)(*[p[0] for p in pend])
         parts = (FS2WgradPart * n)()
         res = {}
