@@ -45,7 +45,7 @@ fetch, write = pmc("pmcb1", "FETCH_SIZE"), pmc("pmcb2", "WRITE_SIZE")
 def variant(name):
     """bench.py's variant key (dtype/A layout/B layout/tile id) of a GEMM kernel name, mangled or demangled"""
     import re
-    if "fs2_gemm_big_km_kernel" in name:
+    if "fs2_gemm_big_km_kernel" in name or "fs2_gemm_big_km_grouped_kernel" in name:       # (single and grouped launches: bench.py times both under one key)
         return "bf16/km/km/129"
     if "fs2_gemm_ws_kernel" in name:
         return "bf16/rm/rm/131"

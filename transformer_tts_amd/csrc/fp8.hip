@@ -214,7 +214,7 @@ extern "C" int fs2_quantize_fp8_repair(const void* src, int src_dtype, void* dst
     FS2_REQUIRE(src_dtype == FS2_BF16, "fs2_quantize_fp8_repair: bf16 sources only (dtype %d)", src_dtype);
     FS2_REQUIRE(n > 0 && src && dst && state && prev, "fs2_quantize_fp8_repair: bad arguments");
     FS2_REQUIRE(fs2_aligned16(src) && fs2_aligned16(dst), "fs2_quantize_fp8_repair: src and dst must be 16-byte aligned");
-    dim3 grid(flat_grid((n + 15) >> 4, 512)), block(TPB);      // (a no-op in the common case: few workgroups)
+    dim3 grid(flat_grid((n + 15) >> 4, 128)), block(TPB);      // (a no-op in the common case: few workgroups)
     if (bf8) hipLaunchKernelGGL((quant_k<bf16_t, true, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)src, (unsigned*)dst, n, state, prev);
     else hipLaunchKernelGGL((quant_k<bf16_t, false, true>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)src, (unsigned*)dst, n, state, prev);
     FS2_CHECK_LAUNCH("fs2_quantize_fp8_repair");
