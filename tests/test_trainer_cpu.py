@@ -248,6 +248,34 @@ def test_autoregressive_trainer_runs_on_the_reference_data_path(fake_ops, tmp_pa
             T.train_step(model, FusedAdam(model), 1, odd, hp)
 
 
+def test_fused_adam_loads_a_reference_optimizer_state_without_entries_for_gradientless_parameters():
+    """the reference's torch.optim.Adam holds no state for parameters that never received a gradient (the post-net convolutions of the
+    autoregressive model: postnets.py prev_version=False): such a `network.optimizer.epochN` must load -- zero moments for those
+    parameters, step and moments of the others restored, and the file FusedAdam writes back loads into torch's Adam"""
+    from transformer_tts_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Conv1d(4, 4, 3), torch.nn.Linear(16, 2))
+    ref = torch.optim.Adam(net.parameters(), lr=1e-3)
+    for _ in range(3):
+        ref.zero_grad()
+        net[2](net[0](torch.randn(5, 8))).sum().backward()       # the Conv1d gets no gradient: no state entry
+        ref.step()
+    sd = ref.state_dict()
+    assert set(sd["state"].keys()) == {0, 1, 4, 5}
+    opt = FusedAdam(net)
+    opt.load_state_dict(sd)
+    assert opt.t == 3
+    for i, (p, o) in enumerate(zip(opt.arena.params, opt.arena.offsets)):
+        m = opt.m[o:o + p.numel()].view_as(p)
+        if i in sd["state"]:
+            assert torch.equal(m, sd["state"][i]["exp_avg"])
+        else:
+            assert float(m.abs().max()) == 0.0
+    back = torch.optim.Adam(net.parameters(), lr=1e-3)
+    back.load_state_dict(opt.state_dict())
+    assert int(back.state_dict()["state"][0]["step"]) == 3
+
+
 def test_bench_launcher_glue_runs_two_ranks_without_a_gpu():
     """`python bench.py --gpus 2` from a plain shell: bench.launch_ranks builds the torch.distributed.run command line, the two rank
     processes rendezvous over 127.0.0.1, run the barrier / MAX-over-ranks protocol of the timed region and rank 0 prints ONE JSON

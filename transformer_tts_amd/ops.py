@@ -384,6 +384,13 @@ def _fp8_eligible(g, M, N, K_total_row, x, w, residual=None, relu_mask=None, sta
         return False
     if residual is not None and relu_mask is not None and residual.dtype != torch.float32:
         return False
+    # the refusals of fs2_gemm_ring_try / fs2_gemm_big_try themselves (the product must stay on bf16 operands then, not fail after its
+    # operands were quantised): 32-bit byte offsets over M + 512 rows of C / mask / residual / A and N + 512 rows of B, conv padding
+    rows = M + 512
+    if rows * N * 4 >= 0x7FFFFFF0 or rows * K_total_row >= 0x7FFFFFF0 or (N + 512) * max(1, g.taps if g.conv == 1 else 1) * K_total_row >= 0x7FFFFFF0:
+        return False
+    if g.conv == 1 and not (0 <= g.pad <= g.taps):
+        return False
     return True
 
 

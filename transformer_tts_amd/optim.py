@@ -123,10 +123,20 @@ class FusedAdam:
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
+        """torch.optim.Adam's format.  A parameter WITHOUT an entry in sd["state"] (torch's Adam creates the state of a parameter at its
+        first gradient: the post-net convolutions of the autoregressive model never get one in the reference, train.py / postnets.py)
+        starts from zero moments, exactly what the reference's optimizer would do if such a parameter ever received a gradient."""
+        state = sd["state"]
+        steps = []
         for i, (p, o) in enumerate(zip(self.arena.params, self.arena.offsets)):
-            st = sd["state"][i]
+            st = state.get(i)
             n = p.numel()
+            if st is None:
+                self.m[o:o + n].zero_()
+                self.v[o:o + n].zero_()
+                continue
             self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
             self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
-        self.t = int(sd["state"][0]["step"])
+            steps.append(int(st["step"]))
+        self.t = max(steps) if steps else 0
         self.param_groups[0]["lr"] = sd["param_groups"][0]["lr"]
