@@ -250,12 +250,14 @@ def ar_batch(seed, batch_size, r=1):
 
 
 def bench_ar(args, hp, dev):
-    """--workload cfg3: BASELINE.json configs[3] (a parity case, reported for completeness: never the headline).  Eager launches
-    (the autoregressive trainer has no graph stepper); a step = reference train.py:156-262 on one resident batch."""
+    """--workload cfg3: BASELINE.json configs[3] (a parity case, reported for completeness: never the headline).  A step = reference
+    train.py:156-262 on one resident batch; timed region = hipGraph replay per batch shape (train.graphed_train_step; --no-graph: eager
+    launches), the GEMM event timer runs over a few eager steps behind it as for configs[1]."""
     from transformer_tts_amd import train as T
+    from transformer_tts_amd import train_fastspeech2 as TF
     from transformer_tts_amd.optim import FusedAdam
     from transformer_tts_amd.utils.utils import init_weight
-    T.DEVICE = dev
+    T.DEVICE = TF.DEVICE = dev
     torch.manual_seed(1234)
     model = T.build_model(hp)
     model.apply(init_weight)
@@ -264,23 +266,30 @@ def bench_ar(args, hp, dev):
     opt = FusedAdam(model, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=hp.clip)
     pool = [tuple(b.to(dev) if torch.is_tensor(b) else b for b in ar_batch(2024 + i, hp.batch_size, hp.reduction_rate)) for i in range(POOL)]
     frames = [int(b[5].sum()) - b[1].shape[0] for b in pool]            # valid mel frames without the go frames
+    use_graph = not args.no_graph
+    stepper = T.graphed_train_step(model, opt, hp) if use_graph else (lambda st, d: T.train_step(model, opt, st, d, hp))
+    warm = max(args.warmup, 2 * POOL) if use_graph else args.warmup     # each shape: 1 eager + 1 capture before replay
     step = 1
-    for i in range(args.warmup):
-        _, _, step = T.train_step(model, opt, step, pool[i % POOL], hp)
-    timer = GemmTimer()
-    timer.calibrate()
-    timer.reserve(2 * 700 * args.steps)
-    timer.install()
+    for i in range(warm):
+        _, _, step = stepper(step, pool[i % POOL])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     done = 0
     for i in range(args.steps):
-        _, _, step = T.train_step(model, opt, step, pool[(args.warmup + i) % POOL], hp)
-        done += frames[(args.warmup + i) % POOL]
+        _, _, step = stepper(step, pool[(warm + i) % POOL])
+        done += frames[(warm + i) % POOL]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    timer = GemmTimer()                 # roofline leg: eager, instrumented steps behind the timed region
+    timer.calibrate()
+    n_inst = min(args.steps, POOL)
+    timer.reserve(2 * 700 * n_inst)
+    timer.install()
+    for i in range(n_inst):
+        _, _, step = T.train_step(model, opt, step, pool[i % POOL], hp)
+    torch.cuda.synchronize()
     timer.remove()
-    return timer, dt, done, int(sum(b[1].shape[0] * b[1].shape[1] for b in pool) / len(pool))
+    return timer, dt, done, int(sum(b[1].shape[0] * b[1].shape[1] for b in pool) / len(pool)), use_graph, n_inst
 
 
 def bench_line(args, timer, dt, done, world, warm, use_graph, padded, BATCH, cpu):
@@ -438,8 +447,10 @@ def main():
     BATCH = hp.batch_size
     if args.workload == "cfg3":
         assert world == 1, "configs[3] is a single-GPU parity case"
-        timer, dt, done, padded = bench_ar(args, hp, dev)
-        line = bench_line(args, timer, dt, done, world, args.warmup, False, padded, BATCH, None)
+        timer, dt, done, padded, ar_graph, n_inst = bench_ar(args, hp, dev)
+        line = bench_line(args, timer, dt, done, world, args.warmup, ar_graph, padded, BATCH, None)
+        if line["roofline"] is not None:        # (the event timer ran over n_inst eager steps whatever the timed region was)
+            line["roofline"]["gemm_ms_per_step"] = round(sum(v[1] for v in timer.summary().values()) / max(1, n_inst), 3)
         print(json.dumps(line), flush=True)
         return
     torch.manual_seed(1234)

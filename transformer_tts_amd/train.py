@@ -76,13 +76,58 @@ def compute_losses(hp, outputs, mel, stop_token):
     return loss, parts
 
 
-def train_step(model, optimizer, step, d, hp):
-    """One iteration of the reference loop body (train.py:156-262, non-amp arithmetic; hp.amp selects the bf16 kernels).
-    Returns (loss tensor, parts, new step)."""
+def _set_lr(optimizer, step, hp):
     if hp.optimizer.lower() != "radam":
         lr = get_learning_rate(step, hp.d_model_decoder, hp.warmup_factor, hp.warmup_step)
         for param_group in optimizer.param_groups:
             param_group["lr"] = lr
+
+
+def step_body(model, optimizer, hp, text, mel, pos_text, pos_mel, stop_token):
+    """device work of one iteration with the fused optimizer and accum_grad = 1 (no host synchronisation: capturable in a hipGraph)"""
+    mel_input, pos_in = decoder_inputs(mel, pos_mel, hp.reduction_rate)
+    src_mask, trg_mask = create_masks(pos_text, pos_in)
+    outputs = model(text, mel_input.contiguous(), src_mask, trg_mask, None)
+    optimizer.zero_grad()
+    loss, parts = compute_losses(hp, outputs, mel, stop_token)
+    loss.backward()
+    optimizer.launch()
+    model.rt.get_rng(text.device).advance()
+    return loss, parts
+
+
+STEP_INPUTS = (0, 1, 2, 3, 6)       # entries of the 8-tuple a step reads: text, mel, pos_text, pos_mel, stop_token
+
+
+def graphed_train_step(model, optimizer, hp, **kw):
+    """train_step with one hipGraph per batch shape (train_fastspeech2.GraphedTrainStep over this module's step): accum_grad = 1 and
+    the fused optimizer only; called as stepper(step, batch) -> (loss, parts, new step)"""
+    from .train_fastspeech2 import GraphedTrainStep
+    assert int(getattr(hp, "accum_grad", 1)) == 1, "the graph stepper applies the optimizer in every captured step"
+    def body(model_, optimizer_, hp_, *static):
+        # rt.check_masks compares the mask tensors on the host (a synchronisation: not capturable); the first occurrence of a batch
+        # shape runs through the eager train_step, where the check is live
+        keep = getattr(model_.rt, "check_masks", False)
+        model_.rt.check_masks = False
+        try:
+            return step_body(model_, optimizer_, hp_, *static)
+        finally:
+            model_.rt.check_masks = keep
+
+    g = GraphedTrainStep(model, optimizer, hp, body=body, inputs=STEP_INPUTS, set_lr=_set_lr,
+                         eager=lambda m, o, st, d, h: train_step(m, o, st, d, h)[:2] + (None,), **kw)
+
+    def stepper(step, d):
+        loss, parts, _ = g(step, d)
+        return loss, parts, step + 1
+    stepper.graphs = g
+    return stepper
+
+
+def train_step(model, optimizer, step, d, hp):
+    """One iteration of the reference loop body (train.py:156-262, non-amp arithmetic; hp.amp selects the bf16 kernels).
+    Returns (loss tensor, parts, new step)."""
+    _set_lr(optimizer, step, hp)
     text, mel, pos_text, pos_mel, text_lengths, mel_lengths, stop_token = d[:7]
     mv = lambda x: x.to(DEVICE, non_blocking=True)
     text, mel, pos_text, pos_mel, stop_token = (mv(x) for x in (text, mel, pos_text, pos_mel, stop_token))
@@ -107,9 +152,10 @@ def train_step(model, optimizer, step, d, hp):
     return loss, parts, step
 
 
-def train_loop(model, optimizer, step, epoch, hp, dataloader, log_every=1):
+def train_loop(model, optimizer, step, epoch, hp, dataloader, log_every=1, stepper=None):
+    """stepper: graphed_train_step(...) (one hipGraph per batch shape) or None = eager train_step"""
     for d in dataloader:
-        loss, parts, step = train_step(model, optimizer, step, d, hp)
+        loss, parts, step = stepper(step, d) if stepper is not None else train_step(model, optimizer, step, d, hp)
         assert not torch.isnan(loss), "loss is nan"          # every iteration, as the reference does (train.py:236)
         if (step - 1) % log_every == 0:
             print(f"step {step - 1}")
@@ -163,11 +209,15 @@ def run_training(hp):
         step = int(loaded["state"][0]["step"]) * int(getattr(hp, "accum_grad", 1))
     else:
         start_epoch, step = 0, 1
+    # on the GPU the device work of a step is captured once per batch shape and replayed (hp.use_graph = False keeps eager launches)
+    stepper = None
+    if DEVICE.type == "cuda" and bool(getattr(hp, "use_graph", True)) and int(getattr(hp, "accum_grad", 1)) == 1:
+        stepper = graphed_train_step(model, optimizer, hp, eager_fallback=True)
     for epoch in range(start_epoch, hp.max_epoch):
         dataloader = DataLoader(dataset_train, batch_sampler=sampler, num_workers=int(getattr(hp, "num_workers", 4)),
                                 collate_fn=collate_fn)
         start_time = time.time()
-        step = train_loop(model, optimizer, step, epoch, hp, dataloader, max(1, int(getattr(hp, "log_every", 1))))
+        step = train_loop(model, optimizer, step, epoch, hp, dataloader, max(1, int(getattr(hp, "log_every", 1))), stepper)
         print("EPOCH {} end".format(epoch + 1))
         print(f"elapsed time {time.time() - start_time}")
     return step

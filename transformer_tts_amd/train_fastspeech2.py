@@ -154,9 +154,13 @@ class GraphedTrainStep:
     Padding is semantically live in this model (BatchNorm statistics and the L1 losses include padded
     positions), so batches are never padded to a common shape -- one graph per (B, L_pad, T_pad)."""
 
-    def __init__(self, model, optimizer, hp, max_graphs=32, eager_fallback=False):
+    def __init__(self, model, optimizer, hp, max_graphs=32, eager_fallback=False, body=None, inputs=None, eager=None, set_lr=None):
+        """body / inputs / eager / set_lr: the device part of a step, the batch entries it reads, the eager step and the learning-rate rule
+        of ANOTHER trainer of this package (transformer_tts_amd.train: the autoregressive model); default: this module's"""
         assert isinstance(optimizer, FusedAdam)
         self.model, self.optimizer, self.hp = model, optimizer, hp
+        self.body, self.inputs = body or step_body, inputs or STEP_INPUTS
+        self.eager, self.set_lr = eager or train_step, set_lr or _set_lr
         self.max_graphs = max_graphs
         self.seen, self.graphs = set(), {}
         self.pool = None
@@ -165,15 +169,15 @@ class GraphedTrainStep:
         self.eager_fallback, self.broken = eager_fallback, False
 
     def __call__(self, step, d):
-        _set_lr(self.optimizer, step, self.hp)
-        tensors = [d[i] for i in STEP_INPUTS]       # text, mel, pos_text, pos_mel, f0, energy, alignment
+        self.set_lr(self.optimizer, step, self.hp)
+        tensors = [d[i] for i in self.inputs]       # text, mel, pos_text, pos_mel, f0, energy, alignment
         key = (tuple(tensors[0].shape), tuple(tensors[1].shape))
         entry = self.graphs.get(key)
         if self.broken:
-            return train_step(self.model, self.optimizer, step, d, self.hp)
+            return self.eager(self.model, self.optimizer, step, d, self.hp)
         if entry is None and (key not in self.seen or len(self.graphs) >= self.max_graphs):
             self.seen.add(key)
-            return train_step(self.model, self.optimizer, step, d, self.hp)
+            return self.eager(self.model, self.optimizer, step, d, self.hp)
         if entry is None:
             static = [t.to(DEVICE).clone() for t in tensors]
             g = torch.cuda.CUDAGraph()
@@ -189,14 +193,14 @@ class GraphedTrainStep:
             mode = os.environ.get("FS2_CAPTURE_ERROR_MODE") or ("thread_local" if _dist_alive() else "global")
             try:
                 with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
-                    loss, parts = step_body(self.model, self.optimizer, self.hp, *static[:4], *static[4:])
+                    loss, parts = self.body(self.model, self.optimizer, self.hp, *static)
             except Exception as e:      # noqa: BLE001  (whatever the runtime raises for an operation it cannot capture)
                 if not self.eager_fallback:
                     raise
                 print(f"GraphedTrainStep: capture failed ({type(e).__name__}: {e}); continuing with eager launches", flush=True)
                 self.broken = True
                 torch.cuda.synchronize()
-                return train_step(self.model, self.optimizer, step, d, self.hp)
+                return self.eager(self.model, self.optimizer, step, d, self.hp)
             entry = self.graphs[key] = (g, static, loss, parts)
         self.optimizer.host_update()
         g, static, loss, parts = entry
