@@ -159,7 +159,7 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     // ---- LDS-DMA: instruction i of this wave covers image rows 4*(i*NW + wave) .. +3 of A (i = 0,1) and of B (i = 0,1);
     //      the lane fetches logical chunk (lane&15) ^ f(row) of row lane>>4 of those
     //      (fp8: ONE instruction per operand, image rows 8*wave .. +7 of 128 B, chunk (lane&7) ^ f8(row) of row lane>>3)
-    constexpr int NI = ES == 2 ? 2 : 1, OPB = BK * 128 * ES;
+    constexpr int NI = ES == 2 ? 2 : 1, OPB = BK * 128 * ES, SBYTES = 2 * OPB;      // (SBYTES: one stage buffer, 64 / 32 KiB)
     auto dma_row = [&](int i) { return ES == 2 ? 4 * (i * NW + wave) + (lane >> 4) : 8 * wave + (lane >> 3); };
     auto dma_col = [&](int i) { return ES == 2 ? ((lane & 15) ^ km_f(dma_row(i))) * 8 : ((lane & 7) ^ km_f8(dma_row(i))) * 16; };
 
@@ -179,7 +179,7 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     auto issue = [&](int buf) __attribute__((always_inline)) {
         const int kb = lst * BK;
         const int shiftB = p.conv == 2 ? ck.tap - p.pad : 0;
-        unsigned char* base = smem + buf * STAGE + 1024 * wave;
+        unsigned char* base = smem + buf * SBYTES + 1024 * wave;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int kk = kb + dma_row(i);
@@ -209,9 +209,38 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nst = ck.st1 - ck.st0;
+        if constexpr (ES == 1) {
+            // ---- fp8: stages of 32 KiB in a 4-deep ring, THREE in flight (the two-buffer form of the bf16 path would leave half of its
+            //      bytes in flight: the kernel is bound by what a CU keeps outstanding on the L2 -> LDS path).  Counted waits: a wave issues
+            //      two LDS-DMA instructions per stage and they retire in order, so stage s has landed once at most 2 x (stages issued
+            //      after it) remain; the buffer stage s+3 goes into was read in iteration s-1, before the barrier every wave has just passed.
+            const int pre = nst < 3 ? nst : 3;
+            for (int i = 0; i < pre; ++i) issue(i);
+            for (int s = 0; s < nst; ++s) {
+                const int younger = nst - 1 - s < 2 ? nst - 1 - s : 2;
+                if (younger == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (s + 3 < nst) issue((s + 3) & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* la = smem + (s & 3) * SBYTES;
+                const unsigned char* lb = la + OPB;
+                long fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = km_frag8(la, wr * 64 + i * 16, 32 * kg, lane);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) fb[jj] = km_frag8(lb, wc * 64 + jj * 16, 32 * kg, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
         issue(0);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const int nst = ck.st1 - ck.st0;
         for (int s = 0; s < nst; ++s) {
             const int buf = s & 1;
             // stage s+1 -> the buffer every wave finished with at the last barrier.  The vector-memory path of a CU takes ~1000
@@ -222,9 +251,9 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
             const bool issue_first = ((wave >> 2) & 1) != 0;
             if (issue_first && s + 1 < nst) issue(buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* la = smem + buf * STAGE;
+            const unsigned char* la = smem + buf * SBYTES;
             const unsigned char* lb = la + OPB;
-            if constexpr (ES == 2) {
+            {
                 bf16x8 fa[4], fb[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fa[i] = km_frag(la, wr * 64 + i * 16, 32 * kg, lane);
@@ -234,21 +263,12 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
-            } else {
-                long fa[4], fb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = km_frag8(la, wr * 64 + i * 16, 32 * kg, lane);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) fb[jj] = km_frag8(lb, wc * 64 + jj * 16, 32 * kg, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);         // (or hipcc moves the late issue back up in front of the MFMAs)
             if (!issue_first && s + 1 < nst) issue(buf ^ 1);
             // own DMA landed, own fragment reads retired; then every wave's
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         }
         // ---- the four k-groups hold partial sums of the same 128 x 128 tile: a two-round tree through LDS (both stage buffers
         //      are free: nothing is staged across work items), plain 16-byte accesses in accumulator order (LDS float atomics
