@@ -68,13 +68,20 @@ extern thread_local int g_last_tile;     // gemm.hip
 // product, a sub-range of the grid in a grouped launch (fs2_gemm_big_km_grouped_kernel: several products, one launch)
 // ES: bytes per operand element -- 2: bf16; 1: fp8 (A = dY in e5m2, B = X in e4m3: the copies the data-gradient / forward products of the
 // fp8 operand mode already hold; half the staged and LDS-read bytes per multiply-add on a kernel that is bound by exactly those)
-template <int ES>
+// KG: k-groups inside the workgroup.  4 (round 2 / fp8): 128 reduction rows per stage, 4 x (2 x 2 waves of 64 x 64).  2 (bf16, round 3): 64
+// rows per stage = 32 KiB, so the 128 KiB hold a 4-deep ring with THREE stages in flight (the 64 KiB stages of the KG = 4 form: one) --
+// the operands of a weight gradient were just written by other kernels, and how many bytes a CU keeps outstanding decides how fast they
+// arrive; 2 x (2 x 4 waves of 64 x 32): 32 accumulators per lane, 6 fragments per 8 MFMAs (LDS reads x 1.5, under the MFMA time).
+template <int ES, int KG = 4>
 __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, const int tilesN, const int splits, const int nitems, const int rot_step,
                                         const int stream_units, float* __restrict__ ws, const int vblock, const int vgrid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
+    static_assert(KG == 4 || (KG == 2 && ES == 2), "two k-groups: bf16 only");
+    constexpr int NJ = KG == 2 ? 2 : 4;              // 16-column blocks of a wave's output tile (64 x 64 or 64 x 32)
+    constexpr int SROWS = KG == 2 ? 64 : BK;          // reduction rows per stage
+    const int kg = KG == 2 ? wave >> 3 : wave >> 2, wr = KG == 2 ? (wave >> 2) & 1 : (wave >> 1) & 1, wc = KG == 2 ? wave & 3 : wave & 1;
     const int g = lane >> 4, i16 = lane & 15;
 
     // ---- items of this block.
@@ -159,7 +166,8 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     // ---- LDS-DMA: instruction i of this wave covers image rows 4*(i*NW + wave) .. +3 of A (i = 0,1) and of B (i = 0,1);
     //      the lane fetches logical chunk (lane&15) ^ f(row) of row lane>>4 of those
     //      (fp8: ONE instruction per operand, image rows 8*wave .. +7 of 128 B, chunk (lane&7) ^ f8(row) of row lane>>3)
-    constexpr int NI = ES == 2 ? 2 : 1, OPB = BK * 128 * ES, SBYTES = 2 * OPB;      // (SBYTES: one stage buffer, 64 / 32 KiB)
+    //      (two k-groups: ONE instruction per operand as well: the 64 rows of a stage = 16 waves x 4 rows)
+    constexpr int NI = (ES == 2 && KG == 4) ? 2 : 1, OPB = SROWS * 128 * ES, SBYTES = 2 * OPB;      // (SBYTES: one stage buffer, 64 / 32 KiB)
     auto dma_row = [&](int i) { return ES == 2 ? 4 * (i * NW + wave) + (lane >> 4) : 8 * wave + (lane >> 3); };
     auto dma_col = [&](int i) { return ES == 2 ? ((lane & 15) ^ km_f(dma_row(i))) * 8 : ((lane & 7) ^ km_f8(dma_row(i))) * 16; };
 
@@ -177,7 +185,7 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
         }
     };
     auto issue = [&](int buf) __attribute__((always_inline)) {
-        const int kb = lst * BK;
+        const int kb = lst * SROWS;
         const int shiftB = p.conv == 2 ? ck.tap - p.pad : 0;
         unsigned char* base = smem + buf * SBYTES + 1024 * wave;
 #pragma unroll
@@ -198,19 +206,44 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
         ++lst;
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 
     const int jbeg = stream_units > 0 ? 0 : slot, jend = stream_units > 0 ? npart : have, jstep = stream_units > 0 ? 1 : nslots;
     for (int j = jbeg; j < jend; j += jstep) {
         ck = decode(j);
         prep(ck);
-        lst = ck.st0;
+        lst = ck.st0 * (BK / SROWS);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nst = ck.st1 - ck.st0;
-        if constexpr (ES == 1) {
+            for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nst = (ck.st1 - ck.st0) * (BK / SROWS);      // (the host plans in units of 128 rows; rows past K read as zeros)
+        if constexpr (KG == 2) {
+            // ---- bf16, two k-groups: 4-deep ring of 32 KiB stages, as the fp8 path below
+            const int pre = nst < 3 ? nst : 3;
+            for (int i = 0; i < pre; ++i) issue(i);
+            for (int s = 0; s < nst; ++s) {
+                const int younger = nst - 1 - s < 2 ? nst - 1 - s : 2;
+                if (younger == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (s + 3 < nst) issue((s + 3) & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* la = smem + (s & 3) * SBYTES;
+                const unsigned char* lb = la + OPB;
+                bf16x8 fa[4], fb[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = km_frag(la, wr * 64 + i * 16, 32 * kg, lane);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) fb[jj] = km_frag(lb, wc * 32 + jj * 16, 32 * kg, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else if constexpr (ES == 1) {
             // ---- fp8: stages of 32 KiB in a 4-deep ring, THREE in flight (the two-buffer form of the bf16 path would leave half of its
             //      bytes in flight: the kernel is bound by what a CU keeps outstanding on the L2 -> LDS path).  Counted waits: a wave issues
             //      two LDS-DMA instructions per stage and they retire in order, so stage s has landed once at most 2 x (stages issued
@@ -270,6 +303,33 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         }
+        float* red = reinterpret_cast<float*>(smem + STAGE);      // the total, row-major [128][128] fp32, in the second 64 KiB
+        if constexpr (KG == 2) {
+            // ---- two k-groups: group 1 parks its accumulators in the first 64 KiB (lane-linear 16-byte slots), group 0 adds its own
+            //      and writes the total row-major
+            float4* red4 = reinterpret_cast<float4*>(smem);
+            const int wslot = (wave & 7) * 512 + lane;                // per wave position: 8 float4 per lane
+            if (kg == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        red4[wslot + (i * 2 + jj) * 64] = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kg == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const float4 v = red4[wslot + (i * 2 + jj) * 64];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            red[(wr * 64 + i * 16 + g * 4 + r) * TN + wc * 32 + jj * 16 + i16] = acc[i][jj][r] + (&v.x)[r];
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        } else {
         // ---- the four k-groups hold partial sums of the same 128 x 128 tile: a two-round tree through LDS (both stage buffers
         //      are free: nothing is staged across work items), plain 16-byte accesses in accumulator order (LDS float atomics
         //      ran this reduction at ~0.35 lanes per clock: 90 us per tile)
@@ -301,7 +361,6 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
                     red4[wslot + (i * 4 + jj) * 64] = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        float* red = reinterpret_cast<float*>(smem + STAGE);      // the total, row-major [128][128] fp32, in the second buffer
         if (kg == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -314,6 +373,7 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
         if (ws != nullptr) {
             // ---- sliced flush (fs2_wgrad_sliced): the 128 x 128 partial tile goes to slice `item` of the workspace with plain
             //      16-byte stores (64 KiB contiguous per workgroup, ~6 TB/s chip-wide against ~1.3 TB/s of float atomics);
@@ -345,11 +405,11 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     }
 }
 
-template <int ES>
+template <int ES, int KG = 4>
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
                                                                   const int nitems, const int rot_step, const int stream_units,
                                                                   float* __restrict__ ws) {
-    km_body<ES>(p, tilesM, tilesN, splits, nitems, rot_step, stream_units, ws, (int)blockIdx.x, (int)gridDim.x);
+    km_body<ES, KG>(p, tilesM, tilesN, splits, nitems, rot_step, stream_units, ws, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Several weight-gradient products in ONE launch (the products of one layer's backward): product d owns the workgroups
@@ -363,11 +423,11 @@ struct KmGroupArgs {
     int tilesM[KM_GROUP], tilesN[KM_GROUP], splits[KM_GROUP], nitems[KM_GROUP], wg_begin[KM_GROUP + 1];
     int n, rot_step;
 };
-template <int ES>
+template <int ES, int KG = 4>
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_grouped_kernel(const KmGroupArgs a) {
     int d = 0;
     while (d + 1 < a.n && (int)blockIdx.x >= a.wg_begin[d + 1]) ++d;
-    km_body<ES>(a.g[d], a.tilesM[d], a.tilesN[d], a.splits[d], a.nitems[d], a.rot_step, 0, a.ws[d], (int)blockIdx.x - a.wg_begin[d],
+    km_body<ES, KG>(a.g[d], a.tilesM[d], a.tilesN[d], a.splits[d], a.nitems[d], a.rot_step, 0, a.ws[d], (int)blockIdx.x - a.wg_begin[d],
             a.wg_begin[d + 1] - a.wg_begin[d]);
 }
 
@@ -416,13 +476,20 @@ bool km_plan(const FS2Gemm& g, int mode, KmPlan& pl, bool allow_f8 = false) {
     return true;
 }
 
+// FS2_KM_KG=4: the round-2 form of the bf16 kernel (four k-groups, 64 KiB stages, one in flight) for A/B measurements; read per call
+bool km_two_groups() {
+    const char* e = getenv("FS2_KM_KG");
+    return !(e != nullptr && atoi(e) == 4);
+}
+
 int km_launch(const FS2Gemm& g, const KmPlan& pl, float* ws, hipStream_t st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr_set[16] = {};            // per device (one process per GPU is the deployment; a process driving several still works)
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the weight-gradient kernel");
             return FS2_ELAUNCH;
         }
@@ -430,11 +497,14 @@ int km_launch(const FS2Gemm& g, const KmPlan& pl, float* ws, hipStream_t st) {
     }
     g_last_tile = 129;          // (measurement aid: the 16-wave weight-gradient kernel)
     static const int rot_step = getenv("FS2_KM_ROT") ? atoi(getenv("FS2_KM_ROT")) : 4;
-    if (g.dtype == FS2_BF16)
-        hipLaunchKernelGGL(fs2_gemm_big_km_kernel<2>, dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
+    if (g.dtype != FS2_BF16)
+        hipLaunchKernelGGL((fs2_gemm_big_km_kernel<1, 4>), dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
+                           pl.stream_units, ws);
+    else if (km_two_groups())
+        hipLaunchKernelGGL((fs2_gemm_big_km_kernel<2, 2>), dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
                            pl.stream_units, ws);
     else
-        hipLaunchKernelGGL(fs2_gemm_big_km_kernel<1>, dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
+        hipLaunchKernelGGL((fs2_gemm_big_km_kernel<2, 4>), dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
                            pl.stream_units, ws);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { fs2_set_error("fs2_gemm(big km): launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
@@ -624,16 +694,18 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
     (void)hipGetDevice(&dev);
     static bool attr_set[16] = {};
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             fs2_set_error("fs2_wgrad_grouped: cannot raise the dynamic LDS limit of the weight-gradient kernel");
             return FS2_ELAUNCH;
         }
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     g_last_tile = 129;
-    if (a.g[0].dtype == FS2_BF16) hipLaunchKernelGGL(fs2_gemm_big_km_grouped_kernel<2>, dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(fs2_gemm_big_km_grouped_kernel<1>, dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
+    if (a.g[0].dtype != FS2_BF16) hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<1, 4>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
+    else if (km_two_groups()) hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<2, 2>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<2, 4>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { fs2_set_error("fs2_wgrad_grouped: launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
     for (int i = 0; i < m; ++i) fill_part(parts + src[i], a.g[i], a.ws[i], pl[i].tilesM, pl[i].tilesN, a.splits[i], pl[i].base);
