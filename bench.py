@@ -310,9 +310,9 @@ def bench_line(args, timer, dt, done, world, warm, use_graph, padded, BATCH, cpu
         roof = dict(bound="hbm" if hbm_bound else "mfma",
                     kernel=(f"fs2_gemm_ws_kernel<{key[0]}, weights-stationary 256-column tile (K = 256 in registers), activation rows streamed through a 4-deep LDS-DMA ring, 8 waves>"
                             if key[3] == 131 else
-                            f"{'fs2_gemm_ring_kernel' if key[0] == 'bf16' else 'fs2_gemm_big_kernel'}<{key[0]}, {128 if key[3] == 130 else key[3]}x256 tile, 16 waves, LDS-DMA> A row-major B row-major"
+                            f"fs2_gemm_ring_kernel<{key[0]}{'' if key[0] == 'bf16' else ' operands, block-scaled 16x16x128 MFMA'}, {128 if key[3] == 130 else key[3]}x256 tile, 16 waves, LDS-DMA ring> A row-major B row-major"
                             if key[3] >= 130 else
-                            f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 4 k-groups, LDS-DMA> A k-major B k-major; a launch = the weight gradients of one layer (fs2_wgrad_grouped, up to 4 products) or one product; partial tiles of the k-split to a workspace, added by wgrad_reduce_k" if key[3] == 129 else
+                            f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 2 k-groups x 8 (fp8: 4 x 4), 4-deep LDS-DMA ring> A k-major B k-major; a launch = the weight gradients of one layer (fs2_wgrad_grouped, up to 4 products) or one product; partial tiles of the k-split to a workspace, added by wgrad_reduce_k" if key[3] == 129 else
                             f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}"),
                     achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
                     unit="GB/s" if hbm_bound else "TFLOP/s",
