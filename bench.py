@@ -64,6 +64,30 @@ def bench_hp(amp=True, workload="cfg2", fp8=False, return_attn=False):
     return hp
 
 
+def gemm_work(g):
+    """(FLOPs, algorithmic bytes, shape tuple) of one fs2_gemm descriptor.  Algorithmic bytes = every DISTINCT operand element once +
+    every output element once: a batch index that does not move an operand (batch stride 0: the X of a fused q/k/v weight gradient,
+    wgrad_batched) or that only shifts its rows (conv = 2: the taps of a Conv1d weight gradient read the same dY and the same X)
+    does not multiply that operand's bytes; conv = 1 reads its A rows once, not once per tap."""
+    taps = g.taps if g.conv == 1 else 1
+    b1, b2 = max(1, g.batch1), max(1, g.batch2)
+    nb = b1 * b2
+    flops = 2.0 * g.M * g.N * g.K * taps * nb
+    es, cs = {0: 4, 1: 2, 2: 1, 3: 1}[g.dtype], (2 if g.c_dtype == 1 else 4)
+    n_a = (b1 if (b1 > 1 and g.sA1 != 0) else 1) * (b2 if (b2 > 1 and g.sA2 != 0 and g.conv != 2) else 1)
+    n_b = (b1 if (b1 > 1 and g.sB1 != 0) else 1) * (b2 if (b2 > 1 and g.sB2 != 0 and g.conv != 2) else 1)
+    abytes = float(es * (g.M * g.K * n_a + g.N * g.K * taps * n_b) + cs * g.M * g.N * nb)
+    flags = ("b" if g.bias else "") + ("r" if g.relu else "") + ("m" if g.relu_mask else "") + ("+" if g.residual else "") + \
+            (f"s{g.colstats_mode}" if g.colstats else "") + ("a" if g.accumulate else "") + ("f" if g.c_dtype == 0 and g.dtype == 1 else "")
+    shape = (g.M, g.N, g.K, taps if g.conv == 1 else (g.batch2 if g.conv == 2 else 1), g.batch1 * g.batch2, g.split_k, flags or "-")
+    return flops, abytes, shape
+
+
+def family(tile):
+    """kernel family of bench.py's tile id (fs2_gemm_last_tile): the instances of ONE kernel template are one family"""
+    return "km" if tile == 129 else "ws" if tile == 131 else "ring" if tile >= 130 else "4wave"
+
+
 class GemmTimer:
     """Wraps ops._gemm_call: a HIP event pair on the launch stream around every fs2_gemm launch."""
 
@@ -91,17 +115,7 @@ class GemmTimer:
         self._orig = ops._gemm_call
         self._last_tile = ops.lib().fs2_gemm_last_tile
 
-        def work(g):
-            taps = g.taps if g.conv == 1 else 1
-            nb = max(1, g.batch1) * max(1, g.batch2)
-            flops = 2.0 * g.M * g.N * g.K * taps * nb
-            es, cs = {0: 4, 1: 2, 2: 1, 3: 1}[g.dtype], (2 if g.c_dtype == 1 else 4)
-            # algorithmic bytes: every operand element once (conv: the A rows once, not once per tap)
-            abytes = (es * (g.M * g.K + g.N * g.K * taps) + cs * g.M * g.N) * float(nb)
-            flags = ("b" if g.bias else "") + ("r" if g.relu else "") + ("m" if g.relu_mask else "") + ("+" if g.residual else "") + \
-                    (f"s{g.colstats_mode}" if g.colstats else "") + ("a" if g.accumulate else "") + ("f" if g.c_dtype == 0 and g.dtype == 1 else "")
-            shape = (g.M, g.N, g.K, taps if g.conv == 1 else (g.batch2 if g.conv == 2 else 1), g.batch1 * g.batch2, g.split_k, flags or "-")
-            return flops, abytes, shape
+        work = gemm_work
 
         def record(g, s, e):
             flops, abytes, shape = work(g)
@@ -129,14 +143,19 @@ class GemmTimer:
             if defer and ops._WG.group and ops._WG.enabled:
                 self._orig_wgrad(g, out, True, extra_bytes, keep)
                 return
+            # (grouping is switched off for this call: with it on, defer=True would only QUEUE the product -- the flush below would then
+            #  launch it through timed_group, and record() would count it a second time with an empty pair)
             s, e = events()
-            ops._gemm_call = self._orig
+            grouped, ops._WG.group = ops._WG.group, False
             try:
+                ops._WG._launch_pending()  # products queued before this one keep their order (timed by timed_group)
+                ops._gemm_call = self._orig
                 s.record()
                 self._orig_wgrad(g, out, True, extra_bytes, keep)
                 e.record()
             finally:
                 ops._gemm_call = timed
+                ops._WG.group = grouped
             if not defer:
                 ops.wgrad_flush()
             record(g, s, e)
@@ -296,34 +315,52 @@ def bench_line(args, timer, dt, done, world, warm, use_graph, padded, BATCH, cpu
     """the ONE JSON line of the contract (metric, value, roofline of the dominant GEMM variant, cpu_baseline)"""
     agg = timer.summary()
     roof = None
+    n_inst_steps = max(1, (min(args.steps, POOL) if use_graph else args.steps))
     if agg:
-        key, (fl, ms, cnt, by) = max(agg.items(), key=lambda kv: kv[1][1])
+        # the dominant KERNEL: the instances of one kernel template (e.g. the 128- / 192- / 256-row tiles of the ring kernel) are one family
+        fam = {}
+        for k, v in agg.items():
+            a = fam.setdefault((k[0], family(k[3])), [0.0, 0.0, 0, 0.0])
+            for i in range(4):
+                a[i] += v[i]
+        key, (fl, ms, cnt, by) = max(fam.items(), key=lambda kv: kv[1][1])
         tflops = fl / (ms * 1e-3) / 1e12
         gbs = by / (ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
-        if os.path.exists(tpath):       # HBM bytes per launch of this variant from the PMC passes (tools/summarize_profiles.py)
-            traffic = json.load(open(tpath)).get("by_variant", {}).get("/".join(str(x) for x in key))
+        if os.path.exists(tpath):       # HBM bytes per launch of this family from the PMC passes (tools/summarize_profiles.py)
+            traffic = json.load(open(tpath)).get("by_family", {}).get("/".join(key))
         # the roof that binds the dominant kernel's launches on average: algorithmic FLOP per algorithmic byte
         # against the machine balance 2.5 PFLOP/s / 8 TB/s
         hbm_bound = (fl / by) < (PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
-        roof = dict(bound="hbm" if hbm_bound else "mfma",
-                    kernel=(f"fs2_gemm_ws_kernel<{key[0]}, weights-stationary 256-column tile (K = 256 in registers), activation rows streamed through a 4-deep LDS-DMA ring, 8 waves>"
-                            if key[3] == 131 else
-                            f"fs2_gemm_ring_kernel<{key[0]}{'' if key[0] == 'bf16' else ' operands, block-scaled 16x16x128 MFMA'}, {128 if key[3] == 130 else key[3]}x256 tile, 16 waves, LDS-DMA ring> A row-major B row-major"
-                            if key[3] >= 130 else
-                            f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 2 k-groups x 8 (fp8: 4 x 4), 4-deep LDS-DMA ring> A k-major B k-major; a launch = the weight gradients of one layer (fs2_wgrad_grouped, up to 4 products) or one product; partial tiles of the k-split to a workspace, added by wgrad_reduce_k" if key[3] == 129 else
-                            f"gemm_kernel<{key[0]}, tile {key[3]}> A {'k-major' if key[1] == 'km' else 'row-major'} B {'k-major' if key[2] == 'km' else 'row-major'}"),
+        names = {"ring": f"fs2_gemm_ring_kernel<{key[0]}{'' if key[0] == 'bf16' else ' operands, block-scaled 16x16x128 MFMA'}, 128 / 192 / 256 x 256 tiles, 16 waves, "
+                         "LDS-DMA ring> A row-major B row-major (linear layers and implicit-GEMM Conv1d, forward and data gradient)",
+                 "ws": f"fs2_gemm_ws_kernel<{key[0]}, weights-stationary 256-column tile (K = 256 in registers), activation rows streamed through a 4-deep LDS-DMA ring, 8 waves>",
+                 "km": f"fs2_gemm_big_km_kernel<{key[0]}, 128x128 tile, 16 waves = 2 k-groups x 8 (fp8: 4 x 4), 4-deep LDS-DMA ring> A k-major B k-major; a launch = the weight "
+                       "gradients of one layer (fs2_wgrad_grouped, up to 4 products) or one product; partial tiles of the k-split to a workspace, added by wgrad_reduce_k",
+                 "4wave": f"gemm_kernel<{key[0]}, 64 / 128-row tiles, 4 waves> (batched attention products, N = 80, short reductions)"}
+        roof = dict(bound="hbm" if hbm_bound else "mfma", kernel=names[key[1]],
                     achieved=round(gbs if hbm_bound else tflops, 2), peak=PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
                     unit="GB/s" if hbm_bound else "TFLOP/s",
                     frac=round((gbs / PEAK_HBM_GBS) if hbm_bound else (tflops / PEAK_BF16_TFLOPS), 4), traffic=traffic,
+                    traffic_over_algorithmic=(round(traffic / (by / cnt), 3) if traffic else None),
                     launches=cnt, avg_launch_us=round(ms * 1e3 / cnt, 2), event_pair_overhead_us=round(timer.overhead_ms * 1e3, 2),
                     algorithmic_bytes_per_launch=round(by / cnt), algorithmic_flops_per_launch=round(fl / cnt),
                     achieved_tflops=round(tflops, 1), mfma_frac=round(tflops / PEAK_BF16_TFLOPS, 4),
                     achieved_gbs=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
-                    gemm_ms_per_step=round(sum(v[1] for v in agg.values()) / max(1, (min(args.steps, POOL) if use_graph else args.steps)), 3),
+                    family_ms_per_step=round(ms / n_inst_steps, 3),
+                    gemm_ms_per_step=round(sum(v[1] for v in agg.values()) / n_inst_steps, 3),
+                    all_families={"/".join(k): dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), mfma_frac=round(v[0] / (v[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                    gbs=round(v[3] / (v[1] * 1e-3) / 1e9, 1), hbm_frac=round(v[3] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                                    ms_per_step=round(v[1] / n_inst_steps, 3), launches=v[2]) for k, v in fam.items()},
                     all_variants={"/".join(str(x) for x in k): dict(tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), gbs=round(v[3] / (v[1] * 1e-3) / 1e9, 1),
                                                      ms=round(v[1], 2), launches=v[2]) for k, v in agg.items()})
+        if args.workload == "cfg2":
+            # path level (SURVEY section 8(d)): the step's algorithmic FLOPs -- 59.7 MFLOP per padded frame = 2.650 TFLOP at the
+            # 44,400 padded frames of the config-2 batch (BASELINE.md section 3) -- over the measured step time, against the MFMA roof
+            step_flop = 2.650e12 * padded / 44400.0
+            roof["step_tflops"] = round(step_flop / (dt / args.steps) / 1e12, 1)
+            roof["step_mfma_frac"] = round(step_flop / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)
     line = {
         "metric": ("mel-frames/sec (train step) autoregressive Transformer-TTS d_model=256" if args.workload == "cfg3" else
                    "mel-frames/sec (train step) FastSpeech2 d_model=256"), "value": round(done / dt, 1),
@@ -517,17 +554,19 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if use_graph:       # roofline leg: the same kernels, launched eagerly with a HIP event pair around every GEMM;
-        timer.install() # one stream only, so that a kernel's event pair times that kernel alone
-        model.rt.overlap_wgrad = False
+        model.rt.overlap_wgrad = False      # one stream only, so that a kernel's event pair times that kernel alone
         # An event pair also counts any time the stream sits idle between the start event and the kernel, i.e. whenever
         # the Python launcher falls behind the GPU. Each instrumented step therefore starts with a spin kernel long
         # enough for the host to enqueue the whole step ahead of the GPU, so every pair brackets back-to-back work.
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record(); torch.cuda._sleep(20_000_000); c1.record(); torch.cuda.synchronize()
         cycles_per_ms = 20_000_000 / max(c0.elapsed_time(c1), 1e-3)
+        train_step(model, opt, step, pool[0], hp); step += 1          # (first eager step after the replays: allocator warm-up)
+        torch.cuda.synchronize()
         t_e = time.perf_counter()
-        train_step(model, opt, step, pool[0], hp); step += 1          # also measures the host time of one eager step
+        train_step(model, opt, step, pool[0], hp); step += 1          # host time of one eager step WITHOUT the event pairs (config.eager_host_ms_per_step)
         host_ms = (time.perf_counter() - t_e) * 1e3
+        timer.install()
         torch.cuda.synchronize()
         timer.records.clear()
         timer.calibrate()
@@ -539,6 +578,23 @@ def main():
             step += 1
         torch.cuda.synchronize()
     timer.remove()
+    attn_true_ms = None
+    if world == 1 and not force_dp and args.workload == "cfg2" and use_graph and not args.return_attn and not args.fp32 and not args.from_host:
+        # the drop-in DEFAULT, hp.return_attn = True (the 14-tuple's attention maps, reference Models/encoder.py:97,105), timed behind the
+        # headline region on the same model and batches: LDS-strip attention kernels, probabilities written to HBM
+        model.rt.return_attn = True
+        g2 = GraphedTrainStep(model, opt, hp)
+        for i in range(2 * POOL):
+            g2(step, pool[i % POOL]); step += 1
+        n2 = max(POOL, min(args.steps, 3 * POOL))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n2):
+            g2(step, pool[i % POOL]); step += 1
+        torch.cuda.synchronize()
+        attn_true_ms = (time.perf_counter() - t1) * 1e3 / n2
+        model.rt.return_attn = False
+        del g2
     if args.gemm_report and rank == 0:
         with open(args.gemm_report, "w") as f:
             f.write(timer.by_shape() + "\n")
@@ -554,6 +610,10 @@ def main():
         if not args.no_cpu_baseline and world == 1 and args.workload == "cfg2":
             cpu = cpu_baseline(hp, synthetic.benchmark_batch(2024, 48))
         line = bench_line(args, timer, dt, done, world, warm, use_graph, int(sum(b[1].shape[0] * b[1].shape[1] for b in pool) / len(pool)), BATCH, cpu)
+        if attn_true_ms is not None:
+            line["config"]["return_attn_true_ms_per_step"] = round(attn_true_ms, 3)
+        if use_graph and world == 1:
+            line["config"]["eager_host_ms_per_step"] = round(host_ms, 3)      # host time of ONE eager step (Python launch path), cf. ms_per_step
         if getattr(opt, "dp", None) is not None:        # the gradient all-reduce schedule of the last eager step (bytes, launched from where)
             plan = opt.dp.describe_plan()
             line["config"]["dp_plan"] = {"buckets": [[q["bytes"], q["launched"]] for q in plan],

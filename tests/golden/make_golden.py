@@ -79,8 +79,10 @@ def shape_arrays(shapes):
     return np.array(keys, dtype=np.str_), dims
 
 
-def build_reference_raw(cfg):
-    """the reference model as its constructor leaves it (PyTorch default initialisation under the caller's seed)"""
+def build_reference_raw(cfg, dropouts=(0.0, 0.0, 0.0)):
+    """the reference model as its constructor leaves it (PyTorch default initialisation under the caller's seed);
+    dropouts = (dropout, dropout_postnet, dropout_variance_adaptor): 0 for the fixtures, the trainer's own 0.1 / 0.5 / 0.5
+    (train_fastspeech2.py:381-389) for the CPU timing of tools/cpu_ref_vs_oracle.py"""
     from Models.fastspeech2 import FastSpeech2
     from utils.utils import fill_variables
     hp = hp_namespace(cfg)
@@ -92,8 +94,8 @@ def build_reference_raw(cfg):
                         concat_after_encoder=hp.concat_after_encoder, d_model_decoder=hp.d_model_decoder,
                         N_d=hp.n_layer_decoder, n_head_decoder=hp.n_head_decoder,
                         ff_conv_kernel_size_decoder=hp.ff_conv_kernel_size_decoder,
-                        concat_after_decoder=hp.concat_after_decoder, dropout_variance_adaptor=0.0,
-                        reduction_rate=hp.reduction_rate, dropout=0.0, dropout_postnet=0.0,
+                        concat_after_decoder=hp.concat_after_decoder, dropout_variance_adaptor=dropouts[2],
+                        reduction_rate=hp.reduction_rate, dropout=dropouts[0], dropout_postnet=dropouts[1],
                         n_bins=hp.nbins, f0_min=hp.f0_min, f0_max=hp.f0_max, energy_min=hp.energy_min,
                         energy_max=hp.energy_max, pitch_pred=hp.pitch_pred, energy_pred=hp.energy_pred,
                         accent_emb=hp.accent_emb, output_type=hp.output_type, num_group=hp.num_group,
@@ -103,8 +105,8 @@ def build_reference_raw(cfg):
     return model, hp, shapes
 
 
-def build_reference(cfg):
-    model, hp, shapes = build_reference_raw(cfg)
+def build_reference(cfg, dropouts=(0.0, 0.0, 0.0)):
+    model, hp, shapes = build_reference_raw(cfg, dropouts)
     model.load_state_dict(synthetic.recipe_state_dict(shapes, cfg["weight_seed"]))
     model.train()
     return model, hp, shapes

@@ -27,10 +27,10 @@ def main():
     cfg = CONFIGS["bench"]
     batch = cfg["batch"]()
     frames = int(batch[5].sum())
-    # ---- the reference's own model and train_loop (dropout rates of the reference: 0.1 / 0.5 / 0.5 via its constructor defaults are
-    #      not reachable through build_reference, which builds with dropout 0; timing is insensitive to the rate: F.dropout runs either way)
+    # ---- the reference's own model and train_loop at the dropout rates its trainer builds it with (train_fastspeech2.py:381-389:
+    #      hp.dropout 0.1, dropout_postnet 0.5, hp.dropout_variance_adaptor 0.5; a rate of 0 would skip F.dropout's mask altogether)
     T = ns["ref_trainer"]()
-    model, hp, _ = ns["build_reference"](cfg)
+    model, hp, _ = ns["build_reference"](cfg, dropouts=(0.1, 0.5, 0.5))
     hp.amp = False
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
     times = []

@@ -1,16 +1,25 @@
 #!/bin/bash
 # Run the GPU-side checks in sequence on the gpurun box; stop at the first step that times out / is killed.
 mkdir -p gpurun_out
+STAMP=$(date +%Y%m%d_%H%M%S)
 run() {  # name, timeout, command...
   local name=$1 tmo=$2; shift 2
-  echo "=== $name" | tee -a gpurun_out/ci.log
-  timeout -k 10 "$tmo" "$@" > "gpurun_out/$name.log" 2>&1
+  # every call keeps its own log (gpurun_out/<name>.<stamp>.log; <name>.log is a copy of the latest): a log that shows a GPU fault is
+  # evidence and must not be overwritten by the next call
+  local log="gpurun_out/$name.$STAMP.log"
+  echo "=== $name  ($(date +%H:%M:%S))  $*" | tee -a gpurun_out/ci.log
+  timeout -k 10 "$tmo" "$@" > "$log" 2>&1
   local rc=$?
+  cp -f "$log" "gpurun_out/$name.log"
   echo "$name rc=$rc" | tee -a gpurun_out/ci.log
-  tail -3 "gpurun_out/$name.log" | tee -a gpurun_out/ci.log
+  tail -3 "$log" | tee -a gpurun_out/ci.log
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "ABORT after $name (timeout/kill)" | tee -a gpurun_out/ci.log; exit 1; fi
+  # a step that died on the GPU (HSA error, memory fault, abort) ends the sequence: no further GPU step in this call
+  if [ $rc -ne 0 ] && grep -q -E "HSA_STATUS_ERROR|Memory access fault|MEMORY_APERTURE|Aborted|core dumped|hipErrorIllegal|GPU core dump" "$log"; then
+    echo "ABORT after $name (GPU fault signature in $log)" | tee -a gpurun_out/ci.log; grep -m5 -E "HSA_STATUS|fault|Abort" "$log" | tee -a gpurun_out/ci.log; exit 1
+  fi
 }
-: > gpurun_out/ci.log
+echo "##### gpu_ci $STAMP: $*" >> gpurun_out/ci.log
 for step in "$@"; do
   case $step in
     kernels) run kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider ;;

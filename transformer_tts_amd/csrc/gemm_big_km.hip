@@ -687,6 +687,16 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
         need += (int64_t)a.nitems[i] * (TM * TN);
     }
     if (need > ws_floats) return 0;
+    // invariants the kernel relies on (cheap, always checked): 8-aligned monotonic workgroup ranges inside one 256-workgroup round, every
+    // taken product with at least one item and no more items than workgroups, its partial tiles inside [ws, ws + ws_floats)
+    for (int i = 0; i < m; ++i) {
+        if (!(a.wg_begin[i] % 8 == 0 && a.wg_begin[i] < a.wg_begin[i + 1] && a.wg_begin[i + 1] <= 256 && a.nitems[i] >= 1 &&
+              a.nitems[i] <= a.wg_begin[i + 1] - a.wg_begin[i] && a.ws[i] >= ws && a.ws[i] + (int64_t)a.nitems[i] * (TM * TN) <= ws + ws_floats &&
+              a.g[i].A != nullptr && a.g[i].B != nullptr && a.g[i].C != nullptr)) {
+            fs2_set_error("fs2_wgrad_grouped: internal plan error for product %d (wg [%d, %d), items %d)", i, a.wg_begin[i], a.wg_begin[i + 1], a.nitems[i]);
+            return FS2_EINVAL;
+        }
+    }
     for (int i = m; i < KM_GROUP; ++i) { a.g[i] = a.g[0]; a.ws[i] = nullptr; a.tilesM[i] = a.tilesN[i] = a.splits[i] = a.nitems[i] = 0; a.wg_begin[i + 1] = a.wg_begin[m]; }
     a.n = m;
     a.rot_step = 0;

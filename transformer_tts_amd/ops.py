@@ -10,6 +10,7 @@ import os
 
 import torch
 
+from . import bounds as _bounds
 from . import build as _build
 
 F32, BF16 = 0, 1
@@ -225,6 +226,8 @@ def _ld(t):
 
 
 def _gemm_call(g):
+    if _bounds.ENABLED:
+        _bounds.check_gemm(g)
     _check(lib().fs2_gemm(ctypes.byref(g), _stream()), "fs2_gemm")
 
 
@@ -612,6 +615,8 @@ class _WgradSlices:
         """one product with its partial tiles in the workspace; False: not in that form (the caller uses fs2_gemm)"""
         ws = self._ws(out.device)
         part = FS2WgradPart()
+        if _bounds.ENABLED:
+            _bounds.check_gemm(g, "fs2_wgrad_sliced")
         for attempt in range(2):
             used = lib().fs2_wgrad_sliced(ctypes.byref(g), ws.data_ptr() + 4 * self.off, self.FLOATS - self.off, ctypes.byref(part), _stream())
             if used < 0:
@@ -622,6 +627,8 @@ class _WgradSlices:
         if used <= 0:
             return False
         if part.splits > 0:             # (0: an fp8 product in the balanced-stream form, already added with float atomics)
+            if _bounds.ENABLED:
+                _bounds.check_part(part, ws.data_ptr() + 4 * self.off, 4 * int(used), "fs2_wgrad_sliced part")
             self.off += int(used)
             self.parts.append(part)
             self.keep.append(out)
@@ -640,6 +647,9 @@ class _WgradSlices:
         descs = (FS2Gemm * n)(*[p[0] for p in pend])
         parts = (FS2WgradPart * n)()
         res = {}
+        if _bounds.ENABLED:
+            for d in descs:
+                _bounds.check_gemm(d, "fs2_wgrad_grouped")
 
         def launch():
             res["used"] = lib().fs2_wgrad_grouped(descs, n, ws.data_ptr() + 4 * self.off, self.FLOATS - self.off, parts, _stream())
@@ -653,6 +663,10 @@ class _WgradSlices:
             _check(int(used), "fs2_wgrad_grouped")
         taken = [used > 0 and parts[i].splits > 0 for i in range(n)]
         if used > 0:
+            if _bounds.ENABLED:
+                for i in range(n):
+                    if taken[i]:
+                        _bounds.check_part(parts[i], ws.data_ptr() + 4 * self.off, 4 * int(used), "fs2_wgrad_grouped part")
             self.off += int(used)
             self.parts.extend(parts[i] for i in range(n) if taken[i])
             self.keep.extend(p[1] for i, p in enumerate(pend) if taken[i])
@@ -664,6 +678,10 @@ class _WgradSlices:
         if self.parts:
             arr = (FS2WgradPart * len(self.parts))(*self.parts)
             n = len(self.parts)
+            if _bounds.ENABLED:
+                ws = self._ws(self.device)
+                for q in self.parts:
+                    _bounds.check_part(q, ws.data_ptr(), 4 * self.FLOATS)
             self.parts, self.keep, self.off = [], [], 0
             _check(lib().fs2_wgrad_reduce(arr, n, _stream()), "fs2_wgrad_reduce")
 
@@ -671,6 +689,11 @@ class _WgradSlices:
         self._launch_pending()
         self._reduce()
         self.spans = []
+
+    def reset(self):
+        """forget queued products and unreduced partial tiles WITHOUT launching anything: what a step that died between queueing and
+        flushing (an exception inside a backward) left behind must not be added into the next step's gradients"""
+        self.pending, self.parts, self.keep, self.spans, self.off = [], [], [], [], 0
 
 
 _WG = _WgradSlices()
@@ -680,6 +703,11 @@ def wgrad_flush():
     """add the partial tiles of every deferred weight-gradient product into its gradient (one launch); the models call it once per
     announced parameter range and at the end of every backward"""
     _WG.flush()
+
+
+def wgrad_reset():
+    """drop whatever a failed step left queued (called at the start of every step, before zero_grad)"""
+    _WG.reset()
 
 
 def _wgrad_call(g, out, defer, extra_bytes=0, keep=()):

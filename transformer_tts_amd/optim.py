@@ -81,6 +81,10 @@ class FusedAdam:
             self.runtime.invalidate()
 
     def zero_grad(self, set_to_none=False):
+        # a step that raised inside its backward may have left weight-gradient products queued (ops._WG): they must not be added
+        # into the gradients of this step (after a complete step nothing is queued and this is a no-op)
+        if hasattr(ops, "wgrad_reset"):
+            ops.wgrad_reset()
         self.arena.g.zero_()
         for p in self.arena.params:     # re-attach if a caller dropped the views
             if p.grad is None:
