@@ -78,3 +78,29 @@ def test_torch_library_registration_and_fake_tensors():
     o, st = torch.ops.fs2.flash_attention(q, q, q, torch.empty(2, 9, dtype=torch.bool, device="meta"), True)
     assert o.shape == (2, 4, 9, 64) and st.shape == (2, 4, 9, 2)
     assert "fs2::linear" in str(torch.ops.fs2.linear.default._schema)
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_header(tmp_path):
+    """every ctypes.Structure of ops.py against the struct of the same name in include/fs2_hip.h: a C program (gcc, the header as it
+    is) prints sizeof and, per field, offsetof / sizeof; the ctypes mirror must agree field by field (FS2Gemm, FS2WgradPart,
+    FS2FlashAttn, FS2CastDesc, FS2QuantDesc, FS2L1Item)"""
+    import ctypes
+    import subprocess
+    from transformer_tts_amd import ops
+    structs = [getattr(ops, n) for n in ("FS2Gemm", "FS2WgradPart", "FS2FlashAttn", "FS2CastDesc", "FS2QuantDesc", "FS2L1Item")]
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "fs2_hip.h"', "int main(void) {"]
+    for S in structs:
+        lines.append(f'  printf("{S.__name__} %zu\\n", sizeof({S.__name__}));')
+        for f, _ in S._fields_:
+            lines.append(f'  printf("{S.__name__}.{f} %zu %zu\\n", offsetof({S.__name__}, {f}), sizeof((({S.__name__}*)0)->{f}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split(" ", 1) for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for S in structs:
+        assert int(got[S.__name__]) == ctypes.sizeof(S), (S.__name__, got[S.__name__], ctypes.sizeof(S))
+        for f, t in S._fields_:
+            off, size = (int(x) for x in got[f"{S.__name__}.{f}"].split())
+            assert (off, size) == (getattr(S, f).offset, ctypes.sizeof(t)), (S.__name__, f, off, size, getattr(S, f).offset)

@@ -1617,8 +1617,36 @@ def test_torch_library_ops(ops):
     yc = torch.ops.fs2.conv1d_cl(xc, wc, None, 2, False)
     ref = torch.nn.functional.conv1d(xc.float().transpose(1, 2), wc.float(), padding=2).transpose(1, 2)
     close(yc.float(), ref, "fs2::conv1d_cl", **tol(dtype))
+    # ... and its autograd: data, weight and bias gradients against torch's conv1d (ReLU on)
+    xc2 = xc.detach().clone().requires_grad_(True)
+    wc2 = wc.detach().clone().requires_grad_(True)
+    bc2 = rnd(128, seed=9).cuda().requires_grad_(True)
+    yc2 = torch.ops.fs2.conv1d_cl(xc2, wc2, bc2, 2, True)
+    xr2, wr2, br2 = (t_.detach().float().requires_grad_(True) for t_ in (xc2, wc2, bc2))
+    yr2 = torch.relu(torch.nn.functional.conv1d(xr2.transpose(1, 2), wr2, br2, padding=2).transpose(1, 2))
+    close(yc2.float(), yr2, "fs2::conv1d_cl + bias + relu", **tol(dtype))
+    gc = rnd(3, 50, 128, dtype=dtype, seed=10).cuda()
+    yc2.backward(gc)
+    yr2.backward(gc.float())
+    for a, r, n in ((xc2.grad, xr2.grad, "conv dx"), (wc2.grad, wr2.grad, "conv dw"), (bc2.grad, br2.grad, "conv db")):
+        err = float((a.float() - r).abs().max() / r.abs().max())
+        assert err < 4e-2, (n, err)
     # attention
     B, H, t, dk = 2, 2, 130, 64
+    # contiguous (B, H, t, dk) inputs -- how ordinary PyTorch code holds q / k / v -- go through as well
+    qc, kc, vc = (rnd(B, H, t, dk, dtype=dtype, seed=20 + j, scale=1.5).cuda().requires_grad_(True) for j in range(3))
+    kmc = torch.ones(B, t, dtype=torch.bool, device="cuda")
+    kmc[0, 77:] = False
+    oc, _ = torch.ops.fs2.flash_attention(qc, kc, vc, kmc, False)
+    qf, kf, vf = (t_.detach().float().requires_grad_(True) for t_ in (qc, kc, vc))
+    oc_ref = torch.softmax(((qf @ kf.transpose(-1, -2)) * dk ** -0.5).masked_fill(~kmc[:, None, None, :], -1e4), -1) @ vf
+    assert float((oc.detach().float() - oc_ref.detach()).abs().max() / oc_ref.detach().abs().max()) < 3e-2
+    goc = rnd(B, H, t, dk, dtype=dtype, seed=24).cuda()
+    oc.backward(goc)
+    oc_ref.backward(goc.float())
+    for a, r, n in ((qc.grad, qf.grad, "dq"), (kc.grad, kf.grad, "dk"), (vc.grad, vf.grad, "dv")):
+        err = float((a.float() - r).abs().max() / r.abs().max())
+        assert err < 4e-2, ("contiguous " + n, err)
     qkv = rnd(B, t, 3, H, dk, dtype=dtype, seed=7, scale=1.5).cuda().requires_grad_(True)
     q, v, k = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
     km = torch.ones(B, t, dtype=torch.bool, device="cuda")

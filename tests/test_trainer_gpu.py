@@ -248,3 +248,31 @@ def test_data_parallel_path_on_a_one_rank_rccl_group_equals_the_plain_step(graph
     np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-3)
     gerr = float((res[0][2] - res[1][2]).norm() / res[0][2].norm())
     assert gerr < 5e-2, gerr
+
+
+def test_graph_stepper_evicts_the_least_recently_replayed_shape():
+    """more batch shapes than max_graphs: every shape still reaches the replay path (capture on its second occurrence evicts the
+    shape replayed longest ago instead of leaving every new shape on eager launches for good), the losses of a shape replayed
+    after its graph was evicted and re-captured stay finite and the stepper never holds more than max_graphs graphs"""
+    from transformer_tts_amd.Models import functional
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep
+    full = batch_to(CONFIGS["small"]["batch"](), "cuda")
+    B = full[0].shape[0]
+    assert B >= 4
+    shapes = [tuple(x[:k] if torch.is_tensor(x) else x for x in full) for k in (2, 3, 4)]      # three (B, L, T) keys
+    functional._site_counter[0] = 9000
+    model, hp, _ = product_model("small", amp=True, dropout=0.1, device="cuda")
+    opt = FusedAdam(model)
+    stepper = GraphedTrainStep(model, opt, hp, max_graphs=2)
+    losses, step = [], 4000
+    for rnd in range(4):
+        for b in shapes:
+            loss, _, _ = stepper(step, b)
+            losses.append(loss)
+            step += 1
+            assert len(stepper.graphs) <= 2
+    torch.cuda.synchronize()
+    assert all(np.isfinite(float(l)) for l in losses)
+    st = stepper.stats
+    assert st["eager"] == 3 and st["evicted"] >= 1 and st["captured"] >= 3 and st["replayed"] == 9, st

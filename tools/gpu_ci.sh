@@ -71,6 +71,16 @@ for step in "$@"; do
     pmcbench) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
              run pmcb1 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcb1 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap
              run pmcb2 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcb2 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap ;;
+    bounds)  # every GEMM / weight-gradient descriptor of the model tests and of one eager step per workload through the host-side validator
+             FS2_CHECK_BOUNDS=1 run bounds_model 900 python -m pytest tests/test_model_gpu.py tests/test_ar_gpu.py -q -m gpu --timeout 600 -p no:cacheprovider -x
+             FS2_CHECK_BOUNDS=1 run bounds_cfg2 400 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph
+             FS2_CHECK_BOUNDS=1 run bounds_cfg3 400 python bench.py --workload cfg3 --steps 3 --warmup 2 --no-cpu-baseline --no-graph
+             FS2_CHECK_BOUNDS=1 run bounds_cfg4 400 python bench.py --workload cfg4 --fp8 --steps 3 --warmup 2 --no-cpu-baseline --no-graph ;;
+    pmcsq)   # SQ counters of every kernel of the step, two passes (8 SQ slots each), kernel trace only
+             cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+             run pmcsq1 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS --output-format csv -d gpurun_out/pmcsq1 -- python bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-graph --no-overlap
+             run pmcsq2 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_BUSY_CU_CYCLES --output-format csv -d gpurun_out/pmcsq2 -- python bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-graph --no-overlap
+             run pmcsq3 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmcsq3 -- python bench.py --steps 2 --warmup 4 --no-cpu-baseline --no-graph --no-overlap ;;
     benchdp) FS2_FORCE_DP=1 run benchdp 400 python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-graph
              FS2_FORCE_DP=1 FS2_GRAPH_DP=1 run benchdpg 400 python bench.py --steps 8 --warmup 4 --no-cpu-baseline
              run benchtr 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 4 --warmup 2 --no-cpu-baseline ;;

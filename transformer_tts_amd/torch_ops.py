@@ -54,10 +54,34 @@ def _conv_meta(x, w, bias, pad, relu):
     return x.new_empty(x.shape[0], x.shape[1], w.shape[0])
 
 
+def _bthd(x):
+    """(B,H,t,dk) tensor re-laid as a (B,t,H,dk) buffer viewed (B,H,t,dk): head stride dk, the layout the model itself uses"""
+    return x if (x.stride(3) == 1 and x.stride(1) == x.shape[3]) else x.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+
+
+def _flash_layout(q, k, v):
+    """the kernels want ONE head stride for q, k, v and the outputs: head-interleaved (B,t,H,dk) views pass as they are, contiguous
+    (B,H,t,dk) tensors of equal length too; anything else is copied into the head-interleaved layout"""
+    B, H, tq, dk = q.shape
+    same = q.stride(3) == k.stride(3) == 1 and k.stride() == v.stride() and q.stride(1) == k.stride(1)
+    if same and q.stride(1) in (dk, tq * dk) and (q.stride(1) == dk or (q.is_contiguous() and k.is_contiguous())):
+        return q, k, v
+    return _bthd(q), _bthd(k), _bthd(v)
+
+
+def _like_heads(ref, t):
+    """empty (B,H,t,dk) tensor with the head stride of `ref`"""
+    B, H, _, dk = ref.shape
+    if ref.stride(1) == dk:
+        return torch.empty((B, t, H, dk), dtype=ref.dtype, device=ref.device).permute(0, 2, 1, 3)
+    return torch.empty((B, H, t, dk), dtype=ref.dtype, device=ref.device)
+
+
 @torch.library.impl(_lib, "flash_attention", "CUDA")
 def _flash_cuda(q, k, v, key_mask, causal):
     B, H, tq, dk = q.shape
-    out = torch.empty((B, tq, H, dk), dtype=q.dtype, device=q.device).permute(0, 2, 1, 3)
+    q, k, v = _flash_layout(q, k, v)
+    out = _like_heads(q, tq)
     stats = torch.empty((B, H, tq, 2), dtype=torch.float32, device=q.device)
     ops.flash_attention_fwd(q, k, v, key_mask, out, stats, None, 1.0 / math.sqrt(dk), 0, 0.0, None, 0, causal=causal)
     return out, stats
@@ -93,12 +117,11 @@ torch.library.register_autograd("fs2::linear", _linear_backward, setup_context=_
 def _flash_backward(ctx, grad_out, _grad_stats):
     q, k, v, key_mask, out, stats = ctx.saved_tensors
     B, H, tq, dk = q.shape
-    dq = torch.empty((B, tq, H, dk), dtype=q.dtype, device=q.device).permute(0, 2, 1, 3)
-    dk_ = torch.empty((B, k.shape[2], H, dk), dtype=q.dtype, device=q.device).permute(0, 2, 1, 3)
-    dv = torch.empty_like(dk_.permute(0, 2, 1, 3)).permute(0, 2, 1, 3)
+    q, k, v = _flash_layout(q, k, v)           # (the same layout decision as the forward: `out` was allocated for it)
+    dq, dk_, dv = _like_heads(q, tq), _like_heads(q, k.shape[2]), _like_heads(q, k.shape[2])
     aux = torch.empty((B, H, tq, 4), dtype=torch.float32, device=q.device)
-    g = grad_out if grad_out.stride(3) == 1 and grad_out.stride(1) == q.stride(1) else \
-        grad_out.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+    g = grad_out if (grad_out.stride(3) == 1 and grad_out.stride() == out.stride()) else \
+        torch.empty_strided(out.shape, out.stride(), dtype=out.dtype, device=out.device).copy_(grad_out)
     ops.flash_attention_bwd(q, k, v, key_mask, out, g, stats, None, aux, dq, dk_, dv, 1.0 / math.sqrt(dk), 0.0, causal=ctx.causal)
     return dq, dk_, dv, None, None
 
@@ -110,3 +133,29 @@ def _flash_setup(ctx, inputs, output):
 
 
 torch.library.register_autograd("fs2::flash_attention", _flash_backward, setup_context=_flash_setup, lib=_lib)
+
+
+def _conv_backward(ctx, grad):
+    """Conv1d backward as kernel calls: data gradient = the same implicit GEMM on the flipped, transposed weight
+    (dst[i][j*O + o] = w[o][i][k-1-j], pad k-1-pad), weight gradient = the k-major product of ops.conv_wgrad in the kernel layout
+    [o][j*I + i], viewed back as (O, I, k)"""
+    x, w, out = ctx.saved_tensors
+    O, I, k = w.shape
+    g = grad.contiguous()
+    if ctx.relu:
+        g = torch.where(out > 0, g, torch.zeros_like(g))
+    w_d = w.flip(2).permute(1, 2, 0).reshape(I, k * O).contiguous().to(x.dtype)
+    dx = ops.conv(g, w_d, k, k - 1 - ctx.pad)
+    dw = torch.zeros((O, k * I), dtype=torch.float32, device=w.device)
+    ops.conv_wgrad(g, x.contiguous(), k, ctx.pad, dw)
+    db = g.float().sum((0, 1)) if ctx.has_bias else None
+    return dx, dw.view(O, k, I).permute(0, 2, 1).to(w.dtype), db, None, None
+
+
+def _conv_setup(ctx, inputs, output):
+    x, w, bias, pad, relu = inputs
+    ctx.pad, ctx.relu, ctx.has_bias = pad, relu, bias is not None
+    ctx.save_for_backward(x, w, output)
+
+
+torch.library.register_autograd("fs2::conv1d_cl", _conv_backward, setup_context=_conv_setup, lib=_lib)

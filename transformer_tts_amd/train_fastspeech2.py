@@ -14,6 +14,7 @@ Differences, all on purpose:
 * losses are printed every ``hp.log_every`` steps (reference: every step, ~10 host syncs per step).
 """
 import argparse
+import collections
 import filecmp
 import os
 import random
@@ -152,9 +153,12 @@ class GraphedTrainStep:
     the ~600 kernel launches of a step stop costing host time (the step is launch-bound in Python otherwise).
     First occurrence of a shape runs eagerly (allocator warm-up), the second is captured, later ones replay.
     Padding is semantically live in this model (BatchNorm statistics and the L1 losses include padded
-    positions), so batches are never padded to a common shape -- one graph per (B, L_pad, T_pad)."""
+    positions), so batches are never padded to a common shape -- one graph per (B, L_pad, T_pad).
+    At most `max_graphs` graphs are kept: capturing one more evicts the least recently replayed (a corpus batched by a frame budget,
+    reference datasets_fastspeech2.py:749-813, produces hundreds of shapes; the graphs share one memory pool, so an evicted graph's
+    activations are reused by the next capture)."""
 
-    def __init__(self, model, optimizer, hp, max_graphs=32, eager_fallback=False, body=None, inputs=None, eager=None, set_lr=None):
+    def __init__(self, model, optimizer, hp, max_graphs=64, eager_fallback=False, body=None, inputs=None, eager=None, set_lr=None):
         """body / inputs / eager / set_lr: the device part of a step, the batch entries it reads, the eager step and the learning-rate rule
         of ANOTHER trainer of this package (transformer_tts_amd.train: the autoregressive model); default: this module's"""
         assert isinstance(optimizer, FusedAdam)
@@ -162,7 +166,8 @@ class GraphedTrainStep:
         self.body, self.inputs = body or step_body, inputs or STEP_INPUTS
         self.eager, self.set_lr = eager or train_step, set_lr or _set_lr
         self.max_graphs = max_graphs
-        self.seen, self.graphs = set(), {}
+        self.seen, self.graphs = set(), collections.OrderedDict()
+        self.stats = {"eager": 0, "captured": 0, "replayed": 0, "evicted": 0}
         self.pool = None
         # eager_fallback: if a capture raises (e.g. a collective that refuses stream capture on some multi-GPU setup), say so once
         # and run every later step eagerly instead of dying -- every rank sees the same failure, so the ranks stay in step
@@ -175,10 +180,15 @@ class GraphedTrainStep:
         entry = self.graphs.get(key)
         if self.broken:
             return self.eager(self.model, self.optimizer, step, d, self.hp)
-        if entry is None and (key not in self.seen or len(self.graphs) >= self.max_graphs):
+        if entry is None and key not in self.seen:
             self.seen.add(key)
+            self.stats["eager"] += 1
             return self.eager(self.model, self.optimizer, step, d, self.hp)
         if entry is None:
+            while len(self.graphs) >= max(1, self.max_graphs):      # LRU: the shape replayed longest ago makes room
+                _, old = self.graphs.popitem(last=False)
+                del old
+                self.stats["evicted"] += 1
             static = [t.to(DEVICE).clone() for t in tensors]
             g = torch.cuda.CUDAGraph()
             if self.pool is None:
@@ -202,6 +212,9 @@ class GraphedTrainStep:
                 torch.cuda.synchronize()
                 return self.eager(self.model, self.optimizer, step, d, self.hp)
             entry = self.graphs[key] = (g, static, loss, parts)
+            self.stats["captured"] += 1
+        self.graphs.move_to_end(key)
+        self.stats["replayed"] += 1
         self.optimizer.host_update()
         g, static, loss, parts = entry
         for dst, src in zip(static, tensors):
