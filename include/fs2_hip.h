@@ -380,7 +380,9 @@ int fs2_length_regulate_bwd(const void* dout, int dtype, const int32_t* starts, 
                             int accumulate, void* stream);
 
 /* torch.bucketize + nn.Embedding adds (Models/varianceadaptor.py:100,116,123-126):
- *   out = x + Ep[#bins_p < f0] + Ee[#bins_e < energy];  idx (int32 [2][M]) saved for the scatter-add backward. */
+ *   out = x + Ep[#bins_p < f0] + Ee[#bins_e < energy];  idx (int32 [2][M]) saved for the scatter-add backward.
+ *   f0 == NULL (hp.pitch_pred False, :93,122) or energy == NULL (hp.energy_pred False, :112,124): that term is left out, its idx row
+ *   holds -1 and its bins / table pointers are not read; fs2_bucket_embed_bwd skips a NULL dEp / dEe. */
 int fs2_bucket_embed_add_fwd(const void* x, int dtype, const float* f0, const float* energy, const float* pbins,
                              const float* ebins, int nbins, const float* Ep, const float* Ee, void* out, int32_t* idx,
                              int64_t M, int d, void* stream);

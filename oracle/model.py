@@ -48,22 +48,27 @@ def attention(q, k, v, d_k, key_mask, p_drop):
 
 
 class MultiHeadAttention(nn.Module):
-    """Models/modules.py:23-70 (concat_after=False).  Registration order q, v, k, out (:32-41)."""
+    """Models/modules.py:23-70.  Registration order q, v, k, out (:32-41); concat_after (:38-41,45-46,66-67): the output
+    projection is Linear(2d -> d) on cat(query input, attention context)."""
 
-    def __init__(self, heads, d_model, dropout):
+    def __init__(self, heads, d_model, dropout, concat_after=False):
         super().__init__()
         self.h, self.d_k, self.p = heads, d_model // heads, dropout
         self.q_linear = nn.Linear(d_model, d_model)
         self.v_linear = nn.Linear(d_model, d_model)
         self.k_linear = nn.Linear(d_model, d_model)
-        self.out = nn.Linear(d_model, d_model)
+        self.concat_after = concat_after
+        self.out = nn.Linear(2 * d_model if concat_after else d_model, d_model)
 
     def forward(self, x, key_mask):
         b, t, d = x.shape
         split = lambda y: y.view(b, t, self.h, self.d_k).transpose(1, 2)
         o, p = attention(split(self.q_linear(x)), split(self.k_linear(x)), split(self.v_linear(x)),
                          self.d_k, key_mask, self.p)
-        return self.out(o.transpose(1, 2).reshape(b, t, d)), p
+        concat = o.transpose(1, 2).reshape(b, t, d)
+        if self.concat_after:
+            concat = torch.cat((x, concat), dim=-1)                    # :66-67
+        return self.out(concat), p
 
 
 class FeedForward(nn.Module):
@@ -84,11 +89,11 @@ class FeedForward(nn.Module):
 class EncoderLayer(nn.Module):
     """Models/layers.py:8-41 (single speaker): pre-LN attention and FFN blocks with outer residuals."""
 
-    def __init__(self, d_model, heads, k, dropout):
+    def __init__(self, d_model, heads, k, dropout, concat_after=False):
         super().__init__()
         self.norm_1 = nn.LayerNorm(d_model)
         self.norm_2 = nn.LayerNorm(d_model)
-        self.attn = MultiHeadAttention(heads, d_model, dropout)
+        self.attn = MultiHeadAttention(heads, d_model, dropout, concat_after)
         self.ff = FeedForward(d_model, k, dropout)
         self.p = dropout
 
@@ -103,11 +108,11 @@ class Encoder(nn.Module):
     """Models/encoder.py:31-112: embed (Embedding pad 0 | Linear) -> PE -> N layers -> LayerNorm;
     attention maps of all layers stacked to (B,N,H,t,t) (:97,105)."""
 
-    def __init__(self, vocab, d_model, N, heads, k, dropout, embedding=True):
+    def __init__(self, vocab, d_model, N, heads, k, dropout, embedding=True, concat_after=False):
         super().__init__()
         self.embed = nn.Embedding(vocab, d_model, padding_idx=0) if embedding else nn.Linear(vocab, d_model)
         self.pe = PositionalEncoder(d_model, dropout=dropout)
-        self.layers = nn.ModuleList([EncoderLayer(d_model, heads, k, dropout) for _ in range(N)])
+        self.layers = nn.ModuleList([EncoderLayer(d_model, heads, k, dropout, concat_after) for _ in range(N)])
         self.norm = nn.LayerNorm(d_model)
 
     def forward(self, src, key_mask):
@@ -171,30 +176,52 @@ def get_mask_from_lengths(lengths):
     return ids <= lengths
 
 
+def scheduled_sampling(predicted, target, p):
+    """Models/varianceadaptor.py:261-282: with probability p (one host draw per utterance, torch.rand(B) on the CPU generator) the
+    utterance's pitch target is replaced by the predicted pitch before it is bucketised (no gradient flows: bucketize)."""
+    if p == 0.0:
+        return target
+    assert predicted.shape == target.shape
+    result = target.clone()
+    rand_vals = torch.rand(predicted.shape[0])
+    for i in range(predicted.shape[0]):
+        if rand_vals[i] < p:
+            result[i] = predicted[i].detach().to(result.dtype)
+    return result
+
+
 class VarianceAdaptor(nn.Module):
-    """Models/varianceadaptor.py:34-129, teacher-forced branch (duration/pitch/energy targets given)."""
+    """Models/varianceadaptor.py:34-129, teacher-forced branch (duration/pitch/energy targets given); pitch_pred / energy_pred
+    False (:93-125): that predictor, its embedding table and its term of the sum do not exist, its prediction is None."""
 
-    def __init__(self, d_model, n_bins, f0_min, f0_max, energy_min, energy_max, dropout):
+    def __init__(self, d_model, n_bins, f0_min, f0_max, energy_min, energy_max, dropout, pitch_pred=True, energy_pred=True):
         super().__init__()
+        self.pitch_pred, self.energy_pred = pitch_pred, energy_pred
         self.duration_predictor = VariancePredictor(d_model, dropout=dropout)
-        self.pitch_predictor = VariancePredictor(d_model, dropout=dropout)
-        # :56,61 -- fp32 boundaries, plain attributes
-        self.pitch_bins = torch.exp(torch.linspace(np.log(f0_min), np.log(f0_max), n_bins - 1))
-        self.pitch_embedding = nn.Embedding(n_bins, d_model)
-        self.energy_predictor = VariancePredictor(d_model, dropout=dropout)
-        self.energy_bins = torch.linspace(energy_min, energy_max, n_bins - 1)
-        self.energy_embedding = nn.Embedding(n_bins, d_model)
+        if pitch_pred:
+            self.pitch_predictor = VariancePredictor(d_model, dropout=dropout)
+            # :56,61 -- fp32 boundaries, plain attributes
+            self.pitch_bins = torch.exp(torch.linspace(np.log(f0_min), np.log(f0_max), n_bins - 1))
+            self.pitch_embedding = nn.Embedding(n_bins, d_model)
+        if energy_pred:
+            self.energy_predictor = VariancePredictor(d_model, dropout=dropout)
+            self.energy_bins = torch.linspace(energy_min, energy_max, n_bins - 1)
+            self.energy_embedding = nn.Embedding(n_bins, d_model)
 
-    def forward(self, x, src_mask, mel_mask, d_target, p_target, e_target):
+    def forward(self, x, src_mask, mel_mask, d_target, p_target, e_target, p_scheduled_sampling=0.0):
         log_d = self.duration_predictor(x, src_mask)                       # :69
         if d_target is None:
             return self.infer(x, log_d)
         x = length_regulate(x, d_target, mel_mask.shape[2])                # :71-73
-        p = self.pitch_predictor(x, mel_mask)                              # :95
-        pe = self.pitch_embedding(torch.bucketize(p_target, self.pitch_bins.to(p_target.dtype)))   # :100
-        e = self.energy_predictor(x, mel_mask)                             # :114
-        ee = self.energy_embedding(torch.bucketize(e_target, self.energy_bins.to(e_target.dtype)))  # :116
-        return x + pe + ee, log_d, p, e, x                                 # :122-129
+        out, p, e = x, None, None
+        if self.pitch_pred:
+            p = self.pitch_predictor(x, mel_mask)                          # :95
+            p_t = scheduled_sampling(p, p_target, p_scheduled_sampling)    # :99
+            out = out + self.pitch_embedding(torch.bucketize(p_t, self.pitch_bins.to(p_t.dtype)))   # :100,123
+        if self.energy_pred:
+            e = self.energy_predictor(x, mel_mask)                         # :114
+            out = out + self.energy_embedding(torch.bucketize(e_target, self.energy_bins.to(e_target.dtype)))  # :116,125
+        return out, log_d, p, e, x                                         # :122-129
 
     def infer(self, x, log_d):
         """Inference branch (:74-84,101-109,117-118; no perturbation): predicted durations, the variance embeddings
@@ -203,11 +230,14 @@ class VarianceAdaptor(nn.Module):
         x = length_regulate(x, dur, None)                                  # :82
         mel_pos = mel_positions(dur)
         mel_mask = get_mask_from_lengths(mel_pos)                          # :84
-        p = self.pitch_predictor(x, mel_mask)                              # :95
-        pe = self.pitch_embedding(torch.bucketize(p, self.pitch_bins.to(p.dtype)))                 # :109
-        e = self.energy_predictor(x, mel_mask)                             # :114
-        ee = self.energy_embedding(torch.bucketize(e, self.energy_bins.to(e.dtype)))               # :118
-        return x + pe + ee, log_d, p, e, x, mel_pos, mel_mask
+        out, p, e = x, None, None
+        if self.pitch_pred:
+            p = self.pitch_predictor(x, mel_mask)                          # :95
+            out = out + self.pitch_embedding(torch.bucketize(p, self.pitch_bins.to(p.dtype)))      # :109,123
+        if self.energy_pred:
+            e = self.energy_predictor(x, mel_mask)                         # :114
+            out = out + self.energy_embedding(torch.bucketize(e, self.energy_bins.to(e.dtype)))    # :118,125
+        return out, log_d, p, e, x, mel_pos, mel_mask
 
 
 class PostConvNet(nn.Module):
@@ -238,13 +268,15 @@ class FastSpeech2(nn.Module):
     transformer encoder/decoder, postnet_pred=True, no speaker / sq-vae / hop / fix_mask / debug."""
 
     def __init__(self, vocab, mel_dim, d_model, N_e, H_e, k_e, N_d, H_d, k_d, dropout, dropout_postnet,
-                 dropout_variance_adaptor, n_bins, f0_min, f0_max, energy_min, energy_max):
+                 dropout_variance_adaptor, n_bins, f0_min, f0_max, energy_min, energy_max, concat_after_encoder=False,
+                 concat_after_decoder=False, pitch_pred=True, energy_pred=True, p_scheduled_sampling=0.0):
         super().__init__()
-        self.encoder = Encoder(vocab, d_model, N_e, H_e, k_e, dropout, embedding=True)
+        self.encoder = Encoder(vocab, d_model, N_e, H_e, k_e, dropout, embedding=True, concat_after=concat_after_encoder)
         self.variance_adaptor = VarianceAdaptor(d_model, n_bins, f0_min, f0_max, energy_min, energy_max,
-                                                dropout_variance_adaptor)
-        self.decoder = Encoder(d_model, d_model, N_d, H_d, k_d, dropout, embedding=False)
+                                                dropout_variance_adaptor, pitch_pred, energy_pred)
+        self.decoder = Encoder(d_model, d_model, N_d, H_d, k_d, dropout, embedding=False, concat_after=concat_after_decoder)
         self.postnet = PostConvNet(d_model, mel_dim, dropout_postnet)
+        self.p_scheduled_sampling = p_scheduled_sampling              # hp.p_scheduled_sampling (Models/fastspeech2.py:178)
 
     @classmethod
     def from_hp(cls, hp, dropout=None, dropout_postnet=0.5, dropout_variance_adaptor=None):
@@ -253,13 +285,19 @@ class FastSpeech2(nn.Module):
                    hp.ff_conv_kernel_size_encoder, hp.n_layer_decoder, hp.n_head_decoder,
                    hp.ff_conv_kernel_size_decoder, hp.dropout if dropout is None else dropout, dropout_postnet,
                    getattr(hp, "dropout_variance_adaptor", 0.5) if dropout_variance_adaptor is None
-                   else dropout_variance_adaptor, hp.nbins, hp.f0_min, hp.f0_max, hp.energy_min, hp.energy_max)
+                   else dropout_variance_adaptor, hp.nbins, hp.f0_min, hp.f0_max, hp.energy_min, hp.energy_max,
+                   bool(getattr(hp, "concat_after_encoder", False)), bool(getattr(hp, "concat_after_decoder", False)),
+                   bool(getattr(hp, "pitch_pred", True)), bool(getattr(hp, "energy_pred", True)),
+                   float(getattr(hp, "p_scheduled_sampling", 0.0)))
 
     def double(self):
         """fp64 reference: also cast the plain-attribute tables."""
         super().double()
         va = self.variance_adaptor
-        va.pitch_bins, va.energy_bins = va.pitch_bins.double(), va.energy_bins.double()
+        if va.pitch_pred:
+            va.pitch_bins = va.pitch_bins.double()
+        if va.energy_pred:
+            va.energy_bins = va.energy_bins.double()
         return self
 
     def forward(self, src, src_mask, mel_mask=None, d_target=None, p_target=None, e_target=None):
@@ -270,7 +308,7 @@ class FastSpeech2(nn.Module):
             mel_mask = mel_mask.unsqueeze(1)       # (B,T) -> key mask (B,1,T); the reference relies on B == 1 here
         else:
             va_out, log_d, p_pred, e_pred, text_dur = self.variance_adaptor(e_out, src_mask, mel_mask, d_target,
-                                                                             p_target, e_target)
+                                                                             p_target, e_target, self.p_scheduled_sampling)
         d_out, attn_dec = self.decoder(va_out, mel_mask)
         mel_before, mel_after = self.postnet(d_out)
         return (mel_before, mel_after, log_d, p_pred, e_pred, va_out, text_dur, attn_enc, attn_dec,

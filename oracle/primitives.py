@@ -523,15 +523,25 @@ def length_regulate_bwd(dout, starts, L, dx=None):
 
 def bucket_embed_add_fwd(x, f0, energy, pbins, ebins, Ep, Ee):
     """x + pitch_embedding(bucketize(f0)) + energy_embedding(bucketize(e)) (varianceadaptor.py:100,116,123-126)."""
-    ip, ie = torch.bucketize(f0, pbins), torch.bucketize(energy, ebins)
-    out = ((_f(x) + _f(Ep[ip])) + _f(Ee[ie])).to(x.dtype)
-    return out, torch.stack([ip.reshape(-1), ie.reshape(-1)]).to(torch.int32)
+    M = x.numel() // x.shape[-1]
+    out = _f(x)
+    none = torch.full((M,), -1, dtype=torch.int64, device=x.device)
+    ip = ie = none
+    if f0 is not None:              # hp.pitch_pred (:93,122-123)
+        ip = torch.bucketize(f0, pbins)
+        out = out + _f(Ep[ip])
+    if energy is not None:          # hp.energy_pred (:112,124-125)
+        ie = torch.bucketize(energy, ebins)
+        out = out + _f(Ee[ie])
+    return out.to(x.dtype), torch.stack([ip.reshape(-1), ie.reshape(-1)]).to(torch.int32)
 
 
 def bucket_embed_bwd(dout, idx, dEp, dEe):
     g = dout.reshape(-1, dout.shape[-1]).float()
-    dEp.index_add_(0, idx[0].long(), g)
-    dEe.index_add_(0, idx[1].long(), g)
+    if dEp is not None:
+        dEp.index_add_(0, idx[0].long(), g)
+    if dEe is not None:
+        dEe.index_add_(0, idx[1].long(), g)
 
 
 def linear1_fwd(x, w, b, mask):

@@ -26,10 +26,15 @@ def losses(outputs, mel, alignment, f0, energy):
         "mel": F.l1_loss(mel_before, mel),
         "post_mel": F.l1_loss(mel_after, mel),
         "duration": F.l1_loss(log_d, torch.log(alignment.to(log_d.dtype) + 1)),
-        "f0": F.l1_loss(p_pred, f0),
-        "energy": F.l1_loss(e_pred, energy),
     }
-    total = parts["mel"] + parts["post_mel"] + parts["f0"] + parts["energy"] + parts["duration"]
+    total = parts["mel"] + parts["post_mel"]
+    if p_pred is not None:                  # hp.pitch_pred (:249-252)
+        parts["f0"] = F.l1_loss(p_pred, f0)
+        total = total + parts["f0"]
+    if e_pred is not None:                  # hp.energy_pred (:254-257)
+        parts["energy"] = F.l1_loss(e_pred, energy)
+        total = total + parts["energy"]
+    total = total + parts["duration"]
     return total, parts
 
 

@@ -41,6 +41,26 @@ CONFIGS = {
                   train_steps=1, start_step=4000),
 }
 
+# In-scope options of the FastSpeech2 path beside the defaults, each on the `tiny` geometry:
+#   opt_concat    concat_after_encoder / concat_after_decoder = True   (Models/modules.py:38-46,66-67)
+#   opt_nopitch   pitch_pred = False, opt_noenergy energy_pred = False (Models/varianceadaptor.py:93-125)
+#   opt_ss1       p_scheduled_sampling = 1.0: every utterance's pitch target replaced by the prediction (:99,261-282)
+#   opt_ss_half   p_scheduled_sampling = 0.5: torch.rand(B) on the CPU generator decides per utterance; `forward_seed` is set with
+#                 torch.manual_seed right before EVERY forward (recipe and tests alike) so that both sides draw the same numbers
+def _opt(seed, **hp):
+    return dict(hp=dict(CONFIGS["tiny"]["hp"], **hp), weight_seed=seed, batch=CONFIGS["tiny"]["batch"], train_steps=2, start_step=4000,
+                forward_seed=1234)
+
+
+OPTION_CONFIGS = {
+    "opt_concat": _opt(31, concat_after_encoder=True, concat_after_decoder=True),
+    "opt_nopitch": _opt(32, pitch_pred=False),
+    "opt_noenergy": _opt(33, energy_pred=False),
+    "opt_ss1": _opt(34, p_scheduled_sampling=1.0),
+    "opt_ss_half": _opt(35, p_scheduled_sampling=0.5),
+}
+CONFIGS.update(OPTION_CONFIGS)
+
 # Autoregressive Transformer-TTS (BASELINE.json configs[3]): hparams the reference's train.py /
 # Models.transformer.Transformer read on top of the common ones.  Batches are the 8-tuple of datasets_transformer.collate_fn
 # (text, mel, pos_text, pos_mel, text_lengths, mel_lengths, stop_token, spk_emb): the first eight fields of the synthetic batch.

@@ -130,20 +130,28 @@ def run(name):
 
     # ---- forward + losses + backward exactly as train_fastspeech2.py:153-167,212-259,312 (non-amp)
     src_mask, trg_mask = T.create_masks(pos_text, pos_mel, task=hp.model)
+    if "forward_seed" in cfg:       # scheduled sampling draws torch.rand(B) on the CPU generator inside the forward
+        torch.manual_seed(cfg["forward_seed"])
     res = model(text, src_mask, trg_mask, align, f0, energy, None, spkr_emb=None, fix_mask=None,
                 temperature=None, hop_size=None)
     names = ["mel_before", "mel_after", "log_d", "p_pred", "e_pred", "va_out", "text_dur", "attn_enc", "attn_dec"]
     assert all(r is None for r in res[9:]), "default branch returns None in slots 9..13"
     L1 = torch.nn.L1Loss()
-    losses = {
-        "mel": L1(res[0], mel), "post_mel": L1(res[1], mel),
-        "duration": L1(res[2], torch.log(align.float() + 1)),
-        "f0": L1(res[3], f0), "energy": L1(res[4], energy)}
-    total = losses["mel"] + losses["post_mel"] + losses["f0"] + losses["energy"] + losses["duration"]
+    losses = {"mel": L1(res[0], mel), "post_mel": L1(res[1], mel), "duration": L1(res[2], torch.log(align.float() + 1))}
+    total = losses["mel"] + losses["post_mel"]
+    if hp.pitch_pred:               # :249-252
+        losses["f0"] = L1(res[3], f0)
+        total = total + losses["f0"]
+    if hp.energy_pred:              # :254-257
+        losses["energy"] = L1(res[4], energy)
+        total = total + losses["energy"]
+    total = total + losses["duration"]
     for p in model.parameters():
         p.grad = None
     total.backward()
     for n, r in zip(names, res[:9]):
+        if r is None:               # p_pred / e_pred with hp.pitch_pred / hp.energy_pred False
+            continue
         r = r.detach()
         if full:
             out[f"out.{n}"] = r.numpy()
@@ -168,6 +176,8 @@ def run(name):
     step = cfg["start_step"]
     log = io.StringIO()
     for s in range(nsteps):
+        if "forward_seed" in cfg:
+            torch.manual_seed(cfg["forward_seed"])
         with contextlib.redirect_stdout(log):
             step = T.train_loop(model, opt, step, 0, SimpleNamespace(n_gpus=0), hp, 1, [batch])
         if s in (0, nsteps - 1):
@@ -505,6 +515,10 @@ if __name__ == "__main__":
         run_ardata()
     elif which == "init":
         run_init()
+    elif which == "options":
+        from golden_configs import OPTION_CONFIGS
+        for n in OPTION_CONFIGS:
+            run(n)
     else:
         for n in (list(CONFIGS) if which == "all" else [which]):
             run(n)

@@ -739,6 +739,20 @@ def test_length_regulator_and_bucket_embed(ops, dtype):
     assert torch.equal(a[1].cpu(), b[1]) and torch.equal(a[5].cpu(), b[5]), "scan / bucket indices bit-exact"
     for i in (2, 3, 4, 6, 7):
         close(a[i], b[i], f"LR/bucket output #{i}", **tol(dtype, k=4))
+    # one term only (hp.pitch_pred / hp.energy_pred False): the missing term's pointers are null, its idx row holds -1
+    for which in ("pitch", "energy"):
+        single = {}
+        for o, dev in ((ops, "cuda"), (P, "cpu")):
+            mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
+            args = (mv(f0), None, mv(pb), None, mv(Ep), None) if which == "pitch" else (None, mv(en), None, mv(eb), None, mv(Ee))
+            v, idx = o.bucket_embed_add_fwd(mv(dout), *args)
+            dE = torch.zeros(256, d, device=dev)
+            o.bucket_embed_bwd(mv(dout), idx, dE if which == "pitch" else None, None if which == "pitch" else dE)
+            single[dev] = (v, idx, dE)
+        assert torch.equal(single["cuda"][1].cpu(), single["cpu"][1]), which
+        assert bool((single["cpu"][1][1 if which == "pitch" else 0] == -1).all())
+        close(single["cuda"][0], single["cpu"][0], f"bucket embed, {which} term only", **tol(dtype, k=4))
+        close(single["cuda"][2], single["cpu"][2], f"bucket embed gradient, {which} term only", **tol(dtype, k=4))
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -16,23 +16,37 @@ def run(model, batch):
     text, mel, pos_text, pos_mel, _, _, _, _, f0, energy, align = batch[:11]
     src_mask, mel_mask = (pos_text != 0).unsqueeze(-2), (pos_mel != 0).unsqueeze(-2)
     out = model(text, src_mask, mel_mask, align, f0, energy)
-    parts = dict(mel=l1_loss(out[0], mel), post_mel=l1_loss(out[1], mel),
-                 duration=l1_loss(out[2], align, True), f0=l1_loss(out[3], f0), energy=l1_loss(out[4], energy))
-    total = parts["mel"] + parts["post_mel"] + parts["f0"] + parts["energy"] + parts["duration"]
+    parts = dict(mel=l1_loss(out[0], mel), post_mel=l1_loss(out[1], mel), duration=l1_loss(out[2], align, True))
+    total = parts["mel"] + parts["post_mel"]
+    if out[3] is not None:          # hp.pitch_pred
+        parts["f0"] = l1_loss(out[3], f0)
+        total = total + parts["f0"]
+    if out[4] is not None:          # hp.energy_pred
+        parts["energy"] = l1_loss(out[4], energy)
+        total = total + parts["energy"]
+    total = total + parts["duration"]
     for p in model.parameters():
         p.grad = None
     total.backward()
     return out, parts, total
 
 
-@pytest.mark.parametrize("name", ["tiny", "small"])
+OPTIONS = ["opt_concat", "opt_nopitch", "opt_noenergy", "opt_ss1", "opt_ss_half"]      # golden_configs.OPTION_CONFIGS
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", *OPTIONS])
 def test_forward_backward_matches_reference(fake_ops, name):
     model, hp, g = product_model(name)
     sd = model.state_dict()
     assert sorted(sd) == sorted(g["shape_keys"].tolist()) and list(sd)[0] == "encoder.embed.weight"
+    if "forward_seed" in CONFIGS[name]:         # scheduled sampling: torch.rand(B) inside the forward, seeded as the recipe does
+        torch.manual_seed(CONFIGS[name]["forward_seed"])
     out, parts, total = run(model, CONFIGS[name]["batch"]())
     assert len(out) == 14 and all(o is None for o in out[9:])
+    assert (out[3] is None) == (not hp.pitch_pred) and (out[4] is None) == (not hp.energy_pred)
     for n, o in zip(OUT_NAMES, out[:9]):
+        if o is None:
+            continue
         np.testing.assert_allclose(o.detach().float().numpy(), g[f"out.{n}"], rtol=2e-5, atol=2e-5, err_msg=n)
     for k, v in parts.items():
         assert abs(v.item() - float(g[f"loss.{k}"])) <= 1e-5 * max(1.0, abs(float(g[f"loss.{k}"]))), k

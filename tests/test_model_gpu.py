@@ -16,6 +16,13 @@ pytestmark = pytest.mark.gpu
 OUT_NAMES = ["mel_before", "mel_after", "log_d", "p_pred", "e_pred", "va_out", "text_dur", "attn_enc", "attn_dec"]
 MEL_L1_TOL_FP32 = 1e-4     # north star: "mel L1 within 1e-4 of reference"
 MEL_L1_TOL_BF16 = 3e-2
+OPTIONS = ["opt_concat", "opt_nopitch", "opt_noenergy", "opt_ss1", "opt_ss_half"]      # golden_configs.OPTION_CONFIGS
+
+
+def _seed(name):
+    """scheduled sampling draws torch.rand(B) on the CPU generator inside the forward: seeded as the fixture recipe seeds it"""
+    if "forward_seed" in CONFIGS[name]:
+        torch.manual_seed(CONFIGS[name]["forward_seed"])
 
 
 def fwd_bwd(model, hp, batch):
@@ -31,12 +38,16 @@ def fwd_bwd(model, hp, batch):
     return out, total, parts
 
 
-@pytest.mark.parametrize("name", ["tiny", "small"])
+@pytest.mark.parametrize("name", ["tiny", "small", *OPTIONS])
 def test_fp32_forward_backward_vs_reference_golden(name):
     model, hp, g = product_model(name, amp=False, device="cuda")
+    _seed(name)
     out, total, parts = fwd_bwd(model, hp, batch_to(CONFIGS[name]["batch"](), "cuda"))
     assert len(out) == 14 and all(o is None for o in out[9:])
+    assert (out[3] is None) == (not hp.pitch_pred) and (out[4] is None) == (not hp.energy_pred)
     for n, o in zip(OUT_NAMES, out[:9]):
+        if o is None:
+            continue
         ref = g[f"out.{n}"]
         got = o.detach().float().cpu().numpy()
         assert got.shape == ref.shape, n
@@ -57,7 +68,7 @@ def test_fp32_forward_backward_vs_reference_golden(name):
     assert float(model.encoder.embed.weight.grad[0].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("name", ["tiny", "small"])
+@pytest.mark.parametrize("name", ["tiny", "small", *OPTIONS])
 def test_fp32_three_train_steps_vs_reference_train_loop(name):
     """FusedAdam (arena, fused clip) + trainer step against the reference's own train_loop digests."""
     from transformer_tts_amd.optim import FusedAdam
@@ -69,6 +80,7 @@ def test_fp32_three_train_steps_vs_reference_train_loop(name):
     losses = []
     n_steps = CONFIGS[name]["train_steps"]
     for s in range(n_steps):
+        _seed(name)
         loss, _, _ = train_step(model, opt, step, batch, hp)
         step += 1
         losses.append(loss.item())
@@ -101,7 +113,7 @@ def test_fp32_vs_oracle_on_unseen_batch_with_dropout_off():
         torch.testing.assert_close(p.grad.cpu(), og, rtol=5e-3, atol=5e-5, msg=lambda m: f"grad {k}: {m}")
 
 
-@pytest.mark.parametrize("name", ["tiny", "small"])
+@pytest.mark.parametrize("name", ["tiny", "small", "opt_concat", "opt_nopitch"])
 def test_bf16_mode_within_stated_tolerance(name):
     model, hp, g = product_model(name, amp=True, device="cuda")
     out, total, parts = fwd_bwd(model, hp, batch_to(CONFIGS[name]["batch"](), "cuda"))

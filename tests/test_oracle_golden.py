@@ -7,11 +7,12 @@ import torch
 from helpers import golden_shapes, CONFIGS, check_digest, is_null_gradient_param, oracle_model
 from oracle import train as otrain
 
+OPTIONS = ["opt_concat", "opt_nopitch", "opt_noenergy", "opt_ss1", "opt_ss_half"]      # golden_configs.OPTION_CONFIGS
 OUT_NAMES = ["mel_before", "mel_after", "log_d", "p_pred", "e_pred", "va_out", "text_dur", "attn_enc", "attn_dec"]
 
 
 def test_state_dict_keys_match_reference():
-    for name in ("tiny", "small", "bench"):
+    for name in ("tiny", "small", "bench", *OPTIONS):
         m, hp, g = oracle_model(name) if name != "bench" else (None, None, None)
         if m is None:
             continue
@@ -21,15 +22,21 @@ def test_state_dict_keys_match_reference():
         assert list(sd)[0] == "encoder.embed.weight"
 
 
-@pytest.mark.parametrize("name", ["tiny", "small"])
+@pytest.mark.parametrize("name", ["tiny", "small", *OPTIONS])
 def test_forward_losses_grads(name):
     m, hp, g = oracle_model(name)
     batch = CONFIGS[name]["batch"]()
     for k, v in zip(("text", "mel", "pos_text", "pos_mel"), batch[:4]):
         np.testing.assert_array_equal(v.numpy(), g[f"in.{k}"])
+    if "forward_seed" in CONFIGS[name]:         # scheduled sampling: torch.rand(B) inside the forward (as the recipe seeds it)
+        torch.manual_seed(CONFIGS[name]["forward_seed"])
     total, parts, out = otrain.forward_backward(m, batch)
     assert all(o is None for o in out[9:]) and len(out) == 14
+    assert (out[3] is None) == (not hp.pitch_pred) and (out[4] is None) == (not hp.energy_pred)
     for n, o in zip(OUT_NAMES, out[:9]):
+        if o is None:
+            assert f"out.{n}" not in g
+            continue
         np.testing.assert_allclose(o.detach().numpy(), g[f"out.{n}"], rtol=2e-5, atol=2e-5, err_msg=n)
     for k, v in parts.items():
         assert abs(v.item() - float(g[f"loss.{k}"])) <= 1e-5 * max(1.0, abs(float(g[f"loss.{k}"]))), k
@@ -45,7 +52,7 @@ def test_forward_losses_grads(name):
     assert float(m.encoder.embed.weight.grad[0].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("name", ["tiny", "small"])
+@pytest.mark.parametrize("name", ["tiny", "small", *OPTIONS])
 def test_three_train_steps(name):
     m, hp, g = oracle_model(name)
     cfg = CONFIGS[name]
@@ -54,6 +61,8 @@ def test_three_train_steps(name):
     step = int(g["train.start_step"])
     losses = []
     for s in range(cfg["train_steps"]):
+        if "forward_seed" in cfg:
+            torch.manual_seed(cfg["forward_seed"])
         loss, step = otrain.train_step(m, opt, step, batch, hp.d_model_decoder, hp.warmup_factor, hp.warmup_step)
         losses.append(loss.item())
         if s in (0, cfg["train_steps"] - 1):

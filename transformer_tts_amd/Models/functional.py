@@ -357,7 +357,12 @@ class EncoderStackFunction(torch.autograd.Function):
                 ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)                             # modules.py:8-9
                 ops.softmax_fwd(S, Pd, km, t, p_att, rng, layer.site_attn)                       # modules.py:11-19
                 ops.bmm(Pd, v, O4, trans_b=False)                                                # modules.py:20
-            a = ops.linear(O.view(M, d), rt.w_fwd(layer.attn.out.weight), layer.attn.out.bias.detach())  # :68
+            wo = rt.w_fwd(layer.attn.out.weight)
+            if layer.attn.concat_after:     # modules.py:45-46,66-67: out(cat(query input, context)) = W[:, :d] h + W[:, d:] O + b, two products,
+                a = ops.linear(ops.view2d(h, M, d), wo[:, :d], layer.attn.out.bias.detach())     # the second adds the first in its epilogue
+                a = ops.linear(O.view(M, d), wo[:, d:], residual=a)
+            else:
+                a = ops.linear(O.view(M, d), wo, layer.attn.out.bias.detach())                    # :68
             n2 = layer.norm_2
             x1, h2, m2, r2 = ops.add_ln_fwd(x, a.view(B, t, d), n2.weight.detach(), n2.bias.detach(), 1e-5, p, rng,
                                             layer.site_res1)                                    # layers.py:33-35
@@ -424,8 +429,17 @@ class EncoderStackFunction(torch.autograd.Function):
             dx, da = ops.add_ln_bwd(dx1, dh2, L["x1"], n2.weight.detach(), L["m2"], L["r2"], grad_of(n2.weight),
                                     grad_of(n2.bias), p, rng, layer.site_res1, dcolsum=grad_of(at.out.bias))
             da2 = ops.view2d(da, M, d)
-            _linear_wgrad(rt, da2, ops.view2d(L["O"], M, d), at.out, bias_done=True)
-            dO = ops.linear(da2, rt.w_dgrad(at.out.weight))
+            dh_cat = None
+            if at.concat_after:             # the two column halves of the (d, 2d) weight: query input | context
+                gwo, wdo = grad_of(at.out.weight), rt.w_dgrad(at.out.weight)
+                with rt.side(da2, L["h"], L["O"]):
+                    ops.wgrad(da2, ops.view2d(L["h"], M, d), gwo[:, :d], defer=rt.defer_wgrad)
+                    ops.wgrad(da2, ops.view2d(L["O"], M, d), gwo[:, d:], defer=rt.defer_wgrad)
+                dh_cat = ops.linear(da2, wdo[:d])          # gradient w.r.t. the query input, added to the q/k/v data gradient below
+                dO = ops.linear(da2, wdo[d:])
+            else:
+                _linear_wgrad(rt, da2, ops.view2d(L["O"], M, d), at.out, bias_done=True)
+                dO = ops.linear(da2, rt.w_dgrad(at.out.weight))
             dO4 = dO.view(B, t, H, dk).permute(0, 2, 1, 3)
             qkv = L["qkv"]
             q5 = qkv.view(B, t, 3, H, dk)
@@ -460,7 +474,7 @@ class EncoderStackFunction(torch.autograd.Function):
                 # the three weight gradients in ONE batched split-K GEMM when they sit at a constant stride (arena)
                 ops.wgrad_batched(dqkv2, h2d, [grad_of(lin.weight) for lin in (at.q_linear, at.v_linear, at.k_linear)], defer=rt.defer_wgrad)
             _, wd, _ = rt.qkv(at)
-            dh = ops.linear(dqkv2, wd).view(B, t, d)
+            dh = ops.linear(dqkv2, wd, residual=dh_cat).view(B, t, d)
             # every gradient of this layer except norm_1's (produced by the next iteration) and the norm that follows the
             # layer (norm_1 of layer i+1 / the final norm) is enqueued: one contiguous arena range -> exchange it now
             rt.announce([q_ for name, q_ in layer.named_parameters() if not name.startswith("norm_1.")] + list(nn_.parameters()))
@@ -547,14 +561,16 @@ class LengthRegulatorFunction(torch.autograd.Function):
 
 
 class BucketEmbedAddFunction(torch.autograd.Function):
-    """Models/varianceadaptor.py:100,116,123-126."""
+    """Models/varianceadaptor.py:100,116,123-126; f0 / energy None: hp.pitch_pred / hp.energy_pred False (:93,112), that term is absent."""
 
     @staticmethod
     def forward(ctx, va, x, f0, energy, *params):
-        out, idx = ops.bucket_embed_add_fwd(x.contiguous(), f0.contiguous(), energy.contiguous(), va.pitch_bins_dev(x.device),
-                                            va.energy_bins_dev(x.device), va.pitch_embedding.weight.detach(),
-                                            va.energy_embedding.weight.detach())
-        ctx.va, ctx.idx = va, idx
+        hp_, he_ = f0 is not None, energy is not None
+        out, idx = ops.bucket_embed_add_fwd(x.contiguous(), f0.contiguous() if hp_ else None, energy.contiguous() if he_ else None,
+                                            va.pitch_bins_dev(x.device) if hp_ else None, va.energy_bins_dev(x.device) if he_ else None,
+                                            va.pitch_embedding.weight.detach() if hp_ else None,
+                                            va.energy_embedding.weight.detach() if he_ else None)
+        ctx.va, ctx.idx, ctx.terms = va, idx, (hp_, he_)
         return out
 
     @staticmethod
@@ -566,12 +582,14 @@ class BucketEmbedAddFunction(torch.autograd.Function):
         # 2 x M x d float atomics that pile up on a few rows (padded frames all select bucket 0)
         d2 = dout.view(-1, dout.shape[-1])
         rt = va.rt
+        embs = [(j, emb) for j, (on, emb) in enumerate(zip(ctx.terms, (getattr(va, "pitch_embedding", None), getattr(va, "energy_embedding", None)))) if on]
         with rt.side(d2, ctx.idx):
-            for j, emb in enumerate((va.pitch_embedding, va.energy_embedding)):
+            for j, emb in embs:
                 oh = ops.onehot(ctx.idx[j], emb.weight.shape[0], dout.dtype)
                 rt._keep.append(oh)
                 ops.wgrad(oh, d2, grad_of(emb.weight))
-        rt.announce([va.pitch_embedding.weight, va.energy_embedding.weight])
+        if embs:
+            rt.announce([emb.weight for _, emb in embs])
         rt.side_join()
         return (None, dout, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
 

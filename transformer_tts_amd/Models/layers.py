@@ -27,6 +27,7 @@ class DecoderLayer(nn.Module):
     def __init__(self, d_model, heads, ff_conv_kernel_size, dropout=0.1, concat_after=False, multi_speaker=False, spk_emb_dim=None):
         super().__init__()
         assert not multi_speaker, "multi-speaker conditioning is outside the accelerated path"
+        assert not concat_after, "concat_after_decoder of the autoregressive decoder is outside the accelerated path (the FFT stacks take it)"
         self.norm_1 = nn.LayerNorm(d_model)
         self.norm_2 = nn.LayerNorm(d_model)
         self.norm_3 = nn.LayerNorm(d_model)

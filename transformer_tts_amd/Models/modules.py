@@ -39,18 +39,18 @@ class PositionalEncoder(nn.Module):
 
 
 class MultiHeadAttention(nn.Module):
-    """q/v/k/out projections registered in the reference's order (Models/modules.py:32-41)."""
+    """q/v/k/out projections registered in the reference's order (Models/modules.py:32-41); concat_after (:38-41): the output
+    projection reads cat(query input, attention context) -- Linear(2d -> d)."""
 
     def __init__(self, heads, q_dim, k_dim, v_dim, d_model, dropout=0.1, concat_after=False):
         super().__init__()
-        assert not concat_after, "concat_after is outside the accelerated path"
         self.d_model, self.d_k, self.h = d_model, d_model // heads, heads
         self.q_linear = nn.Linear(q_dim, d_model)
         self.v_linear = nn.Linear(k_dim, d_model)
         self.k_linear = nn.Linear(v_dim, d_model)
         self.dropout = dropout
-        self.concat_after = concat_after
-        self.out = nn.Linear(d_model, d_model)
+        self.concat_after = bool(concat_after)
+        self.out = nn.Linear(2 * d_model if self.concat_after else d_model, d_model)
 
 
 class FeedForward(nn.Module):

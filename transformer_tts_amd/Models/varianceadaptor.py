@@ -46,24 +46,38 @@ class LengthRegulator(nn.Module):
         return LengthRegulatorFunction.apply(x, duration, T), pos * (pos <= lens.unsqueeze(1))
 
 
+def scheduled_sampling(predicted, target, p):
+    """reference :261-282: with probability p -- ONE draw per utterance, torch.rand(B) on the CPU generator exactly as the reference
+    draws it -- the utterance's pitch target is replaced by the predicted pitch before it is bucketised (no gradient flows through
+    torch.bucketize).  Not capturable in a hipGraph (host randomness): train_loop launches eagerly when hp.p_scheduled_sampling != 0."""
+    if p == 0.0:
+        return target
+    assert predicted.shape == target.shape
+    take = torch.rand(predicted.shape[0]) < p
+    if not bool(take.any()):
+        return target
+    return torch.where(take.to(target.device)[:, None], predicted.detach().to(target.dtype), target)
+
+
 class VarianceAdaptor(nn.Module):
     def __init__(self, d_model_encoder, n_bins=256, f0_min=71.0, f0_max=795.8, energy_min=0.0, energy_max=315.0,
                  log_offset=1., pitch_pred=True, energy_pred=True, dropout=0.5, use_rnn_length=False, use_pos=False,
                  runtime=None):
         super().__init__()
-        assert pitch_pred and energy_pred and not use_rnn_length and not use_pos, \
-            "only the default pitch+energy configuration is on the accelerated path"
+        assert not use_rnn_length and not use_pos, "use_rnn_length / use_pos are outside the accelerated path"
         self.rt = runtime if runtime is not None else Runtime()
-        self.pitch_pred, self.energy_pred = pitch_pred, energy_pred
+        self.pitch_pred, self.energy_pred = bool(pitch_pred), bool(energy_pred)
         self.duration_predictor = VariancePredictor(d_model_encoder, variance_predictor_dropout=dropout, runtime=self.rt)
         self.length_regulator = LengthRegulator()
-        self.pitch_predictor = VariancePredictor(d_model_encoder, variance_predictor_dropout=dropout, runtime=self.rt)
-        # identical host expressions as the reference (:56,61) so the fp32 boundaries match bit for bit
-        self.pitch_bins = torch.exp(torch.linspace(np.log(f0_min), np.log(f0_max), n_bins - 1))
-        self.pitch_embedding = nn.Embedding(n_bins, d_model_encoder)
-        self.energy_predictor = VariancePredictor(d_model_encoder, variance_predictor_dropout=dropout, runtime=self.rt)
-        self.energy_bins = torch.linspace(energy_min, energy_max, n_bins - 1)
-        self.energy_embedding = nn.Embedding(n_bins, d_model_encoder)
+        if self.pitch_pred:             # reference :54-57
+            self.pitch_predictor = VariancePredictor(d_model_encoder, variance_predictor_dropout=dropout, runtime=self.rt)
+            # identical host expressions as the reference (:56,61) so the fp32 boundaries match bit for bit
+            self.pitch_bins = torch.exp(torch.linspace(np.log(f0_min), np.log(f0_max), n_bins - 1))
+            self.pitch_embedding = nn.Embedding(n_bins, d_model_encoder)
+        if self.energy_pred:            # reference :59-62
+            self.energy_predictor = VariancePredictor(d_model_encoder, variance_predictor_dropout=dropout, runtime=self.rt)
+            self.energy_bins = torch.linspace(energy_min, energy_max, n_bins - 1)
+            self.energy_embedding = nn.Embedding(n_bins, d_model_encoder)
         self.log_offset = 1.
         self._bins_dev = {}
 
@@ -79,21 +93,28 @@ class VarianceAdaptor(nn.Module):
     def energy_bins_dev(self, device):
         return self._bins("energy_bins", device)
 
+    def _embed_add(self, x, pitch, energy):
+        """x (+ pitch_embedding[bucketize(pitch)]) (+ energy_embedding[bucketize(energy)])   (reference :100,116,122-125)"""
+        if not (self.pitch_pred or self.energy_pred):
+            return x
+        tables = ([self.pitch_embedding.weight] if self.pitch_pred else []) + ([self.energy_embedding.weight] if self.energy_pred else [])
+        return BucketEmbedAddFunction.apply(self, x, pitch if self.pitch_pred else None, energy if self.energy_pred else None, *tables)
+
     def forward(self, x, src_mask, mel_mask=None, duration_target=None, pitch_target=None, energy_target=None,
                 max_len=None, p_scheduled_sampling=0.0, pitch_perturbation=False, duration_perturbation=False):
-        assert p_scheduled_sampling == 0.0
         log_duration_prediction = self.duration_predictor(x, src_mask)
         if duration_target is None:
             return self._infer(x, log_duration_prediction, max_len, pitch_perturbation, duration_perturbation)
-        assert pitch_target is not None and energy_target is not None
+        assert (pitch_target is not None or not self.pitch_pred) and (energy_target is not None or not self.energy_pred)
         if mel_mask is not None:
             max_len = mel_mask.shape[2]
         x, mel_len = self.length_regulator(x, duration_target, max_len)
-        pitch_prediction = self.pitch_predictor(x, mel_mask)
-        energy_prediction = self.energy_predictor(x, mel_mask)
+        pitch_prediction = self.pitch_predictor(x, mel_mask) if self.pitch_pred else None          # :93-95 / :110
+        energy_prediction = self.energy_predictor(x, mel_mask) if self.energy_pred else None       # :112-114 / :120
+        if self.pitch_pred:
+            pitch_target = scheduled_sampling(pitch_prediction, pitch_target, p_scheduled_sampling)    # :99
         text_dur_predicted = x
-        x = BucketEmbedAddFunction.apply(self, x, pitch_target, energy_target, self.pitch_embedding.weight,
-                                         self.energy_embedding.weight)
+        x = self._embed_add(x, pitch_target, energy_target)
         return x, log_duration_prediction, pitch_prediction, energy_prediction, mel_len, mel_mask, text_dur_predicted
 
     def _infer(self, x, log_duration_prediction, max_len, pitch_perturbation, duration_perturbation):
@@ -109,11 +130,14 @@ class VarianceAdaptor(nn.Module):
         T = x.shape[1]
         ids = torch.arange(0, T, device=x.device).unsqueeze(0).expand(x.shape[0], -1)
         mel_mask = ids <= mel_len                                                    # get_mask_from_lengths, :251-259
-        pitch_prediction = self.pitch_predictor(x, mel_mask)
-        if pitch_perturbation:                                                       # :103-107
-            pitch_prediction = random.sample([0.8, 0.9, 1.0, 1.1, 1.2], 1)[0] * pitch_prediction
-        energy_prediction = self.energy_predictor(x, mel_mask)
+        pitch_prediction = energy_prediction = None
+        if self.pitch_pred:
+            pitch_prediction = self.pitch_predictor(x, mel_mask)
+            if pitch_perturbation:                                                   # :103-107
+                pitch_prediction = random.sample([0.8, 0.9, 1.0, 1.1, 1.2], 1)[0] * pitch_prediction
+        if self.energy_pred:
+            energy_prediction = self.energy_predictor(x, mel_mask)
         text_dur_predicted = x
-        x = BucketEmbedAddFunction.apply(self, x, pitch_prediction.contiguous(), energy_prediction.contiguous(),
-                                         self.pitch_embedding.weight, self.energy_embedding.weight)   # :109,118,122-125
+        x = self._embed_add(x, pitch_prediction.contiguous() if self.pitch_pred else None,
+                            energy_prediction.contiguous() if self.energy_pred else None)          # :109,118,122-125
         return x, log_duration_prediction, pitch_prediction, energy_prediction, mel_len, mel_mask, text_dur_predicted

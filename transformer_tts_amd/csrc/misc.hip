@@ -143,35 +143,35 @@ __global__ __launch_bounds__(TPB) void bucket_embed_add_fwd_k(const T* __restric
     // below its value is four wave ballots -- the binary search cost 2 x 8 dependent loads per row (the same index for sorted
     // boundaries: torch.bucketize, right=False)
     const bool in_regs = nb <= 256;
+    const bool has_p = f0 != nullptr, has_e = en != nullptr;      // hp.pitch_pred / hp.energy_pred False: that term does not exist
     float pb[4], eb[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int i = 4 * lane + c;
-        pb[c] = (in_regs && i < nb) ? pbins[i] : __builtin_huge_valf();
-        eb[c] = (in_regs && i < nb) ? ebins[i] : __builtin_huge_valf();
+        pb[c] = (in_regs && has_p && i < nb) ? pbins[i] : __builtin_huge_valf();
+        eb[c] = (in_regs && has_e && i < nb) ? ebins[i] : __builtin_huge_valf();
     }
     for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < M; r += (int64_t)gridDim.x * 4) {
-        int ip, ie;
+        int ip = 0, ie = 0;
         if (in_regs) {
-            const float vp = f0[r], ve = en[r];
-            ip = ie = 0;
+            const float vp = has_p ? f0[r] : 0.f, ve = has_e ? en[r] : 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 ip += __popcll(__ballot(pb[c] < vp));
                 ie += __popcll(__ballot(eb[c] < ve));
             }
         } else {
-            ip = bucketize(pbins, nb, f0[r]);
-            ie = bucketize(ebins, nb, en[r]);
+            if (has_p) ip = bucketize(pbins, nb, f0[r]);
+            if (has_e) ie = bucketize(ebins, nb, en[r]);
         }
-        if (lane == 0) { idx[r] = ip; idx[M + r] = ie; }
-        const float* ep = Ep + (int64_t)ip * d;
-        const float* ee = Ee + (int64_t)ie * d;
+        if (lane == 0) { idx[r] = has_p ? ip : -1; idx[M + r] = has_e ? ie : -1; }
+        const float* ep = has_p ? Ep + (int64_t)ip * d : nullptr;
+        const float* ee = has_e ? Ee + (int64_t)ie * d : nullptr;
         for (int c = lane * 4; c < d; c += 256) {
             float4 v = load4<T>(x + r * d + c);
-            const float4 a = load4<float>(ep + c), b = load4<float>(ee + c);
             // same association as the reference: (x + pitch_embedding) + energy_embedding
-            v.x = (v.x + a.x) + b.x; v.y = (v.y + a.y) + b.y; v.z = (v.z + a.z) + b.z; v.w = (v.w + a.w) + b.w;
+            if (has_p) { const float4 a = load4<float>(ep + c); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            if (has_e) { const float4 b = load4<float>(ee + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
             store4<T>(out + r * d + c, v);
         }
     }
@@ -181,12 +181,12 @@ __global__ __launch_bounds__(TPB) void bucket_embed_bwd_k(const T* __restrict__ 
         float* __restrict__ dEp, float* __restrict__ dEe, int64_t M, int d) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < M; r += (int64_t)gridDim.x * 4) {
-        float* dp = dEp + (int64_t)idx[r] * d;
-        float* de = dEe + (int64_t)idx[M + r] * d;
+        float* dp = (dEp != nullptr && idx[r] >= 0) ? dEp + (int64_t)idx[r] * d : nullptr;
+        float* de = (dEe != nullptr && idx[M + r] >= 0) ? dEe + (int64_t)idx[M + r] * d : nullptr;
         for (int c = lane * 4; c < d; c += 256) {
             const float4 g = load4<T>(dout + r * d + c);
-            atomicAdd(dp + c, g.x); atomicAdd(dp + c + 1, g.y); atomicAdd(dp + c + 2, g.z); atomicAdd(dp + c + 3, g.w);
-            atomicAdd(de + c, g.x); atomicAdd(de + c + 1, g.y); atomicAdd(de + c + 2, g.z); atomicAdd(de + c + 3, g.w);
+            if (dp) { atomicAdd(dp + c, g.x); atomicAdd(dp + c + 1, g.y); atomicAdd(dp + c + 2, g.z); atomicAdd(dp + c + 3, g.w); }
+            if (de) { atomicAdd(de + c, g.x); atomicAdd(de + c + 1, g.y); atomicAdd(de + c + 2, g.z); atomicAdd(de + c + 3, g.w); }
         }
     }
 }

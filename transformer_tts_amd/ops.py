@@ -1284,12 +1284,18 @@ def length_regulate_bwd(dout, starts, L, dx=None):
 
 
 def bucket_embed_add_fwd(x, f0, energy, pbins, ebins, Ep, Ee):
+    """x + Ep[bucketize(f0, pbins)] + Ee[bucketize(energy, ebins)]; f0 (with pbins, Ep) or energy (with ebins, Ee) may be None:
+    that term is left out (hp.pitch_pred / hp.energy_pred False) and its row of idx holds -1"""
     d = x.shape[-1]
     M = x.numel() // d
     out = torch.empty_like(x)
     idx = torch.empty((2, M), dtype=torch.int32, device=x.device)
-    _check(lib().fs2_bucket_embed_add_fwd(_p(_c(x)), _dt(x), _p(_c(f0)), _p(_c(energy)), _p(pbins), _p(ebins),
-                                          pbins.numel(), _p(_c(Ep)), _p(_c(Ee)), _p(out), _p(idx), M, d, _stream()),
+    nb = (pbins if f0 is not None else ebins).numel() if (f0 is not None or energy is not None) else 1
+    assert f0 is None or energy is None or pbins.numel() == ebins.numel()
+    cp = lambda t: _p(_c(t)) if t is not None else None
+    _check(lib().fs2_bucket_embed_add_fwd(_p(_c(x)), _dt(x), cp(f0), cp(energy), _p(pbins) if f0 is not None else None,
+                                          _p(ebins) if energy is not None else None, nb, cp(Ep) if f0 is not None else None,
+                                          cp(Ee) if energy is not None else None, _p(out), _p(idx), M, d, _stream()),
            "fs2_bucket_embed_add_fwd")
     return out, idx
 

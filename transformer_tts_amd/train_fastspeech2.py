@@ -279,7 +279,8 @@ def train_loop(model, optimizer, step, epoch, args, hp, rank, dataloader):
     # hp.use_graph = False keeps eager launches) fed by a one-batch-ahead copy stream
     on_gpu = isinstance(optimizer, FusedAdam) and optimizer.arena.p.is_cuda
     run = train_step
-    if on_gpu and bool(getattr(hp, "use_graph", True)):
+    # (scheduled sampling draws host random numbers inside the forward, reference Models/varianceadaptor.py:261-282: eager launches)
+    if on_gpu and bool(getattr(hp, "use_graph", True)) and float(getattr(hp, "p_scheduled_sampling", 0.0)) == 0.0:
         stepper = getattr(optimizer, "_fs2_graphed", None)
         if stepper is None or stepper.model is not model:
             stepper = optimizer._fs2_graphed = GraphedTrainStep(model, optimizer, hp, eager_fallback=_dist_alive())   # (N > 1 capture has never run on hardware: a refusal falls back to eager launches, as in bench.py)
