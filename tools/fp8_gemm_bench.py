@@ -54,8 +54,7 @@ for name, (fn, fl, backward) in cases.items():
     line = f"{name:36s} bf16[{tile}] {tw:6.1f}/{tc:6.1f} us ({fl / tw / 1e6:5.0f} TF)"
     ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = True, backward
     try:
-        for label, env, quant in (("f8-ring", "1", cached), ("f8-big", "0", cached), ("f8-ring+quantise", "1", orig)):
-            os.environ["FS2_GEMM_F8_RING"] = env
+        for label, quant in (("f8-ring", cached), ("f8-ring+quantise", orig)):
             ops._fp8_operands = quant
             ops.fp8_begin_step(torch.device(dev))
             out = fn().float()
@@ -68,5 +67,4 @@ for name, (fn, fl, backward) in cases.items():
     finally:
         ops._fp8_operands = orig
         ops.FP8_MODE["on"], ops.FP8_MODE["backward"] = False, False
-        os.environ.pop("FS2_GEMM_F8_RING", None)
     print(line, flush=True)

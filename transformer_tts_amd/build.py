@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 LIB = os.path.join(PKG, "libfs2_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_ring.hip", "gemm_ring_f8.hip", "gemm_ws.hip", "gemm_big.hip", "gemm_big_km.hip", "fp8.hip", "rowops.hip", "misc.hip", "attention.hip", "attention_flash.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_ring.hip", "gemm_ring_f8.hip", "gemm_ws.hip", "gemm_big_km.hip", "fp8.hip", "rowops.hip", "misc.hip", "attention.hip", "attention_flash.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC]
 
 

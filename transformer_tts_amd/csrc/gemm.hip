@@ -29,7 +29,6 @@
 
 bool fs2_gemm_ws_try(const FS2Gemm& g, hipStream_t st, int* rc);      // gemm_ws.hip
 bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc);    // gemm_ring.hip
-bool fs2_gemm_big_try(const FS2Gemm& g, hipStream_t st, int* rc);     // gemm_big.hip
 bool fs2_gemm_big_km_try(const FS2Gemm& g, hipStream_t st, int* rc);  // gemm_big_km.hip
 
 thread_local int g_last_tile = 0;     // rows of the block tile of the last fs2_gemm launch of this thread (measurement aid)
@@ -633,7 +632,6 @@ extern "C" int fs2_gemm(const FS2Gemm* gp, void* stream) {
         int rc = FS2_OK;
         if (fs2_gemm_ring_try(g, (hipStream_t)stream, &rc)) return rc;      // ring kernel, block-scaled 128-deep fp8 MFMA (g_last_tile 130 / 192)
         FS2_REQUIRE(g.q8 == nullptr, "fs2_gemm: FS2Gemm.q8 needs the fp8 ring kernel (bf16 C, contiguous rows, N %% 16 == 0)");
-        if (fs2_gemm_big_try(g, (hipStream_t)stream, &rc)) return rc;       // round-2 kernel, non-scaled fp8 MFMA (FS2_GEMM_F8_RING=0)
         fs2_set_error("fs2_gemm: fp8 operands need a row-major un-batched product with K, lda, ldb multiples of 16, no accumulate / "
                       "split-K, a compiled epilogue combination and 32-bit addressable operands");
         return FS2_EINVAL;

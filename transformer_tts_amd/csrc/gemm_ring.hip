@@ -21,10 +21,7 @@ bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc) {
     if (g.q8 != nullptr) {      // fp8 copy of C: the fp8 form of this kernel only, bf16 C with contiguous rows of a multiple of 16 columns
         if (!f8 || g.c_dtype != FS2_BF16 || g.N % 16 != 0 || g.ldc != g.N || !g.q8_state || !g.q8_prev || !fs2_aligned16(g.q8)) return false;
     }
-    if (f8) {       // FS2_GEMM_F8_RING=0: the round-2 kernel (gemm_big.hip, non-scaled fp8 MFMA) for A/B measurements
-        const int f8_env = getenv("FS2_GEMM_F8_RING") ? atoi(getenv("FS2_GEMM_F8_RING")) : 1;      // (read per call: A/B inside one process)
-        if (!f8_env || sliced || g.K % 16 != 0 || g.lda % 16 != 0 || g.ldb % 16 != 0) return false;
-    }
+    if (f8 && (sliced || g.K % 16 != 0 || g.lda % 16 != 0 || g.ldb % 16 != 0)) return false;
     if (g.accumulate != 0 && !sliced) return false;
     if ((long)g.batch1 * g.batch2 != 1) return false;
     if (!sliced && g.split_k != 1) return false;

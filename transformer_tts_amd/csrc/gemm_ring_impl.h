@@ -1,6 +1,6 @@
 // Row-major x row-major bf16 MFMA GEMM for gfx950, 16 waves: the tall products of the model (linear layers and implicit-GEMM
 // Conv1d, forward and data gradient; M = batch * frames rows against N <= 2048 output channels).  Round 3 form of the
-// large-tile kernel (round 2: gemm_big.hip, which keeps the one-byte-operand instances).
+// large-tile kernel of round 2 (retired in round 4).
 //
 // Geometry (unchanged, it fits the model): BM x 256 block tile, BM = 128 / 192 / 256 chosen per launch, 16 waves of
 // (BM/4) x 64, <= 128 VGPRs (four waves per SIMD), one persistent workgroup per CU walking a flattened stream of k-slots over all
@@ -22,7 +22,7 @@
 //   * sliced split-K for products with few output tiles and a long reduction (the 6144 x 256 x (9 x 1024) encoder convolutions):
 //     every split stores its fp32 partial tile with plain 16-byte stores into its own slice of a workspace; fs2_splitk_reduce sums
 //     the slices and applies bias / ReLU / residual / cast (no float atomics: ~1.3 TB/s chip-wide against ~6 TB/s of plain stores).
-// Results are bit-identical to gemm_big.hip and to the 128-tile kernel of gemm.hip (same MFMA, same k order per accumulator).
+// Results are bit-identical to the 128-tile kernel of gemm.hip (same MFMA, same k order per accumulator).
 #pragma once
 #include "fs2_common.h"
 #include <stdlib.h>

@@ -379,7 +379,7 @@ def fp8_quantize_shadows(shadows):
 
 def _fp8_eligible(g, M, N, K_total_row, x, w, residual=None, relu_mask=None, stats=False):
     """products the fp8 mode takes: bf16 operands, contiguous rows with K a multiple of 16, N a multiple of 8, enough rows for
-    the 16-wave kernel to make sense, and an epilogue combination that kernel is compiled for (gemm_big.hip epi_compiled)"""
+    the 16-wave kernel to make sense, and an epilogue combination that kernel is compiled for (gemm_ring.hip epi_compiled)"""
     if not (FP8_MODE["on"] and g.dtype == BF16 and M >= 1024 and N % 8 == 0 and g.K % 16 == 0 and x.stride(-1) == 1 and
             w.stride(-1) == 1 and x.stride(-2) == x.shape[-1] and w.stride(-2) == w.shape[-1]):
         return False
@@ -387,7 +387,7 @@ def _fp8_eligible(g, M, N, K_total_row, x, w, residual=None, relu_mask=None, sta
         return False
     if residual is not None and relu_mask is not None and residual.dtype != torch.float32:
         return False
-    # the refusals of fs2_gemm_ring_try / fs2_gemm_big_try themselves (the product must stay on bf16 operands then, not fail after its
+    # the refusals of fs2_gemm_ring_try itself (the product must stay on bf16 operands then, not fail after its
     # operands were quantised): 32-bit byte offsets over M + 512 rows of C / mask / residual / A and N + 512 rows of B, conv padding
     rows = M + 512
     if rows * N * 4 >= 0x7FFFFFF0 or rows * K_total_row >= 0x7FFFFFF0 or (N + 512) * max(1, g.taps if g.conv == 1 else 1) * K_total_row >= 0x7FFFFFF0:
