@@ -6,7 +6,8 @@ int fs2_gemm_ring_f8_launch(const FS2Gemm& g, int bm, bool f32, hipStream_t st);
 // false: not eligible / not chosen; true: the product was launched on the ring kernel and *rc holds the result.
 // Split-K form: g.split_k > 1 with g.accumulate == 2 -- C is an fp32 workspace of split_k slices, slice s (stride g.sC1 elements)
 // receives the partial sums of k-range s with plain stores; the caller finishes with fs2_splitk_reduce.
-bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc) {
+bool fs2_gemm_ring_try(const FS2Gemm& g0, hipStream_t st, int* rc) {
+    const FS2Gemm& g = g0;
     // FS2_GEMM_RING: 0 never, 1 (default) where the shape heuristic says so, 2 wherever eligible; FS2_GEMM_BIG_BM forces the row-slab
     // height (128 / 192 / 256).  Read per call so that tests and A/B measurements can switch inside one process.
     const char* e1 = getenv("FS2_GEMM_RING");
@@ -69,9 +70,14 @@ bool fs2_gemm_ring_try(const FS2Gemm& g, hipStream_t st, int* rc) {
         if (tiles < 128 || g.N < 192) return false;
     }
     g_last_tile = bm == 128 ? 130 : bm;       // (measurement aid: 130 / 192 / 256 = rows of the 16-wave row-major tile)
-    if (f8) { *rc = fs2_gemm_ring_f8_launch(g, bm, f32, st); return true; }
-    if (bm == 128) *rc = f32 ? launch_ring1<float, 32>(g, splits, st) : launch_ring1<bf16_t, 32>(g, splits, st);
-    else if (bm == 192) *rc = f32 ? launch_ring1<float, 48>(g, splits, st) : launch_ring1<bf16_t, 48>(g, splits, st);
-    else *rc = f32 ? launch_ring1<float, 64>(g, splits, st) : launch_ring1<bf16_t, 64>(g, splits, st);
+    FS2Gemm gd = g0;
+    {
+        const char* e3 = getenv("FS2_RING_DBG");      // timing-only: drop one buffer's traffic (the kernel's `dbg`); 0 in every product run
+        gd.tile_order = e3 ? atoi(e3) : 0;
+    }
+    if (f8) { *rc = fs2_gemm_ring_f8_launch(gd, bm, f32, st); return true; }
+    if (bm == 128) *rc = f32 ? launch_ring1<float, 32>(gd, splits, st) : launch_ring1<bf16_t, 32>(gd, splits, st);
+    else if (bm == 192) *rc = f32 ? launch_ring1<float, 48>(gd, splits, st) : launch_ring1<bf16_t, 48>(gd, splits, st);
+    else *rc = f32 ? launch_ring1<float, 64>(gd, splits, st) : launch_ring1<bf16_t, 64>(gd, splits, st);
     return true;
 }

@@ -124,9 +124,12 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     __syncthreads();        // (no LDS-DMA is in flight yet: the fence's vmcnt(0) costs nothing here)
 
     // conv: the descriptor base is moved back by `pad` rows so that the scalar slot offset (tap*lda + kb) is never negative
+    // (timing-only switches, FS2_RING_DBG -> p.tile_order: 1 = the output descriptor has zero records (stores dropped), 2 = the activation
+    //  descriptor, 4 = the weight descriptor (zeros staged): prices one buffer's traffic with the instruction stream unchanged; results wrong)
+    const int dbg = p.tile_order;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<const unsigned char*>(p.A) - (int64_t)pad * lda * ES), 0, 0x7FFFFFF0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFF0, 0x00020000);
+        (void*)(reinterpret_cast<const unsigned char*>(p.A) - (int64_t)pad * lda * ES), 0, (dbg & 2) ? 0 : 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (dbg & 4) ? 0 : 0x7FFFFFF0, 0x00020000);
 
     // ---- LDS-DMA source coordinates of this lane: piece i of this wave covers tile rows 8*(i*NW + wave) .. +7; the lane fetches
     //      logical chunk (lane&7) ^ f(row) of row lane>>3 of those (swizzle on the source side)
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
 
     const float alpha = ES == 1 ? p.alpha * (p.scale_a != nullptr ? *p.scale_a : 1.f) * (p.scale_b != nullptr ? *p.scale_b : 1.f) : p.alpha;
     const bool act_e5m2 = p.dtype == FS2_BF8_FP8;                   // (fp8 form) activations / gradients in e5m2, weights always e4m3
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (dbg & 1) ? 0 : 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)p.relu_mask, 0, p.relu_mask ? 0x7FFFFFF0 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, p.residual ? 0x7FFFFFF0 : 0, 0x00020000);
     // fp8 copy of C: speculative scale (the amax of this tensor one step ago), amax of the values as stored for the repair launch
