@@ -476,6 +476,10 @@ int fs2_adam_step_perm(float* p, const float* g, float* m, float* v, int64_t n, 
  * 4 x 64-bit words per workgroup) while it is set; NULL switches the stamps off.  Not used by the product. */
 void fs2_debug_attn_timer(unsigned long long* buf);
 
+/* nbytes (a multiple of 16) of zeros at ptr (16-byte aligned): optimizer.zero_grad() of the reference loops (train_fastspeech2.py:154,
+ * train.py:205) on the flat gradient arena, together with the small per-step accumulators kept behind it. */
+int fs2_zero(void* ptr, int64_t nbytes, void* stream);
+
 /* rng[1] += 1 (one step of the dropout stream). */
 int fs2_rng_advance(uint64_t* rng, void* stream);
 

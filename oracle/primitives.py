@@ -151,6 +151,10 @@ def view2d(x, M, d):
     return x.view(M, d)
 
 
+def zero(t):
+    return t.zero_()
+
+
 def wgrad_flush():
     """the sum of deferred weight-gradient partial tiles (ops.wgrad_flush): nothing is deferred here"""
 

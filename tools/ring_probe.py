@@ -42,3 +42,21 @@ for name, (fn, fl) in cases.items():
             line += f" | {label} {tw:6.1f}/{tc:6.1f} us" + (f" ({fl / tw / 1e6:4.0f}/{fl / tc / 1e6:4.0f} TF)" if dbg == 0 else "")
         print(line, flush=True)
 os.environ.pop("FS2_RING_DBG", None)
+
+# ---- K sweep at M = 44400, N = 256 on the 192-row tile: slope = time per 64-deep slot, intercept = fixed time of a launch
+if not only or "ksweep" in only:
+    os.environ["FS2_GEMM_BIG_BM"] = "192"
+    for K in (256, 512, 1024, 2048, 4096):
+        xa, wa = r(M, K), r(256, K)
+        fn = lambda: ops.linear(xa, wa, bias256)
+        line = f"ksweep 44400x256x{K:<5d} bm 192:"
+        for dbg, label in ((0, "all"), (7, "none")):
+            os.environ["FS2_RING_DBG"] = str(dbg)
+            tw, tc = timeit(fn, False, iters=20), timeit(fn, True)
+            line += f" | {label} {tw:6.1f}/{tc:6.1f} us"
+        print(line, flush=True)
+    # an empty kernel of the same launch geometry would be the floor of the intercept: event pair around a tiny product
+    xs, wsm = r(192 * 232, 64), r(256, 64)
+    os.environ["FS2_RING_DBG"] = "7"
+    print(f"one slot (K = 64), 232 tiles, no traffic: {timeit(lambda: ops.linear(xs, wsm, bias256), False, iters=20):6.1f} us", flush=True)
+    os.environ.pop("FS2_RING_DBG", None)

@@ -50,6 +50,23 @@ class Runtime:
         self._side = None
         self._side_dirty = False
         self._keep = []
+        self._zpool, self._zoff = None, 0
+
+    # ---- small zero-initialised fp32 accumulators of a step (loss terms, BatchNorm sums): slices of the tail FusedAdam keeps behind
+    #      the gradient arena and clears with the gradients (ONE fs2_zero launch per step); without that optimizer: torch.zeros
+    def zpool_reset(self, tail):
+        self._zpool, self._zoff = tail, 0
+
+    def zsmall(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        pool = self._zpool
+        if pool is not None and pool.device == device and self._zoff + n <= pool.numel():
+            v = pool[self._zoff:self._zoff + n].view(shape)
+            self._zoff += (n + 3) // 4 * 4
+            return v
+        return torch.zeros(shape, dtype=torch.float32, device=device)
 
     def get_rng(self, device):
         if self.rng is None:
@@ -219,6 +236,16 @@ class Runtime:
         elif not self_cleaning:
             buf.zero_()
         return buf
+
+
+def announce_list(owner, key, build):
+    """the parameter list a backward announces, built once per (module, key) and kept on the module: walking named_parameters() /
+    parameters() in every backward of every layer cost ~1 ms of host time per eager step"""
+    cache = owner.__dict__.setdefault("_fs2_announce", {})
+    lst = cache.get(key)
+    if lst is None:
+        lst = cache[key] = list(build())
+    return lst
 
 
 def fp8_bwd(fn):
@@ -477,7 +504,8 @@ class EncoderStackFunction(torch.autograd.Function):
             dh = ops.linear(dqkv2, wd, residual=dh_cat).view(B, t, d)
             # every gradient of this layer except norm_1's (produced by the next iteration) and the norm that follows the
             # layer (norm_1 of layer i+1 / the final norm) is enqueued: one contiguous arena range -> exchange it now
-            rt.announce([q_ for name, q_ in layer.named_parameters() if not name.startswith("norm_1.")] + list(nn_.parameters()))
+            rt.announce(announce_list(layer, id(nn_), lambda: [q_ for name, q_ in layer.named_parameters() if not name.startswith("norm_1.")]
+                                      + list(nn_.parameters())))
 
         n1 = enc.layers[0].norm_1
         dx0 = ops.layernorm_bwd(dh, sv["x0"], n1.weight.detach(), sv["mean0"], sv["rstd0"], grad_of(n1.weight),
@@ -538,7 +566,7 @@ class VariancePredictorFunction(torch.autograd.Function):
                                 grad_of(l1.bias), p, rng, mod.site1, relu_mask=True, dcolsum=grad_of(mod.conv1.bias))
         _conv_wgrad(rt, dz1, s["x"], mod.conv1, 1, bias_done=True)
         dx = ops.conv(dz1, rt.w_dgrad(mod.conv1.weight), 3, 1)
-        rt.announce(mod.parameters())
+        rt.announce(announce_list(mod, "all", mod.parameters))
         rt.side_join()
         return (None, dx, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 
@@ -615,7 +643,7 @@ class PostNetFunction(torch.autograd.Function):
         inputs, cs, stats = [], [], []
         h = mel_T
         Cmax = max(cv.weight.shape[0] for cv in convs)
-        sums_all = torch.zeros((len(convs), 2 * Cmax + 4), dtype=torch.float32, device=x.device) if mod.training else None   # one memset
+        sums_all = rt.zsmall((len(convs), 2 * Cmax + 4), x.device) if mod.training else None   # (cleared with the gradients)
         for li, (cv, bn) in enumerate(zip(convs, bns)):
             C = cv.weight.shape[0]
             if not mod.training:        # eval(): BatchNorm1d normalises with its running statistics (postnets.py:58-59)
@@ -661,7 +689,7 @@ class PostNetFunction(torch.autograd.Function):
             dpost_T = dpost if T == torch.float32 else ops.cast(dpost, T)
             _conv_wgrad(rt, dpost_T, s["h_last"], mod.conv2, 4)
             dh = ops.conv(dpost_T, rt.w_dgrad(mod.conv2.weight), 5, 0)
-            red_all = torch.zeros((4, 2 * max(cv.weight.shape[0] for cv in convs[:4])), dtype=torch.float32, device=x.device)   # one memset
+            red_all = rt.zsmall((4, 2 * max(cv.weight.shape[0] for cv in convs[:4])), x.device)   # (cleared with the gradients)
             for li in reversed(range(4)):
                 cv, bn = convs[li], bns[li]
                 C = cv.weight.shape[0]
@@ -696,7 +724,7 @@ class PostNetFunction(torch.autograd.Function):
             term_T = (term if T == torch.float32 else ops.cast(term, T)).view(M, -1)
             _linear_wgrad(rt, term_T, x2, mod.out)
             dx = ops.linear(term_T, rt.w_dgrad(mod.out.weight), residual=dx)
-        rt.announce(mod.parameters())
+        rt.announce(announce_list(mod, "all", mod.parameters))
         rt.side_join()
         return (None, None if dx is None else dx.view(B, t, d)) + (None,) * (len(ctx.needs_input_grad) - 2)
 

@@ -8,7 +8,7 @@ import math
 import torch
 
 from .. import ops
-from .functional import _conv_wgrad, _linear_wgrad, _tp, fp8_bwd, grad_of
+from .functional import _conv_wgrad, _linear_wgrad, _tp, announce_list, fp8_bwd, grad_of
 
 
 def _heads(x2, B, t, n, H, dk):
@@ -239,7 +239,8 @@ class DecoderStackFunction(torch.autograd.Function):
                 ops.wgrad_batched(dqkv, Lr["h"].view(M, d), [grad_of(lin.weight) for lin in (at1.q_linear, at1.v_linear, at1.k_linear)], defer=rt.defer_wgrad)
             _, wd1, _ = rt.qkv(at1)
             dh = ops.linear(dqkv, wd1).view(B, t, d)
-            rt.announce([q_ for name, q_ in layer.named_parameters() if not name.startswith("norm_1.")] + list(nn_.parameters()))
+            rt.announce(announce_list(layer, id(nn_), lambda: [q_ for name, q_ in layer.named_parameters() if not name.startswith("norm_1.")]
+                                      + list(nn_.parameters())))
 
         n1 = dec.layers[0].norm_1
         dx0 = ops.layernorm_bwd(dh, sv["x_pe"], n1.weight.detach(), sv["mean0"], sv["rstd0"], grad_of(n1.weight),
@@ -296,13 +297,13 @@ class LinearFunction(torch.autograd.Function):
                 dxn = ops.linear1_bwd(dy3[:, :, n].contiguous(), x2.view(B, t, K), mod.weight.detach()[n].contiguous(), ctx.ones,
                                       gw[n], gb[n:n + 1])
                 dx = dxn if dx is None else dx.add_(dxn)        # (reduction_rate > 1 only)
-            rt.announce(mod.parameters())
+            rt.announce(announce_list(mod, "all", mod.parameters))
             return (None, None, dx.view(B, t, K), None) + (None,) * len(list(mod.parameters()))
         dy2 = dy.reshape(B * t, N).contiguous()
         dy2 = dy2 if dy2.dtype == T else ops.cast(dy2, T)
         _linear_wgrad(rt, dy2, x2, mod)
         dx = ops.linear(dy2, rt.w_dgrad(mod.weight))
-        rt.announce(mod.parameters())
+        rt.announce(announce_list(mod, "all", mod.parameters))
         rt.side_join()
         return (None, None, dx.view(B, t, K), None) + (None,) * len(list(mod.parameters()))
 

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     // conv: the descriptor base is moved back by `pad` rows so that the scalar slot offset (tap*lda + kb) is never negative
     // (timing-only switches, FS2_RING_DBG -> p.tile_order: 1 = the output descriptor has zero records (stores dropped), 2 = the activation
     //  descriptor, 4 = the weight descriptor (zeros staged): prices one buffer's traffic with the instruction stream unchanged; results wrong)
-    const int dbg = p.tile_order;
+    const int dbg = ES == 2 ? p.tile_order : 0;        // (bf16 instances only: the fp8 192-row instances have no register to spare)
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const unsigned char*>(p.A) - (int64_t)pad * lda * ES), 0, (dbg & 2) ? 0 : 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (dbg & 4) ? 0 : 0x7FFFFFF0, 0x00020000);

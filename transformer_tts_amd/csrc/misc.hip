@@ -953,6 +953,20 @@ extern "C" int fs2_adam_step(float* p, const float* g, float* m, float* v, int64
                              float beta1, float beta2, float eps, float max_norm, void* stream) {
     return fs2_adam_step_perm(p, g, m, v, n, hyper, gsq, beta1, beta2, eps, max_norm, nullptr, 0, stream);
 }
+// n16 16-byte words of zeros (the per-step clear of the gradient arena and of the small accumulators that live behind it)
+__global__ __launch_bounds__(256) void zero_k(float4* __restrict__ p, int64_t n16) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = z;
+}
+extern "C" int fs2_zero(void* ptr, int64_t nbytes, void* stream) {
+    FS2_REQUIRE(ptr != nullptr && nbytes >= 0 && fs2_aligned16(ptr) && nbytes % 16 == 0, "fs2_zero: 16-byte aligned pointer and size required");
+    if (nbytes == 0) return FS2_OK;
+    const int64_t n16 = nbytes / 16;
+    const int64_t want = (n16 + 255) / 256;
+    hipLaunchKernelGGL(zero_k, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, (hipStream_t)stream, (float4*)ptr, n16);
+    FS2_CHECK_LAUNCH("fs2_zero");
+    return FS2_OK;
+}
 extern "C" int fs2_rng_advance(uint64_t* rng, void* stream) {
     hipLaunchKernelGGL(rng_advance_k, dim3(1), dim3(1), 0, (hipStream_t)stream, rng);
     FS2_CHECK_LAUNCH("fs2_rng_advance");

@@ -144,6 +144,7 @@ SIGNATURES = {
     "fs2_adam_step": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P],
     "fs2_adam_step_perm": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P, _I, _P],
     "fs2_rng_advance": [_P, _P],
+    "fs2_zero": [_P, _L, _P],
     "fs2_debug_attn_timer": [_P],      # diagnostics (returns void)
 }
 
@@ -189,7 +190,14 @@ def _p(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    # (the raw handle of the current stream without building a torch.cuda.Stream object: ~1.5 us less per launch on the eager path)
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -844,6 +852,12 @@ def cast(src, dtype, out=None):
         out = torch.empty(src.shape, dtype=dtype, device=src.device)
     _check(lib().fs2_cast(_p(_c(src)), _dt(src), _p(_c(out)), _dt(out), src.numel(), _stream()), "fs2_cast")
     return out
+
+
+def zero(t):
+    """t (contiguous, 16-byte aligned, a multiple of 16 bytes) = 0"""
+    _check(lib().fs2_zero(_p(_c(t)), t.numel() * t.element_size(), _stream()), "fs2_zero")
+    return t
 
 
 def cast_permute_batched(table_dev, n, dtype):

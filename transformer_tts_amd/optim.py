@@ -14,6 +14,7 @@ from . import ops
 
 class ParamArena:
     ALIGN = 4   # elements: keeps every parameter 16-byte aligned for float4 loads
+    ZTAIL = 16384
 
     def __init__(self, params, kernel_layout_grads=True):
         self.params = [p for p in params if p.requires_grad]
@@ -26,7 +27,11 @@ class ParamArena:
             off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.numel = off
         self.p = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.g = torch.zeros(off, dtype=torch.float32, device=dev)
+        # the gradient arena and, behind it, ZTAIL floats for the small zero-initialised accumulators of a step (loss terms, BatchNorm
+        # sums, the gradient norm): optimizer.zero_grad() clears both with ONE launch (fs2_zero) instead of one fill per buffer
+        self._gfull = torch.zeros(off + self.ZTAIL, dtype=torch.float32, device=dev)
+        self.g = self._gfull[:off]
+        self.ztail = self._gfull[off:]
         segs = []
         for p, o in zip(self.params, self.offsets):
             view = self.p[o:o + p.numel()].view_as(p)
@@ -73,7 +78,8 @@ class FusedAdam:
         dev = self.arena.p.device
         self.m = torch.zeros_like(self.arena.p)
         self.v = torch.zeros_like(self.arena.p)
-        self.gsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gsq = self.arena.ztail[:1]            # (cleared by zero_grad with the gradients; launch() clears it itself if called twice)
+        self._gsq_clean = False
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
         self.t = 0
         self.param_groups = [dict(params=self.arena.params, lr=lr, betas=betas, eps=eps)]
@@ -85,7 +91,10 @@ class FusedAdam:
         # into the gradients of this step (after a complete step nothing is queued and this is a no-op)
         if hasattr(ops, "wgrad_reset"):
             ops.wgrad_reset()
-        self.arena.g.zero_()
+        ops.zero(self.arena._gfull)             # gradients + the step's small accumulators (Runtime.zsmall) in one launch
+        self._gsq_clean = True
+        if self.runtime is not None:
+            self.runtime.zpool_reset(self.arena.ztail[4:])
         for p in self.arena.params:     # re-attach if a caller dropped the views
             if p.grad is None:
                 p.grad = p._fs2_grad
@@ -108,7 +117,9 @@ class FusedAdam:
         if self.dp is not None:
             self.dp.finish()
         b1, b2 = self.betas
-        self.gsq.zero_()
+        if not self._gsq_clean:
+            self.gsq.zero_()
+        self._gsq_clean = False
         ops.sqnorm(self.arena.g, self.gsq)
         ops.adam_step(self.arena.p, self.arena.g, self.m, self.v, self.hyper, self.gsq, b1, b2, self.eps,
                       self.max_norm if self.max_norm is not None else 0.0, perm=self.arena.perm)
