@@ -115,13 +115,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     float* cacc = reinterpret_cast<float*>(smem + stats_off);
     const float* biasl = reinterpret_cast<const float*>(smem + bias_off);
     const int ncols = tilesN * BN;
-    if constexpr (STATS) {
-        for (int n = tid; n < (SUMSQ ? 2 : 1) * ncols; n += NT) cacc[n] = 0.f;
-    }
     const bool has_bias = p.bias != nullptr;                    // without a bias the LDS area is 16 zero floats, read by every lane
-    for (int n = tid; n < (has_bias ? ncols : 16); n += NT)
-        reinterpret_cast<float*>(smem + bias_off)[n] = (has_bias && n < p.N) ? p.bias[n] : 0.f;
-    __syncthreads();        // (no LDS-DMA is in flight yet: the fence's vmcnt(0) costs nothing here)
 
     // conv: the descriptor base is moved back by `pad` rows so that the scalar slot offset (tap*lda + kb) is never negative
     // (timing-only switches, FS2_RING_DBG -> p.tile_order: 1 = the output descriptor has zero records (stores dropped), 2 = the activation
@@ -405,6 +399,14 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     prep_item(lj);
     const int ahead = S - 1 < nst ? S - 1 : nst;
     for (int i = 0; i < ahead; ++i) issue();
+    // bias and statistics accumulators go to LDS BEHIND the first slots' requests: the bias fetch overlaps the DMA round trip instead of
+    // preceding it (one memory latency per launch, not two); their first reader is an epilogue, i.e. behind the first slot barrier, which
+    // every thread reaches with its own LDS writes retired (lgkmcnt(0))
+    if constexpr (STATS) {
+        for (int n = tid; n < (SUMSQ ? 2 : 1) * ncols; n += NT) cacc[n] = 0.f;
+    }
+    for (int n = tid; n < (has_bias ? ncols : 16); n += NT)
+        reinterpret_cast<float*>(smem + bias_off)[n] = (has_bias && n < p.N) ? p.bias[n] : 0.f;
 
     // Stores issued by the last epilogue count towards vmcnt like the LDS-DMA pieces; `since_epi` iterations ago this wave issued
     // NSTORES of them.  They are younger than the piece awaited at iteration t when the epilogue ran in iterations t-W .. t-1, with
