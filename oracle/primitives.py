@@ -155,6 +155,10 @@ def zero(t):
     return t.zero_()
 
 
+def wgrad_launch():
+    pass
+
+
 def wgrad_flush():
     """the sum of deferred weight-gradient partial tiles (ops.wgrad_flush): nothing is deferred here"""
 

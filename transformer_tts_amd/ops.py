@@ -713,6 +713,12 @@ def wgrad_flush():
     _WG.flush()
 
 
+def wgrad_launch():
+    """launch the queued weight-gradient products now (their operands may be freed afterwards) but leave the partial tiles in the
+    workspace: the reduce into the gradients waits for wgrad_flush()"""
+    _WG._launch_pending()
+
+
 def wgrad_reset():
     """drop whatever a failed step left queued (called at the start of every step, before zero_grad)"""
     _WG.reset()
