@@ -341,6 +341,8 @@ def test_inference_branch_vs_reference_golden(name):
                 got = out[i].float().cpu().numpy()
                 assert got.shape == ref.shape, (k, got.shape, ref.shape)
                 l1 = float(np.abs(got - ref).mean())
+                if amp and k in ("mel_before", "mel_after"):
+                    record_measure(f"bf16.infer_{name}.utt{b}.{k}.mean_abs_err", l1)
                 assert l1 <= (MEL_L1_TOL_BF16 if amp else MEL_L1_TOL_FP32), f"amp={amp} utt {b} {k}: mean |diff| {l1:.3e}"
         assert int(model.postnet.pre_batchnorm.num_batches_tracked) == 0
 
@@ -364,6 +366,7 @@ def test_inference_batch_of_utterances_bf16():
             if T != int(lens[b]):
                 continue        # bf16 noise moved a duration across a .5 boundary between the two batch shapes
             diff = (full[1][b, :T].float() - one[1][0].float()).abs().mean()
+            record_measure(f"bf16.infer_batched_vs_single.utt{b}.mel_after.mean_abs_diff", float(diff))
             assert float(diff) < MEL_L1_TOL_BF16, (b, float(diff))
 
 
@@ -399,6 +402,8 @@ def test_d_model_512_config_vs_oracle(heads):
         ototal, _, oout = otrain.forward_backward(omodel, batch)
         for n, a, b in zip(OUT_NAMES[:2], out[:2], oout[:2]):
             l1 = float((a.detach().float().cpu() - b.detach()).abs().mean())
+            if amp:
+                record_measure(f"bf16.flash_vs_oracle.{n}.mean_abs_err", l1)
             assert l1 <= (MEL_L1_TOL_BF16 if amp else MEL_L1_TOL_FP32), f"amp={amp} {n}: mean |diff| {l1:.3e}"
         assert abs(total.item() - ototal.item()) <= (2e-2 if amp else 5e-5) * abs(ototal.item())
         og = dict(omodel.named_parameters())

@@ -68,6 +68,7 @@ class FusedAdam:
     ``param_groups[i]['lr']`` (set every step by the Noam schedule), ``zero_grad()``, ``step()``,
     ``state_dict()`` / ``load_state_dict()`` in torch.optim.Adam's format (``state[0]['step']`` is what
     the reference reads on resume, train_fastspeech2.py:444)."""
+    HYPER_RING = 16
 
     def __init__(self, model_or_params, lr=1e-3, betas=(0.9, 0.98), eps=1e-9, max_norm=1.0, runtime=None, dp=None):
         params = list(model_or_params.parameters()) if hasattr(model_or_params, "parameters") else list(model_or_params)
@@ -81,6 +82,7 @@ class FusedAdam:
         self.gsq = self.arena.ztail[:1]            # (cleared by zero_grad with the gradients; launch() clears it itself if called twice)
         self._gsq_clean = False
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hyper_pin, self._hyper_ev = None, None
         self.t = 0
         self.param_groups = [dict(params=self.arena.params, lr=lr, betas=betas, eps=eps)]
         if self.runtime is not None:
@@ -110,7 +112,26 @@ class FusedAdam:
         world = self.dp.world if self.dp is not None else 1
         lr = float(self.param_groups[0]["lr"])
         b1, b2 = self.betas
-        self.hyper.copy_(torch.tensor([lr, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, 1.0 / world], dtype=torch.float32))
+        vals = [lr, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t, 1.0 / world]
+        if not self.hyper.is_cuda:
+            self.hyper.copy_(torch.tensor(vals, dtype=torch.float32))
+            return
+        # Asynchronous, from a small ring of PINNED staging rows: a copy from pageable host memory returns only when the stream has
+        # executed it, i.e. it made the training thread wait for the whole previous step at the start of every step -- the GPU then idled
+        # while the host caught up (eager steps: 9.2 ms against 7.6 ms of device work; graph replays: the gap between two replays).
+        # A row is rewritten only after the copy that read it last has completed (its event).
+        if self._hyper_pin is None:
+            self._hyper_pin = torch.empty((self.HYPER_RING, 4), dtype=torch.float32).pin_memory()
+            self._hyper_ev = [None] * self.HYPER_RING
+        i = self.t % self.HYPER_RING
+        if self._hyper_ev[i] is not None:
+            self._hyper_ev[i].synchronize()
+        row = self._hyper_pin[i]
+        row[0], row[1], row[2], row[3] = vals
+        self.hyper.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_ev[i] = ev
 
     def launch(self):
         """device half of a step (graph-capturable): finish the gradient exchange, global norm, clip + Adam"""
