@@ -440,6 +440,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32", action="store_true", help="exact-fp32 parity mode instead of bf16 (not the headline)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--no-gemm-timer", action="store_true",
+                    help="with --no-graph: time the eager steps WITHOUT the event pair around every GEMM (the speed a never-repeating batch "
+                         "shape trains at; no roofline block)")
     ap.add_argument("--gemm-report", type=str, default=None, help="write per-shape GEMM timings to this file")
     ap.add_argument("--no-overlap", action="store_true", help="(default) keep the weight-gradient GEMMs on the main stream")
     ap.add_argument("--overlap", action="store_true", help="run the weight-gradient GEMMs on a second stream (measured slower: DESIGN.md)")
@@ -518,7 +521,7 @@ def main():
         run(step, pool[i % POOL])
         step += 1
     timer = GemmTimer()
-    if not use_graph:
+    if not use_graph and not args.no_gemm_timer:
         timer.install()
     if world > 1:
         dist.barrier()
@@ -577,7 +580,8 @@ def main():
             train_step(model, opt, step, pool[i % POOL], hp)
             step += 1
         torch.cuda.synchronize()
-    timer.remove()
+    if use_graph or not args.no_gemm_timer:
+        timer.remove()
     attn_true_ms = None
     if world == 1 and not force_dp and args.workload == "cfg2" and use_graph and not args.return_attn and not args.fp32 and not args.from_host:
         # the drop-in DEFAULT, hp.return_attn = True (the 14-tuple's attention maps, reference Models/encoder.py:97,105), timed behind the

@@ -3,9 +3,9 @@
 Exact-fp32 mode (hp.amp=False; f32-input MFMA) is the parity mode of BASELINE.json's north star:
 mel L1 distance to the reference forward <= 1e-4 (measured here against golden vectors produced by the
 imported reference, tests/golden/*.npz) -- the tolerance is written in the asserts below.  bf16 mode
-(hp.amp=True) is the throughput mode; its stated tolerance is mean |mel - ref| <= 3e-2 (the reference's
-own CPU bf16 autocast is 2e-3..7e-3 off its fp64 forward; here additionally the
-residual-free activations, attention probabilities and their gradients are stored in bf16)."""
+(hp.amp=True) is the throughput mode; its stated tolerance is mean |mel - ref| <= 1.6e-2 = twice the largest
+measured value (the reference's own CPU bf16 autocast is 2e-3..7e-3 off its fp64 forward; here
+additionally the residual-free activations, attention probabilities and their gradients are stored in bf16)."""
 import numpy as np
 import pytest
 import torch
@@ -15,7 +15,10 @@ from helpers import CONFIGS, batch_to, check_digest, is_null_gradient_param, ora
 pytestmark = pytest.mark.gpu
 OUT_NAMES = ["mel_before", "mel_after", "log_d", "p_pred", "e_pred", "va_out", "text_dur", "attn_enc", "attn_dec"]
 MEL_L1_TOL_FP32 = 1e-4     # north star: "mel L1 within 1e-4 of reference"
-MEL_L1_TOL_BF16 = 3e-2
+# bf16 mode: 2 x the largest error measured on the MI355X over every fixture (mel_before 3.5e-3 .. 4.7e-3, mel_after 3.2e-3 .. 8.0e-3 mean
+# |mel - reference|: tiny, small, the option fixtures, the inference fixtures, the configs[1] digests; gpurun_out/measured.jsonl of round
+# 4, recorded by record_measure below) -- the reference's own CPU bf16 autocast sits at 2.1e-3 / 7.1e-3 against its fp64 forward
+MEL_L1_TOL_BF16 = 1.6e-2
 OPTIONS = ["opt_concat", "opt_nopitch", "opt_noenergy", "opt_ss1", "opt_ss_half"]      # golden_configs.OPTION_CONFIGS
 
 
@@ -158,7 +161,7 @@ def test_benchmark_config_fp32_anchors():
 @pytest.mark.parametrize("return_attn", [True, False])
 def test_benchmark_config_bf16_within_stated_tolerance(return_attn):
     """The TIMED configuration (BASELINE.json configs[1] at full size, hp.amp=True: bf16 MFMA, LDS-strip / flash attention,
-    split-K forward, XCD-aware tile walk) against the reference's digests.  Stated bf16 tolerance: mean |mel - ref| <= 3e-2
+    split-K forward, XCD-aware tile walk) against the reference's digests.  Stated bf16 tolerance: mean |mel - ref| <= 1.6e-2
     (here over the digest's 64 evenly spaced samples and through the l2 norms), losses within 2 %, gradient norm within
     2 %, per-tensor gradient norms within 10 % for every sizeable non-null-gradient tensor."""
     model, hp, g = product_model("bench", amp=True, device="cuda", return_attn=return_attn)
@@ -367,7 +370,7 @@ def test_inference_batch_of_utterances_bf16():
                 continue        # bf16 noise moved a duration across a .5 boundary between the two batch shapes
             diff = (full[1][b, :T].float() - one[1][0].float()).abs().mean()
             record_measure(f"bf16.infer_batched_vs_single.utt{b}.mel_after.mean_abs_diff", float(diff))
-            assert float(diff) < MEL_L1_TOL_BF16, (b, float(diff))
+            assert float(diff) < 2 * MEL_L1_TOL_BF16, (b, float(diff))      # (two bf16 results against each other: measured 1.7e-2)
 
 
 @pytest.mark.parametrize("heads", [2, 4])
@@ -421,9 +424,12 @@ def test_d_model_512_config_vs_oracle(heads):
 
 # fp8 operand mode (BASELINE.json configs[4]): e4m3 activations / weights, e5m2 gradients, per-tensor power-of-two scaling.
 # e4m3 carries 3 mantissa bits (relative step 2^-4 .. 2^-3 per operand element, errors average out over K >= 256 products):
-MEL_L1_TOL_FP8 = 8e-2          # mean |mel - oracle| with every eligible forward product in fp8 (bf16 mode: 3e-2)
-GRAD_REL_TOL_FP8 = 0.25        # relative L2 error of the whole parameter gradient (bf16 mode: 6e-2)
-GRAD_REL_TOL_BF16 = 8e-2
+# fp8 operand mode, 6+6 layers / d_model 512 against the fp32 oracle: 2 x the measured values (round 4, MI355X: mel 2.27e-2, whole-gradient
+# relative L2 error 3.2e-2, loss 1.2e-5 relative; bf16 mode on the same model: 1.8e-3, 7.4e-3, 2e-7)
+MEL_L1_TOL_FP8 = 5e-2          # mean |mel - oracle| with every eligible forward product in fp8
+GRAD_REL_TOL_FP8 = 7e-2        # relative L2 error of the whole parameter gradient
+GRAD_REL_TOL_BF16 = 1.5e-2
+LOSS_REL_TOL_FP8 = 1e-3
 
 
 def _config4_hp(layers, batch, fp8, amp=True):
@@ -477,7 +483,7 @@ def test_config4_model_fp8_vs_oracle():
         record_measure(f"{mode}.config4_6+6.grad_rel_l2_err", r[2])
     assert res[False][0] <= MEL_L1_TOL_BF16 and res[False][2] < GRAD_REL_TOL_BF16, res[False][:3]
     assert res[True][0] <= MEL_L1_TOL_FP8, f"fp8 mel L1 {res[True][0]:.3e}"
-    assert res[True][1] <= 5e-2, f"fp8 loss error {res[True][1]:.3e}"
+    assert res[True][1] <= LOSS_REL_TOL_FP8, f"fp8 loss error {res[True][1]:.3e}"
     assert res[True][2] <= GRAD_REL_TOL_FP8, f"fp8 gradient error {res[True][2]:.3e}"
     assert float((res[True][3] - res[False][3]).abs().mean()) > 1e-4, "fp8 mode produced the bf16 result: it did not run"
 

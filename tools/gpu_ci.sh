@@ -33,6 +33,7 @@ for step in "$@"; do
              run bench4_fp8 500 python bench.py --workload cfg4 --fp8 --steps 24 --warmup 16 --no-cpu-baseline ;;
     benchq)  run benchq 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report.txt ;;
     benche)  run benche 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-graph ;;
+    benchee) run benchee 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-graph --no-gemm-timer ;;
     prof)    cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
              run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap ;;
     ncclgraph) run ncclgraph 200 python tools/exp_nccl_graph.py ;;
