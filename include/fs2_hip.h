@@ -348,6 +348,11 @@ typedef struct FS2FlashAttn {
 } FS2FlashAttn;
 int fs2_flash_attention_fwd(const FS2FlashAttn* d, void* stream);
 int fs2_flash_attention_bwd(const FS2FlashAttn* d, void* stream);
+/* The attention maps the reference returns (Models/modules.py:19-21: the probabilities AFTER dropout; Models/encoder.py:97,105 stacks them per
+ * layer) written after the fact from q, k, stats and keep_bits of a finished fs2_flash_attention_fwd call with the same descriptor (set
+ * `pregenerated`: no rng is read): probs[b * probs_batch_stride + (h * tq + i) * tkp + j] (bf16), keys in [tk, tkp) and every key the forward
+ * skipped as exactly-zero written as 0.  The layer's arithmetic (forward and backward) never reads them. */
+int fs2_flash_attention_probs(const FS2FlashAttn* d, void* probs, int64_t probs_batch_stride, void* stream);
 int64_t fs2_flash_attn_keep_words_rect(int B, int H, int tq, int tk);
 /* The round-2 entry points below are the self-attention, d_k = 128 case of the two calls above (q, k, v rows of one fused projection
  * tensor: common strides; tq = tk = t).                                                                                           */

@@ -547,6 +547,22 @@ def test_flash_attention_fwd_bwd(ops, p, t, H):
     # keeps them in fp32: compare against the scale of the output
     err = float((O.float().cpu() - O_ref.float()).abs().max() / O_ref.float().abs().amax().clamp_min(1e-2))
     assert err < 3e-2, ("O", t, err)
+    # the attention map written after the fact (fs2_flash_attention_probs): the post-dropout probabilities of the strip path, the SAME
+    # dropped positions, zeros in the pad columns [t, tp) and beyond every row's last visible key
+    maps = torch.full((B, NL, H, t, tp), float("nan"), dtype=dtype, device="cuda")
+    ops.flash_attention_probs(q, k, v, km.cuda(), O.permute(0, 2, 1, 3), stats, keep, maps[:, 1], dk ** -0.5, p, key_info=kinfo)
+    got, want = maps[:, 1].float().cpu(), Pd_ref.float()
+    assert torch.isnan(maps[:, 0]).all() and not torch.isnan(got).any()
+    assert float(got[..., t:].abs().max() if tp > t else 0.0) == 0.0
+    for b, n in enumerate(lens):
+        assert float(got[b, :, :, n:].abs().max() if n < tp else 0.0) <= 1e-30, ("masked keys", b)
+    assert float((got - want).abs().max()) < 3e-2 * float(want.max()), ("map", t, float((got - want).abs().max()), float(want.max()))
+    if p > 0:
+        vis = torch.zeros(B, 1, 1, tp, dtype=torch.bool)
+        for b, n in enumerate(lens):
+            vis[b, ..., :n] = True
+        big = vis & (P_ref.float() > 1e-3)        # (pre-dropout probability well away from underflow: a zero there is a dropped position)
+        assert bool(((got == 0) == (want == 0))[big.expand_as(want)].all()), "the map's dropped positions differ from the strip path's"
     close(O.float().cpu().mean(), O_ref.float().mean(), "mean of O", rtol=2e-2, atol=2e-3)
     # statistics: the row maximum of the masked scaled scores and the sum of exponentials
     s = torch.einsum("bthd,bshd->bhts", qkv[:, :, 0].float(), qkv[:, :, 2].float()) * dk ** -0.5

@@ -365,9 +365,14 @@ class EncoderStackFunction(torch.autograd.Function):
 
         # hp.return_attn = False: the maps are not wanted -> flash kernels, no (t x t) tensor in HBM; the Philox counters are
         # those of the (B,N,H,t,tp) layout either way, so both modes draw the same dropout masks
-        flash = (not rt.return_attn) and ops.flash_attn_supported(t, dk, T)
+        # hp.return_attn = True (the reference's 14-tuple): the same flash kernels do the layer's arithmetic and the post-dropout map of
+        # each layer is written after the fact from q, k, the row statistics and the stashed keep-bits (fs2_flash_attention_probs: half a
+        # forward's matrix work + one pass of stores) instead of routing forward AND backward through (t x t) tensors in HBM.
+        # FS2_FLASH_MAPS=0: the LDS-strip kernels with the probabilities in HBM, as in rounds 1-3 (A/B measurements).
+        flash = ops.flash_attn_supported(t, dk, T) and (not rt.return_attn or os.environ.get("FS2_FLASH_MAPS", "1") != "0")
         if flash:
-            attn = attn_drop = None
+            attn = None
+            attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if rt.return_attn else None
             stats = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
             # dropout keep-bits, one bit per probability (the only (t x t)-sized state of this mode: t*t/8 bytes per head)
             keep = torch.empty((N, ops.flash_attn_keep_words(B, H, t)), dtype=torch.int16, device=dev) if p_att > 0 else None
@@ -398,6 +403,9 @@ class EncoderStackFunction(torch.autograd.Function):
                     rt.side_join()
                 ops.flash_attn_fwd(q, k, v, km, O4, stats[i], keep[i] if keep is not None else None, t, scale, N * H * t * tp, p_att,
                                    rng, layer.site_attn, pregenerated=pregen and i >= 1, key_info=kinfo)
+                if attn_drop is not None:               # the map of this layer for the return value (modules.py:19-21, encoder.py:97,105)
+                    ops.flash_attention_probs(q, k, v, km, O4, stats[i], keep[i] if keep is not None else None, attn_drop[:, i], scale,
+                                              p_att, key_info=kinfo)
             elif ops.attn_probs_supported(t, dk, T):    # scores stay in LDS (one kernel)
                 S, Pd = attn[:, i], attn_drop[:, i]
                 pv = ops.attn_second_product_supported(dk)
@@ -432,11 +440,12 @@ class EncoderStackFunction(torch.autograd.Function):
             layers.append(L)
             x, h = x2, hn
 
-        ctx.enc, ctx.sv, ctx.layers, ctx.attn, ctx.attn_drop = enc, sv, layers, attn, attn_drop
+        ctx.enc, ctx.sv, ctx.layers = enc, sv, layers
+        ctx.attn, ctx.attn_drop = (None, None) if flash else (attn, attn_drop)      # (flash: the backward recomputes, the maps are only returned)
         ctx.src, ctx.km = src, km
         ctx.flash, ctx.stats, ctx.keep, ctx.kinfo = flash, (stats if flash else None), (keep if flash else None), (kinfo if flash else None)
         ctx.set_materialize_grads(False)
-        attn_out = attn_drop[..., :t] if not flash else torch.empty(0, dtype=T, device=dev)
+        attn_out = attn_drop[..., :t] if attn_drop is not None else torch.empty(0, dtype=T, device=dev)
         ctx.mark_non_differentiable(attn_out)
         return h, attn_out
 

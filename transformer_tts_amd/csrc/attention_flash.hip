@@ -475,6 +475,91 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ attention maps after the fact
+// The (tq x tkp) maps the reference returns (dropout(softmax(mask(alpha Q K^T))), Models/modules.py:19-21) WITHOUT routing the arithmetic of
+// the layer through them: the forward / backward kernels above run as in the map-free mode and this kernel writes the map of one layer
+// from Q, K, the row statistics {m, l} and the stashed keep-bits of the forward.  Half of a forward's matrix work (no P V product), one
+// pass of stores.  P[b][h][q][key] at pm + b*pm_batch + (h*tq + q)*tp + key, bf16; keys in [tk, tkp) and every tile the forward skipped
+// (beyond the last unmasked key, or after the block's queries in a causal launch: probability exactly 0) are written as zeros.
+// LDS: K images [2][TILE] at 0, key mask, two reduction words.
+template <bool DROP, int DK>
+__global__ __launch_bounds__(512, 4) void flash_probs_k(const FlashArgs a, bf16_t* __restrict__ pm, const int64_t pm_batch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int KS = DK / 32;
+    int blk, h, b;
+    if (!flash_item(a, a.tq, blk, h, b)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, i16 = lane & 15;
+    const int t = a.t, tq = a.tq, tp = a.tp;
+    const int qrow = blk * 128 + wave * 16 + i16;
+    unsigned char* kimg = smem;                       // [2][TILE]
+    unsigned char* lmask = smem + 2 * TILE;
+    int* red = reinterpret_cast<int*>(smem + 2 * TILE + a.mb);
+    const FragAddr fa = frag_addr(lane, (unsigned)(uintptr_t)(lds_void_t*)smem);
+    const int64_t hbq = (int64_t)b * a.batch + (int64_t)h * a.head, hbk = (int64_t)b * a.kvbatch + (int64_t)h * a.head;
+    const int rowst = (int)a.row, kvrow = (int)a.kvrow;
+    const __amdgpu_buffer_rsrc_t rs_q = make_rsrc(a.q + hbq), rs_k = make_rsrc_rows<DK>(a.k + hbk, t, kvrow);
+    const unsigned voff0 = stage_voff<DK>(kvrow, wave, lane);
+    stage_tile(rs_k, kimg, 0, kvrow, wave, voff0);
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = ld16(rs_q, qrow < tq ? (unsigned)((qrow * rowst + 32 * ks + 8 * g) * 2) : OOB);
+    int kfull, kmax;
+    mask_setup<512>(a, b, t, lmask, red, tid, kfull, kmax);
+    const int nkt = key_tiles(a, kfull, kmax, min(blk * 128 + 127, tq - 1));      // the tiles the forward visited
+    const int nkt_all = (tp + 63) >> 6;                                            // the tiles of the stored row
+    const int cq = a.causal ? qrow : NO_CAUSAL;
+    const bool qok = qrow < tq;
+    const float2 st = qok ? *reinterpret_cast<const float2*>(a.stats + (((int64_t)b * a.H + h) * tq + qrow) * 2) : make_float2(0.f, 1.f);
+    const float c2 = a.alpha * LOG2E, masked_raw = MASKED_NAT / a.alpha;
+    const float nm = -st.x * LOG2E;                  // stats hold m * alpha
+    const float scale = DROP ? 65536.f / (65536.f - (float)(uint32_t)(a.pdrop * 65536.f + 0.5f)) : 1.f;
+    const float inv = scale / st.y;
+    bf16_t* prow = pm + (int64_t)b * pm_batch + ((int64_t)h * tq + (qok ? qrow : 0)) * tp;
+    const uint16_t* keep = a.keep + ((((int64_t)b * a.H + h) * a.nkt) * tq + (qok ? qrow : 0)) * 4;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    auto tile = [&](const int kt, auto BUFC) {
+        constexpr int BUF = decltype(BUFC)::value;
+        constexpr int KOFF = BUF * TILE;
+        if (kt + 1 < nkt) stage_tile(rs_k, kimg + (BUF ^ 1) * TILE, 64 * (kt + 1), kvrow, wave, voff0);
+        uint2 kw = make_uint2(0u, 0u);
+        if (DROP && qok) kw = *reinterpret_cast<const uint2*>(keep + (int64_t)kt * tq * 4);      // the four 16-key words of this query and tile
+        float x[4][4];
+        float tmax = NOKEY;
+        score_tiles<KOFF, KS>(64 * (kt + 1) > kfull || (a.causal && 64 * (kt + 1) - 1 > blk * 128), fa, qf, lmask, kt, t, cq, masked_raw, lane, x, tmax);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const unsigned w16 = ((T & 2) ? kw.y : kw.x) >> ((T & 1) * 16);
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[T][r], c2, nm)) * inv;
+                if (DROP) pv = and_mask(pv, keep_mask(w16, (unsigned)(4 * g + r)));
+                o[r] = (bf16_t)pv;
+            }
+            const int key0 = 64 * kt + 16 * T + 4 * g;
+            if (qok && key0 < tp) *reinterpret_cast<bf16x4*>(prow + key0) = o;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, IC<0>{});
+        if (kt + 1 < nkt) tile(kt + 1, IC<1>{});
+    }
+    // tiles the forward skipped: zeros
+    if (qok) {
+        const bf16x4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        for (int kt = nkt; kt < nkt_all; ++kt)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                const int key0 = 64 * kt + 16 * T + 4 * g;
+                if (key0 < tp) *reinterpret_cast<bf16x4*>(prow + key0) = z;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ aux)
 // Same shape as the forward (4 waves x 32 queries); recomputes S^T and dPd^T = V dO^T per 64-key tile, dS^T = P (dPd keep / (1-p) -
 // delta) (0 at masked keys: masked_fill's backward), dQ^T += K^T dS^T.  Also writes aux = {-m log2 e, 1/l, delta, 0} per query for
@@ -917,6 +1002,21 @@ int launch_bwd(const FlashArgs& a, hipStream_t st) {
     return FS2_OK;
 }
 
+template <int DK>
+int launch_probs(const FlashArgs& a, bf16_t* pm, int64_t pm_batch, hipStream_t st) {
+    const int lds = 2 * TILE + a.mb + 16;
+    static Fs2PerDevice attr_set;
+    if (attr_set.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_probs_k<false, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + MASK_MAX + 128);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_probs_k<true, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TILE + MASK_MAX + 128);
+    }
+    const dim3 grid(flash_grid(a.B, a.H, a.tq, 128));
+    if (a.pdrop > 0.f) hipLaunchKernelGGL((flash_probs_k<true, DK>), grid, dim3(512), lds, st, a, pm, pm_batch);
+    else hipLaunchKernelGGL((flash_probs_k<false, DK>), grid, dim3(512), lds, st, a, pm, pm_batch);
+    FS2_CHECK_LAUNCH("fs2_flash_attention_probs");
+    return FS2_OK;
+}
+
 }  // namespace
 
 extern "C" int64_t fs2_flash_attn_keep_words(int B, int H, int t) { return (int64_t)B * H * ((t + 63) / 64) * t * 4; }
@@ -932,6 +1032,18 @@ extern "C" int fs2_flash_attention_fwd(const FS2FlashAttn* dp, void* stream) {
     if (d.dk == 128) return launch_fwd<128>(a, mode, (hipStream_t)stream);
     if (d.dk == 96) return launch_fwd<96>(a, mode, (hipStream_t)stream);
     return launch_fwd<64>(a, mode, (hipStream_t)stream);
+}
+
+extern "C" int fs2_flash_attention_probs(const FS2FlashAttn* dp, void* probs, int64_t probs_batch_stride, void* stream) {
+    FS2_REQUIRE(dp != nullptr && probs != nullptr, "fs2_flash_attention_probs: null argument");
+    const FS2FlashAttn& d = *dp;
+    const int rc = check_desc("fs2_flash_attention_probs", d, false);
+    if (rc != FS2_OK) return rc;
+    FS2_REQUIRE(probs_batch_stride % 4 == 0 && ((uintptr_t)probs & 7) == 0, "fs2_flash_attention_probs: map rows must be 8-byte aligned");
+    const FlashArgs a = to_args(d);
+    if (d.dk == 128) return launch_probs<128>(a, (bf16_t*)probs, probs_batch_stride, (hipStream_t)stream);
+    if (d.dk == 96) return launch_probs<96>(a, (bf16_t*)probs, probs_batch_stride, (hipStream_t)stream);
+    return launch_probs<64>(a, (bf16_t*)probs, probs_batch_stride, (hipStream_t)stream);
 }
 
 extern "C" int fs2_flash_attention_bwd(const FS2FlashAttn* dp, void* stream) {

@@ -109,6 +109,7 @@ SIGNATURES = {
     "fs2_flash_attn_keep_words_rect": [_I, _I, _I, _I],  # returns int64
     "fs2_flash_attention_fwd": [ctypes.POINTER(FS2FlashAttn), _P],
     "fs2_flash_attention_bwd": [ctypes.POINTER(FS2FlashAttn), _P],
+    "fs2_flash_attention_probs": [ctypes.POINTER(FS2FlashAttn), _P, _L, _P],
     "fs2_flash_attn_mask_info": [_P, _I, _I, _P, _P],
     "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _I, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
     "fs2_flash_attn_keep_bits": [_P, _L, _I, _I, _I, _I, _F, _P, _U32, _P],
@@ -1150,6 +1151,19 @@ def flash_attention_fwd(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p=0
     d = _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p, causal, key_info)
     d.rng, d.site, d.pregenerated = _rng_ptr(rng, p), site, int(bool(pregenerated))
     _check(lib().fs2_flash_attention_fwd(ctypes.byref(d), _stream()), "fs2_flash_attention_fwd")
+
+
+def flash_attention_probs(q, k, v, key_mask, out, stats, keep, probs, alpha, p=0.0, causal=False, key_info=None):
+    """probs (B,H,tq,tkp) bf16 view (batch stride free, the rest contiguous) = the post-dropout attention map of a finished
+    flash_attention_fwd call with the same q, k, key_mask, stats, keep (the reference's return value, Models/modules.py:19-21)"""
+    B, H, tq, dk = q.shape
+    tk = k.shape[2]
+    tkp = (tk + 7) // 8 * 8
+    assert probs.dtype == torch.bfloat16 and probs.shape == (B, H, tq, tkp) and probs.stride()[1:] == (tq * tkp, tkp, 1)
+    d = _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, 0, p, causal, key_info)
+    d.pregenerated = 1
+    _check(lib().fs2_flash_attention_probs(ctypes.byref(d), _p(probs), probs.stride(0), _stream()), "fs2_flash_attention_probs")
+    return probs
 
 
 def flash_attention_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv, alpha, p=0.0, causal=False, dbias=None, key_info=None):
