@@ -379,10 +379,11 @@ def bench_line(args, timer, dt, done, world, warm, use_graph, padded, BATCH, cpu
                                                                           if args.fp8 else "bf16 operands")),
                    "global_batch": BATCH * world, "parallelism": f"dp{world}",
                    "padded_frames_per_step": padded,
-                   "attention": (("hp.return_attn=True: scores GEMM -> softmax (causal / rectangular) -> P V GEMM, probabilities in HBM" if args.return_attn
+                   "attention": (("hp.return_attn=True: flash kernels (causal / rectangular) + the returned maps written after the fact (fs2_flash_attention_probs)" if args.return_attn
                                   else "hp.return_attn=False: flash kernels, causal (decoder self-attention) and rectangular (encoder-decoder) modes")
                                  if args.workload == "cfg3" else
-                                 "hp.return_attn=True: LDS-strip kernels, attention maps written to HBM" if args.return_attn or args.fp32
+                                 "hp.return_attn=True: LDS-strip kernels, attention maps written to HBM (exact-fp32 mode)" if args.fp32 else
+                                 "hp.return_attn=True: flash kernels + the returned (B,N,H,t,t) maps written after the fact (fs2_flash_attention_probs)" if args.return_attn
                                  else "hp.return_attn=False: flash kernels (no (t x t) tensor in HBM; the loop never reads the maps)"),
                    "launch": "hipGraph replay per batch shape" if use_graph else "eager"},
         "roofline": roof, "cpu_baseline": cpu,

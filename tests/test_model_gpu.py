@@ -195,26 +195,39 @@ def test_benchmark_config_bf16_within_stated_tolerance(return_attn):
             assert abs(l2 - dig[2]) <= 0.10 * dig[2], f"grad {k}: l2 {l2} vs {dig[2]}"
 
 
-def test_flash_and_strip_attention_draw_the_same_masks():
-    """hp.return_attn False (flash kernels: no probabilities in HBM) against True (LDS-strip kernels) on the benchmark
-    configuration with dropout 0.2: the Philox counters are those of the (B,N,H,t,tp) layout in both modes, so the two runs
-    see the same masks everywhere and differ by bf16 rounding only."""
+def test_flash_and_strip_attention_draw_the_same_masks(monkeypatch):
+    """Three routes of the attention on the benchmark configuration with dropout 0.2: the LDS-strip kernels with the probabilities in
+    HBM (hp.return_attn True, FS2_FLASH_MAPS=0: rounds 1-3), the flash kernels + the maps written after the fact (hp.return_attn True:
+    the default) and the flash kernels alone (hp.return_attn False).  The Philox counters are those of the (B,N,H,t,tp) layout in every
+    route, so all three see the same masks and differ by bf16 rounding only -- also in the returned maps, whose dropped positions
+    coincide."""
     res = {}
     model, hp, g = product_model("bench", amp=True, dropout=0.2, device="cuda", return_attn=True)
     batch = batch_to(CONFIGS["bench"]["batch"](), "cuda")
-    for ra in (True, False):
+    for route, ra, maps in (("strip", True, "0"), ("flash+maps", True, "1"), ("flash", False, "1")):
+        monkeypatch.setenv("FS2_FLASH_MAPS", maps)
         model.rt.return_attn = ra           # same model: same call-site ids, same rng offset
         out, total, parts = fwd_bwd(model, hp, batch)
         assert (out[7] is None) == (not ra) and (out[8] is None) == (not ra)
-        res[ra] = (total.item(), {k: p.grad.double().flatten().cpu() for k, p in model.named_parameters()}, out[1].double().cpu())
-    assert abs(res[True][0] - res[False][0]) <= 5e-3 * abs(res[True][0]), (res[True][0], res[False][0])
-    a, b = res[True][2], res[False][2]
-    assert float((a - b).abs().mean()) <= 2e-2 * max(1.0, float(a.abs().mean()))
-    for k, ga in res[True][1].items():
-        gb = res[False][1][k]
-        if ga.numel() >= 1024 and not is_null_gradient_param(k) and float(ga.norm()) > 1e-6:
-            cos = float(ga @ gb / (ga.norm() * gb.norm() + 1e-30))
-            assert cos > 0.97, (k, cos)
+        res[route] = (total.item(), {k: p.grad.double().flatten().cpu() for k, p in model.named_parameters()}, out[1].double().cpu(),
+                      (out[7][:8].float().cpu(), out[8][:4, :2].float().cpu()) if ra else None)
+    for other in ("flash+maps", "flash"):
+        assert abs(res["strip"][0] - res[other][0]) <= 5e-3 * abs(res["strip"][0]), (other, res["strip"][0], res[other][0])
+        a, b = res["strip"][2], res[other][2]
+        assert float((a - b).abs().mean()) <= 2e-2 * max(1.0, float(a.abs().mean())), other
+        for k, ga in res["strip"][1].items():
+            gb = res[other][1][k]
+            if ga.numel() >= 1024 and not is_null_gradient_param(k) and float(ga.norm()) > 1e-6:
+                cos = float(ga @ gb / (ga.norm() * gb.norm() + 1e-30))
+                assert cos > 0.97, (other, k, cos)
+    # the returned maps (encoder: 8 utterances, decoder: 4 utterances x 2 layers): values to bf16 rounding, dropped positions identical
+    for ms, mf, what in zip(res["strip"][3], res["flash+maps"][3], ("attn_enc", "attn_dec")):
+        assert ms.shape == mf.shape
+        assert float((ms - mf).abs().max()) <= 3e-2 * float(ms.max()), (what, float((ms - mf).abs().max()), float(ms.max()))
+        sure = (ms > 1e-3) | (mf > 1e-3)            # (a position that holds a sizeable probability in one route ...)
+        assert bool(((ms == 0) == (mf == 0))[sure].all()), f"{what}: the two routes dropped different positions"
+        rows = ms.sum(-1)
+        assert float((mf.sum(-1) - rows).abs().max()) <= 3e-2 * max(1.0, float(rows.max())), what
 
 
 def test_dropout_statistics_and_replay():

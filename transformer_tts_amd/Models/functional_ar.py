@@ -4,6 +4,7 @@ the output / stop-token projections and the stop-token loss of the reference's t
 gfx950 kernels as the FastSpeech2 path (functional.py).  Hand-written backward: PyTorch's autograd only carries tensors
 between these blocks."""
 import math
+import os
 
 import torch
 
@@ -60,9 +61,13 @@ class DecoderStackFunction(torch.autograd.Function):
         # hp.return_attn = False: the maps are not wanted -> flash kernels in their causal (self-attention) and rectangular
         # (encoder-decoder) modes, no (T x T) / (T x L) tensor in HBM; the Philox counters are those of the (B,N,H,t,tp) layouts
         # either way, so both modes draw the same dropout masks
-        flash = (not rt.return_attn) and ops.flash_attn_supported(max(t, L), dk, T)
+        # hp.return_attn = True: the same kernels, and the maps of each layer written after the fact (fs2_flash_attention_probs) for the return
+        # value; FS2_FLASH_MAPS=0: the unfused scores / softmax / product path with the probabilities in HBM (A/B measurements)
+        flash = ops.flash_attn_supported(max(t, L), dk, T) and (not rt.return_attn or os.environ.get("FS2_FLASH_MAPS", "1") != "0")
         if flash:
-            attn1 = attn1_drop = attn2 = attn2_drop = None
+            attn1 = attn2 = None
+            attn1_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if rt.return_attn else None
+            attn2_drop = torch.empty((B, N, H, t, Lp), dtype=T, device=dev) if rt.return_attn else None
             stats1 = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
             stats2 = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
             keep1 = torch.empty((N, ops.flash_attn_keep_words_rect(B, H, t, t)), dtype=torch.int16, device=dev) if p_att > 0 else None
@@ -83,6 +88,9 @@ class DecoderStackFunction(torch.autograd.Function):
             if flash:
                 ops.flash_attention_fwd(q, k, v, trg_km, O.permute(0, 2, 1, 3), stats1[i], keep1[i] if keep1 is not None else None, scale,
                                         N * H * t * tp, p_att, rng, layer.site_attn1, causal=True, key_info=kinfo_trg)
+                if attn1_drop is not None:
+                    ops.flash_attention_probs(q, k, v, trg_km, O.permute(0, 2, 1, 3), stats1[i], keep1[i] if keep1 is not None else None,
+                                              attn1_drop[:, i], scale, p_att, causal=True, key_info=kinfo_trg)
             else:
                 S, Pd = attn1[:, i], attn1_drop[:, i]
                 ops.bmm(q, k, S[..., :t], trans_b=True, alpha=scale)
@@ -101,6 +109,9 @@ class DecoderStackFunction(torch.autograd.Function):
             if flash:
                 ops.flash_attention_fwd(qc, kc, vc, src_km, O2.permute(0, 2, 1, 3), stats2[i], keep2[i] if keep2 is not None else None, scale,
                                         N * H * t * Lp, p_att, rng, layer.site_attn2, causal=False, key_info=kinfo_src)
+                if attn2_drop is not None:
+                    ops.flash_attention_probs(qc, kc, vc, src_km, O2.permute(0, 2, 1, 3), stats2[i], keep2[i] if keep2 is not None else None,
+                                              attn2_drop[:, i], scale, p_att, causal=False, key_info=kinfo_src)
             else:
                 S2, Pd2 = attn2[:, i], attn2_drop[:, i]
                 ops.bmm(qc, kc, S2[..., :L], trans_b=True, alpha=scale)
@@ -123,11 +134,11 @@ class DecoderStackFunction(torch.autograd.Function):
             x, h = x3, hn
 
         ctx.dec, ctx.sv, ctx.layers = dec, sv, layers
-        ctx.attn = (attn1, attn1_drop, attn2, attn2_drop)
+        ctx.attn = (None, None, None, None) if flash else (attn1, attn1_drop, attn2, attn2_drop)
         ctx.flash = (stats1, stats2, keep1, keep2, kinfo_trg, kinfo_src, trg_km, src_km) if flash else None
         ctx.e2, ctx.dims = e2, (B, t, L, mel_dim)
         ctx.set_materialize_grads(False)
-        if flash:
+        if attn1_drop is None:
             a1_out, a2_out = torch.empty((B, N, H, 0, 0), dtype=T, device=dev), torch.empty((B, N, H, 0, 0), dtype=T, device=dev)
         else:
             a1_out, a2_out = attn1_drop[..., :t], attn2_drop[..., :L]
