@@ -405,147 +405,6 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// WIDE form (round 4): 256 x 128 output tiles, bf16, uniform k-split, partial tiles to the workspace (fs2_wgrad_sliced / _grouped).
-// The 128 x 128 form stages 2 x 128 operand columns per 2 x 128 x 128 multiply-adds of a reduction row; it runs at the pace of the
-// L2 -> LDS path (12 TB/s of staging chip-wide, section 6 of DESIGN.md).  A 256-row tile stages 384 columns for twice the work: a
-// quarter fewer staged bytes per multiply-add, a third fewer LDS fragment reads (wave tiles of 64 x 64 instead of 64 x 32) and twice the
-// matrix work between two barriers.  16 waves = 2 k-groups x (4 x 2 waves of 64 x 64); a stage = 64 reduction rows = three 16 KiB
-// images [A: columns m0 .. m0+127][A: m0+128 .. m0+255][B: n0 .. n0+127] in the k-major image format of the 128 x 128 form; a 3-deep ring
-// (144 KiB) keeps two stages = 96 KiB in flight, as the 4-deep ring of 32 KiB stages does.  The 256 x 128 total leaves as the TWO
-// 128 x 128 tiles the reduce kernel knows (slices ((y * splits + split) * tiles + tile) of the workspace): its launch, the part
-// descriptors and the workspace size are those of the 128 x 128 form.
-constexpr int KW_IMG = 64 * 256, KW_STAGE = 3 * KW_IMG, KW_RING = 3, KW_SMEM = KW_RING * KW_STAGE;      // 16 KiB, 48 KiB, 144 KiB
-
-__device__ __forceinline__ void km_body_wide(const FS2Gemm& p, const int tilesM, const int tilesN, const int splits, const int nitems,
-                                             float* __restrict__ ws, const int vblock, const int vgrid) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = wave >> 3, wr = (wave >> 1) & 3, wc = wave & 1;
-    const int g = lane >> 4, i16 = lane & 15;
-    // items: (256-row tile, column tile) fastest, then k-split, then tap / batch; XCD group x owns a contiguous range (as km_body)
-    const int x = vblock & 7, slot = vblock >> 3, nslots = vgrid >> 3;
-    const int per_x = (nitems + 7) >> 3;
-    const int ibeg = x * per_x, iend = min(nitems, ibeg + per_x);
-    const int have = iend - ibeg;
-    if (have <= slot) return;
-    const int tilesMb = (tilesM + 1) >> 1, tilesb = tilesMb * tilesN, tiles = tilesM * tilesN;
-    const int taps = p.conv == 2 ? p.batch2 : 1;
-    const int nb2 = p.conv == 2 ? 1 : p.batch2;
-    const int Kb = p.Kb > 0 ? p.Kb : p.K;
-    const int nstk = (p.K + BK - 1) / BK;                   // (the host plans in units of 128 reduction rows)
-    const int per = (nstk + splits - 1) / splits;
-    const int lda = (int)p.lda, ldb = (int)p.ldb, seq = p.seq_len;
-    const int drow = 4 * wave + (lane >> 4);                // image row of this lane's LDS-DMA piece (one piece per image per wave)
-    const int dcol = ((lane & 15) ^ km_f(drow)) * 8;
-
-    for (int j = slot; j < have; j += nslots) {
-        int z = ibeg + j;
-        const int sp = (z / tilesb) % splits;
-        const int y = z / (tilesb * splits);                // (tap, batch) index, as fs2_wgrad_reduce numbers it
-        z %= tilesb;
-        const int tmb = z / tilesN, tn = z - tmb * tilesN;
-        const int tap = y % taps, yy = y / taps;
-        const int b2 = yy % nb2, b1 = yy / nb2;
-        const int m0 = tmb * 256, n0 = tn * TN;
-        const int64_t aoff = b1 * p.sA1 + (p.conv == 2 ? 0 : b2 * p.sA2), boff = b1 * p.sB1 + (p.conv == 2 ? 0 : b2 * p.sB2);
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const bf16_t*>(p.A) + aoff), 0, 0x7FFFFFF0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const bf16_t*>(p.B) + boff), 0, 0x7FFFFFF0, 0x00020000);
-        const bool colA0 = m0 + dcol < p.M, colA1 = m0 + 128 + dcol < p.M, colB = n0 + dcol < p.N;
-        const int shiftB = p.conv == 2 ? tap - p.pad : 0;
-        int lst = (sp * per) * (BK / 64);                                   // next 64-row stage to request
-        const int nst = (min(nstk, sp * per + per) - sp * per) * (BK / 64);
-        auto issue = [&](int buf) __attribute__((always_inline)) {
-            const int kk = lst * 64 + drow;
-            unsigned char* base = smem + buf * KW_STAGE + 1024 * wave;
-            const bool okk = kk < p.K;
-            const unsigned offA = (unsigned)((kk * lda + m0 + dcol) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)base, 16, (int)((okk && colA0) ? offA : OOB), 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + KW_IMG), 16, (int)((okk && colA1) ? offA + 256 : OOB), 0, 0, 0);
-            bool okb = colB && kk < Kb;
-            if (p.conv == 2) { const int tt = (kk % seq) + shiftB; okb = okb && tt >= 0 && tt < seq; }
-            const unsigned offB = (unsigned)(((kk + shiftB) * ldb + n0 + dcol) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + 2 * KW_IMG), 16, (int)(okb ? offB : OOB), 0, 0, 0);
-            ++lst;
-        };
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int pre = nst < 2 ? nst : 2;
-        for (int i = 0; i < pre; ++i) issue(i);
-        int buf = 0;
-        for (int s = 0; s < nst; ++s) {
-            // stage s has landed once at most the 3 pieces of stage s+1 (if it exists) are outstanding; the buffer stage s+2 goes into was
-            // read in iteration s-1, before the barrier every wave passes here
-            if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (s + 2 < nst) issue(buf == 0 ? 2 : buf - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* la = smem + buf * KW_STAGE + (wr >> 1) * KW_IMG;
-            const unsigned char* lb = smem + buf * KW_STAGE + 2 * KW_IMG;
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = km_frag(la, (wr & 1) * 64 + i * 16, 32 * kg, lane);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) fb[jj] = km_frag(lb, wc * 64 + jj * 16, 32 * kg, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            buf = buf == 2 ? 0 : buf + 1;
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // ---- the two k-groups hold partial sums of the same 256 x 128 tile.  Per 128-row half: group 1 parks its accumulators in the first
-        //      64 KiB (lane-linear 16-byte slots), group 0 adds its own and writes the total row-major into the second 64 KiB, all 16 waves
-        //      copy it to its workspace slice with 16-byte stores (the slice fs2_wgrad_reduce expects for this 128 x 128 tile)
-        float4* red4 = reinterpret_cast<float4*>(smem);
-        float* red = reinterpret_cast<float*>(smem + 65536);
-        const int wv = (wr & 1) * 2 + wc;
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            const bool mine = (wr >> 1) == half;
-            if (mine && kg == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        red4[wv * 1024 + (i * 4 + jj) * 64 + lane] = make_float4(acc[i][jj][0], acc[i][jj][1], acc[i][jj][2], acc[i][jj][3]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (mine && kg == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const float4 v = red4[wv * 1024 + (i * 4 + jj) * 64 + lane];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            red[((wr & 1) * 64 + i * 16 + g * 4 + r) * TN + wc * 64 + jj * 16 + i16] = acc[i][jj][r] + (&v.x)[r];
-                    }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const int tm = 2 * tmb + half;
-            if (tm < tilesM) {
-                float4* dst = reinterpret_cast<float4*>(ws + ((int64_t)(y * splits + sp) * tiles + (int64_t)tm * tilesN + tn) * (TM * TN));
-                const float4* src = reinterpret_cast<const float4*>(red);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dst[tid + NT * i] = src[tid + NT * i];
-            }
-            // the LDS is free again before the second half parks / the next item's first stage is staged
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-    }
-}
-
-__global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_wide_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
-                                                                       const int nitems, float* __restrict__ ws) {
-    km_body_wide(p, tilesM, tilesN, splits, nitems, ws, (int)blockIdx.x, (int)gridDim.x);
-}
-
 template <int ES, int KG = 4>
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
                                                                   const int nitems, const int rot_step, const int stream_units,
@@ -570,13 +429,6 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_grouped_kernel(const 
     while (d + 1 < a.n && (int)blockIdx.x >= a.wg_begin[d + 1]) ++d;
     km_body<ES, KG>(a.g[d], a.tilesM[d], a.tilesN[d], a.splits[d], a.nitems[d], a.rot_step, 0, a.ws[d], (int)blockIdx.x - a.wg_begin[d],
             a.wg_begin[d + 1] - a.wg_begin[d]);
-}
-
-__global__ __launch_bounds__(1024, 4) void fs2_gemm_big_km_wide_grouped_kernel(const KmGroupArgs a) {
-    int d = 0;
-    while (d + 1 < a.n && (int)blockIdx.x >= a.wg_begin[d + 1]) ++d;
-    km_body_wide(a.g[d], a.tilesM[d], a.tilesN[d], a.splits[d], a.nitems[d], a.ws[d], (int)blockIdx.x - a.wg_begin[d],
-                 a.wg_begin[d + 1] - a.wg_begin[d]);
 }
 
 namespace {
@@ -622,28 +474,6 @@ bool km_plan(const FS2Gemm& g, int mode, KmPlan& pl, bool allow_f8 = false) {
     pl.grid = stream_units > 0 ? 8 * (int)(((total + stream_units - 1) / stream_units + 7) / 8) : 8 * (int)(per_x < 32 ? per_x : 32);
     pl.splits = splits; pl.stream_units = stream_units; pl.nitems = nitems; pl.base = base;
     return true;
-}
-
-// the 256 x 128 form (km_body_wide): bf16 operands, uniform k-split, at least two 128-row tiles; FS2_KM_WIDE=0 keeps the 128 x 128 form (A/B)
-bool km_wide_ok(const FS2Gemm& g, const KmPlan& pl) {
-    const char* e = getenv("FS2_KM_WIDE");
-    if (e != nullptr && atoi(e) == 0) return false;
-    return g.dtype == FS2_BF16 && pl.stream_units == 0 && pl.tilesM >= 2;
-}
-// its decomposition: items = (256-row tile, column tile, k-split, tap / batch); about one item per CU, at least 2 stages of 128 rows per split
-void km_wide_plan(const FS2Gemm& g, const KmPlan& pl, int& splits, long& nitems, int& grid, long& slices) {
-    const long nb = (long)g.batch1 * g.batch2;
-    const long base = (long)((pl.tilesM + 1) / 2) * pl.tilesN * nb;
-    const int nstk = (g.K + BK - 1) / BK;
-    splits = (int)(256 / base);
-    if (splits > nstk / 2) splits = nstk / 2 > 0 ? nstk / 2 : 1;
-    if (splits < 1) splits = 1;
-    const int per = (nstk + splits - 1) / splits;
-    splits = (nstk + per - 1) / per;
-    nitems = base * splits;
-    const long per_x = (nitems + 7) / 8;
-    grid = 8 * (int)(per_x < 32 ? per_x : 32);
-    slices = nb * splits * (long)pl.tilesM * pl.tilesN;         // 128 x 128 partial tiles written
 }
 
 // FS2_KM_KG=4: the round-2 form of the bf16 kernel (four k-groups, 64 KiB stages, one in flight) for A/B measurements; read per call
@@ -786,25 +616,6 @@ extern "C" int64_t fs2_wgrad_sliced(const FS2Gemm* gp, float* ws, int64_t ws_flo
         part->splits = 0;
         return 1;
     }
-    if (km_wide_ok(g, pl)) {
-        int wsplits, wgrid; long witems, wslices;
-        km_wide_plan(g, pl, wsplits, witems, wgrid, wslices);
-        const int64_t wneed = wslices * (int64_t)(TM * TN);
-        if (witems <= wgrid && wneed <= ws_floats) {
-            static Fs2PerDevice attr_set;
-            if (attr_set.need() &&
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KW_SMEM) != hipSuccess) {
-                fs2_set_error("fs2_wgrad_sliced: cannot raise the dynamic LDS limit of the weight-gradient kernel");
-                return FS2_ELAUNCH;
-            }
-            g_last_tile = 129;
-            hipLaunchKernelGGL(fs2_gemm_big_km_wide_kernel, dim3(wgrid), dim3(NT), KW_SMEM, (hipStream_t)stream, g, pl.tilesM, pl.tilesN, wsplits, (int)witems, ws);
-            hipError_t e_ = hipGetLastError();
-            if (e_ != hipSuccess) { fs2_set_error("fs2_wgrad_sliced(wide): launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
-            fill_part(part, g, ws, pl.tilesM, pl.tilesN, wsplits, pl.base);
-            return wneed;
-        }
-    }
     const int64_t need = pl.nitems * (int64_t)(TM * TN);
     if (need > ws_floats || pl.nitems > pl.grid) return 0;          // (one item per workgroup: every slice is written exactly once)
     const int rc = km_launch(g, pl, ws, (hipStream_t)stream);
@@ -840,22 +651,14 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
     int nstk[KM_GROUP], src[KM_GROUP];       // src[k]: index in descs of the k-th product the group takes
     long work = 0, tiles = 0;
     int m = 0;
-    // the 256 x 128 form takes the group when every candidate is eligible for it (bf16, at least two 128-row tiles)
-    bool wide = true;
-    for (int i = 0; i < n; ++i) {
-        FS2Gemm gt; KmPlan pt;
-        if (wgrad_desc_ok(descs + i, gt) && km_plan(gt, mode, pt, true) && pt.stream_units == 0 && !km_wide_ok(gt, pt)) wide = false;
-    }
-    long wbase[KM_GROUP] = {0, 0, 0, 0};      // items of a product per k-split: its 128 x 128 tiles, or its 256 x 128 tiles in the wide form
     for (int i = 0; i < n; ++i) {
         parts[i].splits = 0;                 // "not taken" until proven otherwise
         if (!wgrad_desc_ok(descs + i, a.g[m]) || !km_plan(a.g[m], mode, pl[m], true) || pl[m].stream_units > 0) continue;
         if (m > 0 && a.g[m].dtype != a.g[0].dtype) continue;            // (one operand format per launch)
-        wbase[m] = wide ? (long)((pl[m].tilesM + 1) / 2) * pl[m].tilesN * ((long)a.g[m].batch1 * a.g[m].batch2) : pl[m].base;
-        if (tiles + wbase[m] > 224) continue;
+        if (tiles + pl[m].base > 224) continue;
         nstk[m] = (a.g[m].K + BK - 1) / BK;
-        work += wbase[m] * nstk[m];
-        tiles += wbase[m];
+        work += pl[m].base * nstk[m];
+        tiles += pl[m].base;
         src[m++] = i;
     }
     if (m == 0) return 0;
@@ -869,7 +672,7 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
             const int pi = (nstk[i] + sp - 1) / sp;
             sp = (nstk[i] + pi - 1) / pi;                             // no empty split
             a.splits[i] = sp;
-            a.nitems[i] = (int)(wbase[i] * sp);
+            a.nitems[i] = (int)(pl[i].base * sp);
             a.wg_begin[i] = wgs;
             wgs += 8 * ((a.nitems[i] + 7) / 8);
         }
@@ -878,19 +681,17 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
         if (per > (1 << 20)) return 0;
     }
     int64_t need = 0;
-    int64_t slices[KM_GROUP] = {0, 0, 0, 0};          // 128 x 128 partial tiles a product writes
     for (int i = 0; i < m; ++i) {
         a.ws[i] = ws + need;
         a.tilesM[i] = pl[i].tilesM; a.tilesN[i] = pl[i].tilesN;
-        slices[i] = pl[i].base * a.splits[i];
-        need += slices[i] * (TM * TN);
+        need += (int64_t)a.nitems[i] * (TM * TN);
     }
     if (need > ws_floats) return 0;
     // invariants the kernel relies on (cheap, always checked): 8-aligned monotonic workgroup ranges inside one 256-workgroup round, every
     // taken product with at least one item and no more items than workgroups, its partial tiles inside [ws, ws + ws_floats)
     for (int i = 0; i < m; ++i) {
         if (!(a.wg_begin[i] % 8 == 0 && a.wg_begin[i] < a.wg_begin[i + 1] && a.wg_begin[i + 1] <= 256 && a.nitems[i] >= 1 &&
-              a.nitems[i] <= a.wg_begin[i + 1] - a.wg_begin[i] && a.ws[i] >= ws && a.ws[i] + slices[i] * (TM * TN) <= ws + ws_floats &&
+              a.nitems[i] <= a.wg_begin[i + 1] - a.wg_begin[i] && a.ws[i] >= ws && a.ws[i] + (int64_t)a.nitems[i] * (TM * TN) <= ws + ws_floats &&
               a.g[i].A != nullptr && a.g[i].B != nullptr && a.g[i].C != nullptr)) {
             fs2_set_error("fs2_wgrad_grouped: internal plan error for product %d (wg [%d, %d), items %d)", i, a.wg_begin[i], a.wg_begin[i + 1], a.nitems[i]);
             return FS2_EINVAL;
@@ -912,15 +713,6 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
         if (dev >= 0 && dev < 16) attr_set[dev] = true;
     }
     g_last_tile = 129;
-    if (wide) {
-        static Fs2PerDevice wide_attr;
-        if (wide_attr.need() &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_wide_grouped_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KW_SMEM) != hipSuccess) {
-            fs2_set_error("fs2_wgrad_grouped: cannot raise the dynamic LDS limit of the weight-gradient kernel");
-            return FS2_ELAUNCH;
-        }
-        hipLaunchKernelGGL(fs2_gemm_big_km_wide_grouped_kernel, dim3(a.wg_begin[m]), dim3(NT), KW_SMEM, (hipStream_t)stream, a);
-    } else
     if (a.g[0].dtype != FS2_BF16) hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<1, 4>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
     else if (km_two_groups()) hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<2, 2>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<2, 4>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
