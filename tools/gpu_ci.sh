@@ -31,6 +31,11 @@ for step in "$@"; do
     bench3)  run bench3 500 python bench.py --workload cfg3 --steps 24 --warmup 8 --no-cpu-baseline ;;
     bench4)  run bench4_bf16 500 python bench.py --workload cfg4 --steps 24 --warmup 16 --no-cpu-baseline
              run bench4_fp8 500 python bench.py --workload cfg4 --fp8 --steps 24 --warmup 16 --no-cpu-baseline ;;
+    bench3a) run bench3a 500 python bench.py --workload cfg3 --return-attn --steps 24 --warmup 8 --no-cpu-baseline ;;
+    prof4)   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+             run prof4_bf16 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof4_bf16 -- python bench.py --workload cfg4 --steps 3 --warmup 4 --no-cpu-baseline --no-graph --no-gemm-timer
+             run prof4_fp8 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof4_fp8 -- python bench.py --workload cfg4 --fp8 --steps 3 --warmup 4 --no-cpu-baseline --no-graph --no-gemm-timer ;;
+    aten)    run aten 300 python tools/aten_ops_in_step.py ;;
     benchq)  run benchq 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --gemm-report gpurun_out/gemm_report.txt ;;
     benche)  run benche 400 python bench.py --steps 16 --warmup 8 --no-cpu-baseline --no-graph ;;
     benchee) run benchee 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-graph --no-gemm-timer ;;
