@@ -28,3 +28,53 @@ for ev in prof.events():
         sites[(ev.name, st[0] if st else "?")] += 1
 for (name, site), n in sorted(sites.items(), key=lambda kv: -kv[1]):
     print(n, name, site)
+
+# ---- device copies by call site: Tensor.contiguous / clone / copy_ / to that actually move bytes on the GPU (hipMemcpyAsync -> the
+#      runtime's copyBuffer blit kernel in a kernel trace)
+import traceback
+sites2 = collections.Counter()
+
+
+def _site():
+    for f in reversed(traceback.extract_stack()[:-2]):
+        if "transformer_tts_amd" in f.filename or f.filename.endswith("bench.py"):
+            return f"{f.filename.split('transformer_tts_amd/')[-1]}:{f.lineno}"
+    return "?"
+
+
+_orig = {n: getattr(torch.Tensor, n) for n in ("contiguous", "clone", "copy_", "to")}
+
+
+def _wrap(name):
+    fn = _orig[name]
+
+    def w(self, *a, **k):
+        out = fn(self, *a, **k)
+        moved = (name == "contiguous" and self.is_cuda and out.data_ptr() != self.data_ptr()) or (name == "clone" and self.is_cuda) or \
+                (name == "copy_" and (self.is_cuda or (a and torch.is_tensor(a[0]) and a[0].is_cuda))) or \
+                (name == "to" and torch.is_tensor(out) and (out.is_cuda != self.is_cuda or (out.is_cuda and out.data_ptr() != self.data_ptr())))
+        if moved:
+            sites2[(name, _site(), tuple(self.shape))] += 1
+        return out
+    return w
+
+
+for n in _orig:
+    setattr(torch.Tensor, n, _wrap(n))
+train_step(model, opt, 6, batch, hp)
+torch.cuda.synchronize()
+for n, f in _orig.items():
+    setattr(torch.Tensor, n, f)
+print("--- device copies of one step by call site")
+for (name, site, shape), n in sorted(sites2.items(), key=lambda kv: -kv[1]):
+    print(n, name, site, shape)
+
+# ---- runtime memcpy calls of the profiled step with their Python stacks
+print("--- hipMemcpy* runtime calls of the profiled step, by innermost package frame")
+mc = collections.Counter()
+for ev in prof.events():
+    if "emcpy" in ev.name or "emset" in ev.name:
+        st = [f for f in (ev.stack or []) if "transformer_tts_amd" in f or "bench.py" in f or "torch/" in f]
+        mc[(ev.name, st[0] if st else "?")] += 1
+for (name, site), n in sorted(mc.items(), key=lambda kv: -kv[1])[:30]:
+    print(n, name, site)
