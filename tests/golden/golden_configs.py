@@ -56,6 +56,11 @@ OPTION_CONFIGS = {
     "opt_concat": _opt(31, concat_after_encoder=True, concat_after_decoder=True),
     "opt_nopitch": _opt(32, pitch_pred=False),
     "opt_noenergy": _opt(33, energy_pred=False),
+    # the same three for the INFERENCE fixtures (infer_<name>.npz): weight seeds under which every utterance gets predicted durations > 0
+    # (the reference's inference branch dies on an utterance whose durations all round to 0) and no duration sits within 2e-3 of a .5 tie
+    "inf_concat": dict(_opt(40, concat_after_encoder=True, concat_after_decoder=True), shapes_from="opt_concat"),
+    "inf_nopitch": dict(_opt(41, pitch_pred=False), shapes_from="opt_nopitch"),
+    "inf_noenergy": dict(_opt(41, energy_pred=False), shapes_from="opt_noenergy"),
     "opt_ss1": _opt(34, p_scheduled_sampling=1.0),
     "opt_ss_half": _opt(35, p_scheduled_sampling=0.5),
 }

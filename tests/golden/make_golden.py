@@ -219,7 +219,8 @@ def run_infer(name):
         out[f"u{b}.duration_rounded"] = dur.numpy()
         out[f"u{b}.round_margin"] = np.float64((frac - 0.5).abs().min())       # distance of the closest call to a .5 tie
         for k, r in zip(names, res[:7]):
-            out[f"u{b}.{k}"] = r.numpy()
+            if r is not None:           # (p_pred / e_pred are None with hp.pitch_pred / hp.energy_pred False)
+                out[f"u{b}.{k}"] = r.numpy()
         out[f"u{b}.attn_dec_dig"] = digest(res[8])
         print(name, "utt", b, "L", n, "T", int(dur.sum()), "round margin", float(out[f"u{b}.round_margin"]))
     path = os.path.join(OUT, f"infer_{name}.npz")
@@ -502,7 +503,7 @@ if __name__ == "__main__":
         del argv[i:i + 2]
     which = argv[0] if argv else "all"
     if which.startswith("infer"):
-        for n in ("tiny", "small"):
+        for n in (("inf_concat", "inf_nopitch", "inf_noenergy") if which == "infer_options" else ("tiny", "small")):
             run_infer(n)
     elif which == "ar":
         for n in AR_CONFIGS:
@@ -518,7 +519,8 @@ if __name__ == "__main__":
     elif which == "options":
         from golden_configs import OPTION_CONFIGS
         for n in OPTION_CONFIGS:
-            run(n)
+            if n.startswith("opt_"):
+                run(n)
     else:
         for n in (list(CONFIGS) if which == "all" else [which]):
             run(n)

@@ -24,7 +24,7 @@ def oracle_model(name, dtype=torch.float32):
     from oracle.model import FastSpeech2
     cfg = CONFIGS[name]
     hp = hp_namespace(cfg)
-    g = load_golden(name)
+    g = load_golden(cfg.get("shapes_from", name))       # (the inference-only option configs take their state_dict shapes from the opt_* fixture)
     m = FastSpeech2.from_hp(hp, dropout=0.0, dropout_postnet=0.0, dropout_variance_adaptor=0.0)
     m.load_state_dict(synthetic.recipe_state_dict(golden_shapes(g), cfg["weight_seed"]))
     m.train()
@@ -67,7 +67,7 @@ def product_model(name, amp=False, dropout=0.0, device="cpu", return_attn=True):
     hp.amp = amp
     hp.return_attn = return_attn
     fill_variables(hp, verbose=False)
-    g = load_golden(name)
+    g = load_golden(cfg.get("shapes_from", name))
     m = FastSpeech2(hp=hp, src_vocab=hp.vocab_size, trg_vocab=hp.mel_dim, d_model_encoder=hp.d_model_encoder,
                     N_e=hp.n_layer_encoder, n_head_encoder=hp.n_head_encoder,
                     ff_conv_kernel_size_encoder=hp.ff_conv_kernel_size_encoder,

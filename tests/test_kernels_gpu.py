@@ -1694,3 +1694,13 @@ def test_torch_library_ops(ops):
     o_ref.backward(go.float())
     err = float((qkv.grad.float() - qr.grad).abs().max() / qr.grad.abs().max())
     assert err < 4e-2, err
+
+
+def test_zero(ops):
+    """fs2_zero (optimizer.zero_grad on the gradient arena): every byte of the range, nothing beyond it"""
+    for n in (4, 16384 + 4, (1 << 22) + 12):
+        buf = torch.full((n + 8,), 3.0, device="cuda")
+        ops.zero(buf[4:4 + n])
+        assert float(buf[4:4 + n].abs().max()) == 0.0 and buf[:4].tolist() == [3.0] * 4 and buf[4 + n:].tolist() == [3.0] * 4
+    with pytest.raises(RuntimeError):
+        ops.zero(torch.ones(6, device="cuda")[1:5])       # not 16-byte aligned
