@@ -61,6 +61,17 @@ class ParamArena:
         return lo, hi
 
 
+_HYPER = {}
+
+
+def _hyper_ring():
+    """the pinned staging rows of FusedAdam.host_update: ONE ring per process, never freed (a pinned block that the garbage collector
+    releases while some stream is capturing a hipGraph aborts the process: the host allocator's free path queries events)"""
+    if not _HYPER:
+        _HYPER.update(pin=torch.empty((FusedAdam.HYPER_RING, 4), dtype=torch.float32).pin_memory(), ev=[None] * FusedAdam.HYPER_RING, next=0)
+    return _HYPER
+
+
 class FusedAdam:
     """Adam with the reference's hyper-parameters, global-norm clipping fused in, over a ParamArena.
 
@@ -82,7 +93,6 @@ class FusedAdam:
         self.gsq = self.arena.ztail[:1]            # (cleared by zero_grad with the gradients; launch() clears it itself if called twice)
         self._gsq_clean = False
         self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
-        self._hyper_pin, self._hyper_ev = None, None
         self.t = 0
         self.param_groups = [dict(params=self.arena.params, lr=lr, betas=betas, eps=eps)]
         if self.runtime is not None:
@@ -119,19 +129,18 @@ class FusedAdam:
         # Asynchronous, from a small ring of PINNED staging rows: a copy from pageable host memory returns only when the stream has
         # executed it, i.e. it made the training thread wait for the whole previous step at the start of every step -- the GPU then idled
         # while the host caught up (eager steps: 9.2 ms against 7.6 ms of device work; graph replays: the gap between two replays).
-        # A row is rewritten only after the copy that read it last has completed (its event).
-        if self._hyper_pin is None:
-            self._hyper_pin = torch.empty((self.HYPER_RING, 4), dtype=torch.float32).pin_memory()
-            self._hyper_ev = [None] * self.HYPER_RING
-        i = self.t % self.HYPER_RING
-        if self._hyper_ev[i] is not None:
-            self._hyper_ev[i].synchronize()
-        row = self._hyper_pin[i]
+        # A row is rewritten only after the copy that read it last has completed (its event).  The ring belongs to the process.
+        ring = _hyper_ring()
+        i = ring["next"]
+        ring["next"] = (i + 1) % self.HYPER_RING
+        if ring["ev"][i] is not None:
+            ring["ev"][i].synchronize()
+        row = ring["pin"][i]
         row[0], row[1], row[2], row[3] = vals
         self.hyper.copy_(row, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._hyper_ev[i] = ev
+        ring["ev"][i] = ev
 
     def launch(self):
         """device half of a step (graph-capturable): finish the gradient exchange, global norm, clip + Adam"""

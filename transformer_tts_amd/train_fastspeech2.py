@@ -16,6 +16,7 @@ Differences, all on purpose:
 import argparse
 import collections
 import filecmp
+import gc
 import os
 import random
 import shutil
@@ -201,16 +202,27 @@ class GraphedTrainStep:
             # from ANOTHER thread invalidates the capture in progress.  "thread_local" restricts the unsafe-call check to
             # the capturing thread; work submitted to the capturing stream by the autograd thread is captured either way.
             mode = os.environ.get("FS2_CAPTURE_ERROR_MODE") or ("thread_local" if _dist_alive() else "global")
+            # No garbage collection while the stream is capturing: a collection that happens to run inside the capture destroys whatever
+            # cyclic garbage earlier code left behind -- CUDA graphs, events, tensors of another stepper -- and a HIP call refused in
+            # capture mode inside such a destructor ends the process (seen once in the GPU suite: "Fatal Python error: Aborted" with the
+            # collector on the stack of this capture).  Collect first, then keep the collector off until the capture has ended.
+            gc_on = gc.isenabled()
+            gc.collect()
+            gc.disable()
             try:
                 with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
                     loss, parts = self.body(self.model, self.optimizer, self.hp, *static)
             except Exception as e:      # noqa: BLE001  (whatever the runtime raises for an operation it cannot capture)
+                if gc_on:
+                    gc.enable()
                 if not self.eager_fallback:
                     raise
                 print(f"GraphedTrainStep: capture failed ({type(e).__name__}: {e}); continuing with eager launches", flush=True)
                 self.broken = True
                 torch.cuda.synchronize()
                 return self.eager(self.model, self.optimizer, step, d, self.hp)
+            if gc_on:
+                gc.enable()
             entry = self.graphs[key] = (g, static, loss, parts)
             self.stats["captured"] += 1
         self.graphs.move_to_end(key)
