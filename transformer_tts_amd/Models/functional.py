@@ -238,6 +238,7 @@ class Runtime:
 
     def refresh(self, model):
         """bring every weight shadow up to date with ONE kernel launch (no-op when nothing changed)"""
+        self._final_flush_queued = False        # (a backward pass that raised never ran its completion callback: do not rely on it)
         if getattr(self, "_table", None) is None or \
                 self._table_sig != tuple(p.data_ptr() for _, ps, _ in self._records for p in ps):
             self._build_table(model)
