@@ -149,16 +149,27 @@ class GemmTimer:
             grouped, ops._WG.group = ops._WG.group, False
             try:
                 ops._WG._launch_pending()  # products queued before this one keep their order (timed by timed_group)
-                ops._gemm_call = self._orig
+                ops._gemm_call, ops._WG.on_one = self._orig, None
                 s.record()
                 self._orig_wgrad(g, out, True, extra_bytes, keep)
                 e.record()
             finally:
-                ops._gemm_call = timed
+                ops._gemm_call, ops._WG.on_one = timed, timed_one
                 ops._WG.group = grouped
             if not defer:
                 ops.wgrad_flush()
             record(g, s, e)
+
+        def timed_one(g, launch):
+            # a product of a group that the grouped launch did not take (balanced stream: the encoder's Conv1d weight gradients), launched
+            # on its own with its partial tiles in the workspace; 0: not in that form either (fs2_gemm follows: timed there)
+            s, e = events()
+            s.record()
+            used = launch()
+            e.record()
+            if used > 0:
+                record(g, s, e)
+            return used
 
         def timed_group(descs, launch):
             # the weight gradients of one layer in one launch (fs2_wgrad_grouped): one event pair, the group's FLOPs and bytes summed
@@ -179,12 +190,13 @@ class GemmTimer:
         ops._gemm_call = timed
         ops._wgrad_call = timed_wgrad
         ops._WG.on_group = timed_group
+        ops._WG.on_one = timed_one
 
     def remove(self):
         from transformer_tts_amd import ops
         ops._gemm_call = self._orig
         ops._wgrad_call = self._orig_wgrad
-        ops._WG.on_group = None
+        ops._WG.on_group = ops._WG.on_one = None
 
     def summary(self):
         agg = {}

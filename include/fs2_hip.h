@@ -128,7 +128,9 @@ int fs2_splitk_reduce(const float* slices, int nsplit, int64_t slice_stride, int
  * the workspace `ws` (64 KiB per workgroup, ~6 TB/s chip-wide against ~1.3 TB/s of float atomics) and describes them in `part`;
  * fs2_wgrad_reduce(parts, n) later adds the partial tiles of n such products into their gradients, one launch for all of them (the
  * trainer reduces once per announced parameter range).  Returns the number of floats of `ws` used, 0 when the product does not run
- * in that form (the caller then calls fs2_gemm), negative on error.                                                            */
+ * in that form (the caller then calls fs2_gemm), negative on error.  part->splits > 0: uniform k-split (slice = item number);
+ * part->splits = -U < 0: balanced stream of U stages per workgroup (slice = workgroup + tile; part->reserved = stages of the whole
+ * reduction, bit 30 set for conv = 2): fs2_wgrad_reduce reads both forms.                                                      */
 typedef struct FS2WgradPart {
     const float* ws;
     float* dst;
@@ -142,7 +144,8 @@ typedef struct FS2WgradPart {
 int64_t fs2_wgrad_sliced(const FS2Gemm* g, float* ws, int64_t ws_floats, FS2WgradPart* part, void* stream);
 /* fp8 operands (dtype FS2_BF8_FP8: A = dY in e5m2, B = X in e4m3, one byte per element, lda / ldb multiples of 16, FS2Gemm.scale_a / scale_b)
  * are taken by fs2_wgrad_sliced / fs2_wgrad_grouped only.  fs2_wgrad_plan tells beforehand how a product would run: 0 the 16-wave kernel
- * does not take it, 1 uniform k-split (partial tiles), 2 balanced stream or more than 256 output tiles -- bf16: through fs2_gemm (fs2_wgrad_sliced returns 0); fp8:
+ * does not take it, 1 uniform k-split (partial tiles), 2 balanced stream (partial tiles while the workspace has room) or more than 256
+ * output tiles.  Where a form-2 product does not get partial tiles: bf16 goes through fs2_gemm (fs2_wgrad_sliced returns 0); fp8:
  * fs2_wgrad_sliced launches it with the float-atomic flush, returns 1 and sets part->splits = 0 (complete, nothing to reduce). */
 int fs2_wgrad_plan(const FS2Gemm* g);
 /* n <= 4 such products in ONE launch (the weight gradients of one layer's backward, launched when the last of them is known): one

@@ -1622,6 +1622,32 @@ def test_sliced_weight_gradients(ops, big_km):
     ops.wgrad_flush()
     close(o1, a[0], "fallback: linear", rtol=1e-4, atol=1e-3)
     close(o2, P.conv_wgrad(dys, xs, 9, 4, torch.zeros(1024, 9 * 256)), "fallback: stream-mode conv", rtol=2e-3, atol=2e-3 * 1024 ** 0.5)
+    # balanced-stream products leave partial tiles too (slice = workgroup + tile; FS2WgradPart.splits < 0): a plain product with ragged
+    # edges (8 x 18 tiles of 1000 x 2296) and the nine taps of a Conv1d, onto non-zero gradients, one reduce for both; against the oracle
+    # and against the float-atomic flush of the same decomposition
+    dyp, xp = rnd(2048, 1000, dtype=torch.bfloat16, seed=10), rnd(2048, 2296, dtype=torch.bfloat16, seed=11)
+    g1, g2 = rnd(1000, 2296, seed=12), rnd(1024, 9 * 256, seed=13)
+    o3, o4 = g1.cuda(), g2.cuda()
+    ops.wgrad(dyp.cuda(), xp.cuda(), o3, defer=True)
+    ops.conv_wgrad(dys.cuda(), xs.cuda(), 9, 4, o4, defer=True)
+    ops.wgrad_launch()
+    assert [q.splits < 0 for q in wg.parts] == [True, True], [q.splits for q in wg.parts]
+    assert torch.equal(o3.cpu(), g1) and torch.equal(o4.cpu(), g2)       # nothing added before the reduce
+    ops.wgrad_flush()
+    r3, r4 = g1.clone(), g2.clone()
+    P.wgrad(dyp, xp, r3)
+    P.conv_wgrad(dys, xs, 9, 4, r4)
+    close(o3, r3, "stream-mode product, partial tiles", rtol=2e-3, atol=2e-3 * 2048 ** 0.5)
+    close(o4, r4, "stream-mode conv, partial tiles", rtol=2e-3, atol=2e-3 * 1024 ** 0.5)
+    wg.enabled = False
+    try:
+        o5, o6 = g1.cuda(), g2.cuda()
+        ops.wgrad(dyp.cuda(), xp.cuda(), o5)
+        ops.conv_wgrad(dys.cuda(), xs.cuda(), 9, 4, o6)
+    finally:
+        wg.enabled = True
+    close(o3, o5, "stream: partial tiles vs atomics", rtol=1e-4, atol=1e-3)
+    close(o4, o6, "stream conv: partial tiles vs atomics", rtol=1e-4, atol=1e-3)
 
 
 def test_torch_library_ops(ops):

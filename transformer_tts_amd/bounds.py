@@ -134,7 +134,12 @@ def part_ranges(p):
     one = 4 * ((p.M - 1) * p.ldc + p.N)
     last = (n1 - 1) * abs(p.sC1) + (n2 - 1) * abs(p.sC2)
     items = [("part.dst", p.dst + 4 * (i * p.sC1 + j * p.sC2), one) for i in range(n1) for j in range(n2)] if (p.dst and last > 0) else None
-    out = [("part.ws", p.ws, 4 * p.nbatch * p.splits * tiles * 128 * 128), ("part.dst", p.dst, 4 * last + one, items)]
+    if p.splits > 0:
+        slices = p.nbatch * p.splits * tiles
+    else:               # balanced stream: slice (workgroup + tile); -splits units per workgroup, reserved & (2^30 - 1) stages per tile
+        nstk = p.reserved & ((1 << 30) - 1)
+        slices = -(-(p.nbatch * tiles * nstk) // -p.splits) + p.nbatch * tiles
+    out = [("part.ws", p.ws, 4 * slices * 128 * 128), ("part.dst", p.dst, 4 * last + one, items)]
     for nm in ("scale_a", "scale_b"):
         if getattr(p, nm):
             out.append((nm, getattr(p, nm), 4))
@@ -143,7 +148,7 @@ def part_ranges(p):
 
 def check_part(p, ws_ptr, ws_bytes, what="fs2_wgrad_reduce"):
     STATS["descriptors"] += 1
-    assert p.splits >= 1 and p.tilesM >= 1 and p.tilesN >= 1 and p.nbatch >= 1, f"FS2_CHECK_BOUNDS: {what}: bad part"
+    assert p.splits != 0 and (p.splits > 0 or 1 <= -p.splits <= (p.reserved & ((1 << 30) - 1))) and p.tilesM >= 1 and p.tilesN >= 1 and p.nbatch >= 1, f"FS2_CHECK_BOUNDS: {what}: bad part"
     assert p.tilesM == -(-p.M // 128) and p.tilesN == -(-p.N // 128), f"FS2_CHECK_BOUNDS: {what}: tile counts do not match M, N"
     r = part_ranges(p)
     lo, n = r[0][1], r[0][2]

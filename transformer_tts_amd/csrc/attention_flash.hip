@@ -129,6 +129,31 @@ __device__ __forceinline__ bf16x8 pack8(const float (&a)[4], const float (&b)[4]
     for (int c = 0; c < 4; ++c) { o[c] = (bf16_t)a[c]; o[4 + c] = (bf16_t)b[c]; }
     return o;
 }
+// the same with the keep-bits of a dropout applied on the way: element r of `a` survives iff bit r of ba is set (b / bb alike).  Written
+// in instructions -- one v_bfe_i32 + one v_and_b32 per element, one v_cvt_pk_bf16_f32 per PAIR: hipcc turns the plain form into
+// v_and + v_cmp + v_cndmask + a single-element convert per element and a v_perm per pair (72 vector instructions per 16 x 64 tile
+// against 40 here, in a kernel whose vector issue is 3x its matrix time)
+template <int R> __device__ __forceinline__ float keep_elem(float v, unsigned bits) {
+    int m;
+    float o;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(bits), "n"(R));
+    asm("v_and_b32 %0, %1, %2" : "=v"(o) : "v"(v), "v"(m));
+    return o;
+}
+__device__ __forceinline__ unsigned cvt_pk(float lo, float hi) {
+    unsigned o;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(lo), "v"(hi));
+    return o;
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 pack8_keep(const float (&a)[4], unsigned ba, const float (&b)[4], unsigned bb) {
+    u32x4 o;
+    o[0] = cvt_pk(keep_elem<0>(a[0], ba), keep_elem<1>(a[1], ba));
+    o[1] = cvt_pk(keep_elem<2>(a[2], ba), keep_elem<3>(a[3], ba));
+    o[2] = cvt_pk(keep_elem<0>(b[0], bb), keep_elem<1>(b[1], bb));
+    o[3] = cvt_pk(keep_elem<2>(b[2], bb), keep_elem<3>(b[3], bb));
+    return __builtin_bit_cast(bf16x8, o);
+}
 __device__ __forceinline__ float xor16_32_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -431,19 +456,20 @@ __global__ __launch_bounds__(512, 4) void flash_fwd_k(const FlashArgs a) {
             m = m_new;
         }
         const float nm = -m * c2;
+        unsigned bT[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int T = 0; T < 4; ++T) {
-            unsigned bT = 0;
-            if (DROP != 0) bT = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
+            if (DROP != 0) bT[T] = (unsigned)__shfl((int)mybits, i16 + 16 * T, 64) >> (4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(x[T][r], c2, nm));
                 l += pv;
-                x[T][r] = DROP != 0 ? and_mask(pv, keep_mask(bT, r)) : pv;
+                x[T][r] = pv;
             }
         }
         // ---- O^T += V^T P^T: k-step kp covers the keys of score tiles 2kp, 2kp+1 (in the accumulators' own order)
-        const bf16x8 pb0 = pack8(x[0], x[1]), pb1 = pack8(x[2], x[3]);
+        const bf16x8 pb0 = DROP != 0 ? pack8_keep(x[0], bT[0], x[1], bT[1]) : pack8(x[0], x[1]);
+        const bf16x8 pb1 = DROP != 0 ? pack8_keep(x[2], bT[2], x[3], bT[3]) : pack8(x[2], x[3]);
         // 2 DT V fragments, read one ahead: the reads of fragment n+1 are in flight while fragment n feeds its MFMA
         TrFrag vf[2];
         tr_issue<VOFF>(fa, 0, vf[0]);

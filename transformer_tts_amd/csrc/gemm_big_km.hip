@@ -112,11 +112,11 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     struct Item { int m0, n0, tap, st0, st1, rot; int64_t aoff, boff, coff; };
     // balanced stream: the (at most two) parts of this workgroup, head of the second tile first
     int npart = 0, part_tile[2] = {0, 0}, part_s0[2] = {0, 0}, part_s1[2] = {0, 0};
+    // (workgroups b and b + 8 share an XCD: give each XCD a contiguous range of the list -- with the tile order below that is the
+    //  (column tile, tap) tiles of ONE row block of the output, which all read the same columns of A)
+    const int Lw = x * nslots + slot;
     if (stream_units > 0) {
         const long total = (long)nitems * nstk;               // (nitems = tiles x taps x batch here)
-        // (workgroups b and b + 8 share an XCD: give each XCD a contiguous range of the list -- with the tile order below that is the
-        //  (column tile, tap) tiles of ONE row block of the output, which all read the same columns of A)
-        const int Lw = x * nslots + slot;
         const long ubeg = (long)Lw * stream_units;
         if (ubeg >= total) return;
         const long uend = ubeg + stream_units < total ? ubeg + stream_units : total;
@@ -377,8 +377,12 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
         if (ws != nullptr) {
             // ---- sliced flush (fs2_wgrad_sliced): the 128 x 128 partial tile goes to slice `item` of the workspace with plain
             //      16-byte stores (64 KiB contiguous per workgroup, ~6 TB/s chip-wide against ~1.3 TB/s of float atomics);
-            //      fs2_wgrad_reduce adds the slices of every tile into the gradient.  Uniform k-split only (item = ibeg + j).
-            float4* dst = reinterpret_cast<float4*>(ws + (int64_t)(ibeg + j) * (TM * TN));
+            //      fs2_wgrad_reduce adds the slices of every tile into the gradient.  Uniform k-split: slice = item number ibeg + j.
+            //      Balanced stream: slice = Lw + tile -- strictly increasing along the unit list (workgroup L + 1 starts in the tile
+            //      workgroup L ended in, or a later one), so no two parts share a slice and the (<= nstk / U + 2) parts of tile z are the
+            //      slices L + z of the workgroups L whose unit range meets [z * nstk, (z + 1) * nstk).
+            const int64_t slice = stream_units > 0 ? (int64_t)Lw + part_tile[j == 0 ? 0 : 1] : (int64_t)(ibeg + j);
+            float4* dst = reinterpret_cast<float4*>(ws + slice * (TM * TN));
             const float4* src = reinterpret_cast<const float4*>(red);
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[tid + NT * i] = src[tid + NT * i];
@@ -512,7 +516,10 @@ int km_launch(const FS2Gemm& g, const KmPlan& pl, float* ws, hipStream_t st) {
 }
 
 // out[m][n] += alpha * sum_s ws[((y * splits + s) * tiles + tile) * 128 * 128 + ...]: one workgroup per (descriptor, batch item y, tile,
-// block of 8 rows), one float4 per thread, the slices of the k-split read 8 loads deep
+// block of 8 rows), one float4 per thread, the slices of the k-split read 8 loads deep.
+// Balanced-stream products (splits = -U < 0, reserved = stages of the whole reduction | conv flag): tile z of the stream's tile order (column
+// tile fastest, then tap, then row block, then batch) is the sum of the slices L + z of the workgroups L = z*nstk / U .. ((z+1)*nstk - 1) / U.
+constexpr int KM_STREAM_CONV = 1 << 30;
 struct ReduceArgs { FS2WgradPart parts[40]; int n; };
 __global__ __launch_bounds__(256) void wgrad_reduce_k(const ReduceArgs a) {
     int b = blockIdx.x, d = 0;
@@ -522,28 +529,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_k(const ReduceArgs a) {
     const int chunk = b & 15;
     b >>= 4;
     const int tiles = p.tilesM * p.tilesN;
-    const int y = b / tiles, tile = b - y * tiles;
-    const int m0 = (tile / p.tilesN) * TM, n0 = (tile % p.tilesN) * TN;
     const int tid = threadIdx.x;
     const int row = chunk * 8 + (tid >> 5), col = (tid & 31) * 4;
-    const int m = m0 + row, n = n0 + col;
-    if (m >= p.M || n >= p.N) return;
-    const int c2 = y % p.n2, b1 = y / p.n2;
-    const float* __restrict__ src = p.ws + ((int64_t)y * p.splits * tiles + tile) * (TM * TN) + row * TN + col;
-    const int64_t sstride = (int64_t)tiles * (TM * TN);
+    int tm, tn, c2, b1;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    int s = 0;
-    for (; s + 8 <= p.splits; s += 8) {
-        float4 w[8];
+    if (p.splits < 0) {
+        const int U = -p.splits, nstk = p.reserved & (KM_STREAM_CONV - 1);
+        int z = b;
+        tn = z % p.tilesN; z /= p.tilesN;
+        if (p.reserved & KM_STREAM_CONV) { c2 = z % p.n2; z /= p.n2; tm = z % p.tilesM; b1 = z / p.tilesM; }
+        else { tm = z % p.tilesM; z /= p.tilesM; c2 = z % p.n2; b1 = z / p.n2; }
+        if (tm * TM + row >= p.M || tn * TN + col >= p.N) return;
+        const long u0 = (long)b * nstk;
+        const int L0 = (int)(u0 / U), L1 = (int)((u0 + nstk - 1) / U);
+        const float* __restrict__ src = p.ws + ((int64_t)L0 + b) * (TM * TN) + row * TN + col;
+        for (int L = L0; L <= L1; ++L, src += TM * TN) {
+            const float4 w = *reinterpret_cast<const float4*>(src);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+    } else {
+        const int y = b / tiles, tile = b - y * tiles;
+        tm = tile / p.tilesN; tn = tile % p.tilesN;
+        if (tm * TM + row >= p.M || tn * TN + col >= p.N) return;
+        c2 = y % p.n2; b1 = y / p.n2;
+        const float* __restrict__ src = p.ws + ((int64_t)y * p.splits * tiles + tile) * (TM * TN) + row * TN + col;
+        const int64_t sstride = (int64_t)tiles * (TM * TN);
+        int s = 0;
+        for (; s + 8 <= p.splits; s += 8) {
+            float4 w[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride);
+            for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(src + (s + u) * sstride);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { v.x += w[u].x; v.y += w[u].y; v.z += w[u].z; v.w += w[u].w; }
+            for (int u = 0; u < 8; ++u) { v.x += w[u].x; v.y += w[u].y; v.z += w[u].z; v.w += w[u].w; }
+        }
+        for (; s < p.splits; ++s) {
+            const float4 w = *reinterpret_cast<const float4*>(src + s * sstride);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
     }
-    for (; s < p.splits; ++s) {
-        const float4 w = *reinterpret_cast<const float4*>(src + s * sstride);
-        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-    }
+    const int m = tm * TM + row, n = tn * TN + col;
     const float alpha = p.alpha * (p.scale_a != nullptr ? *p.scale_a : 1.f) * (p.scale_b != nullptr ? *p.scale_b : 1.f);    // (fp8 operands)
     float* o = p.dst + (int64_t)b1 * p.sC1 + (int64_t)c2 * p.sC2 + (int64_t)m * p.ldc + n;
     if (n + 3 < p.N && ((uintptr_t)o & 15) == 0) {
@@ -588,7 +612,7 @@ void fill_part(FS2WgradPart* part, const FS2Gemm& g, const float* ws, int tilesM
     const int taps = g.conv == 2 ? g.batch2 : 1, nb2 = g.conv == 2 ? 1 : g.batch2;
     part->ws = ws; part->dst = (float*)g.C; part->ldc = g.ldc; part->sC1 = g.sC1; part->sC2 = g.sC2;
     part->M = g.M; part->N = g.N; part->tilesM = tilesM; part->tilesN = tilesN; part->splits = splits;
-    part->n2 = g.conv == 2 ? taps : nb2; part->nbatch = (int)(base / ((long)tilesM * tilesN)); part->alpha = g.alpha; part->block_begin = 0;
+    part->n2 = g.conv == 2 ? taps : nb2; part->nbatch = (int)(base / ((long)tilesM * tilesN)); part->alpha = g.alpha; part->block_begin = 0; part->reserved = 0;
     part->scale_a = g.dtype == FS2_BF8_FP8 ? g.scale_a : nullptr;
     part->scale_b = g.dtype == FS2_BF8_FP8 ? g.scale_b : nullptr;
 }
@@ -596,8 +620,8 @@ void fill_part(FS2WgradPart* part, const FS2Gemm& g, const float* ws, int tilesM
 
 // Sliced weight gradient: the product of fs2_gemm(a_kmajor = b_kmajor = 1, accumulate = 1) with the partial tiles of the k-split stored
 // with plain stores into `ws` instead of float atomics on C; fs2_wgrad_reduce adds them to C later.  Returns the number of floats of
-// `ws` it used and fills `part` -- or 0 when the product does not run in the uniform k-split form (not eligible, balanced-stream
-// decomposition, workspace too small): the caller then uses fs2_gemm.  Negative: error.
+// `ws` it used and fills `part` -- or 0 when the product does not run in that form (not eligible, more than 256 output tiles, workspace
+// too small): the caller then uses fs2_gemm.  Negative: error.  part->splits > 0: uniform k-split; < 0: balanced stream (-units per workgroup).
 extern "C" int64_t fs2_wgrad_sliced(const FS2Gemm* gp, float* ws, int64_t ws_floats, FS2WgradPart* part, void* stream) {
     if (gp == nullptr || ws == nullptr || part == nullptr) { fs2_set_error("fs2_wgrad_sliced: null argument"); return FS2_EINVAL; }
     FS2Gemm g;
@@ -606,10 +630,24 @@ extern "C" int64_t fs2_wgrad_sliced(const FS2Gemm* gp, float* ws, int64_t ws_flo
     const int mode = e1 ? atoi(e1) : 1;
     KmPlan pl;
     if (mode == 0 || !km_plan(g, mode, pl, true)) return 0;
+    static const int stream_sliced = getenv("FS2_KM_STREAM_SLICED") ? atoi(getenv("FS2_KM_STREAM_SLICED")) : 1;      // 0: atomics (A/B measurements)
+    if (pl.stream_units > 0 && stream_sliced) {
+        // balanced stream: every workgroup stores its one or two partial tiles to slice (workgroup + tile) of the workspace
+        const int nstk = (g.K + BK - 1) / BK;
+        const long nwg = (pl.base * nstk + pl.stream_units - 1) / pl.stream_units;
+        const int64_t need = (nwg + pl.base) * (int64_t)(TM * TN);
+        if (need <= ws_floats) {
+            const int rc = km_launch(g, pl, ws, (hipStream_t)stream);
+            if (rc != FS2_OK) return rc;
+            fill_part(part, g, ws, pl.tilesM, pl.tilesN, -pl.stream_units, pl.base);
+            part->reserved = nstk | (g.conv == 2 ? KM_STREAM_CONV : 0);
+            return need;
+        }
+    }
     if (pl.stream_units > 0 || pl.nitems > pl.grid) {
-        // balanced stream, or more items than workgroups (> 256 output tiles): float-atomic flush straight into the gradient.  bf16
-        // operands take that road through fs2_gemm; fp8 operands (which fs2_gemm does not accept k-major) are launched here: the
-        // product is complete on return, nothing to reduce
+        // balanced stream without room in the workspace, or more items than workgroups (> 256 output tiles): float-atomic flush straight
+        // into the gradient.  bf16 operands take that road through fs2_gemm; fp8 operands (which fs2_gemm does not accept k-major) are
+        // launched here: the product is complete on return, nothing to reduce
         if (g.dtype != FS2_BF8_FP8) return 0;
         const int rc = km_launch(g, pl, nullptr, (hipStream_t)stream);
         if (rc != FS2_OK) return rc;
@@ -625,7 +663,7 @@ extern "C" int64_t fs2_wgrad_sliced(const FS2Gemm* gp, float* ws, int64_t ws_flo
 }
 
 // How fs2_wgrad_sliced / fs2_wgrad_grouped would run the product: 0 not at all (fs2_gemm's own kernels), 1 uniform k-split with partial
-// tiles (the only form that takes fp8 operands), 2 balanced stream (bf16, float-atomic flush through fs2_gemm)
+// tiles, 2 balanced stream (partial tiles when the workspace has room, else float atomics) or more than 256 output tiles (float atomics)
 extern "C" int fs2_wgrad_plan(const FS2Gemm* gp) {
     FS2Gemm g;
     if (gp == nullptr || !wgrad_desc_ok(gp, g)) return 0;
@@ -730,8 +768,12 @@ extern "C" int fs2_wgrad_reduce(const FS2WgradPart* parts, int n, void* stream) 
         int blocks = 0;
         for (int i = 0; i < a.n; ++i) {
             a.parts[i] = parts[i0 + i];
-            FS2_REQUIRE(a.parts[i].ws && a.parts[i].dst && a.parts[i].splits >= 1 && a.parts[i].tilesM >= 1 && a.parts[i].tilesN >= 1 && a.parts[i].nbatch >= 1 &&
+            FS2_REQUIRE(a.parts[i].ws && a.parts[i].dst && a.parts[i].splits != 0 && a.parts[i].tilesM >= 1 && a.parts[i].tilesN >= 1 && a.parts[i].nbatch >= 1 &&
                             a.parts[i].n2 >= 1, "fs2_wgrad_reduce: bad part %d", i0 + i);
+            if (a.parts[i].splits < 0) {          // balanced stream: U units per workgroup, never more than the stages of one tile
+                const int nstk = a.parts[i].reserved & (KM_STREAM_CONV - 1);
+                FS2_REQUIRE(nstk >= 1 && -a.parts[i].splits <= nstk, "fs2_wgrad_reduce: bad balanced-stream part %d", i0 + i);
+            }
             a.parts[i].block_begin = blocks;
             blocks += 16 * a.parts[i].nbatch * a.parts[i].tilesM * a.parts[i].tilesN;
         }

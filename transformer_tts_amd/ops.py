@@ -422,7 +422,7 @@ def _wgrad_fp8(g, dy, x):
     g2 = FS2Gemm.from_buffer_copy(g)
     g2.A, g2.B, g2.dtype = _p(a[0]), _p(b[0]), BF8_FP8
     g2.scale_a, g2.scale_b = _p(a[1][1:]), _p(b[1][1:])
-    if lib().fs2_wgrad_plan(ctypes.byref(g2)) == 0:       # (1: uniform k-split, partial tiles; 2: balanced stream, atomic flush)
+    if lib().fs2_wgrad_plan(ctypes.byref(g2)) == 0:       # (1: uniform k-split; 2: balanced stream / > 256 output tiles)
         return None
     return g2, (a, b)
 
@@ -575,7 +575,7 @@ class _WgradSlices:
     reduce.  One workspace per device, reused from offset 0 after every reduce (the stream is in order), so the same ~64 MiB stay hot.
     Deferred products (the models' backward, defer=True) are not even launched at once: up to four of them -- the weight gradients of
     one layer -- go into ONE launch when wgrad_flush() is called (or a fifth arrives); their operands are kept alive until then."""
-    FLOATS = 48 << 20          # 192 MiB: three products of 256 workgroups each hold 48 MiB
+    FLOATS = 128 << 20         # 512 MiB: the partial tiles of a whole backward pass (one reduce at its end) -- ~16-25 MiB per product
 
     def __init__(self):
         self.ws = {}
@@ -588,6 +588,7 @@ class _WgradSlices:
         self.enabled = os.environ.get("FS2_WGRAD_SLICED", "1") != "0"
         self.group = os.environ.get("FS2_WGRAD_GROUP", "1") != "0"
         self.on_group = None   # measurement hook: callable(descriptors, launch) that must call launch() once (bench.py)
+        self.on_one = None     # measurement hook for a product of a group launched on its own: callable(descriptor, launch) -> launch()
 
     def _ws(self, device):
         ws = self.ws.get(device)
@@ -626,8 +627,10 @@ class _WgradSlices:
         part = FS2WgradPart()
         if _bounds.ENABLED:
             _bounds.check_gemm(g, "fs2_wgrad_sliced")
+        def launch():
+            return lib().fs2_wgrad_sliced(ctypes.byref(g), ws.data_ptr() + 4 * self.off, self.FLOATS - self.off, ctypes.byref(part), _stream())
         for attempt in range(2):
-            used = lib().fs2_wgrad_sliced(ctypes.byref(g), ws.data_ptr() + 4 * self.off, self.FLOATS - self.off, ctypes.byref(part), _stream())
+            used = self.on_one(g, launch) if self.on_one is not None else launch()
             if used < 0:
                 _check(int(used), "fs2_wgrad_sliced")
             if used > 0 or not self.parts or attempt == 1:
@@ -635,7 +638,7 @@ class _WgradSlices:
             self._reduce()         # perhaps the workspace was full: retry from offset 0
         if used <= 0:
             return False
-        if part.splits > 0:             # (0: an fp8 product in the balanced-stream form, already added with float atomics)
+        if part.splits != 0:            # (0: an fp8 product flushed with float atomics, complete; < 0: balanced stream, partial tiles)
             if _bounds.ENABLED:
                 _bounds.check_part(part, ws.data_ptr() + 4 * self.off, 4 * int(used), "fs2_wgrad_sliced part")
             self.off += int(used)
