@@ -82,8 +82,9 @@ for step in "$@"; do
     pmcbench) cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
              run pmcb1 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcb1 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap
              run pmcb2 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcb2 -- python bench.py --steps 4 --warmup 8 --no-cpu-baseline --no-graph --no-overlap ;;
-    bounds)  # every GEMM / weight-gradient descriptor of the model tests and of one eager step per workload through the host-side validator
+    bounds)  # every GEMM / weight-gradient / flash-attention descriptor of the model tests and of one eager step per workload through the host-side validator
              FS2_CHECK_BOUNDS=1 run bounds_model 900 python -m pytest tests/test_model_gpu.py tests/test_ar_gpu.py -q -m gpu --timeout 600 -p no:cacheprovider -x
+             FS2_CHECK_BOUNDS=1 run bounds_kernels 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 300 -p no:cacheprovider -x -k "flash or wgrad or big_km or gemm or linear or conv"
              FS2_CHECK_BOUNDS=1 run bounds_cfg2 400 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph
              FS2_CHECK_BOUNDS=1 run bounds_cfg3 400 python bench.py --workload cfg3 --steps 3 --warmup 2 --no-cpu-baseline --no-graph
              FS2_CHECK_BOUNDS=1 run bounds_cfg4 400 python bench.py --workload cfg4 --fp8 --steps 3 --warmup 2 --no-cpu-baseline --no-graph ;;

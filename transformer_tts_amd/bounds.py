@@ -1,5 +1,5 @@
-"""FS2_CHECK_BOUNDS=1: host-side validation of every GEMM / weight-gradient descriptor before its launch (a debugging aid: the
-product path is unchanged without the switch).
+"""FS2_CHECK_BOUNDS=1: host-side validation of every GEMM / weight-gradient / flash-attention descriptor before its launch (a debugging
+aid: the product path is unchanged without the switch).
 
 Every operand of an FS2Gemm / FS2WgradPart is turned into the byte range [ptr, ptr + extent) its kernel may touch -- extents computed
 as the kernels' own guards do (16-byte chunks: a row is read up to the chunk that holds its last element; batch strides; the taps of a
@@ -155,3 +155,40 @@ def check_part(p, ws_ptr, ws_bytes, what="fs2_wgrad_reduce"):
     if not (ws_ptr <= lo and lo + n <= ws_ptr + ws_bytes):
         raise RuntimeError(f"FS2_CHECK_BOUNDS: {what}: partial tiles [{lo:#x}, +{n}) outside the workspace [{ws_ptr:#x}, +{ws_bytes})")
     check_ranges(r, what)
+
+
+def flash_ranges(d, backward, keep_words, probs=None, probs_batch=0):
+    """byte ranges a flash attention launch of descriptor d (include/fs2_hip.h, FS2FlashAttn) may read or write: rows of d.dk contiguous
+    bf16 at base + b * batch_stride + h * head_stride + row * row_stride for b < B, h < H, row < tq (queries: q, o, d_out, dq) or tk (keys:
+    k, v, dk_out, dv_out); the key mask, the row statistics, the keep-bit stash, aux, the bias-gradient vectors and the map"""
+    B, H, tq, tk = d.B, d.H, d.tq, d.tk
+
+    def rows(name, ptr, n, row, batch, esz=2):
+        return (name, ptr, ((B - 1) * abs(batch) + (H - 1) * abs(d.head_stride) + (n - 1) * abs(row) + d.dk) * esz)
+    out = [rows("q", d.q, tq, d.q_row_stride, d.q_batch_stride), rows("k", d.k, tk, d.kv_row_stride, d.kv_batch_stride),
+           rows("v", d.v, tk, d.kv_row_stride, d.kv_batch_stride), rows("o", d.o, tq, d.o_row_stride, d.o_batch_stride),
+           ("key_mask", d.key_mask, B * tk), ("stats", d.stats, B * H * tq * 2 * 4)]
+    if d.key_info:
+        out.append(("key_info", d.key_info, B * 3 * 4))
+    if d.p > 0:
+        out.append(("keep_bits", d.keep_bits, 2 * keep_words))
+        if not backward and not d.pregenerated:
+            out.append(("rng", d.rng, 16))
+    if backward:
+        out += [rows("d_out", d.d_out, tq, d.do_row_stride, d.do_batch_stride), ("aux", d.aux, B * H * tq * 4 * 4),
+                rows("dq", d.dq, tq, d.dq_row_stride, d.dq_batch_stride), rows("dk_out", d.dk_out, tk, d.dkv_row_stride, d.dkv_batch_stride),
+                rows("dv_out", d.dv_out, tk, d.dkv_row_stride, d.dkv_batch_stride)]
+        for nm in ("dbias_q", "dbias_k", "dbias_v"):
+            if getattr(d, nm):
+                out.append((nm, getattr(d, nm), H * d.dk * 4))
+    if probs is not None:
+        out.append(("probs", probs, ((B - 1) * abs(probs_batch) + H * tq * d.tkp) * 2))
+    return out
+
+
+def check_flash(d, what, backward=False, keep_words=0, probs=None, probs_batch=0):
+    STATS["descriptors"] += 1
+    assert d.B > 0 and d.H > 0 and d.tq > 0 and d.tk > 0 and d.dk in (64, 96, 128) and d.tkp == -(-d.tk // 8) * 8, \
+        f"FS2_CHECK_BOUNDS: {what}: bad shape B={d.B} H={d.H} tq={d.tq} tk={d.tk} dk={d.dk} tkp={d.tkp}"
+    check_ranges(flash_ranges(d, backward, keep_words, probs, probs_batch),
+                 f"{what} B={d.B} H={d.H} tq={d.tq} tk={d.tk} dk={d.dk} causal={d.causal} p={d.p:.3g}")

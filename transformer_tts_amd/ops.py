@@ -1145,6 +1145,20 @@ def _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p, causal, 
     return d
 
 
+def _flash_desc_bwd(d, d_out, aux, dq, dk_, dv, dbias):
+    H, dk = d.H, d.dk
+    d.d_out, d.do_row_stride, d.do_batch_stride, d.aux = _p(d_out), d_out.stride(2), d_out.stride(0), _p(aux)
+    d.dq, d.dk_out, d.dv_out = _p(dq), _p(dk_), _p(dv)
+    d.dq_row_stride, d.dq_batch_stride, d.dkv_row_stride, d.dkv_batch_stride = dq.stride(2), dq.stride(0), dk_.stride(2), dk_.stride(0)
+    if dbias is not None:
+        assert all(x.dtype == torch.float32 and x.is_contiguous() and x.numel() == H * dk for x in dbias)
+        d.dbias_q, d.dbias_k, d.dbias_v = (_p(x) for x in dbias)
+
+
+def _keep_words(d):
+    return flash_attn_keep_words_rect(d.B, d.H, d.tq, d.tk) if d.p > 0 else 0
+
+
 def flash_attention_fwd(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p=0.0, rng=None, site=0, causal=False, key_info=None,
                         pregenerated=False):
     """out = dropout_p(softmax(mask(alpha q k^T))) v without the probabilities in HBM, general form: q (B,H,tq,dk), k / v (B,H,tk,dk)
@@ -1153,6 +1167,8 @@ def flash_attention_fwd(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p=0
     (B,[layers],H,tq,tkp) probability tensor (the Philox counters of softmax_rect_fwd / attn_probs_fwd: the same masks)."""
     d = _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p, causal, key_info)
     d.rng, d.site, d.pregenerated = _rng_ptr(rng, p), site, int(bool(pregenerated))
+    if _bounds.ENABLED:
+        _bounds.check_flash(d, "fs2_flash_attention_fwd", keep_words=_keep_words(d))
     _check(lib().fs2_flash_attention_fwd(ctypes.byref(d), _stream()), "fs2_flash_attention_fwd")
 
 
@@ -1165,6 +1181,8 @@ def flash_attention_probs(q, k, v, key_mask, out, stats, keep, probs, alpha, p=0
     assert probs.dtype == torch.bfloat16 and probs.shape == (B, H, tq, tkp) and probs.stride()[1:] == (tq * tkp, tkp, 1)
     d = _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, 0, p, causal, key_info)
     d.pregenerated = 1
+    if _bounds.ENABLED:
+        _bounds.check_flash(d, "fs2_flash_attention_probs", keep_words=_keep_words(d), probs=_p(probs), probs_batch=probs.stride(0))
     _check(lib().fs2_flash_attention_probs(ctypes.byref(d), _p(probs), probs.stride(0), _stream()), "fs2_flash_attention_probs")
     return probs
 
@@ -1178,12 +1196,9 @@ def flash_attention_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_
     assert dk_.stride() == dv.stride() and dk_.stride(3) == 1 and dk_.stride(1) == q.stride(1) and dk_.shape == k.shape
     assert all(x.dtype == torch.bfloat16 for x in (d_out, dq, dk_, dv)) and aux.dtype == torch.float32 and aux.is_contiguous()
     assert aux.numel() == B * H * tq * 4
-    d.d_out, d.do_row_stride, d.do_batch_stride, d.aux = _p(d_out), d_out.stride(2), d_out.stride(0), _p(aux)
-    d.dq, d.dk_out, d.dv_out = _p(dq), _p(dk_), _p(dv)
-    d.dq_row_stride, d.dq_batch_stride, d.dkv_row_stride, d.dkv_batch_stride = dq.stride(2), dq.stride(0), dk_.stride(2), dk_.stride(0)
-    if dbias is not None:
-        assert all(x.dtype == torch.float32 and x.is_contiguous() and x.numel() == H * dk for x in dbias)
-        d.dbias_q, d.dbias_k, d.dbias_v = (_p(x) for x in dbias)
+    _flash_desc_bwd(d, d_out, aux, dq, dk_, dv, dbias)
+    if _bounds.ENABLED:
+        _bounds.check_flash(d, "fs2_flash_attention_bwd", backward=True, keep_words=_keep_words(d))
     _check(lib().fs2_flash_attention_bwd(ctypes.byref(d), _stream()), "fs2_flash_attention_bwd")
 
 
@@ -1223,6 +1238,10 @@ def flash_attn_fwd(q, k, v, key_mask, out, stats, keep, t, alpha, p_batch, p=0.0
         return flash_attention_fwd(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p, rng, site, False, key_info, pregenerated)
     if p > 0:
         assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t)
+    if _bounds.ENABLED:     # (the same kernels as the general entry point: validate the descriptor that one would build)
+        d = _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, p_batch, p, False, key_info)
+        d.rng, d.pregenerated = _rng_ptr(rng, p), int(bool(pregenerated))
+        _bounds.check_flash(d, "fs2_flash_attn_fwd", keep_words=_keep_words(d))
     _check(lib().fs2_flash_attn_fwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(key_info), _p(out),
                                     out.stride(2), out.stride(0), _p(stats), _p(keep) if p > 0 else None, int(bool(pregenerated)), int(p_batch), B, H, t,
                                     (t + 7) // 8 * 8, float(alpha), p, _rng_ptr(rng, p), site, _stream()), "fs2_flash_attn_fwd")
@@ -1244,6 +1263,10 @@ def flash_attn_bwd(q, k, v, key_mask, out, d_out, stats, keep, aux, dq, dk_, dv,
         assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t)
     if dbias is not None:
         assert all(x.dtype == torch.float32 and x.is_contiguous() and x.numel() == H * dk for x in dbias)
+    if _bounds.ENABLED:
+        d = _flash_desc(q, k, v, key_mask, out, stats, keep, alpha, 0, p, False, key_info)
+        _flash_desc_bwd(d, d_out, aux, dq, dk_, dv, dbias)
+        _bounds.check_flash(d, "fs2_flash_attn_bwd", backward=True, keep_words=_keep_words(d))
     _check(lib().fs2_flash_attn_bwd(_p(q), _p(k), _p(v), q.stride(2), q.stride(0), q.stride(1), _p(_c(key_mask)), _p(key_info), _p(out),
                                     out.stride(2), out.stride(0), _p(d_out), d_out.stride(2), d_out.stride(0), _p(stats),
                                     _p(keep) if p > 0 else None, _p(aux), _p(dq), _p(dk_), _p(dv), dq.stride(2), dq.stride(0),
