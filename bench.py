@@ -207,14 +207,28 @@ class GemmTimer:
         return agg
 
     def by_shape(self):
+        """per product shape: launches, time, TFLOP/s, algorithmic MB per launch and GB/s, and the product's own roofline floor
+        max(bytes / 8 TB/s, FLOP / 2.5 PFLOP/s) with the ratio measured / floor; a footer sums both per kernel family"""
         agg = {}
         for key, flops, s, e, shape, abytes in self.records:
-            a = agg.setdefault(key[:3] + shape, [0.0, 0.0, 0])
-            a[0] += flops; a[1] += max(s.elapsed_time(e) - self.overhead_ms, 1e-4); a[2] += 1
-        lines = ["variant M N K taps batch split epilogue(b=bias r=relu m=relu_mask +=residual sN=colstats a=accumulate f=fp32 out) | launches total_ms avg_us TFLOP/s"]
-        for k, (fl, ms, n) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            a = agg.setdefault(key[:3] + shape, [0.0, 0.0, 0, 0.0, key[3]])
+            a[0] += flops; a[1] += max(s.elapsed_time(e) - self.overhead_ms, 1e-4); a[2] += 1; a[3] += abytes
+        lines = ["variant M N K taps batch split epilogue(b=bias r=relu m=relu_mask +=residual sN=colstats a=accumulate f=fp32 out) | launches total_ms avg_us "
+                 "TFLOP/s | algorithmic MB/launch GB/s | floor_us = max(MB / 8 TB/s, FLOP / 2.5 PFLOP/s) bound measured/floor"]
+        fam = {}
+        for k, (fl, ms, n, by, tile) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            t_hbm, t_mfma = by / 8.0e12 * 1e3, fl / 2.5e15 * 1e3          # ms over all launches of the shape
+            floor = max(t_hbm, t_mfma)
             lines.append(f"{'/'.join(k[:3])} {k[3]} {k[4]} {k[5]} {k[6]} {k[7]} {k[8]} {k[9]} | {n} {ms:.2f} {ms * 1e3 / n:.1f} "
-                         f"{fl / (ms * 1e-3) / 1e12:.1f}")
+                         f"{fl / (ms * 1e-3) / 1e12:.1f} | {by / n / 1e6:.1f} {by / (ms * 1e-3) / 1e9:.0f} | {floor * 1e3 / n:.1f} "
+                         f"{'hbm' if t_hbm >= t_mfma else 'mfma'} {ms / floor:.2f}")
+            f = fam.setdefault(family(tile), [0.0, 0.0, 0.0, 0.0])
+            f[0] += ms; f[1] += floor; f[2] += t_hbm; f[3] += t_mfma
+        lines.append("family: measured_ms  sum of per-product floors_ms (hbm-only, mfma-only)  measured/floor   [over the instrumented steps]")
+        for name, (ms, floor, th, tm) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+            lines.append(f"{name}: {ms:.2f}  {floor:.2f} ({th:.2f}, {tm:.2f})  {ms / floor:.2f}")
+        tot = [sum(v[i] for v in fam.values()) for i in range(4)]
+        lines.append(f"all GEMMs: {tot[0]:.2f}  {tot[1]:.2f} ({tot[2]:.2f}, {tot[3]:.2f})  {tot[0] / tot[1]:.2f}")
         return "\n".join(lines)
 
 

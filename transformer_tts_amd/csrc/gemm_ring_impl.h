@@ -46,18 +46,27 @@ template <int WTM> struct RG {
     static constexpr int SMAX = WTM == 32 ? 3 : 2;
 };
 
+template <int N> struct IC { static constexpr int value = N; };
+
 // 16-B chunk swizzles: A rows are read 16 consecutive rows per fragment; weight rows 16*(i>>2) + 4*jt + (i&3)
 __device__ __forceinline__ int fA(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int fB(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
 
-// wait until at most n of this wave's vector-memory operations are outstanding, and for its LDS reads; then the workgroup barrier
+// wait until at most n of this wave's vector-memory operations are outstanding, and for its LDS reads; then the workgroup barrier.
+// s_waitcnt takes an immediate: n is rounded DOWN to one of six counts (waiting for a few operations more than necessary is always
+// right) -- a switch over every count compiled into a tree of ~10 taken branches and ~25 scalar instructions on the path of the hot
+// counts, and every scalar instruction between a slot barrier and the first MFMA behind it costs its full latency: all waves of the
+// workgroup run this section at the same moment, nothing overlaps it (measured: 64 extra s_add per slot = +0.34 us per slot,
+// profiles/r04_ring_probe.txt)
 __device__ __forceinline__ void wait_barrier(int n) {
-#define FS2_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    switch (n) {
-        FS2_W(0) FS2_W(1) FS2_W(2) FS2_W(3) FS2_W(4) FS2_W(5) FS2_W(6) FS2_W(7) FS2_W(8) FS2_W(9) FS2_W(10) FS2_W(11) FS2_W(12)
-        FS2_W(13) FS2_W(14) FS2_W(15) FS2_W(16) FS2_W(17) FS2_W(18) FS2_W(19) FS2_W(20) FS2_W(21) FS2_W(22) FS2_W(23)
-        default: asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    }
+#define FS2_W(N) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // (the steady-state counts first: 0 with a 2-deep ring, 3 or 4 = the pieces of one younger slot with a 3-deep ring)
+    if (__builtin_expect(n < 3, 1)) { FS2_W(0); return; }
+    if (__builtin_expect(n == 3, 1)) { FS2_W(3); return; }
+    if (n < 6) { FS2_W(4); return; }
+    if (n < 8) { FS2_W(6); return; }
+    if (n < 12) { FS2_W(8); return; }
+    FS2_W(12);
 #undef FS2_W
 }
 
@@ -158,30 +167,43 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
         ltap = s0 / nkt;
         lkb = (s0 - ltap * nkt) * SK;
     };
-    auto issue = [&]() __attribute__((always_inline)) {
+    // (as few instructions as possible: this runs between a slot barrier and the MFMAs behind it.  The per-lane offsets already say OOB
+    //  for rows outside the matrix; only the last k-slot of a row whose K is not a multiple of the slot, and the taps of a convolution
+    //  at the ends of an utterance, need a per-lane decision: two instantiations, chosen by a workgroup-uniform branch)
+    auto issue_pieces = [&](auto PLAINC) __attribute__((always_inline)) {
+        constexpr bool PLAIN = decltype(PLAINC)::value != 0;
         const int kb = lkb, tap = ltap;
-        const int sA = (tap * lda + kb) * ES;
-        const int sB = (tap * p.K + kb) * ES;
+        const int sA = PLAIN ? kb * ES : (tap * lda + kb) * ES;
+        const int sB = PLAIN ? kb * ES : (tap * p.K + kb) * ES;
         unsigned char* base = smem + rp_i + 1024 * wave;
+        const bool ktail = !PLAIN && kb + SK > p.K;             // (workgroup-uniform)
 #pragma unroll
         for (int i = 0; i < G::AI; ++i) {
             if (i * NW + wave < G::AQ) {          // wave-uniform (BM = 192: 24 pieces for 16 waves)
-                bool ok = voffA[i] != OOB;
-                if (!plain) {
-                    ok = ok && (kb + a_k8(i) < p.K);
-                    if (conv) ok = ok && ((unsigned)(tA[i] + tap) < (unsigned)p.seq_len);
+                unsigned v = voffA[i];
+                if constexpr (!PLAIN) {
+                    if (conv) v = ((unsigned)(tA[i] + tap) < (unsigned)p.seq_len) ? v : OOB;
+                    if (ktail) v = (kb + a_k8(i) < p.K) ? v : OOB;
                 }
                 // (voffset must be an int expression: an unsigned one makes the host-side instantiation of the kernel template fail
                 //  silently -- no stub, undefined symbol when the library is loaded)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)(ok ? voffA[i] : OOB), sA, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)v, sA, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < G::BI; ++i) {
-            bool ok = voffB[i] != OOB;
-            if (!plain) ok = ok && (kb + b_k8(i) < p.K);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + G::A_BYTES + 1024 * NW * i), 16, (int)(ok ? voffB[i] : OOB), sB, 0, 0);
+            unsigned v = voffB[i];
+            if constexpr (!PLAIN) {
+                if (ktail) v = (kb + b_k8(i) < p.K) ? v : OOB;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + G::A_BYTES + 1024 * NW * i), 16, (int)v, sB, 0, 0);
         }
+    };
+    auto issue_dma = [&]() __attribute__((always_inline)) {
+        if (plain) issue_pieces(IC<1>{});
+        else issue_pieces(IC<0>{});
+    };
+    auto advance_cursor = [&]() __attribute__((always_inline)) {
         lkb += SK;
         if (lkb >= p.K) { lkb = 0; ++ltap; }
         if (++lsl == lend) {
@@ -192,6 +214,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
         rp_i += SLOT;
         if (rp_i == ring_bytes) rp_i = 0;
     };
+    auto issue = [&]() __attribute__((always_inline)) { issue_dma(); advance_cursor(); };
 
     // ---- fragment read addresses (lane part; A row tile `it` adds it*2048, weight tile jt adds jt*512, ring position rp_c):
     //      bf16: k-step ks (32 k = 64 B) of a row is chunks 4ks .. 4ks+3, lane group g takes chunk 4ks + g (8 elements);
@@ -413,16 +436,29 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     // W = S - 1 when the slot issue of an item-end iteration precedes its epilogue, S - 2 when it follows it (EPI_LOADS).
     int since_epi = 1 << 20;
     constexpr int W_OFF = EPI_LOADS ? 2 : 1;
+    // Order inside a slot (bf16): barrier -> LDS reads of the first k-step -> LDS-DMA requests of slot t+S-1 -> MFMAs -> bookkeeping.
+    // Every wave of the workgroup leaves the barrier at the same moment and nothing overlaps what a wave does before its first MFMA:
+    // each scalar instruction there costs the whole workgroup its latency (measured: 64 extra s_add per slot = +0.34 us per slot; slot
+    // time = matrix time + ~0.4 us at every tile height before this order, profiles/r04_ring_probe.txt).  So the wait count of the NEXT
+    // barrier, the load cursor and the ring pointers are updated BEHIND the MFMAs (the matrix pipes are still draining then), and the
+    // DMA requests sit in the shadow of the fragment reads' latency.
+    auto next_wait = [&](int t1) __attribute__((always_inline)) {
+        const int younger = (S - 2 < nst - 1 - t1) ? S - 2 : nst - 1 - t1;        // slots issued after slot t1 by the time it is awaited
+        return younger * pw + (since_epi <= S - W_OFF ? NSTORES : 0);
+    };
+    int n_wait = next_wait(0);
 
+    constexpr bool LEGACY = ES == 2 && MT == 3 && HAS_MASK && STATS;     // (the one instance whose registers do not allow the new order)
     for (int t = 0; t < nst; ++t) {
-        const int younger = (S - 2 < nst - 1 - t) ? S - 2 : nst - 1 - t;        // slots issued after slot t so far
-        wait_barrier(younger * pw + (since_epi <= S - W_OFF ? NSTORES : 0));
+        if constexpr (LEGACY) n_wait = next_wait(t);
+        wait_barrier(n_wait);
         const bool tile_end = (csl + 1 == cend);
         const bool more = t + S - 1 < nst;
         // slot t+S-1 -> the ring position every wave finished reading before the barrier it has just passed
-        if (more && !(EPI_LOADS && tile_end)) issue();
-        __builtin_amdgcn_sched_barrier(0);
+        const bool do_issue = !LEGACY && more && !(EPI_LOADS && tile_end);
         if constexpr (ES == 1) {
+            if (do_issue) issue_dma();
+            __builtin_amdgcn_sched_barrier(0);
             typedef __attribute__((ext_vector_type(8))) int i32x8;
             const unsigned char* lb = smem + rp_c;
             union F8 { struct { u32x4 lo, hi; } s; i32x8 v; };
@@ -450,20 +486,64 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
                 }
             }
         } else {
+            // (the instance with ReLU mask + column sums at 192 rows has no register to spare: requests first, plain fragment order)
+            constexpr bool TIGHT = MT >= 4 || (MT == 3 && HAS_MASK && STATS);
             const unsigned char* lb = smem + rp_c;
+            bf16x8 fa[MT], fb[4];
+            if constexpr (TIGHT && MT == 3) {
+                if (more && !(EPI_LOADS && tile_end)) issue();
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[MT], fb[4];
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(lb + rdA[0] + i * 2048);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(lb + rdA[ks] + i * 2048);
+            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rdB[0] + j * 512);
+            if constexpr (!(TIGHT && MT == 3)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (do_issue) issue_dma();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (!TIGHT) {
+                // the weight fragments of the second k-step are requested before the first k-step's MFMAs, its activation fragments
+                // into the registers of the first k-step's as those retire: the second k-step starts without an LDS round trip in
+                // front of it (the 256-row tile has no registers for the second weight set: plain order there)
+                bf16x8 fb2[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rdB[ks] + j * 512);
+                for (int j = 0; j < 4; ++j) fb2[j] = *reinterpret_cast<const bf16x8*>(lb + rdB[1] + j * 512);
+                __builtin_amdgcn_sched_barrier(0);        // (hipcc otherwise sinks these reads to just in front of their first use)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]: weights as the A operand
+                    fa[i] = *reinterpret_cast<const bf16x8*>(lb + rdA[1] + i * 2048);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);   // D[n][m]: weights as the A operand
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb2[j], fa[i], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(lb + rdA[1] + i * 2048);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(lb + rdB[1] + j * 512);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LEGACY) {
+            if (do_issue) advance_cursor();
         }
         rp_c += SLOT;
         if (rp_c == ring_bytes) rp_c = 0;
@@ -480,6 +560,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
         } else {
             ++csl;
         }
+        if constexpr (!LEGACY) n_wait = next_wait(t + 1);
         __builtin_amdgcn_sched_barrier(0);
     }
 

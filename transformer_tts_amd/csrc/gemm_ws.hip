@@ -41,15 +41,16 @@ constexpr int EPI_MASK = 1, EPI_RES_F32 = 2, EPI_RES_BF16 = 4, EPI_STATS = 8, EP
 
 __device__ __forceinline__ int fA(int r) { return (r >> 1) & 7; }
 
-__device__ __forceinline__ void ws_wait_barrier(int n) {
-#define FS2_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    switch (n) {
-        FS2_W(0) FS2_W(1) FS2_W(2) FS2_W(3) FS2_W(4) FS2_W(5) FS2_W(6) FS2_W(7) FS2_W(8) FS2_W(9) FS2_W(10) FS2_W(11) FS2_W(12)
-        FS2_W(13) FS2_W(14) FS2_W(15) FS2_W(16) FS2_W(17) FS2_W(18) FS2_W(19) FS2_W(20) FS2_W(21) FS2_W(22) FS2_W(23) FS2_W(24)
-        FS2_W(25) FS2_W(26) FS2_W(27) FS2_W(28) FS2_W(29) FS2_W(30) FS2_W(31)
-        default: asm volatile("s_waitcnt vmcnt(32) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
-    }
-#undef FS2_W
+// wait until at most 8 + NST * nepi of this wave's vector-memory operations are outstanding (the pieces of two younger slabs and the stores of
+// `nepi` <= 3 epilogues), and for its LDS reads; then the workgroup barrier.  s_waitcnt takes an immediate: four cases, the steady state
+// (nepi = 3) first -- a switch over every count compiled into a tree of taken branches on the path between a barrier and the work behind it
+template <int NST>
+__device__ __forceinline__ void ws_wait_barrier(int nepi) {
+    constexpr int N3 = 8 + 3 * NST > 63 ? 63 : 8 + 3 * NST, N2 = 8 + 2 * NST > 63 ? 63 : 8 + 2 * NST, N1 = 8 + NST;
+    if (__builtin_expect(nepi >= 3, 1)) { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N3) : "memory"); return; }
+    if (nepi == 2) { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N2) : "memory"); return; }
+    if (nepi == 1) { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N1) : "memory"); return; }
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 }  // namespace
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(512, 2) void fs2_gemm_ws_kernel(const FS2Gemm p, co
         if (sl >= ns) { plain_barrier(); return; }
         int nepi = wr == 0 ? sl : sl - 1;
         nepi = nepi < 0 ? 0 : (nepi > WS_RING - 1 ? WS_RING - 1 : nepi);
-        ws_wait_barrier(4 * (WS_RING - 2) + NSTORES * nepi);
+        static_assert(WS_RING == 4, "the wait counts assume two younger slabs");
+        ws_wait_barrier<NSTORES>(nepi);
         issue();
     };
     auto mfma_phase = [&](int sl) __attribute__((always_inline)) {
