@@ -5,7 +5,7 @@ budget of every kernel family:
 
     fs2_gemm_ring_kernel   <= 128 VGPRs (four waves per SIMD), 0 bytes of scratch -- every instance, bf16 and fp8
     fs2_gemm_ws_kernel     <= 256 VGPRs (two waves per SIMD),  0 bytes of scratch -- every instance
-    fs2_gemm_big_km_kernel <= 128 VGPRs, <= 32 bytes of scratch (outside the stage loop)
+    fs2_gemm_big_km_kernel <= 128 VGPRs, 0 bytes of scratch -- every instance
 
     python tools/check_resources.py            # prints one line per instance, exit code 1 on a violation
 """
@@ -21,10 +21,8 @@ BUDGET = {            # kernel-name prefix -> (source file, max VGPRs, max scrat
     "fs2_gemm_ring_kernel": ("gemm_ring.hip", 128, 0),
     "fs2_gemm_ring_kernel ": ("gemm_ring_f8.hip", 128, 0),      # (the one-byte-operand instances: same kernel template, own source file)
     "fs2_gemm_ws_kernel": ("gemm_ws.hip", 256, 0),
-    # (weight-gradient kernel: 6 dwords of per-item state are parked in scratch before the stage loop and reloaded for the flush -- no
-    #  scratch access inside the loop, checked in the ISA: the 6 stores precede the first v_mfma, the 6 loads follow the last)
-    "fs2_gemm_big_km_kernel": ("gemm_big_km.hip", 128, 32),
-    "fs2_gemm_big_km_grouped_kernel": ("gemm_big_km.hip", 128, 32),
+    "fs2_gemm_big_km_kernel": ("gemm_big_km.hip", 128, 0),
+    "fs2_gemm_big_km_grouped_kernel": ("gemm_big_km.hip", 128, 0),
 }
 
 

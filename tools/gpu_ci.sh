@@ -67,10 +67,6 @@ for step in "$@"; do
              FS2_GEMM_RING=1 run abring1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_GEMM_RING=2 run abring2b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_GEMM_WS=2 run abws2b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline ;;
-    abkg)    FS2_KM_KG=4 run abkg4 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
-             run abkg2 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
-             FS2_KM_KG=4 run abkg4b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
-             run abkg2b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline ;;
     abwg)    FS2_WGRAD_SLICED=0 run abwg0 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_WGRAD_SLICED=1 run abwg1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_WGRAD_SLICED=0 run abwg0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline

@@ -25,6 +25,7 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+template <int N> struct KIC { static constexpr int value = N; };
 
 constexpr unsigned OOB = 0x80000000u;
 constexpr int NT = 1024, NW = 16, TM = 128, TN = 128, BK = 128;
@@ -68,8 +69,9 @@ extern thread_local int g_last_tile;     // gemm.hip
 // product, a sub-range of the grid in a grouped launch (fs2_gemm_big_km_grouped_kernel: several products, one launch)
 // ES: bytes per operand element -- 2: bf16; 1: fp8 (A = dY in e5m2, B = X in e4m3: the copies the data-gradient / forward products of the
 // fp8 operand mode already hold; half the staged and LDS-read bytes per multiply-add on a kernel that is bound by exactly those)
-// KG: k-groups inside the workgroup.  4 (round 2 / fp8): 128 reduction rows per stage, 4 x (2 x 2 waves of 64 x 64).  2 (bf16, round 3): 64
-// rows per stage = 32 KiB, so the 128 KiB hold a 4-deep ring with THREE stages in flight (the 64 KiB stages of the KG = 4 form: one) --
+// KG: k-groups inside the workgroup.  4 (fp8): 128 reduction rows per stage of 32 KiB, 4 x (2 x 2 waves of 64 x 64).  2 (bf16, round 3): 64
+// rows per stage = 32 KiB, so the 128 KiB hold a 4-deep ring with THREE stages in flight (the bf16 form of round 2 -- four k-groups, 64 KiB
+// stages, one in flight -- was retired in round 4) --
 // the operands of a weight gradient were just written by other kernels, and how many bytes a CU keeps outstanding decides how fast they
 // arrive; 2 x (2 x 4 waves of 64 x 32): 32 accumulators per lane, 6 fragments per 8 MFMAs (LDS reads x 1.5, under the MFMA time).
 template <int ES, int KG = 4>
@@ -78,7 +80,7 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    static_assert(KG == 4 || (KG == 2 && ES == 2), "two k-groups: bf16 only");
+    static_assert((KG == 4 && ES == 1) || (KG == 2 && ES == 2), "bf16: two k-groups; fp8: four");
     constexpr int NJ = KG == 2 ? 2 : 4;              // 16-column blocks of a wave's output tile (64 x 64 or 64 x 32)
     constexpr int SROWS = KG == 2 ? 64 : BK;          // reduction rows per stage
     const int kg = KG == 2 ? wave >> 3 : wave >> 2, wr = KG == 2 ? (wave >> 2) & 1 : (wave >> 1) & 1, wc = KG == 2 ? wave & 3 : wave & 1;
@@ -171,38 +173,73 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     auto dma_row = [&](int i) { return ES == 2 ? 4 * (i * NW + wave) + (lane >> 4) : 8 * wave + (lane >> 3); };
     auto dma_col = [&](int i) { return ES == 2 ? ((lane & 15) ^ km_f(dma_row(i))) * 8 : ((lane & 7) ^ km_f8(dma_row(i))) * 16; };
 
+    // Per work item: the per-lane byte offsets of the lane's 16-byte chunk in reduction row dma_row(i) of the item's operands (OOB outside the
+    // matrix' columns), and the scalar byte offset of the next stage's first row -- a stage request is then an s_mov m0 + a buffer_load per
+    // piece.  What a wave does between a stage barrier and its first MFMA is paid by the whole workgroup (every wave is there at the same
+    // moment; measured on the ring kernel: profiles/r04_d_ring_slot_overhead.txt), and the per-stage form of this address arithmetic
+    // was ~70 vector instructions (a 32 x 32 multiply, a modulo for the taps) for 8 MFMAs.  Row validity: only the last stage of a
+    // reduction can cross K (workgroup-uniform test); Conv1d taps (conv = 2): the frame index of the lane's row is carried along, the
+    // base address is moved back by `pad` rows so that the scalar offset (rows + tap) is never negative.
     __amdgpu_buffer_rsrc_t rsA, rsB;
-    bool colA[2], colB[2];
+    unsigned voA[NI], voB[NI];
+    int tB[NI];
+    int sA = 0, sB = 0;
     Item ck;
     int lst = 0;                          // next stage to stage
+    const bool conv2 = p.conv == 2;
     auto prep = [&](const Item& k) {
         rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.A) + k.aoff * ES), 0, 0x7FFFFFF0, 0x00020000);
-        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.B) + k.boff * ES), 0, 0x7FFFFFF0, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const unsigned char*>(p.B) + (k.boff - (conv2 ? (int64_t)p.pad * ldb : 0)) * ES), 0,
+                                                0x7FFFFFF0, 0x00020000);
+        lst = k.st0 * (BK / SROWS);
+        const int kb0 = lst * SROWS;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            colA[i] = k.m0 + dma_col(i) < p.M;
-            colB[i] = k.n0 + dma_col(i) < p.N;
+            voA[i] = k.m0 + dma_col(i) < p.M ? (unsigned)((dma_row(i) * lda + k.m0 + dma_col(i)) * ES) : OOB;
+            voB[i] = k.n0 + dma_col(i) < p.N ? (unsigned)((dma_row(i) * ldb + k.n0 + dma_col(i)) * ES) : OOB;
+            tB[i] = conv2 ? (kb0 + dma_row(i)) % seq : 0;
         }
+        sA = kb0 * lda * ES;
+        sB = (kb0 + (conv2 ? k.tap : 0)) * ldb * ES;
     };
     auto issue = [&](int buf) __attribute__((always_inline)) {
         const int kb = lst * SROWS;
-        const int shiftB = p.conv == 2 ? ck.tap - p.pad : 0;
         unsigned char* base = smem + buf * SBYTES + 1024 * wave;
+        if constexpr (ES == 1) {
+            // (fp8 operands: the per-stage form of the arithmetic -- with the lean requests below the configs[4] step in fp8 measured 0.8 %
+            //  SLOWER, 30.3 -> 30.55 ms, alternating builds on one box; the bf16 kernel gains 4-7 % from them)
+            const int shiftB = conv2 ? ck.tap : 0;                  // (rsB starts `pad` rows before the matrix)
+            const int kk = kb + dma_row(0);
+            const bool okA = voA[0] != OOB && kk < p.K;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)base, 16, (int)(okA ? (unsigned)((kk * lda + ck.m0 + dma_col(0)) * ES) : OOB), 0, 0, 0);
+            bool okB = voB[0] != OOB && kk < Kb;
+            if (conv2) { const int tt = (kk % seq) + ck.tap - p.pad; okB = okB && tt >= 0 && tt < seq; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + OPB), 16,
+                                                     (int)(okB ? (unsigned)(((kk + shiftB) * ldb + ck.n0 + dma_col(0)) * ES) : OOB), 0, 0, 0);
+            ++lst;
+            return;
+        }
+        const bool tailA = kb + SROWS > p.K, tailB = kb + SROWS > Kb;          // (workgroup-uniform)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int kk = kb + dma_row(i);
-            const bool ok = colA[i] && kk < p.K;
-            const unsigned off = (unsigned)((kk * lda + ck.m0 + dma_col(i)) * ES);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)(ok ? off : OOB), 0, 0, 0);
+            unsigned v = voA[i];
+            if (tailA) v = kb + dma_row(i) < p.K ? v : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)v, sA, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int kk = kb + dma_row(i);
-            bool ok = colB[i] && kk < Kb;
-            if (p.conv == 2) { const int tt = (kk % seq) + shiftB; ok = ok && tt >= 0 && tt < seq; }
-            const unsigned off = (unsigned)(((kk + shiftB) * ldb + ck.n0 + dma_col(i)) * ES);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + OPB + 1024 * NW * i), 16, (int)(ok ? off : OOB), 0, 0, 0);
+            unsigned v = voB[i];
+            if (tailB) v = kb + dma_row(i) < Kb ? v : OOB;
+            if (conv2) {
+                v = (unsigned)(tB[i] + ck.tap - p.pad) < (unsigned)seq ? v : OOB;
+                tB[i] += SROWS;
+                if (seq >= SROWS) tB[i] = tB[i] >= seq ? tB[i] - seq : tB[i];
+                else tB[i] %= seq;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + OPB + 1024 * NW * i), 16, (int)v, sB, 0, 0);
         }
+        sA += SROWS * lda * ES;
+        sB += SROWS * ldb * ES;
         ++lst;
     };
 
@@ -212,7 +249,6 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
     for (int j = jbeg; j < jend; j += jstep) {
         ck = decode(j);
         prep(ck);
-        lst = ck.st0 * (BK / SROWS);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -222,25 +258,36 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
             // ---- bf16, two k-groups: 4-deep ring of 32 KiB stages, as the fp8 path below
             const int pre = nst < 3 ? nst : 3;
             for (int i = 0; i < pre; ++i) issue(i);
-            for (int s = 0; s < nst; ++s) {
-                const int younger = nst - 1 - s < 2 ? nst - 1 - s : 2;
-                if (younger == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // one stage; the ring position is a compile-time constant (the loop below is unrolled by the ring depth): the fragment addresses
+            // are lane offsets + immediates instead of twelve vector adds per stage.  Order: barrier -> fragment reads -> the request of
+            // stage s+3 (in the shadow of the reads' latency) -> MFMAs.
+            auto stage = [&](auto BUFC, const int s) __attribute__((always_inline)) {
+                constexpr int BUF = decltype(BUFC)::value;
+                const int younger = nst - 1 - s;
+                if (__builtin_expect(younger >= 2, 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else if (younger == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (s + 3 < nst) issue((s + 3) & 3);
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned char* la = smem + (s & 3) * SBYTES;
+                const unsigned char* la = smem + BUF * SBYTES;
                 const unsigned char* lb = la + OPB;
                 bf16x8 fa[4], fb[2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fa[i] = km_frag(la, wr * 64 + i * 16, 32 * kg, lane);
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) fb[jj] = km_frag(lb, wc * 32 + jj * 16, 32 * kg, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 3 < nst) issue((BUF + 3) & 3);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+            };
+            for (int s = 0; s < nst; s += 4) {
+                stage(KIC<0>{}, s);
+                if (s + 1 < nst) stage(KIC<1>{}, s + 1);
+                if (s + 2 < nst) stage(KIC<2>{}, s + 2);
+                if (s + 3 < nst) stage(KIC<3>{}, s + 3);
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else if constexpr (ES == 1) {
@@ -250,9 +297,10 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
             //      after it) remain; the buffer stage s+3 goes into was read in iteration s-1, before the barrier every wave has just passed.
             const int pre = nst < 3 ? nst : 3;
             for (int i = 0; i < pre; ++i) issue(i);
+            // (request first, ring position at run time: the reads-first / unrolled order of the bf16 stage above measured 1-3 % SLOWER here)
             for (int s = 0; s < nst; ++s) {
-                const int younger = nst - 1 - s < 2 ? nst - 1 - s : 2;
-                if (younger == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const int younger = nst - 1 - s;
+                if (__builtin_expect(younger >= 2, 1)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else if (younger == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (s + 3 < nst) issue((s + 3) & 3);
@@ -271,37 +319,6 @@ __device__ __forceinline__ void km_body(const FS2Gemm& p, const int tilesM, cons
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else {
-        issue(0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        for (int s = 0; s < nst; ++s) {
-            const int buf = s & 1;
-            // stage s+1 -> the buffer every wave finished with at the last barrier.  The vector-memory path of a CU takes ~1000
-            // cycles for the 64 KiB of a stage and a wave BLOCKS at its DMA instructions while the queue is full (shader-clock stamps:
-            // 12-27 % of a workgroup's time); with every wave issuing first, all four waves of a SIMD sat there together and the MFMA
-            // pipe idled.  Half of the waves (two per SIMD) therefore issue their share AFTER their MFMAs: -8...12 % warm, -4...7 % cold on
-            // the stand-alone products (tools/gemm_big_bench.py), 0.5 % inside the training step.
-            const bool issue_first = ((wave >> 2) & 1) != 0;
-            if (issue_first && s + 1 < nst) issue(buf ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned char* la = smem + buf * SBYTES;
-            const unsigned char* lb = la + OPB;
-            {
-                bf16x8 fa[4], fb[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = km_frag(la, wr * 64 + i * 16, 32 * kg, lane);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) fb[jj] = km_frag(lb, wc * 64 + jj * 16, 32 * kg, lane);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);         // (or hipcc moves the late issue back up in front of the MFMAs)
-            if (!issue_first && s + 1 < nst) issue(buf ^ 1);
-            // own DMA landed, own fragment reads retired; then every wave's
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
         }
         float* red = reinterpret_cast<float*>(smem + STAGE);      // the total, row-major [128][128] fp32, in the second 64 KiB
         if constexpr (KG == 2) {
@@ -480,19 +497,12 @@ bool km_plan(const FS2Gemm& g, int mode, KmPlan& pl, bool allow_f8 = false) {
     return true;
 }
 
-// FS2_KM_KG=4: the round-2 form of the bf16 kernel (four k-groups, 64 KiB stages, one in flight) for A/B measurements; read per call
-bool km_two_groups() {
-    const char* e = getenv("FS2_KM_KG");
-    return !(e != nullptr && atoi(e) == 4);
-}
-
 int km_launch(const FS2Gemm& g, const KmPlan& pl, float* ws, hipStream_t st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     static bool attr_set[16] = {};            // per device (one process per GPU is the deployment; a process driving several still works)
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             fs2_set_error("fs2_gemm: cannot raise the dynamic LDS limit of the weight-gradient kernel");
             return FS2_ELAUNCH;
@@ -504,11 +514,8 @@ int km_launch(const FS2Gemm& g, const KmPlan& pl, float* ws, hipStream_t st) {
     if (g.dtype != FS2_BF16)
         hipLaunchKernelGGL((fs2_gemm_big_km_kernel<1, 4>), dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
                            pl.stream_units, ws);
-    else if (km_two_groups())
-        hipLaunchKernelGGL((fs2_gemm_big_km_kernel<2, 2>), dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
-                           pl.stream_units, ws);
     else
-        hipLaunchKernelGGL((fs2_gemm_big_km_kernel<2, 4>), dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
+        hipLaunchKernelGGL((fs2_gemm_big_km_kernel<2, 2>), dim3(pl.grid), dim3(NT), SMEM, st, g, pl.tilesM, pl.tilesN, pl.splits, (int)pl.nitems, rot_step,
                            pl.stream_units, ws);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { fs2_set_error("fs2_gemm(big km): launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
@@ -742,8 +749,7 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
     (void)hipGetDevice(&dev);
     static bool attr_set[16] = {};
     if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(&fs2_gemm_big_km_grouped_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) {
             fs2_set_error("fs2_wgrad_grouped: cannot raise the dynamic LDS limit of the weight-gradient kernel");
             return FS2_ELAUNCH;
@@ -752,8 +758,7 @@ extern "C" int64_t fs2_wgrad_grouped(const FS2Gemm* descs, int n, float* ws, int
     }
     g_last_tile = 129;
     if (a.g[0].dtype != FS2_BF16) hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<1, 4>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
-    else if (km_two_groups()) hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<2, 2>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<2, 4>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((fs2_gemm_big_km_grouped_kernel<2, 2>), dim3(a.wg_begin[m]), dim3(NT), SMEM, (hipStream_t)stream, a);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { fs2_set_error("fs2_wgrad_grouped: launch failed: %s", hipGetErrorString(e_)); return FS2_ELAUNCH; }
     for (int i = 0; i < m; ++i) fill_part(parts + src[i], a.g[i], a.ws[i], pl[i].tilesM, pl[i].tilesN, a.splits[i], pl[i].base);
