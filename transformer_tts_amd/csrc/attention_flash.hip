@@ -179,7 +179,7 @@ __device__ __forceinline__ unsigned drop_bits16(const DropCtx& c, uint64_t e0) {
     return bits;
 }
 template <int N> __device__ __forceinline__ unsigned row_share(unsigned v) {       // lane N of the caller's row of 16 lanes
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + N, 0xF, 0xF, false);
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x150 + N, 0xF, 0xF, true);        // (no `old` operand: hipcc otherwise emits a v_mov 0 per call)
 }
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -771,7 +771,9 @@ template <int T> __device__ __forceinline__ void row_share4(unsigned bits, unsig
     kb[0] = row_share<4 * T>(bits); kb[1] = row_share<4 * T + 1>(bits); kb[2] = row_share<4 * T + 2>(bits); kb[3] = row_share<4 * T + 3>(bits);
 }
 
-template <bool DROP, int NW, int DK>
+// CAUSAL: the launch masks key j > query i (a.causal); a template parameter because the visibility test costs four vector instructions per
+// probability (a quarter of the kernel's element-wise work) that the self-attention of FastSpeech2 does not need
+template <bool DROP, int NW, int DK, bool CAUSAL>
 __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KS = DK / 32, DT = DK / 16;
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a)
     };
     const int nqt = (tq + 63) >> 6;
     // causal: the queries before this block's first key do not see it (their probabilities are exactly 0 once key 0 is visible to them)
-    const int qt0 = (a.causal && key0_visible) ? min((blk * KB) >> 6, nqt - 1) : 0;
+    const int qt0 = (CAUSAL && key0_visible) ? min((blk * KB) >> 6, nqt - 1) : 0;
     stage(qt0, 0);
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -838,7 +840,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a)
     const float bl = !kvalid ? NOKEY : (on ? 0.f : MASKED_NAT * LOG2E);
     const float ml = on ? 1.f : 0.f;                   // masked_fill's backward
     const float bl_causal = kvalid ? MASKED_NAT * LOG2E : NOKEY;       // ... of a key that lies after the query (causal launches)
-    const int ckey = a.causal ? key : -1;              // query >= ckey sees this key
+    const int ckey = CAUSAL ? key : -1;                // query >= ckey sees this key
     const float scale = DROP ? 65536.f / (65536.f - (float)(uint32_t)(a.pdrop * 65536.f + 0.5f)) : 1.f;
     // keep-bits of the wave's 16 keys for query 64qt + 16(i16>>2) + 4g + (i16&3): element (T, r) = (i16>>2, i16&3) of this
     // lane's row of 16 lanes
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(64 * NW, 2) void flash_bwd_dkv_k(const FlashArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float4 ax = aux[16 * T + 4 * g + r];                         // {-m log2 e, 1/l, delta, -}; zeros for q >= tq
-                    const bool vis = 64 * qt + 16 * T + 4 * g + r >= ckey;             // (always true when the launch is not causal)
+                    const bool vis = !CAUSAL || 64 * qt + 16 * T + 4 * g + r >= ckey;
                     const float pn = __builtin_amdgcn_exp2f((vis ? __builtin_fmaf(s[r], cl, bl) : bl_causal) + ax.x) * ax.y;
                     float t1 = dp[r], pk = pn;
                     if (DROP) {
@@ -1009,8 +1011,10 @@ int launch_bwd(const FlashArgs& a, hipStream_t st) {
     if (attr_set.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<false, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE + MASK_MAX + 128);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dq_k<true, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE + MASK_MAX + 128);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 4, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 4, DK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 4, DK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 4, DK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<false, 4, DK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_bwd_dkv_k<true, 4, DK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
     }
     // dK/dV: 64 keys per workgroup (4 waves, two workgroups per CU).  Every non-empty key block costs the same (all queries), and at
     // config 2 there are ~2.1 blocks of 128 keys per CU: three rounds for two rounds' worth of work.  Half-size blocks leave a
@@ -1019,10 +1023,12 @@ int launch_bwd(const FlashArgs& a, hipStream_t st) {
     const dim3 grid(flash_grid(a.B, a.H, a.tq, 128)), grid_kv(flash_grid(a.B, a.H, a.t, 64));
     if (a.pdrop > 0.f) {
         hipLaunchKernelGGL((flash_bwd_dq_k<true, DK>), grid, dim3(FQ_THREADS), lds_q, st, a);
-        hipLaunchKernelGGL((flash_bwd_dkv_k<true, 4, DK>), grid_kv, dim3(256), lds_kv, st, a);
+        if (a.causal) hipLaunchKernelGGL((flash_bwd_dkv_k<true, 4, DK, true>), grid_kv, dim3(256), lds_kv, st, a);
+        else hipLaunchKernelGGL((flash_bwd_dkv_k<true, 4, DK, false>), grid_kv, dim3(256), lds_kv, st, a);
     } else {
         hipLaunchKernelGGL((flash_bwd_dq_k<false, DK>), grid, dim3(FQ_THREADS), lds_q, st, a);
-        hipLaunchKernelGGL((flash_bwd_dkv_k<false, 4, DK>), grid_kv, dim3(256), lds_kv, st, a);
+        if (a.causal) hipLaunchKernelGGL((flash_bwd_dkv_k<false, 4, DK, true>), grid_kv, dim3(256), lds_kv, st, a);
+        else hipLaunchKernelGGL((flash_bwd_dkv_k<false, 4, DK, false>), grid_kv, dim3(256), lds_kv, st, a);
     }
     FS2_CHECK_LAUNCH("fs2_flash_attn_bwd");
     return FS2_OK;
