@@ -170,18 +170,21 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     // (as few instructions as possible: this runs between a slot barrier and the MFMAs behind it.  The per-lane offsets already say OOB
     //  for rows outside the matrix; only the last k-slot of a row whose K is not a multiple of the slot, and the taps of a convolution
     //  at the ends of an utterance, need a per-lane decision: two instantiations, chosen by a workgroup-uniform branch)
-    auto issue_pieces = [&](auto PLAINC) __attribute__((always_inline)) {
-        constexpr bool PLAIN = decltype(PLAINC)::value != 0;
+    // MODE 1: plain (no convolution, K a multiple of the slot); 2: convolution with K a multiple of the slot (the taps' frame test is
+    // the only per-lane decision: three vector instructions per activation piece); 0: general (K tail as well)
+    auto issue_pieces = [&](auto MODEC) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(MODEC)::value;
         const int kb = lkb, tap = ltap;
-        const int sA = PLAIN ? kb * ES : (tap * lda + kb) * ES;
-        const int sB = PLAIN ? kb * ES : (tap * p.K + kb) * ES;
+        const int sA = MODE == 1 ? kb * ES : (tap * lda + kb) * ES;
+        const int sB = MODE == 1 ? kb * ES : (tap * p.K + kb) * ES;
         unsigned char* base = smem + rp_i + 1024 * wave;
-        const bool ktail = !PLAIN && kb + SK > p.K;             // (workgroup-uniform)
+        const bool ktail = MODE == 0 && kb + SK > p.K;             // (workgroup-uniform)
 #pragma unroll
         for (int i = 0; i < G::AI; ++i) {
             if (i * NW + wave < G::AQ) {          // wave-uniform (BM = 192: 24 pieces for 16 waves)
                 unsigned v = voffA[i];
-                if constexpr (!PLAIN) {
+                if constexpr (MODE == 2) v = ((unsigned)(tA[i] + tap) < (unsigned)p.seq_len) ? v : OOB;
+                if constexpr (MODE == 0) {
                     if (conv) v = ((unsigned)(tA[i] + tap) < (unsigned)p.seq_len) ? v : OOB;
                     if (ktail) v = (kb + a_k8(i) < p.K) ? v : OOB;
                 }
@@ -193,14 +196,16 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
 #pragma unroll
         for (int i = 0; i < G::BI; ++i) {
             unsigned v = voffB[i];
-            if constexpr (!PLAIN) {
+            if constexpr (MODE == 0) {
                 if (ktail) v = (kb + b_k8(i) < p.K) ? v : OOB;
             }
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(base + G::A_BYTES + 1024 * NW * i), 16, (int)v, sB, 0, 0);
         }
     };
+    const int issue_mode = plain ? 1 : (conv && p.K % SK == 0) ? 2 : 0;
     auto issue_dma = [&]() __attribute__((always_inline)) {
-        if (plain) issue_pieces(IC<1>{});
+        if (issue_mode == 1) issue_pieces(IC<1>{});
+        else if (issue_mode == 2) issue_pieces(IC<2>{});
         else issue_pieces(IC<0>{});
     };
     auto advance_cursor = [&]() __attribute__((always_inline)) {
