@@ -48,6 +48,14 @@ template <int WTM> struct RG {
 
 template <int N> struct IC { static constexpr int value = N; };
 
+// Division by the launch's invariants (work-item decoding, k-split bounds, the frame index of a Conv1d row) without the ~25-instruction
+// sequences an integer division compiles into: the host passes, for every divisor d, M = ceil(2^(31+l) / d) and the shift 31 + l with
+// l = ceil(log2 d); (n * M) >> shift = n / d exactly for 0 <= n < 2^31 (the error n * (M d - 2^(31+l)) / (d 2^(31+l)) is below 2^-l <= 1/d).
+// The kernel's prologue (every wave runs it before the first LDS-DMA request leaves: ~600 instructions, 8 divisions) is on the
+// critical path of every launch.
+struct RingMagic { unsigned m_nslots, s_nslots, m_splits, s_splits, m_tn, s_tn, m_tns, s_tns, m_nkt, s_nkt, m_seq, s_seq; };
+__device__ __forceinline__ int fdiv(int n, unsigned M, unsigned sh) { return (int)(((unsigned long long)(unsigned)n * M) >> sh); }
+
 // 16-B chunk swizzles: A rows are read 16 consecutive rows per fragment; weight rows 16*(i>>2) + 4*jt + (i&3)
 __device__ __forceinline__ int fA(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int fB(int r) { return (((r >> 4) & 3) << 1) | ((r >> 1) & 1); }
@@ -80,7 +88,7 @@ extern thread_local int g_last_splits;
 // per-tensor scales multiply alpha): twice the bf16 MFMA rate, half the staged and LDS-read bytes per multiply-add.
 template <typename TC, int WTM, int EPI, int ES = 2>
 __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p, const int tilesM, const int tilesN, const int splits,
-                                                               const int S, const int stats_off, const int bias_off) {
+                                                               const int S, const int stats_off, const int bias_off, const RingMagic mg) {
     typedef RG<WTM> G;
     constexpr int MT = G::MT, BM = G::BM, SLOT = G::SLOT;
     constexpr int SK = 128 / ES, CE = 16 / ES;                      // k elements per slot / per 16-byte chunk
@@ -102,12 +110,12 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
     const int slabs = tilesM > x ? (tilesM - x + 7) >> 3 : 0;
     const int items = slabs * tilesN * splits;
-    const int nmine = items > slot ? (items - slot + nslots - 1) / nslots : 0;
+    const int nmine = items > slot ? fdiv(items - slot + nslots - 1, mg.m_nslots, mg.s_nslots) : 0;
     if (nmine == 0) return;
     const bool conv = p.conv == 1;
     const int nkt = (p.K + SK - 1) / SK;
     const int ntot = (conv ? p.taps : 1) * nkt;                 // slots of a whole reduction
-    const int per = (ntot + splits - 1) / splits;               // slots per split (the host made every split non-empty)
+    const int per = fdiv(ntot + splits - 1, mg.m_splits, mg.s_splits);      // slots per split (the host made every split non-empty)
     const int pad = conv ? p.pad : 0;
     const int lda = (int)p.lda, ldb = (int)p.ldb;
     const int ring_bytes = S * SLOT;
@@ -116,7 +124,8 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     if (splits == 1) nst = nmine * ntot;
     else
         for (int j = slot; j < items; j += nslots) {
-            const int sp = (j / tilesN) % splits;
+            const int jt = fdiv(j, mg.m_tn, mg.s_tn);
+            const int sp = jt - fdiv(jt, mg.m_splits, mg.s_splits) * splits;
             nst += min(ntot, sp * per + per) - sp * per;
         }
 
@@ -148,14 +157,14 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     unsigned voffA[G::AI], voffB[G::BI];
     int tA[G::AI];
     auto prep_item = [&](int j) {
-        const int q = j / (tilesN * splits), rem = j - q * (tilesN * splits);
-        const int sp = rem / tilesN, nt = rem - sp * tilesN;
+        const int q = fdiv(j, mg.m_tns, mg.s_tns), rem = j - q * (tilesN * splits);
+        const int sp = fdiv(rem, mg.m_tn, mg.s_tn), nt = rem - sp * tilesN;
         const int m0 = (x + 8 * q) * BM, n0 = nt * BN;
 #pragma unroll
         for (int i = 0; i < G::AI; ++i) {
             const int m = m0 + dma_row(i);
             voffA[i] = (m < p.M) ? (unsigned)((m * lda + a_k8(i)) * ES) : OOB;
-            tA[i] = conv ? (m % p.seq_len) - pad : 0;
+            tA[i] = conv ? m - fdiv(m, mg.m_seq, mg.s_seq) * p.seq_len - pad : 0;
         }
 #pragma unroll
         for (int i = 0; i < G::BI; ++i) {
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
         }
         const int s0 = sp * per;
         lend = min(ntot, s0 + per) - s0;
-        ltap = s0 / nkt;
+        ltap = fdiv(s0, mg.m_nkt, mg.s_nkt);
         lkb = (s0 - ltap * nkt) * SK;
     };
     // (as few instructions as possible: this runs between a slot barrier and the MFMAs behind it.  The per-lane offsets already say OOB
@@ -245,8 +254,8 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
     int cj = slot, csl = 0, cend = 0, rp_c = 0;
     int cm0 = 0, cn0 = 0, csp = 0;
     auto decode_c = [&](int j) {
-        const int q = j / (tilesN * splits), rem = j - q * (tilesN * splits);
-        csp = rem / tilesN;
+        const int q = fdiv(j, mg.m_tns, mg.s_tns), rem = j - q * (tilesN * splits);
+        csp = fdiv(rem, mg.m_tn, mg.s_tn);
         const int nt = rem - csp * tilesN;
         cm0 = (x + 8 * q) * BM; cn0 = nt * BN;
         const int s0 = csp * per;
@@ -628,7 +637,22 @@ int launch_ring2(const FS2Gemm& g, int splits, hipStream_t st) {
     }
     const long per_xcd = (long)((tilesM + 7) / 8) * tilesN * splits;
     const int grid = 8 * (int)(per_xcd < 32 ? per_xcd : 32);
-    hipLaunchKernelGGL((fs2_gemm_ring_kernel<TC, WTM, EPI, ES>), dim3(grid), dim3(NT), lds, st, g, tilesM, tilesN, splits, S, stats_off, bias_off);
+    auto magic = [](unsigned d, unsigned& M, unsigned& sh) {
+        if (d < 1) d = 1;
+        int l = 0;
+        while ((1u << l) < d) ++l;
+        M = (unsigned)((((unsigned long long)1 << (31 + l)) + d - 1) / d);
+        sh = 31 + l;
+    };
+    RingMagic mg;
+    const int SKh = 128 / ES;
+    magic((unsigned)(grid >> 3), mg.m_nslots, mg.s_nslots);
+    magic((unsigned)splits, mg.m_splits, mg.s_splits);
+    magic((unsigned)tilesN, mg.m_tn, mg.s_tn);
+    magic((unsigned)(tilesN * splits), mg.m_tns, mg.s_tns);
+    magic((unsigned)((g.K + SKh - 1) / SKh), mg.m_nkt, mg.s_nkt);
+    magic((unsigned)(g.conv == 1 ? g.seq_len : 1), mg.m_seq, mg.s_seq);
+    hipLaunchKernelGGL((fs2_gemm_ring_kernel<TC, WTM, EPI, ES>), dim3(grid), dim3(NT), lds, st, g, tilesM, tilesN, splits, S, stats_off, bias_off, mg);
     FS2_CHECK_LAUNCH("fs2_gemm(ring)");
     return FS2_OK;
 }
