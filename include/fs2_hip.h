@@ -364,6 +364,10 @@ int64_t fs2_flash_attn_keep_words(int B, int H, int t);
  * the r-th longest unmasked prefix (the kernels start the longest rows first).  Optional: pass it as key_info to the calls below
  * (one scan per stack instead of one per workgroup), or NULL: every workgroup scans its mask row itself, rows in batch order. */
 int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, int32_t* info, void* stream);
+/* The reference's create_masks for the FastSpeech2 task (train_fastspeech2.py:55-82: mask = pos != pad on the (B, t) int64 positions the
+ * collate function made) and the row bounds / ranking above in ONE launch: mask[b][j] = pos[b][j] != pad (bytes 0 / 1), info as
+ * fs2_flash_attn_mask_info writes it.  B <= 1024. */
+int fs2_pad_mask_info(const int64_t* pos, int64_t pad, int B, int t, uint8_t* mask, int32_t* info, void* stream);
 int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                        const uint8_t* key_mask, const int32_t* key_info, void* o_out, int64_t o_row_stride, int64_t o_batch_stride,
                        float* stats, uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
@@ -445,7 +449,8 @@ int fs2_l1_fwd(const void* pred, int pred_dtype, const void* target, int target_
 int fs2_l1_bwd(const void* pred, int pred_dtype, const void* target, int target_mode, int64_t n, const float* gscale,
                void* dpred, int dpred_dtype, void* stream);
 /* up to 8 L1 terms in one launch each way (the trainer's five nn.L1Loss() terms, train_fastspeech2.py:212-259):
- * losses[i] += mean |pred_i - target_i| (zeroed by the caller, who also adds the terms up);
+ * losses[i] += mean |pred_i - target_i| for i < n_items and losses[n_items] += the same, i.e. the slot behind the terms receives their
+ * sum (n_items + 1 floats, zeroed by the caller);
  * backward: dpred_i = gscale[0] * sign(pred_i - target_i) / n_i  (gscale = d(loss)/d(sum of the terms), on the device). */
 typedef struct {
     const void* pred;       /* n elements, pred_dtype (FS2_F32 / FS2_BF16) */

@@ -657,9 +657,11 @@ def l1_bwd(pred, target, gscale, dpred_dtype, log1p_int_target=False):
 
 
 def l1_multi_fwd(preds, targets, modes, losses):
-    """the same terms, one after the other (train_fastspeech2.py:212-259)"""
+    """the same terms, one after the other, and their sum in the slot behind them (train_fastspeech2.py:212-259)"""
     for i, (pr, tg, md) in enumerate(zip(preds, targets, modes)):
-        losses[i] += (_f(pr) - _f(_l1_target(tg, md))).abs().mean().float()
+        term = (_f(pr) - _f(_l1_target(tg, md))).abs().mean().float()
+        losses[i] += term
+        losses[len(preds)] += term
     return losses
 
 

@@ -493,6 +493,38 @@ def test_flash_mask_info_ranks_rows_longest_first(ops):
     assert info[:, 2].tolist() == sorted(range(B), key=lambda i: (-int(lens[i]), i))
 
 
+@pytest.mark.parametrize("B,t", [(300, 200), (1100, 37), (48, 925), (1, 1)])
+def test_flash_mask_info_one_launch_and_two_launch_forms(ops, B, t):
+    """B <= 1024 rows take the one-workgroup kernel, more rows the scan + ranking pair: both against the host computation"""
+    g = np.random.default_rng(B + t)
+    lens = g.integers(1, t + 1, size=B)
+    km = torch.from_numpy(np.arange(t)[None, :] < lens[:, None])
+    info = ops.flash_mask_info(km.cuda()).cpu()
+    assert info[:, 0].tolist() == info[:, 1].tolist() == [int(n) for n in lens]
+    assert info[:, 2].tolist() == sorted(range(B), key=lambda i: (-int(lens[i]), i))
+
+
+@pytest.mark.parametrize("B,t,pad", [(48, 925, 0), (3, 7, 0), (1, 1, 0), (130, 129, 5), (1024, 33, 0)])
+def test_pad_mask_info_is_create_masks_plus_mask_info(ops, B, t, pad):
+    """fs2_pad_mask_info = the reference's (pos != pad) of create_masks (train_fastspeech2.py:55-82) + fs2_flash_attn_mask_info, bit for
+    bit, including positions that hit the pad value in the middle of a row and all-pad rows"""
+    g = np.random.default_rng(B * 7 + t)
+    lens = g.integers(0, t + 1, size=B)
+    lens[0] = t
+    pos = torch.from_numpy(np.where(np.arange(t)[None, :] < lens[:, None], np.arange(1, t + 1)[None, :] + (pad if pad else 0), pad)).long()
+    if t > 4:
+        pos[B // 2, 2] = pad                  # a hole
+    mask, info = ops.pad_mask_info(pos.cuda(), pad)
+    want = pos != pad
+    assert mask.dtype == torch.bool and torch.equal(mask.cpu(), want)
+    ref = ops.flash_mask_info(want.cuda()).cpu()
+    assert torch.equal(info.cpu(), ref)
+    from transformer_tts_amd.train_fastspeech2 import create_masks
+    s, m = create_masks(pos.cuda(), pos.cuda(), task="fastspeech2", src_pad=pad, trg_pad=pad)
+    assert s.shape == (B, 1, t) and torch.equal(s.cpu(), want.unsqueeze(-2)) and torch.equal(m.cpu(), want.unsqueeze(-2))
+    assert torch.equal(s._fs2_kinfo.cpu(), ref)
+
+
 def _oracle_attention(qkv, dO, km, t, p, seed, site, NL=2, layer=1):
     """attention() forward + backward composed from the oracle's primitives on the fused-qkv layout: O, dqkv."""
     B, _, _, H, dk = qkv.shape
@@ -929,7 +961,7 @@ def test_l1_multi(ops):
     for o, dev in ((ops, "cuda"), (P, "cpu")):
         mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
         pr, tg = [mv(t) for t in preds], [mv(t) for t in targets]
-        losses = torch.zeros(len(pr), device=dev)
+        losses = torch.zeros(len(pr) + 1, device=dev)       # the terms and, behind them, their sum
         o.l1_multi_fwd(pr, tg, modes, losses)
         d = o.l1_multi_bwd(pr, tg, modes, torch.tensor([0.7], device=dev), [torch.float32, torch.bfloat16, torch.float32, torch.bfloat16, torch.float32])
         res[dev] = [losses] + d
@@ -937,6 +969,7 @@ def test_l1_multi(ops):
         close(a, b, f"l1_multi output #{i}", rtol=1e-5 if a.dtype == torch.float32 else 1e-2, atol=1e-6)
     ref = torch.nn.L1Loss()(preds[0], targets[0])
     close(res["cuda"][0][0], ref, "vs nn.L1Loss", rtol=1e-5, atol=1e-6)
+    close(res["cuda"][0][len(shapes)], res["cuda"][0][:len(shapes)].sum(), "sum slot", rtol=1e-5, atol=1e-6)
 
 
 def test_adam_matches_torch_optimizer(ops):

@@ -60,6 +60,7 @@ for step in "$@"; do
              FS2_KM_STREAM_SLICED=1 run abstream1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-gemm-timer
              FS2_KM_STREAM_SLICED=0 run abstream0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-gemm-timer
              FS2_KM_STREAM_SLICED=1 run abstream1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-gemm-timer ;;
+    overlap) run overlap 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-gemm-timer --overlap ;;
     wgradk)  run wgradk 400 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider -k "wgrad or big_km" ;;
     abring)  FS2_GEMM_RING=1 run abring1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline
              FS2_GEMM_RING=2 run abring2 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline

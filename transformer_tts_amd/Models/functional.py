@@ -69,6 +69,14 @@ class Runtime:
             return v
         return torch.zeros(shape, dtype=torch.float32, device=device)
 
+    def seed_grad(self, loss):
+        """d(loss)/d(loss) = 1 for loss.backward(): a tensor made once per device (autograd otherwise fills a fresh ones_like(loss)
+        every step: one torch fill kernel)"""
+        one = self.scratch.get(("one", loss.device))
+        if one is None:
+            one = self.scratch[("one", loss.device)] = torch.ones((), dtype=torch.float32, device=loss.device)
+        return one if loss.dtype == torch.float32 and loss.dim() == 0 else None
+
     def get_rng(self, device):
         if self.rng is None:
             self.rng = ops.Rng(self.seed, device)
@@ -377,7 +385,10 @@ class EncoderStackFunction(torch.autograd.Function):
             stats = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
             # dropout keep-bits, one bit per probability (the only (t x t)-sized state of this mode: t*t/8 bytes per head)
             keep = torch.empty((N, ops.flash_attn_keep_words(B, H, t)), dtype=torch.int16, device=dev) if p_att > 0 else None
-            kinfo = ops.flash_mask_info(km)          # first masked key / last unmasked key of every row: one scan for the 3N kernels
+            # first masked key / last unmasked key of every row: one scan for the 3N kernels (create_masks already made it on the GPU)
+            kinfo = getattr(key_mask, "_fs2_kinfo", None)
+            if kinfo is None or kinfo.shape != (B, 3) or kinfo.device != dev:
+                kinfo = ops.flash_mask_info(km)
         else:
             attn = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
             attn_drop = torch.empty((B, N, H, t, tp), dtype=T, device=dev) if p_att > 0 else attn
@@ -566,13 +577,18 @@ class VariancePredictorFunction(torch.autograd.Function):
     """Models/varianceadaptor.py:216-231."""
 
     @staticmethod
-    def forward(ctx, mod, x, mask, *params):
+    def forward(ctx, mod, x, mask, chain, *params):
+        """chain: also return x itself (an alias).  The next reader of x takes that alias, so x has ONE consumer in the autograd graph and
+        this Function's backward adds its data gradient to the gradient arriving through the alias inside the epilogue of its last
+        product (`residual=`) -- the fan-in of the three readers of the length-regulated sequence (pitch predictor, energy predictor,
+        embedding add; reference varianceadaptor.py:93-125) and of the two readers of the encoder output costs no add passes."""
         rt = mod.rt
         T = rt.dtype
         rng = rt.get_rng(x.device)
         p = mod.dropout if mod.training else 0.0
         B, t, _ = x.shape
         km = mask.reshape(B, t).contiguous()
+        ctx.set_materialize_grads(False)
         c1 = ops.conv(x, rt.w_fwd(mod.conv1.weight), 3, 1, mod.conv1.bias.detach(), relu=True)
         l1 = mod.layer_norm1
         n1, m1, r1 = ops.layernorm_fwd(c1, l1.weight.detach(), l1.bias.detach(), T, 1e-5, p, rng, mod.site1)
@@ -583,12 +599,15 @@ class VariancePredictorFunction(torch.autograd.Function):
         out, m2, r2 = ops.ln_linear1_fwd(c2, l2.weight.detach(), l2.bias.detach(), lin.weight.detach().view(-1), lin.bias.detach(), km,
                                          1e-5, p, rng, mod.site2)
         ctx.mod, ctx.sv = mod, dict(x=x, km=km, c1=c1, n1=n1, m1=m1, r1=r1, c2=c2, m2=m2, r2=r2)
-        return out
+        return (out, x) if chain else out
 
     @staticmethod
     @fp8_bwd
-    def backward(ctx, dout):
+    def backward(ctx, dout, dpass=None):
         mod, s = ctx.mod, ctx.sv
+        nin = len(ctx.needs_input_grad)
+        if dout is None:            # the prediction was not used: only the alias carries a gradient
+            return (None, dpass) + (None,) * (nin - 2)
         rt = mod.rt
         rng, p = rt.rng, mod.dropout
         lin, l1, l2 = mod.linear_layer, mod.layer_norm1, mod.layer_norm2
@@ -601,10 +620,12 @@ class VariancePredictorFunction(torch.autograd.Function):
         dz1 = ops.layernorm_bwd(dn1, s["c1"], l1.weight.detach(), s["m1"], s["r1"], grad_of(l1.weight),
                                 grad_of(l1.bias), p, rng, mod.site1, relu_mask=True, dcolsum=grad_of(mod.conv1.bias))
         _conv_wgrad(rt, dz1, s["x"], mod.conv1, 1, bias_done=True)
-        dx = ops.conv(dz1, rt.w_dgrad(mod.conv1.weight), 3, 1)
+        if dpass is not None and (dpass.dtype != dz1.dtype or not dpass.is_contiguous()):
+            dpass = dpass.to(dz1.dtype).contiguous()
+        dx = ops.conv(dz1, rt.w_dgrad(mod.conv1.weight), 3, 1, residual=dpass)
         rt.announce(announce_list(mod, "all", mod.parameters))
         rt.side_join()
-        return (None, dx, None) + (None,) * (len(ctx.needs_input_grad) - 3)
+        return (None, dx) + (None,) * (nin - 2)
 
 
 # ================================================================================================ length regulator
@@ -793,31 +814,38 @@ class MultiL1LossFunction(torch.autograd.Function):
     (losses, total): losses[i] = the i-th term (for the log lines; not differentiable), total = their sum (differentiable)."""
 
     @staticmethod
-    def forward(ctx, modes, *tensors):
+    def forward(ctx, modes, rt, *tensors):
         preds = [t.contiguous() for t in tensors[0::2]]
         targets = [t.contiguous() for t in tensors[1::2]]
-        losses = torch.zeros(len(preds), dtype=torch.float32, device=preds[0].device)
-        ops.l1_multi_fwd(preds, targets, modes, losses)
+        n = len(preds)
+        # the terms and, in the slot behind them, their sum -- written by the ONE launch (no torch fill in front of it when the
+        # accumulators come from the tail FusedAdam clears with the gradients, no torch reduction behind it)
+        acc = rt.zsmall((n + 1,), preds[0].device) if rt is not None else torch.zeros(n + 1, dtype=torch.float32, device=preds[0].device)
+        ops.l1_multi_fwd(preds, targets, modes, acc)
         ctx.preds, ctx.targets, ctx.modes = preds, targets, modes
-        total = losses.sum()
+        ctx.set_materialize_grads(False)            # (the terms are for the log lines: no zero gradient is made up for them)
+        losses, total = acc[:n], acc[n]
         ctx.mark_non_differentiable(losses)
         return losses, total
 
     @staticmethod
     @fp8_bwd
     def backward(ctx, _dlosses, g):
+        if g is None:
+            return (None,) * (2 + 2 * len(ctx.preds))
         gs = g.reshape(1).to(torch.float32).contiguous()
         d = ops.l1_multi_bwd(ctx.preds, ctx.targets, ctx.modes, gs, [p.dtype for p in ctx.preds])
-        grads = [None]
+        grads = [None, None]
         for dp in d:
             grads += [dp, None]
         return tuple(grads)
 
 
-def l1_loss_multi(items):
-    """items: [(pred, target, log1p_int_target), ...] -> (list of the terms, their sum)"""
+def l1_loss_multi(items, rt=None):
+    """items: [(pred, target, log1p_int_target), ...] -> (list of the terms, their sum); rt: the model's Runtime, whose zero-initialised
+    accumulator pool (cleared by FusedAdam.zero_grad with the gradients) then holds the terms"""
     flat = []
     for pred, target, _ in items:
         flat += [pred, target]
-    losses, total = MultiL1LossFunction.apply(tuple(bool(m) for _, _, m in items), *flat)
+    losses, total = MultiL1LossFunction.apply(tuple(bool(m) for _, _, m in items), rt, *flat)
     return [losses[i] for i in range(len(items))], total

@@ -27,8 +27,10 @@ class VariancePredictor(nn.Module):
         self.site1, self.site2 = next_site(), next_site()
         self.rt = runtime if runtime is not None else Runtime()
 
-    def forward(self, encoder_output, mask):
-        return VariancePredictorFunction.apply(self, encoder_output, mask, *self.parameters())
+    def forward(self, encoder_output, mask, chain=False):
+        """chain=True: returns (prediction, alias of encoder_output) -- the caller hands the alias to the next reader of the sequence
+        (VariancePredictorFunction: the gradient fan-in then happens inside this predictor's last data-gradient product)."""
+        return VariancePredictorFunction.apply(self, encoder_output, mask, bool(chain), *self.parameters())
 
 
 class LengthRegulator(nn.Module):
@@ -102,15 +104,28 @@ class VarianceAdaptor(nn.Module):
 
     def forward(self, x, src_mask, mel_mask=None, duration_target=None, pitch_target=None, energy_target=None,
                 max_len=None, p_scheduled_sampling=0.0, pitch_perturbation=False, duration_perturbation=False):
-        log_duration_prediction = self.duration_predictor(x, src_mask)
+        chain = self.training and torch.is_grad_enabled() and x.requires_grad
+        if chain:                   # (the alias of x goes on to the length regulator: one consumer of x, no gradient add pass)
+            log_duration_prediction, x = self.duration_predictor(x, src_mask, chain=True)
+        else:
+            log_duration_prediction = self.duration_predictor(x, src_mask)
         if duration_target is None:
             return self._infer(x, log_duration_prediction, max_len, pitch_perturbation, duration_perturbation)
         assert (pitch_target is not None or not self.pitch_pred) and (energy_target is not None or not self.energy_pred)
         if mel_mask is not None:
             max_len = mel_mask.shape[2]
         x, mel_len = self.length_regulator(x, duration_target, max_len)
-        pitch_prediction = self.pitch_predictor(x, mel_mask) if self.pitch_pred else None          # :93-95 / :110
-        energy_prediction = self.energy_predictor(x, mel_mask) if self.energy_pred else None       # :112-114 / :120
+        pitch_prediction = energy_prediction = None
+        if self.pitch_pred:                                                                         # :93-95 / :110
+            if chain:
+                pitch_prediction, x = self.pitch_predictor(x, mel_mask, chain=True)
+            else:
+                pitch_prediction = self.pitch_predictor(x, mel_mask)
+        if self.energy_pred:                                                                        # :112-114 / :120
+            if chain:
+                energy_prediction, x = self.energy_predictor(x, mel_mask, chain=True)
+            else:
+                energy_prediction = self.energy_predictor(x, mel_mask)
         if self.pitch_pred:
             pitch_target = scheduled_sampling(pitch_prediction, pitch_target, p_scheduled_sampling)    # :99
         text_dur_predicted = x

@@ -258,8 +258,12 @@ __global__ __launch_bounds__(TPB) void l1_multi_fwd_k(const L1Items items, int n
     const float acc = it.pred_dtype == FS2_F32 ? l1_partial<float>(reinterpret_cast<const float*>(it.pred), it.target, it.target_mode, it.n)
                                                : l1_partial<bf16_t>(reinterpret_cast<const bf16_t*>(it.pred), it.target, it.target_mode, it.n);
     const float s = block_sum(acc, lds4);
-    // one address per term: <= 256 blocks each (contended atomics serialise); the caller adds the terms up
-    if (threadIdx.x == 0 && s != 0.f) atomicAdd(losses + blockIdx.y, s / (float)it.n);
+    // one address per term: <= 256 blocks each (contended atomics serialise); losses[n_items] collects the sum of the terms (the
+    // trainer's total: no torch reduction behind this launch)
+    if (threadIdx.x == 0 && s != 0.f) {
+        atomicAdd(losses + blockIdx.y, s / (float)it.n);
+        atomicAdd(losses + n_items, s / (float)it.n);
+    }
 }
 template <typename T, typename TG>
 __device__ __forceinline__ void l1_grad(const T* pred, const void* tgt, int mode, int64_t n, float g, TG* dpred) {

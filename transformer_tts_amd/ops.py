@@ -111,6 +111,7 @@ SIGNATURES = {
     "fs2_flash_attention_bwd": [ctypes.POINTER(FS2FlashAttn), _P],
     "fs2_flash_attention_probs": [ctypes.POINTER(FS2FlashAttn), _P, _L, _P],
     "fs2_flash_attn_mask_info": [_P, _I, _I, _P, _P],
+    "fs2_pad_mask_info": [_P, _L, _I, _I, _P, _P, _P],
     "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _I, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
     "fs2_flash_attn_keep_bits": [_P, _L, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _F,
@@ -483,6 +484,20 @@ def view2d(x, M, d):
     return y
 
 
+def _q8_of(x):
+    """the fp8 copy kept with x, or with the tensor x is a whole-tensor alias of (an autograd Function that returns its input hands out
+    `x.view_as(x)`: a new tensor object over the same elements)"""
+    pre = getattr(x, "_fs2_q8", None)
+    if pre is None:
+        base = x._base
+        if base is not None and base.numel() == x.numel() and base.is_contiguous() and x.is_contiguous() \
+                and base.storage_offset() == x.storage_offset():
+            pre = getattr(base, "_fs2_q8", None)
+            if pre is not None:
+                pre = (pre[0].view(x.shape), pre[1], pre[2])
+    return pre
+
+
 def _fp8_operands(g, x2, w, pre=None):
     """quantise both operands of a row-major product and point the descriptor at them (pre: the fp8 copy the producer of x2 wrote)"""
     if pre is not None and pre[2] == bool(FP8_MODE["backward"]) and pre[0].numel() == x2.numel():
@@ -520,7 +535,7 @@ def linear(x, w, bias=None, relu=False, residual=None, relu_mask=None, colstats=
     split = _splitk_plan(M, N, K, g, relu_mask, colstats, colsum, alpha)
     if split > 1:
         return _splitk_run(g, M, N, split, out, bias, relu, residual)
-    keep = _fp8_operands(g, x, w, getattr(x, "_fs2_q8", None)) \
+    keep = _fp8_operands(g, x, w, _q8_of(x)) \
         if _fp8_eligible(g, M, N, K, x, w, residual, relu_mask, colstats is not None or colsum is not None) else None
     _epilogue(g, out, bias, relu, residual, relu_mask, colstats, alpha, colsum)
     handle = _fp8_q8_request(g, out, relu_mask, colstats, colsum, residual) if (q8_out and keep is not None and alpha == 1.0) else None
@@ -552,7 +567,7 @@ def conv(x, w, taps, pad, bias=None, relu=False, residual=None, relu_mask=None, 
     if split > 1:
         _splitk_run(g, B * t, N, split, o2, bias, relu, r2)
         return out
-    keep = _fp8_operands(g, x2, w, getattr(x, "_fs2_q8", None)) \
+    keep = _fp8_operands(g, x2, w, _q8_of(x)) \
         if _fp8_eligible(g, B * t, N, C, x2, w, residual, relu_mask, colstats is not None or colsum is not None) else None
     _epilogue(g, o2, bias, relu, r2, m2, colstats, 1.0, colsum)
     handle = _fp8_q8_request(g, o2, m2, colstats, colsum, r2) if (q8_out and keep is not None) else None
@@ -1218,6 +1233,21 @@ def flash_mask_info(key_mask):
     return info
 
 
+PAD_MASK_MAX_B, PAD_MASK_MAX_T = 1024, 16384
+
+
+def pad_mask_info(pos, pad=0):
+    """create_masks of the FastSpeech2 task (reference train_fastspeech2.py:55-82) and flash_mask_info in ONE launch:
+    pos (B, t) int64 -> (mask (B, t) bool = pos != pad, info (B, 3) int32 as flash_mask_info returns it)"""
+    assert pos.dtype == torch.int64 and pos.dim() == 2
+    pos = _c(pos)
+    B, t = pos.shape
+    mask = torch.empty((B, t), dtype=torch.bool, device=pos.device)
+    info = torch.empty((B, 3), dtype=torch.int32, device=pos.device)
+    _check(lib().fs2_pad_mask_info(_p(pos), int(pad), B, t, _p(mask), _p(info), _stream()), "fs2_pad_mask_info")
+    return mask, info
+
+
 def flash_keep_bits(keep, B, H, t, p_batch, p, rng, site):
     """draw the dropout keep-bits of one flash_attn_fwd call ahead of time (pass pregenerated=True to that call)"""
     assert keep.dtype == torch.int16 and keep.is_contiguous() and keep.numel() >= flash_attn_keep_words(B, H, t) and p > 0
@@ -1486,8 +1516,9 @@ def _l1_items(preds, targets, modes, dpreds=None):
 
 
 def l1_multi_fwd(preds, targets, modes, losses):
-    """losses[i] += mean |pred_i - target_i| (modes[i]: the target is log(int64 target + 1)); ONE launch"""
-    assert losses.dtype == torch.float32 and losses.numel() >= len(preds) and losses.is_contiguous()
+    """losses[i] += mean |pred_i - target_i| (modes[i]: the target is log(int64 target + 1)) and losses[len(preds)] += the same
+    (the sum of the terms); ONE launch"""
+    assert losses.dtype == torch.float32 and losses.numel() >= len(preds) + 1 and losses.is_contiguous()
     arr, keep = _l1_items(preds, targets, modes)
     _check(lib().fs2_l1_multi_fwd(ctypes.cast(arr, ctypes.c_void_p), len(preds), _p(losses), _stream()), "fs2_l1_multi_fwd")
     return losses

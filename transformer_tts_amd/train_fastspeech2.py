@@ -44,14 +44,26 @@ def npeak_mask(size):
     return torch.tril(torch.ones((1, size, size), dtype=torch.bool, device=DEVICE))
 
 
+def _pad_mask(pos, pad):
+    """(pos != pad).unsqueeze(-2).  On the GPU: one launch that also leaves the row bounds / ranking the attention kernels of the stack
+    read (ops.pad_mask_info) with the mask (`_fs2_kinfo`: EncoderStackFunction picks it up instead of scanning the mask again)."""
+    from . import ops
+    if pos.is_cuda and pos.dim() == 2 and pos.dtype == torch.int64 and pos.shape[0] <= ops.PAD_MASK_MAX_B and 0 < pos.shape[1] <= ops.PAD_MASK_MAX_T:
+        mask, info = ops.pad_mask_info(pos, pad)
+        mask = mask.unsqueeze(-2)
+        mask._fs2_kinfo = info
+        return mask
+    return (pos != pad).unsqueeze(-2)
+
+
 def create_masks(src_pos, trg_pos, task="transformer", src_pad=0, trg_pad=0, debug=False):
     """reference :55-82.  (B,t) positions -> (B,1,t) bool key masks for the FastSpeech2 / LightSpeech tasks; for the general
     transformer task the target mask is additionally combined with the no-peak mask -> (B,t,t).  (debug: the +-3 context
     window of the reference is computed and then unused there; it is not reproduced.)"""
     assert not debug, "the reference's debug branch builds a context-window mask it never uses"
-    src_mask = (src_pos != src_pad).unsqueeze(-2)
     if task.lower() in ("fastspeech2", "lightspeech"):
-        return src_mask, (trg_pos != trg_pad).unsqueeze(-2)
+        return _pad_mask(src_pos, src_pad), _pad_mask(trg_pos, trg_pad)
+    src_mask = (src_pos != src_pad).unsqueeze(-2)
     if trg_pos is None:
         return src_mask, None
     trg_mask = (trg_pos != trg_pad).unsqueeze(-2)
@@ -74,8 +86,9 @@ def loss_mel(hp, pred, y, channel_wise=False, loss="l1", channel_weight=None):
     return l1_loss(pred, y)
 
 
-def compute_losses(hp, outputs, mel, alignment, f0, energy):
-    """The five nn.L1Loss() terms of the reference (:212-259); returns (total, dict of parts)."""
+def compute_losses(hp, outputs, mel, alignment, f0, energy, rt=None):
+    """The five nn.L1Loss() terms of the reference (:212-259); returns (total, dict of parts).  rt: the model's Runtime (its
+    accumulator pool holds the terms: no fill / sum kernels of torch's around the one loss launch)."""
     outputs_prenet, outputs_postnet, log_d_prediction, p_prediction, e_prediction = outputs[:5]
     if not getattr(hp, "channel_wise", False):      # every term in one launch each way (sum in the reference's order of terms)
         names, items = ["frame_before"], [(outputs_prenet, mel, False)]
@@ -86,7 +99,7 @@ def compute_losses(hp, outputs, mel, alignment, f0, energy):
         if hp.energy_pred:
             names.append("energy"); items.append((e_prediction, energy, False))
         names.append("duration"); items.append((log_d_prediction, alignment, True))     # target log(alignment + 1)
-        terms, total = l1_loss_multi(items)
+        terms, total = l1_loss_multi(items, rt)
         return total, dict(zip(names, terms))
     parts = {"frame_before": l1_loss(outputs_prenet, mel)}
     loss = parts["frame_before"]
@@ -118,8 +131,8 @@ def step_body(model, optimizer, hp, text, mel, pos_text, pos_mel, f0, energy, al
     optimizer.zero_grad()
     outputs = model(text, src_mask, trg_mask, alignment, f0, energy, None, spkr_emb=None, fix_mask=hp.fix_mask,
                     temperature=None, hop_size=None)
-    loss, parts = compute_losses(hp, outputs, mel, alignment, f0, energy)
-    loss.backward()
+    loss, parts = compute_losses(hp, outputs, mel, alignment, f0, energy, rt=model.rt)
+    loss.backward(model.rt.seed_grad(loss))
     if isinstance(optimizer, FusedAdam):
         optimizer.launch()                                  # global-norm clip (1.0) fused into the Adam kernel
     else:
