@@ -457,6 +457,56 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def shapes_leg(args, model, opt, hp, dev, BATCH):
+    """N batches with N distinct (B, L_pad, T_pad) at the configs[1] frame budget (batch sizes BATCH - 4 .. BATCH + 4, fresh seeds until
+    N distinct shapes exist), resident in HBM; epochs over them in a fixed shuffled order through GraphedTrainStep: epoch 1 = every shape
+    at first sight (eager launches, allocator growing), epoch 2 = second sight (the stepper's capture policy decides), epochs 3-4 =
+    steady state.  Reported per epoch: wall ms per step and ms per 44,400 padded frames (the fixed-shape headline's step size)."""
+    import random as _random
+    from transformer_tts_amd import synthetic
+    from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep
+    batches, seen, seed = [], set(), 50_000
+    while len(batches) < args.shapes:
+        bsz = BATCH - 4 + (seed % 9)
+        b = synthetic.make_batch(seed, bsz)
+        seed += 1
+        key = (tuple(b[0].shape), tuple(b[1].shape))
+        if key in seen:
+            continue
+        seen.add(key)
+        batches.append(tuple(x.to(dev) if torch.is_tensor(x) else x for x in b))
+    padded = [b[1].shape[0] * b[1].shape[1] for b in batches]
+    frames = [int(b[5].sum()) for b in batches]
+    graphed = GraphedTrainStep(model, opt, hp)
+    order = list(range(len(batches)))
+    step, epochs = 1, []
+    # fixed-shape reference on the same process: eager, capture, then replays of batch 0
+    for _ in range(4):
+        graphed(step, batches[0]); step += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(32):
+        graphed(step, batches[0]); step += 1
+    torch.cuda.synchronize()
+    fixed_ms = (time.perf_counter() - t0) * 1e3 / 32 * 44400.0 / padded[0]
+    for ep in range(4):
+        _random.Random(ep).shuffle(order)
+        before = dict(graphed.stats)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in order:
+            graphed(step, batches[i]); step += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        epochs.append({"epoch": ep + 1, "ms_per_step": round(dt * 1e3 / len(order), 3),
+                       "ms_per_44400_padded_frames": round(dt * 1e3 * 44400.0 / sum(padded), 3),
+                       "valid_frames_per_s": round(sum(frames) / dt, 1),
+                       **{k: graphed.stats[k] - before[k] for k in graphed.stats}})
+    print(json.dumps({"metric": "dynamic shapes: FastSpeech2 train step over distinct batch shapes", "distinct_shapes": len(batches),
+                      "max_graphs": graphed.max_graphs, "fixed_shape_replay_ms_per_44400_padded_frames": round(fixed_ms, 3),
+                      "epochs": epochs, "policy": getattr(graphed, "policy", None)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -482,6 +532,11 @@ def main():
                     help="feed the timed steps from pinned host memory through the trainer's one-batch-ahead copy stream "
                          "(the PCIe-inclusive rate quoted in DESIGN.md; never the headline `value`)")
     ap.add_argument("--fp8", action="store_true", help="fp8 operand mode of the row-major GEMMs (configs[4]; not the headline)")
+    ap.add_argument("--shapes", type=int, default=0,
+                    help="dynamic-shape leg (SURVEY 8(f) N3: a corpus batched by a frame budget never repeats a (B, L_pad, T_pad) for "
+                         "long): N batches of DISTINCT shapes at the configs[1] frame budget, three epochs through the graph stepper "
+                         "(first sight eager, second captured, then replayed / evicted), ms per step reported per epoch beside the "
+                         "fixed-shape replay; prints its own JSON line instead of the headline")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -530,6 +585,9 @@ def main():
     if world > 1 or force_dp:
         from transformer_tts_amd.parallel import DataParallel
         opt.dp = DataParallel(model, opt.arena)
+
+    if args.shapes > 0:
+        return shapes_leg(args, model, opt, hp, dev, BATCH)
 
     # synthetic batches, resident in HBM before the timed region; different data on every rank
     pool = [tuple(b.to(dev) if torch.is_tensor(b) else b for b in synthetic.benchmark_batch(2024 + 1000 * rank + i, BATCH))

@@ -162,6 +162,9 @@ int fs2_wgrad_reduce(const FS2WgradPart* parts, int n, void* stream);
 int fs2_cast_permute(const float* src, void* dst, int O, int I, int k, int64_t dld, int mode, int dtype, void* stream);
 int fs2_permute_add(float* scratch, float* grad, int O, int I, int k, int rezero_scratch, void* stream);
 int fs2_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* dst (dst_dtype) = a + b, both fp32, n elements: the two gradient terms that reach the post-net's mel_pred (reference
+ * Models/postnets.py:67,74-75: mel_pred feeds the loss directly and the convolution stack) as one operand. */
+int fs2_add_cast(const float* a, const float* b, void* dst, int dst_dtype, int64_t n, void* stream);
 /* All weight shadows of a model in ONE launch: `table` is a DEVICE array of n descriptors. */
 typedef struct FS2CastDesc {
     const float* src;
@@ -366,8 +369,9 @@ int64_t fs2_flash_attn_keep_words(int B, int H, int t);
 int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, int32_t* info, void* stream);
 /* The reference's create_masks for the FastSpeech2 task (train_fastspeech2.py:55-82: mask = pos != pad on the (B, t) int64 positions the
  * collate function made) and the row bounds / ranking above in ONE launch: mask[b][j] = pos[b][j] != pad (bytes 0 / 1), info as
- * fs2_flash_attn_mask_info writes it.  B <= 1024. */
-int fs2_pad_mask_info(const int64_t* pos, int64_t pad, int B, int t, uint8_t* mask, int32_t* info, void* stream);
+ * fs2_flash_attn_mask_info writes it.  B <= 1024.  ticket: one 32-bit word, zero-filled ONCE by the caller (the launch leaves it zero
+ * again), used by one stream at a time. */
+int fs2_pad_mask_info(const int64_t* pos, int64_t pad, int B, int t, uint8_t* mask, int32_t* info, uint32_t* ticket, void* stream);
 int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                        const uint8_t* key_mask, const int32_t* key_info, void* o_out, int64_t o_row_stride, int64_t o_batch_stride,
                        float* stats, uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,
@@ -449,8 +453,10 @@ int fs2_l1_fwd(const void* pred, int pred_dtype, const void* target, int target_
 int fs2_l1_bwd(const void* pred, int pred_dtype, const void* target, int target_mode, int64_t n, const float* gscale,
                void* dpred, int dpred_dtype, void* stream);
 /* up to 8 L1 terms in one launch each way (the trainer's five nn.L1Loss() terms, train_fastspeech2.py:212-259):
- * losses[i] += mean |pred_i - target_i| for i < n_items and losses[n_items] += the same, i.e. the slot behind the terms receives their
- * sum (n_items + 1 floats, zeroed by the caller);
+ * forward: losses[i] = mean |pred_i - target_i| for i < n_items and losses[n_items] = their sum in the order of the terms (n_items + 1
+ * floats, STORED: no zero fill needed; two launches -- partial sums, then one block that adds them in a fixed order -- without float
+ * atomics: the same bits on every run).  workspace: fs2_l1_multi_workspace_floats() floats of scratch (no initialisation needed), used
+ * by one stream at a time;
  * backward: dpred_i = gscale[0] * sign(pred_i - target_i) / n_i  (gscale = d(loss)/d(sum of the terms), on the device). */
 typedef struct {
     const void* pred;       /* n elements, pred_dtype (FS2_F32 / FS2_BF16) */
@@ -459,7 +465,8 @@ typedef struct {
     int64_t n;
     int32_t pred_dtype, target_mode, dpred_dtype, reserved;
 } FS2L1Item;
-int fs2_l1_multi_fwd(const FS2L1Item* items, int n_items, float* losses, void* stream);
+int64_t fs2_l1_multi_workspace_floats(void);
+int fs2_l1_multi_fwd(const FS2L1Item* items, int n_items, float* losses, float* workspace, void* stream);
 int fs2_l1_multi_bwd(const FS2L1Item* items, int n_items, const float* gscale, void* stream);
 
 /* Stop-token loss of the autoregressive model: F.binary_cross_entropy_with_logits(x, y, reduction='mean',

@@ -209,6 +209,11 @@ def cast(src, dtype, out=None):
     return out
 
 
+def add_cast(a, b, dtype):
+    """the two gradient terms of the post-net's mel_pred (Models/postnets.py:67,74-75) as one tensor"""
+    return (_f(a) + _f(b)).to(dtype)
+
+
 def make_cast_table(entries, device):
     return list(entries)
 
@@ -657,11 +662,13 @@ def l1_bwd(pred, target, gscale, dpred_dtype, log1p_int_target=False):
 
 
 def l1_multi_fwd(preds, targets, modes, losses):
-    """the same terms, one after the other, and their sum in the slot behind them (train_fastspeech2.py:212-259)"""
+    """the same terms, one after the other, and their sum in the slot behind them (train_fastspeech2.py:212-259); stored, not added"""
+    total = 0.0
     for i, (pr, tg, md) in enumerate(zip(preds, targets, modes)):
         term = (_f(pr) - _f(_l1_target(tg, md))).abs().mean().float()
-        losses[i] += term
-        losses[len(preds)] += term
+        losses[i] = term
+        total = total + term
+    losses[len(preds)] = total
     return losses
 
 

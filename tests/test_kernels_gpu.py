@@ -495,7 +495,7 @@ def test_flash_mask_info_ranks_rows_longest_first(ops):
 
 @pytest.mark.parametrize("B,t", [(300, 200), (1100, 37), (48, 925), (1, 1)])
 def test_flash_mask_info_one_launch_and_two_launch_forms(ops, B, t):
-    """B <= 1024 rows take the one-workgroup kernel, more rows the scan + ranking pair: both against the host computation"""
+    """row bounds and ranking of the key masks for a few batch sizes (up to more rows than one block of the ranking kernel has threads) against the host computation"""
     g = np.random.default_rng(B + t)
     lens = g.integers(1, t + 1, size=B)
     km = torch.from_numpy(np.arange(t)[None, :] < lens[:, None])
@@ -948,6 +948,27 @@ def test_ln_linear1_fused_equals_two_kernels(ops, dtype, p, d):
     assert torch.all(res["fused"][0].cpu()[~mask] == 0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,ld", [(1, 4, 4), (7, 80, 80), (44400, 80, 80), (1001, 128, 160), (999, 20, 24), (3000, 132, 132), (513, 64, 64)])
+def test_colsum_narrow_and_wide(ops, dtype, M, N, ld):
+    """column sums of narrow matrices (N <= 128: several rows per wave; the 80 mel channels of the bias gradients) and of wider
+    ones, contiguous and as a column slice of a wider tensor, accumulated onto a non-zero vector"""
+    x = rnd(M, ld, dtype=dtype, seed=M + N)
+    init = rnd(N, seed=5)
+    a = ops.colsum(x.cuda()[:, :N], init.clone().cuda())
+    b = P.colsum(x[:, :N], init.clone())
+    close(a, b, f"colsum {M}x{N}", rtol=1e-4, atol=2e-4 * M ** 0.5)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1027, 44400 * 80])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_add_cast(ops, n, dtype):
+    """(a + b).to(dtype) in one pass (the post-net's two gradient terms of mel_pred), tails that are not a multiple of four"""
+    a, b = rnd(n, seed=1), rnd(n, seed=2)
+    out = ops.add_cast(a.cuda(), b.cuda(), dtype)
+    assert out.dtype == dtype and torch.equal(out.cpu(), P.add_cast(a, b, dtype))
+
+
 def test_l1_multi(ops):
     """the trainer's L1 terms in one launch each way against the oracle (fp32 and bf16 predictions, an int64 log1p target, odd
     sizes, unaligned tails) and against nn.L1Loss"""
@@ -961,8 +982,12 @@ def test_l1_multi(ops):
     for o, dev in ((ops, "cuda"), (P, "cpu")):
         mv = (lambda t: t.cuda()) if dev == "cuda" else (lambda t: t.clone())
         pr, tg = [mv(t) for t in preds], [mv(t) for t in targets]
-        losses = torch.zeros(len(pr) + 1, device=dev)       # the terms and, behind them, their sum
+        losses = torch.full((len(pr) + 1,), 7.0, device=dev)       # the terms and, behind them, their sum: stored over whatever was there
         o.l1_multi_fwd(pr, tg, modes, losses)
+        if dev == "cuda":           # no float atomics: the same bits on every launch (and the ticket word is back at zero)
+            again = torch.empty_like(losses)
+            o.l1_multi_fwd(pr, tg, modes, again)
+            assert torch.equal(again, losses)
         d = o.l1_multi_bwd(pr, tg, modes, torch.tensor([0.7], device=dev), [torch.float32, torch.bfloat16, torch.float32, torch.bfloat16, torch.float32])
         res[dev] = [losses] + d
     for i, (a, b) in enumerate(zip(res["cuda"], res["cpu"])):

@@ -264,7 +264,7 @@ def test_graph_stepper_evicts_the_least_recently_replayed_shape():
     functional._site_counter[0] = 9000
     model, hp, _ = product_model("small", amp=True, dropout=0.1, device="cuda")
     opt = FusedAdam(model)
-    stepper = GraphedTrainStep(model, opt, hp, max_graphs=2)
+    stepper = GraphedTrainStep(model, opt, hp, max_graphs=2, policy="lru")
     losses, step = [], 4000
     for rnd in range(4):
         for b in shapes:
@@ -276,3 +276,38 @@ def test_graph_stepper_evicts_the_least_recently_replayed_shape():
     assert all(np.isfinite(float(l)) for l in losses)
     st = stepper.stats
     assert st["eager"] == 3 and st["evicted"] >= 1 and st["captured"] >= 3 and st["replayed"] == 9, st
+
+
+def test_graph_stepper_does_not_recapture_a_cycling_shape_set():
+    """policy "frequency" (the default): more shapes than max_graphs coming round in a cycle -- the first max_graphs shapes are captured
+    once and replayed, the others are launched eagerly every time (same speed: DESIGN.md section 6) instead of being re-captured at
+    every occurrence, which is what always-evict does with such a cycle; a shape that then shows up MORE often than a cached one takes
+    its place"""
+    from transformer_tts_amd.Models import functional
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep
+    full = batch_to(CONFIGS["small"]["batch"](), "cuda")
+    assert full[0].shape[0] >= 4
+    shapes = [tuple(x[:k] if torch.is_tensor(x) else x for x in full) for k in (2, 3, 4)]
+    functional._site_counter[0] = 9000
+    model, hp, _ = product_model("small", amp=True, dropout=0.1, device="cuda")
+    opt = FusedAdam(model)
+    stepper = GraphedTrainStep(model, opt, hp, max_graphs=2)
+    assert stepper.policy == "frequency"
+    losses, step = [], 4000
+    for rnd in range(4):
+        for b in shapes:
+            loss, _, _ = stepper(step, b)
+            losses.append(float(loss))
+            step += 1
+    st = dict(stepper.stats)
+    # round 1: three eager; round 2: shapes 0 and 1 captured (+ replayed), shape 2 eager; rounds 3-4: two replays + one eager each
+    assert st["captured"] == 2 and st["evicted"] == 0 and st["eager"] == 3 + 3 and st["replayed"] == 6, st
+    for _ in range(8):              # shape 2 alone: once it has been seen clearly more often (+2) than the least recently replayed cached shape it is captured
+        loss, _, _ = stepper(step, shapes[2])
+        losses.append(float(loss))
+        step += 1
+    torch.cuda.synchronize()
+    st = stepper.stats
+    assert st["captured"] == 3 and st["evicted"] == 1 and len(stepper.graphs) == 2, st
+    assert all(np.isfinite(l) for l in losses)

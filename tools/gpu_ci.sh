@@ -60,6 +60,8 @@ for step in "$@"; do
              FS2_KM_STREAM_SLICED=1 run abstream1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-gemm-timer
              FS2_KM_STREAM_SLICED=0 run abstream0b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-gemm-timer
              FS2_KM_STREAM_SLICED=1 run abstream1b 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-gemm-timer ;;
+    shapes)  FS2_GRAPH_POLICY=lru run shapes_lru 600 python bench.py --shapes 200 --no-cpu-baseline
+             run shapes 600 python bench.py --shapes 200 --no-cpu-baseline ;;
     overlap) run overlap 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline --no-gemm-timer --overlap ;;
     wgradk)  run wgradk 400 python -m pytest tests/test_kernels_gpu.py -q -m gpu --timeout 180 -p no:cacheprovider -k "wgrad or big_km" ;;
     abring)  FS2_GEMM_RING=1 run abring1 400 python bench.py --steps 32 --warmup 16 --no-cpu-baseline

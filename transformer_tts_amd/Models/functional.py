@@ -771,14 +771,16 @@ class PostNetFunction(torch.autograd.Function):
                     dh = ops.conv(dc, rt.w_dgrad(cv.weight), 5, 0)
                 else:   # gradient w.r.t. mel_pred through conv1, plus the residual path of `post`
                     dmel_conv = ops.conv(dc, rt.w_dgrad(cv.weight), 5, 0, residual=dpost, out_dtype=torch.float32)
-        # mel_pred = out(x): d(mel_pred) = dmel (direct) + dmel_conv; the Linear is linear, so run it per term
+        # mel_pred = out(x): d(mel_pred) = dmel (direct) + dmel_conv -- added (and cast) in one pass, so the output Linear's weight
+        # gradient, bias sum and data gradient run once instead of once per term
         x2 = x.reshape(M, d)
         dx = None
-        for term in (dmel_conv, dmel):
-            if term is None:
-                continue
-            term = term.contiguous()
-            term_T = (term if T == torch.float32 else ops.cast(term, T)).view(M, -1)
+        if dmel_conv is not None and dmel is not None and dmel.dtype == dmel_conv.dtype == torch.float32:
+            terms = (ops.add_cast(dmel_conv.contiguous(), dmel.contiguous(), T),)
+        else:
+            terms = tuple(tm.contiguous() if tm.dtype == T else ops.cast(tm.contiguous(), T) for tm in (dmel_conv, dmel) if tm is not None)
+        for term_T in terms:
+            term_T = term_T.view(M, -1)
             _linear_wgrad(rt, term_T, x2, mod.out)
             dx = ops.linear(term_T, rt.w_dgrad(mod.out.weight), residual=dx)
         rt.announce(announce_list(mod, "all", mod.parameters))
@@ -814,13 +816,13 @@ class MultiL1LossFunction(torch.autograd.Function):
     (losses, total): losses[i] = the i-th term (for the log lines; not differentiable), total = their sum (differentiable)."""
 
     @staticmethod
-    def forward(ctx, modes, rt, *tensors):
+    def forward(ctx, modes, *tensors):
         preds = [t.contiguous() for t in tensors[0::2]]
         targets = [t.contiguous() for t in tensors[1::2]]
         n = len(preds)
-        # the terms and, in the slot behind them, their sum -- written by the ONE launch (no torch fill in front of it when the
-        # accumulators come from the tail FusedAdam clears with the gradients, no torch reduction behind it)
-        acc = rt.zsmall((n + 1,), preds[0].device) if rt is not None else torch.zeros(n + 1, dtype=torch.float32, device=preds[0].device)
+        # the terms and, in the slot behind them, their sum -- STORED by the one launch into a fresh tensor (no torch fill in front
+        # of it, no torch reduction behind it; the values stay what they are when the next step runs)
+        acc = torch.empty(n + 1, dtype=torch.float32, device=preds[0].device)
         ops.l1_multi_fwd(preds, targets, modes, acc)
         ctx.preds, ctx.targets, ctx.modes = preds, targets, modes
         ctx.set_materialize_grads(False)            # (the terms are for the log lines: no zero gradient is made up for them)
@@ -832,20 +834,19 @@ class MultiL1LossFunction(torch.autograd.Function):
     @fp8_bwd
     def backward(ctx, _dlosses, g):
         if g is None:
-            return (None,) * (2 + 2 * len(ctx.preds))
+            return (None,) * (1 + 2 * len(ctx.preds))
         gs = g.reshape(1).to(torch.float32).contiguous()
         d = ops.l1_multi_bwd(ctx.preds, ctx.targets, ctx.modes, gs, [p.dtype for p in ctx.preds])
-        grads = [None, None]
+        grads = [None]
         for dp in d:
             grads += [dp, None]
         return tuple(grads)
 
 
-def l1_loss_multi(items, rt=None):
-    """items: [(pred, target, log1p_int_target), ...] -> (list of the terms, their sum); rt: the model's Runtime, whose zero-initialised
-    accumulator pool (cleared by FusedAdam.zero_grad with the gradients) then holds the terms"""
+def l1_loss_multi(items):
+    """items: [(pred, target, log1p_int_target), ...] -> (list of the terms, their sum)"""
     flat = []
     for pred, target, _ in items:
         flat += [pred, target]
-    losses, total = MultiL1LossFunction.apply(tuple(bool(m) for _, _, m in items), rt, *flat)
+    losses, total = MultiL1LossFunction.apply(tuple(bool(m) for _, _, m in items), *flat)
     return [losses[i] for i in range(len(items))], total

@@ -308,49 +308,53 @@ __global__ __launch_bounds__(256) void flash_order_k(int B, int32_t* __restrict_
     }
 }
 
-// The two kernels above in ONE launch of one workgroup (B <= INFO_MAXB rows; a wave per row, the ranks behind a barrier), optionally
-// straight from the collate function's position tensor: mask[b][j] = pos[b][j] != pad is written on the way (the reference's
-// create_masks, train_fastspeech2.py:55-82: one launch instead of torch's compare + the scan + the ranking).
+// The reference's create_masks for the FastSpeech2 task (train_fastspeech2.py:55-82: mask = pos != pad on the (B, t) int64 positions of
+// the collate function) and the two kernels above in ONE launch: block b compares and scans row b (all of a row's loads in flight at
+// once), the block that takes the last ticket (a persistent word, zero before and after every launch) ranks the rows.
 constexpr int INFO_MAXB = 1024;
-template <bool FROM_POS>
-__global__ __launch_bounds__(1024) void pad_mask_info_k(const int64_t* __restrict__ pos, const int64_t pad, uint8_t* __restrict__ mask,
-                                                        const int B, const int t, int32_t* __restrict__ info) {
+__global__ __launch_bounds__(256) void pad_mask_info_k(const int64_t* __restrict__ pos, const int64_t pad, uint8_t* __restrict__ mask,
+                                                       const int B, const int t, int32_t* __restrict__ info, unsigned* __restrict__ ticket) {
+    __shared__ int red[2];
     __shared__ int kx[INFO_MAXB];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b = wave; b < B; b += 16) {
-        int first = t, last = 0;
-        for (int j = lane; j < t; j += 64) {
-            bool on;
-            if constexpr (FROM_POS) {
-                on = pos[(int64_t)b * t + j] != pad;
-                mask[(int64_t)b * t + j] = on ? 1 : 0;
-            } else {
-                on = mask[(int64_t)b * t + j] != 0;
-            }
-            if (on) last = max(last, j + 1);
-            else first = min(first, j);
-        }
+    __shared__ int last;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) { red[0] = t; red[1] = 0; }
+    __syncthreads();
+    int first = t, lastk = 0;
+    for (int j = threadIdx.x; j < t; j += 256) {
+        const bool on = pos[(int64_t)b * t + j] != pad;
+        mask[(int64_t)b * t + j] = on ? 1 : 0;
+        if (on) lastk = max(lastk, j + 1);
+        else first = min(first, j);
+    }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            first = min(first, __shfl_xor(first, o));
-            last = max(last, __shfl_xor(last, o));
-        }
-        if (lane == 0) {
-            kx[b] = last;
-            info[3 * b] = first;
-            info[3 * b + 1] = last;
-        }
+    for (int o = 32; o > 0; o >>= 1) {
+        first = min(first, __shfl_xor(first, o));
+        lastk = max(lastk, __shfl_xor(lastk, o));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&red[0], first); atomicMax(&red[1], lastk); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        info[3 * b] = red[0];
+        __hip_atomic_store(info + 3 * b + 1, red[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == (unsigned)B - 1;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < B; i += 1024) {
+    if (!last) return;
+    __threadfence();
+    for (int i = threadIdx.x; i < B; i += 256) kx[i] = __hip_atomic_load(info + 3 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 256) {
         const int ki = kx[i];
         int rank = 0;
-        for (int j = 0; j < B; ++j) {
-            const int kj = kx[j];
-            rank += (kj > ki || (kj == ki && j < i)) ? 1 : 0;
+        for (int j2 = 0; j2 < B; ++j2) {
+            const int kj = kx[j2];
+            rank += (kj > ki || (kj == ki && j2 < i)) ? 1 : 0;
         }
         info[3 * rank + 2] = i;
     }
+    if (threadIdx.x == 0) *ticket = 0u;
 }
 
 // stage one 64-row tile with NW waves: instruction i of wave w covers tile rows 4*(NW i + w) .. +3; lane -> row lane>>4, logical
@@ -1149,12 +1153,6 @@ extern "C" int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, i
 
 extern "C" int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, int32_t* info, void* stream) {
     FS2_REQUIRE(key_mask && info && B > 0 && t > 0 && t <= MASK_MAX, "fs2_flash_attn_mask_info: bad arguments");
-    if (B <= INFO_MAXB) {       // one launch of one workgroup
-        hipLaunchKernelGGL(pad_mask_info_k<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const int64_t*)nullptr, (int64_t)0,
-                           const_cast<uint8_t*>(key_mask), B, t, info);
-        FS2_CHECK_LAUNCH("fs2_flash_attn_mask_info");
-        return FS2_OK;
-    }
     hipLaunchKernelGGL(flash_mask_info_k, dim3(B), dim3(512), 0, (hipStream_t)stream, key_mask, t, info);
     FS2_CHECK_LAUNCH("fs2_flash_attn_mask_info");
     hipLaunchKernelGGL(flash_order_k, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, info);
@@ -1162,10 +1160,10 @@ extern "C" int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, i
     return FS2_OK;
 }
 
-extern "C" int fs2_pad_mask_info(const int64_t* pos, int64_t pad, int B, int t, uint8_t* mask, int32_t* info, void* stream) {
-    FS2_REQUIRE(pos && mask && info && B > 0 && B <= INFO_MAXB && t > 0 && t <= MASK_MAX,
-                "fs2_pad_mask_info: need pos, mask, info, 0 < B <= %d and 0 < t <= %d (B=%d t=%d)", INFO_MAXB, MASK_MAX, B, t);
-    hipLaunchKernelGGL(pad_mask_info_k<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, pos, pad, mask, B, t, info);
+extern "C" int fs2_pad_mask_info(const int64_t* pos, int64_t pad, int B, int t, uint8_t* mask, int32_t* info, uint32_t* ticket, void* stream) {
+    FS2_REQUIRE(pos && mask && info && ticket && B > 0 && B <= INFO_MAXB && t > 0 && t <= MASK_MAX,
+                "fs2_pad_mask_info: need pos, mask, info, ticket, 0 < B <= %d and 0 < t <= %d (B=%d t=%d)", INFO_MAXB, MASK_MAX, B, t);
+    hipLaunchKernelGGL(pad_mask_info_k, dim3(B), dim3(256), 0, (hipStream_t)stream, pos, pad, mask, B, t, info, ticket);
     FS2_CHECK_LAUNCH("fs2_pad_mask_info");
     return FS2_OK;
 }

@@ -252,18 +252,30 @@ __device__ __forceinline__ float l1_partial(const T* pred, const void* tgt, int 
         acc += fabsf(to_f32<T>(pred[i]) - l1_target<T>(tgt, mode, i));
     return acc;
 }
-__global__ __launch_bounds__(TPB) void l1_multi_fwd_k(const L1Items items, int n_items, float* __restrict__ losses) {
+// Two stages, no float atomics: block (x, term) of the first launch leaves its partial sum in workspace[term * L1_BLOCKS + x]; the one
+// block of the second launch adds every term's partials in a fixed order and STORES losses[term] = mean and losses[n_items] = the sum
+// of the terms in their order (the trainer's total: no zero fill in front, no torch reduction behind, the same bits on every run).
+// (One launch with a last-block ticket was measured first: 53-60 us against 16 -- an agent-scope fence writes back the XCD's L2, and
+//  1280 blocks issue one each.  The kernel boundary is the cheap fence.)
+constexpr int L1_BLOCKS = 256, L1_WS = 8 * L1_BLOCKS;
+__global__ __launch_bounds__(TPB) void l1_multi_fwd_k(const L1Items items, float* __restrict__ workspace) {
     __shared__ float lds4[4];
     const FS2L1Item it = items.it[blockIdx.y];
     const float acc = it.pred_dtype == FS2_F32 ? l1_partial<float>(reinterpret_cast<const float*>(it.pred), it.target, it.target_mode, it.n)
                                                : l1_partial<bf16_t>(reinterpret_cast<const bf16_t*>(it.pred), it.target, it.target_mode, it.n);
     const float s = block_sum(acc, lds4);
-    // one address per term: <= 256 blocks each (contended atomics serialise); losses[n_items] collects the sum of the terms (the
-    // trainer's total: no torch reduction behind this launch)
-    if (threadIdx.x == 0 && s != 0.f) {
-        atomicAdd(losses + blockIdx.y, s / (float)it.n);
-        atomicAdd(losses + n_items, s / (float)it.n);
+    if (threadIdx.x == 0) workspace[blockIdx.y * L1_BLOCKS + blockIdx.x] = s;
+}
+struct L1Counts { int64_t n[8]; };
+__global__ __launch_bounds__(TPB) void l1_multi_finish_k(const L1Counts counts, int n_items, const float* __restrict__ workspace, float* __restrict__ losses) {
+    __shared__ float lds4[4];
+    float total = 0.f;
+    for (int t = 0; t < n_items; ++t) {        // (TPB = L1_BLOCKS threads: one partial each, block_sum adds them in a fixed tree)
+        const float mean = block_sum(workspace[t * L1_BLOCKS + threadIdx.x], lds4) / (float)counts.n[t];
+        if (threadIdx.x == 0) losses[t] = mean;
+        total += mean;                          // (the reference's order of terms)
     }
+    if (threadIdx.x == 0) losses[n_items] = total;
 }
 template <typename T, typename TG>
 __device__ __forceinline__ void l1_grad(const T* pred, const void* tgt, int mode, int64_t n, float g, TG* dpred) {
@@ -338,6 +350,19 @@ template <typename TS, typename TD>
 __global__ __launch_bounds__(TPB) void cast_k(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
         dst[i] = from_f32<TD>(to_f32<TS>(src[i]));
+}
+// dst = a + b (fp32 operands, four elements per thread; the post-net's two gradient terms of mel_pred become ONE operand of the
+// output Linear's backward products: Models/postnets.py:67,74-75)
+template <typename TD>
+__global__ __launch_bounds__(TPB) void add_cast_k(const float* __restrict__ a, const float* __restrict__ b, TD* __restrict__ dst, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        dst[4 * i] = from_f32<TD>(x.x + y.x); dst[4 * i + 1] = from_f32<TD>(x.y + y.y);
+        dst[4 * i + 2] = from_f32<TD>(x.z + y.z); dst[4 * i + 3] = from_f32<TD>(x.w + y.w);
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+        dst[i] = from_f32<TD>(a[i] + b[i]);
 }
 // src (O, I, k) fp32 -> dst; one thread per destination element (destination-contiguous)
 template <typename T>
@@ -539,6 +564,43 @@ __global__ __launch_bounds__(TPB) void colsum_k(const T* __restrict__ x, int64_t
                          red[threadIdx.x] + red[256 + threadIdx.x] + red[512 + threadIdx.x] + red[768 + threadIdx.x]);
 }
 
+// The same for NARROW matrices (N <= 128: the 80 mel channels): a wave of colsum_k has only N/4 of its 64 lanes on a row, so a wave
+// here takes 64 / (N/4) consecutive rows per step (lane -> row lane / (N/4), column group lane % (N/4)): three times the bytes in
+// flight at N = 80; the sub-rows of a wave are added up with the waves at the end.
+template <typename T>
+__global__ __launch_bounds__(TPB) void colsum_narrow_k(const T* __restrict__ x, int64_t M, int N, int64_t ldx,
+        float* __restrict__ out, int seg_cols, int64_t seg_stride) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = N >> 2, rpw = 64 / cg;
+    const int sub = lane / cg, col = (lane - sub * cg) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sub < rpw) {
+        const int64_t stride = (int64_t)gridDim.y * 4 * rpw;
+        int64_t r = ((int64_t)blockIdx.y * 4 + wave) * rpw + sub;
+        for (; r + 7 * stride < M; r += 8 * stride) {       // 8 independent row loads in flight
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = load4<T>(x + (r + u * stride) * ldx + col);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        }
+        for (; r < M; r += stride) {
+            const float4 v = load4<T>(x + r * ldx + col);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    *reinterpret_cast<float4*>(red + wave * 256 + lane * 4) = acc;
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < N) {
+        float t = 0.f;
+        for (int w = 0; w < 4; ++w)
+            for (int sr = 0; sr < rpw; ++sr) t += red[w * 256 + (sr * cg) * 4 + c];
+        atomicAdd(out + (int64_t)(c / seg_cols) * seg_stride + c % seg_cols, t);
+    }
+}
+
 // ------------------------------------------------------------------ optimizer
 __global__ __launch_bounds__(TPB) void sqnorm_k(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     __shared__ float lds4[4];
@@ -721,13 +783,19 @@ static int l1_items_check(const char* who, const FS2L1Item* items, int n_items, 
     }
     return FS2_OK;
 }
-extern "C" int fs2_l1_multi_fwd(const FS2L1Item* items, int n_items, float* losses, void* stream) {
+extern "C" int64_t fs2_l1_multi_workspace_floats(void) { return L1_WS; }
+extern "C" int fs2_l1_multi_fwd(const FS2L1Item* items, int n_items, float* losses, float* workspace, void* stream) {
     L1Items a = {};
     const int rc = l1_items_check("fs2_l1_multi_fwd", items, n_items, false, &a);
     if (rc != FS2_OK) return rc;
-    FS2_REQUIRE(losses != nullptr, "fs2_l1_multi_fwd: null losses");
-    hipLaunchKernelGGL(l1_multi_fwd_k, dim3(256, (unsigned)n_items), dim3(TPB), 0, (hipStream_t)stream, a, n_items, losses);
+    FS2_REQUIRE(losses != nullptr && workspace != nullptr, "fs2_l1_multi_fwd: null losses / workspace");
+    static_assert(TPB == L1_BLOCKS, "the finishing block reads one partial per thread");
+    L1Counts c = {};
+    for (int i = 0; i < n_items; ++i) c.n[i] = a.it[i].n;
+    hipLaunchKernelGGL(l1_multi_fwd_k, dim3(L1_BLOCKS, (unsigned)n_items), dim3(TPB), 0, (hipStream_t)stream, a, workspace);
     FS2_CHECK_LAUNCH("fs2_l1_multi_fwd");
+    hipLaunchKernelGGL(l1_multi_finish_k, dim3(1), dim3(TPB), 0, (hipStream_t)stream, c, n_items, workspace, losses);
+    FS2_CHECK_LAUNCH("fs2_l1_multi_fwd (finish)");
     return FS2_OK;
 }
 extern "C" int fs2_l1_multi_bwd(const FS2L1Item* items, int n_items, const float* gscale, void* stream) {
@@ -781,6 +849,16 @@ extern "C" int fs2_cast(const void* src, int src_dtype, void* dst, int dst_dtype
     else if (src_dtype == FS2_F32) hipLaunchKernelGGL((cast_k<float, float>), grid, block, 0, st, (const float*)src, (float*)dst, n);
     else hipLaunchKernelGGL((cast_k<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
     FS2_CHECK_LAUNCH("fs2_cast");
+    return FS2_OK;
+}
+extern "C" int fs2_add_cast(const float* a, const float* b, void* dst, int dst_dtype, int64_t n, void* stream) {
+    CHECK_DT("fs2_add_cast", dst_dtype);
+    if (n <= 0) return FS2_OK;
+    FS2_REQUIRE(a && b && dst && fs2_aligned16(a) && fs2_aligned16(b), "fs2_add_cast: null or unaligned operand");
+    dim3 grid(flat_grid((n + 3) / 4)), block(TPB);
+    if (dst_dtype == FS2_BF16) hipLaunchKernelGGL((add_cast_k<bf16_t>), grid, block, 0, (hipStream_t)stream, a, b, (bf16_t*)dst, n);
+    else hipLaunchKernelGGL((add_cast_k<float>), grid, block, 0, (hipStream_t)stream, a, b, (float*)dst, n);
+    FS2_CHECK_LAUNCH("fs2_add_cast");
     return FS2_OK;
 }
 extern "C" int fs2_cast_permute(const float* src, void* dst, int O, int I, int k, int64_t dld, int mode, int dtype,
@@ -914,6 +992,16 @@ static int colsum_launch(const char* name, const void* x, int dtype, int64_t M, 
     if (M <= 0) return FS2_OK;
     int64_t slabs = (M + 3) / 4;
     if (slabs > 512) slabs = 512;
+    if (N <= 128) {         // narrow: several rows per wave
+        const int rpw = 64 / (N / 4);
+        // (every block ends with N atomics on the same N addresses: 512 blocks serialised ~15 of this kernel's 19 us at 44,400 x 80)
+        slabs = (M + 32 * rpw - 1) / (32 * rpw);
+        if (slabs > 128) slabs = 128;
+        dim3 gridn(1, (unsigned)slabs);
+        T_DISPATCH(dtype, T, { hipLaunchKernelGGL((colsum_narrow_k<T>), gridn, dim3(TPB), 0, (hipStream_t)stream, (const T*)x, M, N, ldx, out, seg_cols, seg_stride); });
+        FS2_CHECK_LAUNCH(name);
+        return FS2_OK;
+    }
     dim3 grid((N + 255) / 256, (unsigned)slabs);
     T_DISPATCH(dtype, T, { hipLaunchKernelGGL((colsum_k<T>), grid, dim3(TPB), 0, (hipStream_t)stream, (const T*)x, M, N, ldx, out, seg_cols, seg_stride); });
     FS2_CHECK_LAUNCH(name);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "fs2_cast_permute": [_P, _P, _I, _I, _I, _L, _I, _I, _P],
     "fs2_permute_add": [_P, _P, _I, _I, _I, _I, _P],
     "fs2_cast": [_P, _I, _P, _I, _L, _P],
+    "fs2_add_cast": [_P, _P, _P, _I, _L, _P],
     "fs2_cast_permute_batched": [_P, _I, _I, _P],
     "fs2_onehot": [_P, _P, _I, _L, _I, _P],
     "fs2_colsum_segmented": [_P, _I, _L, _I, _L, _P, _I, _L, _P],
@@ -111,7 +112,7 @@ SIGNATURES = {
     "fs2_flash_attention_bwd": [ctypes.POINTER(FS2FlashAttn), _P],
     "fs2_flash_attention_probs": [ctypes.POINTER(FS2FlashAttn), _P, _L, _P],
     "fs2_flash_attn_mask_info": [_P, _I, _I, _P, _P],
-    "fs2_pad_mask_info": [_P, _L, _I, _I, _P, _P, _P],
+    "fs2_pad_mask_info": [_P, _L, _I, _I, _P, _P, _P, _P],
     "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _I, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
     "fs2_flash_attn_keep_bits": [_P, _L, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _F,
@@ -141,7 +142,8 @@ SIGNATURES = {
     "fs2_ln_linear1_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _I, _P],
     "fs2_ffn_tail_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _U32, _P],
     "fs2_ffn_tail_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _U32, _P],
-    "fs2_l1_multi_fwd": [_P, _I, _P, _P],
+    "fs2_l1_multi_workspace_floats": [],                 # returns int64
+    "fs2_l1_multi_fwd": [_P, _I, _P, _P, _P],
     "fs2_l1_multi_bwd": [_P, _I, _P, _P],
     "fs2_adam_step": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P],
     "fs2_adam_step_perm": [_P, _P, _P, _P, _L, _P, _P, _F, _F, _F, _F, _P, _I, _P],
@@ -172,6 +174,7 @@ def lib():
         l.fs2_last_error.restype = ctypes.c_char_p
         l.fs2_flash_attn_keep_words.restype = ctypes.c_int64
         l.fs2_flash_attn_keep_words_rect.restype = ctypes.c_int64
+        l.fs2_l1_multi_workspace_floats.restype = ctypes.c_int64
         l.fs2_wgrad_sliced.restype = ctypes.c_int64
         l.fs2_wgrad_grouped.restype = ctypes.c_int64
         l.fs2_abi_version.restype = ctypes.c_int
@@ -879,6 +882,14 @@ def cast(src, dtype, out=None):
     return out
 
 
+def add_cast(a, b, dtype):
+    """(a + b).to(dtype) for two fp32 tensors of one shape, one pass"""
+    assert a.dtype == b.dtype == torch.float32 and a.shape == b.shape
+    out = torch.empty(a.shape, dtype=dtype, device=a.device)
+    _check(lib().fs2_add_cast(_p(_c(a)), _p(_c(b)), _p(out), _dt(out), a.numel(), _stream()), "fs2_add_cast")
+    return out
+
+
 def zero(t):
     """t (contiguous, 16-byte aligned, a multiple of 16 bytes) = 0"""
     _check(lib().fs2_zero(_p(_c(t)), t.numel() * t.element_size(), _stream()), "fs2_zero")
@@ -1234,6 +1245,7 @@ def flash_mask_info(key_mask):
 
 
 PAD_MASK_MAX_B, PAD_MASK_MAX_T = 1024, 16384
+_PAD_TICKET = {}
 
 
 def pad_mask_info(pos, pad=0):
@@ -1244,7 +1256,10 @@ def pad_mask_info(pos, pad=0):
     B, t = pos.shape
     mask = torch.empty((B, t), dtype=torch.bool, device=pos.device)
     info = torch.empty((B, 3), dtype=torch.int32, device=pos.device)
-    _check(lib().fs2_pad_mask_info(_p(pos), int(pad), B, t, _p(mask), _p(info), _stream()), "fs2_pad_mask_info")
+    tk = _PAD_TICKET.get(pos.device)
+    if tk is None:      # the ticket word of the launch's last-block-ranks-the-rows step: zero once, the kernel leaves it zero
+        tk = _PAD_TICKET[pos.device] = torch.zeros(4, dtype=torch.int32, device=pos.device)
+    _check(lib().fs2_pad_mask_info(_p(pos), int(pad), B, t, _p(mask), _p(info), _p(tk), _stream()), "fs2_pad_mask_info")
     return mask, info
 
 
@@ -1515,12 +1530,18 @@ def _l1_items(preds, targets, modes, dpreds=None):
     return arr, keep
 
 
+_L1_WS = {}
+
+
 def l1_multi_fwd(preds, targets, modes, losses):
-    """losses[i] += mean |pred_i - target_i| (modes[i]: the target is log(int64 target + 1)) and losses[len(preds)] += the same
-    (the sum of the terms); ONE launch"""
+    """losses[i] = mean |pred_i - target_i| (modes[i]: the target is log(int64 target + 1)) and losses[len(preds)] = their sum;
+    results stored (losses needs no zero fill), no float atomics: partial sums + one finishing block"""
     assert losses.dtype == torch.float32 and losses.numel() >= len(preds) + 1 and losses.is_contiguous()
+    ws = _L1_WS.get(losses.device)
+    if ws is None:      # the partial sums between the two launches (one buffer per device: this process launches on one stream)
+        ws = _L1_WS[losses.device] = torch.empty(int(lib().fs2_l1_multi_workspace_floats()), dtype=torch.float32, device=losses.device)
     arr, keep = _l1_items(preds, targets, modes)
-    _check(lib().fs2_l1_multi_fwd(ctypes.cast(arr, ctypes.c_void_p), len(preds), _p(losses), _stream()), "fs2_l1_multi_fwd")
+    _check(lib().fs2_l1_multi_fwd(ctypes.cast(arr, ctypes.c_void_p), len(preds), _p(losses), _p(ws), _stream()), "fs2_l1_multi_fwd")
     return losses
 
 

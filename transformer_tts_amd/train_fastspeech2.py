@@ -86,9 +86,8 @@ def loss_mel(hp, pred, y, channel_wise=False, loss="l1", channel_weight=None):
     return l1_loss(pred, y)
 
 
-def compute_losses(hp, outputs, mel, alignment, f0, energy, rt=None):
-    """The five nn.L1Loss() terms of the reference (:212-259); returns (total, dict of parts).  rt: the model's Runtime (its
-    accumulator pool holds the terms: no fill / sum kernels of torch's around the one loss launch)."""
+def compute_losses(hp, outputs, mel, alignment, f0, energy):
+    """The five nn.L1Loss() terms of the reference (:212-259); returns (total, dict of parts)."""
     outputs_prenet, outputs_postnet, log_d_prediction, p_prediction, e_prediction = outputs[:5]
     if not getattr(hp, "channel_wise", False):      # every term in one launch each way (sum in the reference's order of terms)
         names, items = ["frame_before"], [(outputs_prenet, mel, False)]
@@ -99,7 +98,7 @@ def compute_losses(hp, outputs, mel, alignment, f0, energy, rt=None):
         if hp.energy_pred:
             names.append("energy"); items.append((e_prediction, energy, False))
         names.append("duration"); items.append((log_d_prediction, alignment, True))     # target log(alignment + 1)
-        terms, total = l1_loss_multi(items, rt)
+        terms, total = l1_loss_multi(items)
         return total, dict(zip(names, terms))
     parts = {"frame_before": l1_loss(outputs_prenet, mel)}
     loss = parts["frame_before"]
@@ -131,7 +130,7 @@ def step_body(model, optimizer, hp, text, mel, pos_text, pos_mel, f0, energy, al
     optimizer.zero_grad()
     outputs = model(text, src_mask, trg_mask, alignment, f0, energy, None, spkr_emb=None, fix_mask=hp.fix_mask,
                     temperature=None, hop_size=None)
-    loss, parts = compute_losses(hp, outputs, mel, alignment, f0, energy, rt=model.rt)
+    loss, parts = compute_losses(hp, outputs, mel, alignment, f0, energy)
     loss.backward(model.rt.seed_grad(loss))
     if isinstance(optimizer, FusedAdam):
         optimizer.launch()                                  # global-norm clip (1.0) fused into the Adam kernel
@@ -168,11 +167,16 @@ class GraphedTrainStep:
     First occurrence of a shape runs eagerly (allocator warm-up), the second is captured, later ones replay.
     Padding is semantically live in this model (BatchNorm statistics and the L1 losses include padded
     positions), so batches are never padded to a common shape -- one graph per (B, L_pad, T_pad).
-    At most `max_graphs` graphs are kept: capturing one more evicts the least recently replayed (a corpus batched by a frame budget,
-    reference datasets_fastspeech2.py:749-813, produces hundreds of shapes; the graphs share one memory pool, so an evicted graph's
-    activations are reused by the next capture)."""
+    At most `max_graphs` graphs are kept (a corpus batched by a frame budget, reference datasets_fastspeech2.py:749-813, produces
+    hundreds of shapes; the graphs share one memory pool, so an evicted graph's activations are reused by the next capture).  When the
+    cache is full, policy "frequency" (default) captures a shape only if it has been seen clearly more often (by max(2, 25 %)) than the
+    least recently replayed cached shape (which it then evicts); otherwise the step is launched eagerly -- the eager launch path runs at the replay speed
+    ("Dynamic shapes"), while a capture costs tens of milliseconds, so a shape set larger than the cache must not
+    be re-captured in a cycle.  Policy "lru" (the round-4a behaviour, FS2_GRAPH_POLICY=lru): always capture, evict the least recently
+    replayed."""
 
-    def __init__(self, model, optimizer, hp, max_graphs=64, eager_fallback=False, body=None, inputs=None, eager=None, set_lr=None):
+    def __init__(self, model, optimizer, hp, max_graphs=64, eager_fallback=False, body=None, inputs=None, eager=None, set_lr=None,
+                 policy=None):
         """body / inputs / eager / set_lr: the device part of a step, the batch entries it reads, the eager step and the learning-rate rule
         of ANOTHER trainer of this package (transformer_tts_amd.train: the autoregressive model); default: this module's"""
         assert isinstance(optimizer, FusedAdam)
@@ -180,7 +184,10 @@ class GraphedTrainStep:
         self.body, self.inputs = body or step_body, inputs or STEP_INPUTS
         self.eager, self.set_lr = eager or train_step, set_lr or _set_lr
         self.max_graphs = max_graphs
-        self.seen, self.graphs = set(), collections.OrderedDict()
+        self.seen, self.graphs = collections.Counter(), collections.OrderedDict()
+        self.tick, self.last_used = 0, {}
+        self.policy = policy or os.environ.get("FS2_GRAPH_POLICY", "frequency")
+        assert self.policy in ("frequency", "lru")
         self.stats = {"eager": 0, "captured": 0, "replayed": 0, "evicted": 0}
         self.pool = None
         # eager_fallback: if a capture raises (e.g. a collective that refuses stream capture on some multi-GPU setup), say so once
@@ -194,13 +201,26 @@ class GraphedTrainStep:
         entry = self.graphs.get(key)
         if self.broken:
             return self.eager(self.model, self.optimizer, step, d, self.hp)
-        if entry is None and key not in self.seen:
-            self.seen.add(key)
+        self.seen[key] += 1
+        self.tick += 1
+        if entry is not None:
+            self.last_used[key] = self.tick
+        if entry is None and self.seen[key] == 1:
             self.stats["eager"] += 1
             return self.eager(self.model, self.optimizer, step, d, self.hp)
+        if entry is None and self.policy == "frequency" and len(self.graphs) >= max(1, self.max_graphs):
+            victim = next(iter(self.graphs))            # (the least recently replayed cached shape)
+            stale = self.tick - self.last_used.get(victim, 0) > 64 * max(1, self.max_graphs)      # (a shape the corpus no longer produces)
+            # (clearly more often: shapes that come round once per epoch differ by one sight depending on where the epoch's shuffle put
+            #  them -- without the margin such a set keeps re-capturing, at ~100 ms per capture against 7.5 ms per eager step)
+            margin = max(2, self.seen[victim] // 4)
+            if self.seen[key] <= self.seen[victim] + margin and not stale:     # eager launch, the cache stays as it is
+                self.stats["eager"] += 1
+                return self.eager(self.model, self.optimizer, step, d, self.hp)
         if entry is None:
-            while len(self.graphs) >= max(1, self.max_graphs):      # LRU: the shape replayed longest ago makes room
-                _, old = self.graphs.popitem(last=False)
+            while len(self.graphs) >= max(1, self.max_graphs):      # the shape replayed longest ago makes room
+                okey, old = self.graphs.popitem(last=False)
+                self.last_used.pop(okey, None)
                 del old
                 self.stats["evicted"] += 1
             static = [t.to(DEVICE).clone() for t in tensors]
@@ -237,6 +257,7 @@ class GraphedTrainStep:
             if gc_on:
                 gc.enable()
             entry = self.graphs[key] = (g, static, loss, parts)
+            self.last_used[key] = self.tick
             self.stats["captured"] += 1
         self.graphs.move_to_end(key)
         self.stats["replayed"] += 1
