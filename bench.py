@@ -317,6 +317,7 @@ def bench_ar(args, hp, dev):
     step = 1
     for i in range(warm):
         _, _, step = stepper(step, pool[i % POOL])
+    TF.settle_gc(force=True)            # (as the trainers do after their first steps)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     done = 0
@@ -483,6 +484,8 @@ def shapes_leg(args, model, opt, hp, dev, BATCH):
     # fixed-shape reference on the same process: eager, capture, then replays of batch 0
     for _ in range(4):
         graphed(step, batches[0]); step += 1
+    from transformer_tts_amd.train_fastspeech2 import settle_gc
+    settle_gc(force=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(32):
@@ -608,6 +611,10 @@ def main():
     timer = GemmTimer()
     if not use_graph and not args.no_gemm_timer:
         timer.install()
+    # what the shipped train_loop does after its first steps: the model, arenas, descriptor caches and captured graphs leave the
+    # garbage collector's generations (a full collection walking them took 58 ms on the launch thread: DESIGN.md section 6)
+    from transformer_tts_amd.train_fastspeech2 import settle_gc
+    settle_gc(force=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -127,6 +127,7 @@ class Runtime:
         if self.dp is None and self.defer_wgrad and not self._side_dirty:
             ops.wgrad_launch()
             self._flush_at_end_of_backward()
+            self._keep.clear()
             return
         ops.wgrad_flush()
         if self._side_dirty:
@@ -671,7 +672,8 @@ class BucketEmbedAddFunction(torch.autograd.Function):
         with rt.side(d2, ctx.idx):
             for j, emb in embs:
                 oh = ops.onehot(ctx.idx[j], emb.weight.shape[0], dout.dtype)
-                rt._keep.append(oh)
+                if rt.overlap_wgrad:        # (side stream only: on one stream the allocator's stream order keeps `oh` valid for its reader;
+                    rt._keep.append(oh)     #  appended unconditionally this list grew by 45 MB of one-hot rows per eager step, rounds 1-4)
                 ops.wgrad(oh, d2, grad_of(emb.weight))
         if embs:
             rt.announce([emb.weight for _, emb in embs])

@@ -154,8 +154,13 @@ def train_step(model, optimizer, step, d, hp):
 
 def train_loop(model, optimizer, step, epoch, hp, dataloader, log_every=1, stepper=None):
     """stepper: graphed_train_step(...) (one hipGraph per batch shape) or None = eager train_step"""
+    n_run = 0
     for d in dataloader:
         loss, parts, step = stepper(step, d) if stepper is not None else train_step(model, optimizer, step, d, hp)
+        n_run += 1
+        if n_run == 3:              # (train_fastspeech2.settle_gc: the run's long-lived objects leave the garbage collector's generations)
+            from .train_fastspeech2 import settle_gc
+            settle_gc()
         assert not torch.isnan(loss), "loss is nan"          # every iteration, as the reference does (train.py:236)
         if (step - 1) % log_every == 0:
             print(f"step {step - 1}")

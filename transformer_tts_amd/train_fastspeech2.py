@@ -154,6 +154,23 @@ def train_step(model, optimizer, step, d, hp):
     return loss, parts, mel.shape[0]
 
 
+_GC_SETTLED = [False]
+
+
+def settle_gc(force=False):
+    """Once per process, when the long-lived objects of a run exist (model, parameter arenas, weight-shadow tables, cached descriptor
+    lists, the first captured graphs): collect what the set-up left behind and FREEZE the survivors (gc.freeze: they move to a permanent
+    generation the collector never walks again).  Without it every full collection of the cyclic garbage a training step produces (the
+    autograd contexts of the hand-written Functions: ~10 young collections per 64 steps) also traverses all of those: 58 ms measured
+    (`gpurun_ab.py`, round 4), during which the launch thread enqueues nothing -- one such pause inside a 100-step window reads as
+    +0.3-0.6 ms per step, and the eager launch path (6 ms of host time per 7.2 ms step) falls behind the GPU for the steps after it."""
+    if _GC_SETTLED[0] and not force:
+        return
+    _GC_SETTLED[0] = True
+    gc.collect()
+    gc.freeze()
+
+
 def _dist_alive():
     return dist.is_available() and dist.is_initialized()
 
@@ -332,8 +349,12 @@ def train_loop(model, optimizer, step, epoch, args, hp, rank, dataloader):
             stepper = optimizer._fs2_graphed = GraphedTrainStep(model, optimizer, hp, eager_fallback=_dist_alive())   # (N > 1 capture has never run on hardware: a refusal falls back to eager launches, as in bench.py)
         run = lambda m, o, st, d, h: stepper(st, d)
     batches = DevicePrefetcher(dataloader, optimizer.arena.p.device, indices=STEP_INPUTS) if on_gpu else dataloader
+    n_run = 0
     for d in batches:
         loss, parts, batch_size = run(model, optimizer, step, d, hp)
+        n_run += 1
+        if n_run == 3:              # (the model, the optimizer and the first graph exist: keep the collector off them from here on)
+            settle_gc()
         if step % log_every == 0:
             print(f"loss_frame_before = {parts['frame_before'].item()}")
             print(f"loss_duration = {parts['duration'].item()}")
