@@ -438,6 +438,13 @@ int fs2_bn_finalize(const float* sums, float count, const float* count_dev, floa
 int fs2_bn_tanh_fwd(const void* x, int dtype, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, void* y, int64_t M, int C, float p, const uint64_t* rng, uint32_t site,
                     void* stream);
+/* fs2_bn_finalize + fs2_bn_tanh_fwd in one launch (training forward of a post-net layer, reference Models/postnets.py:58-59,71-73):
+ * mean / rstd are derived from `sums` = [sum | sum of squares] (+ count, or count_dev on the device) by every wave, stored for the
+ * backward pass and folded into the running statistics by the first wave of the grid. */
+int fs2_bn_stats_tanh_fwd(const void* x, int dtype, const float* sums, float count, const float* count_dev, float eps, float momentum,
+                          const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float p, const uint64_t* rng,
+                          uint32_t site, void* stream);
 int fs2_bn_tanh_bwd_reduce(const void* dy, const void* x, int dtype, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, float* red, int64_t M, int C, float p,
                            const uint64_t* rng, uint32_t site, void* stream);

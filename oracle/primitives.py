@@ -621,6 +621,13 @@ def bn_tanh_fwd(x, mean, rstd, gamma, beta, p=0.0, rng=None, site=0):
     return (th * drop_scale(tuple(x.shape), p, rng, site)).to(x.dtype)
 
 
+def bn_stats_tanh_fwd(x, sums, count, eps, momentum, running_mean, running_var, num_batches_tracked, gamma, beta, p=0.0, rng=None,
+                      site=0, count_dev=None):
+    """the two steps above, one after the other (Models/postnets.py:58-59,71-73) -> (y, mean, rstd)"""
+    mean, rstd = bn_finalize(sums, count, eps, momentum, running_mean, running_var, num_batches_tracked, count_dev)
+    return bn_tanh_fwd(x, mean, rstd, gamma, beta, p, rng, site), mean, rstd
+
+
 def bn_tanh_bwd_reduce(dy, x, mean, rstd, gamma, beta, red, p=0.0, rng=None, site=0):
     C = x.shape[-1]
     xh, th = _bn_z(x, mean, rstd, gamma, beta)

@@ -826,6 +826,13 @@ def test_batchnorm_tanh(ops, dtype, p, C):
         dgm, dbt = z(C) + 0.25, z(C) - 0.5          # the apply kernel adds the affine gradients (the reduced sums) itself
         dx = o.bn_tanh_bwd_apply(mv(dy), mv(x), mean, rstd, mv(gm), mv(bt), red, 1.0, dgm, dbt, p, rng, 31, count_dev=cd)
         out[dev] = (sums, mean, rstd, rm, rv, nbt.float(), y, red, dx, dgm, dbt)
+        # the two forward steps as ONE launch (fs2_bn_stats_tanh_fwd): same statistics, running statistics and output as the pair
+        rm2, rv2, nbt2 = z(C) + 0.1, z(C) + 1.0, torch.zeros((), dtype=torch.int64, device=dev)
+        y2, mean2, rstd2 = o.bn_stats_tanh_fwd(mv(x), sums, 0.0 if dev == "cuda" else M, 1e-5, 0.1, rm2, rv2, nbt2, mv(gm), mv(bt), p, rng, 31, count_dev=cd)
+        assert int(nbt2) == 1
+        for nm, u, v in (("mean", mean2, mean), ("rstd", rstd2, rstd), ("running_mean", rm2, rm), ("running_var", rv2, rv)):
+            close(u, v, f"fused bn {nm} ({dev})", rtol=1e-6, atol=1e-7)
+        assert torch.equal(y2, y), f"fused bn output ({dev})"
     for i, (a_, b_) in enumerate(zip(out["cuda"], out["cpu"])):
         close(a_, b_, f"bn output #{i}", rtol=2e-3 if i in (0, 7, 9, 10) else tol(dtype)["rtol"],
               atol=(5e-2 if i in (0, 7, 9, 10) else tol(dtype, k=2)["atol"]))
@@ -946,6 +953,20 @@ def test_ln_linear1_fused_equals_two_kernels(ops, dtype, p, d):
             k = 30 if n in ("dgamma", "dbeta", "dw", "db", "dcolsum") else 2
             close(a, b_, f"{n} vs {other}", **tol(a.dtype if a.dtype != torch.float32 else dtype, k=k))
     assert torch.all(res["fused"][0].cpu()[~mask] == 0)
+
+
+@pytest.mark.parametrize("B,L,T,d", [(48, 128, 925, 256), (3, 1, 7, 8), (2, 2100, 300, 16), (5, 70, 33, 64), (2, 64, 32, 256)])
+def test_length_regulator_one_launch_and_two_launch_forms(ops, B, L, T, d):
+    """the scan + gather launch (L <= 2048: the utterance's prefix sums live in LDS) and the scan / gather pair behind it: frames, padding
+    beyond the utterance, cropping at T and the prefix sums kept for the backward pass, bit for bit against the oracle"""
+    g = np.random.default_rng(B * L + T)
+    dur = torch.from_numpy(g.integers(0, max(2, 2 * T // L + 2), size=(B, L)))
+    dur[0] = 0
+    dur[0, L // 2] = 3
+    x = rnd(B, L, d, dtype=torch.bfloat16, seed=1)
+    y, starts = ops.length_regulate_fwd(x.cuda(), dur.cuda(), T)
+    yo, so = P.length_regulate_fwd(x, dur, T)
+    assert torch.equal(starts.cpu(), so) and torch.equal(y.cpu(), yo)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])

@@ -718,10 +718,9 @@ class PostNetFunction(torch.autograd.Function):
                 sums[2 * C:].fill_(float(M))
                 rt.dp.allreduce_sum(sums)
                 count = sums[2 * C:2 * C + 1]
-            mean, rstd = ops.bn_finalize(sums, M, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                                         bn.num_batches_tracked, count_dev=count)
             inputs.append(h)
-            h = ops.bn_tanh_fwd(c, mean, rstd, bn.weight.detach(), bn.bias.detach(), p, rng, mod.sites[li])  # :71-73
+            h, mean, rstd = ops.bn_stats_tanh_fwd(c, sums, M, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                                  bn.weight.detach(), bn.bias.detach(), p, rng, mod.sites[li], count_dev=count)  # :58-59,71-73
             cs.append(c)
             stats.append((mean, rstd, count))
         post = ops.conv(h, rt.w_fwd(mod.conv2.weight), 5, 4, mod.conv2.bias.detach(), residual=mel_pred,

@@ -102,6 +102,53 @@ __global__ __launch_bounds__(TPB) void lr_gather_k(const T* __restrict__ x, cons
     }
 }
 
+// scan + gather in one launch (L <= LR_LMAX): block (utterance b, chunk of LR_FRAMES output frames) repeats the utterance's prefix
+// sums into LDS with its first wave (two wave scans at L = 128; the first chunk's block also stores them for the backward pass) and
+// gathers its frames with the binary search running on the LDS copy.
+constexpr int LR_LMAX = 2048, LR_FRAMES = 32;
+template <typename T>
+__global__ __launch_bounds__(TPB) void lr_scan_gather_k(const T* __restrict__ x, const int64_t* __restrict__ dur, int32_t* __restrict__ starts,
+        T* __restrict__ out, int L, int Tn, int d, int nchunk) {
+    __shared__ int st[LR_LMAX + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x / nchunk, ch = blockIdx.x - b * nchunk;
+    if (wave == 0) {
+        int carry = 0;
+        for (int base = 0; base < L; base += 64) {
+            const int i = base + lane;
+            int v = 0;
+            if (i < L) { const int64_t xv = dur[(int64_t)b * L + i]; v = xv > 0 ? (int)xv : 0; }
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int up = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += up;
+            }
+            if (i < L) st[i] = carry + inc - v;
+            carry += __shfl(inc, 63, 64);
+        }
+        if (lane == 0) st[L] = carry;
+    }
+    __syncthreads();
+    if (ch == 0)
+        for (int i = threadIdx.x; i <= L; i += TPB) starts[(int64_t)b * (L + 1) + i] = st[i];
+    const int f_end = min(Tn, (ch + 1) * LR_FRAMES);
+    for (int f = ch * LR_FRAMES + wave; f < f_end; f += 4) {
+        T* dst = out + ((int64_t)b * Tn + f) * d;
+        if (f >= st[L]) {   // beyond the utterance: zero padding
+            for (int c = lane * 4; c < d; c += 256) store4<T>(dst + c, make_float4(0.f, 0.f, 0.f, 0.f));
+            continue;
+        }
+        int lo = 0, hi = L;   // invariant: st[lo] <= f < st[hi]  (phonemes of zero duration are skipped automatically)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (st[mid] <= f) lo = mid; else hi = mid;
+        }
+        const T* src = x + ((int64_t)b * L + lo) * d;
+        for (int c = lane * 4; c < d; c += 256) store4<T>(dst + c, load4<T>(src + c));
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(TPB) void lr_bwd_k(const T* __restrict__ dout, const int32_t* __restrict__ starts,
         T* __restrict__ dx, int B, int L, int Tn, int d, int accumulate) {
@@ -714,6 +761,12 @@ extern "C" int fs2_length_regulate_fwd(const void* x, int dtype, const int64_t* 
     CHECK_DT("fs2_length_regulate_fwd", dtype);
     FS2_REQUIRE(B > 0 && L > 0 && T > 0 && d > 0 && d % 4 == 0, "fs2_length_regulate_fwd: bad shape B=%d L=%d T=%d d=%d", B, L, T, d);
     hipStream_t st = (hipStream_t)stream;
+    const int nchunk = (T + LR_FRAMES - 1) / LR_FRAMES;
+    if (L <= LR_LMAX && (int64_t)B * nchunk <= 0x7FFFFFFF) {       // one launch
+        T_DISPATCH(dtype, TT, { hipLaunchKernelGGL((lr_scan_gather_k<TT>), dim3((unsigned)(B * nchunk)), dim3(TPB), 0, st, (const TT*)x, dur, starts, (TT*)out, L, T, d, nchunk); });
+        FS2_CHECK_LAUNCH("fs2_length_regulate_fwd");
+        return FS2_OK;
+    }
     hipLaunchKernelGGL(lr_scan_k, dim3(B), dim3(64), 0, st, dur, starts, L);
     FS2_CHECK_LAUNCH("fs2_length_regulate_fwd(scan)");
     T_DISPATCH(dtype, TT, { hipLaunchKernelGGL((lr_gather_k<TT>), dim3(wave_rows_grid((int64_t)B * T)), dim3(TPB), 0, st, (const TT*)x, starts, (TT*)out, B, L, T, d); });

@@ -1216,6 +1216,70 @@ __global__ __launch_bounds__(ROW_BLOCK) void bn_tanh_fwd_k(const T* __restrict__
     }
 }
 
+// bn_finalize_k + bn_tanh_fwd_k in one launch (the training forward of a post-net layer: four launches less per step): every wave
+// derives mean / rstd of its channels from the column sums the producing GEMM's epilogue left (the same arithmetic as bn_finalize_k),
+// wave 0 of block 0 stores them for the backward pass and updates the running statistics.
+template <typename T, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void bn_stats_tanh_fwd_k(const T* __restrict__ x, const float* __restrict__ sums, float count,
+        const float* __restrict__ count_dev, float eps, float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+        T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ running_mean,
+        float* __restrict__ running_var, int64_t* __restrict__ nbt, int64_t M, int C, float p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 sc[NG], sh[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        if (count_dev != nullptr) count = count_dev[0];
+        float4 s1[NG], s2[NG], gm[NG], bt[NG], mu[NG], rs[NG], vr[NG];
+        row_load<NG, float>(sums, C, lane, s1); row_load<NG, float>(sums + C, C, lane, s2);
+        row_load<NG, float>(gamma, C, lane, gm); row_load<NG, float>(beta, C, lane, bt);
+        const double icount = 1.0 / (double)count;       // (one division per lane; bn_finalize_k divides per channel: equal to ~1e-16 relative)
+        auto fin = [&](float a, float b, float& m, float& r, float& v) {
+            const double mud = (double)a * icount;
+            m = (float)mud;
+            v = fmaxf((float)((double)b * icount - mud * mud), 0.f);      // biased batch variance
+            r = __builtin_amdgcn_rsqf(v + eps);
+            r = r * (1.5f - 0.5f * (v + eps) * r * r);                    // one Newton step: rsq to full fp32 precision
+        };
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            fin(s1[g].x, s2[g].x, mu[g].x, rs[g].x, vr[g].x); fin(s1[g].y, s2[g].y, mu[g].y, rs[g].y, vr[g].y);
+            fin(s1[g].z, s2[g].z, mu[g].z, rs[g].z, vr[g].z); fin(s1[g].w, s2[g].w, mu[g].w, rs[g].w, vr[g].w);
+            sc[g] = mul4(rs[g], gm[g]);
+            sh[g] = make_float4(bt[g].x - mu[g].x * sc[g].x, bt[g].y - mu[g].y * sc[g].y,
+                                bt[g].z - mu[g].z * sc[g].z, bt[g].w - mu[g].w * sc[g].w);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 64) {
+            row_store<NG, float>(mean, C, lane, mu);
+            row_store<NG, float>(rstd, C, lane, rs);
+            if (running_mean != nullptr) {
+                float4 rm[NG], rv[NG];
+                row_load<NG, float>(running_mean, C, lane, rm); row_load<NG, float>(running_var, C, lane, rv);
+                const float ub = count > 1.f ? count / (count - 1.f) : 1.f;
+                auto upd = [&](float old, float now) { return (1.f - momentum) * old + momentum * now; };
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    rm[g] = make_float4(upd(rm[g].x, mu[g].x), upd(rm[g].y, mu[g].y), upd(rm[g].z, mu[g].z), upd(rm[g].w, mu[g].w));
+                    rv[g] = make_float4(upd(rv[g].x, vr[g].x * ub), upd(rv[g].y, vr[g].y * ub), upd(rv[g].z, vr[g].z * ub), upd(rv[g].w, vr[g].w * ub));
+                }
+                row_store<NG, float>(running_mean, C, lane, rm);
+                row_store<NG, float>(running_var, C, lane, rv);
+            }
+            if (threadIdx.x == 0 && nbt != nullptr) nbt[0] += 1;
+        }
+    }
+    ROW_LOOP(M) {
+        float4 v[NG];
+        row_load<NG, T>(x + row * C, C, lane, v);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g].x = tanh_fast(v[g].x * sc[g].x + sh[g].x); v[g].y = tanh_fast(v[g].y * sc[g].y + sh[g].y);
+            v[g].z = tanh_fast(v[g].z * sc[g].z + sh[g].z); v[g].w = tanh_fast(v[g].w * sc[g].w + sh[g].w);
+            if (dc.on && GCOL(g) < C) v[g] = mul4(v[g], drop_scale4(dc, (uint64_t)(row * C + GCOL(g)) >> 2));
+        }
+        row_store<NG, T>(y + row * C, C, lane, v);
+    }
+}
+
 // MODE 0: accumulate red[0..C) += sum dz, red[C..2C) += sum dz*xhat.   MODE 1: write dx.
 template <typename T, int NG, int MODE>
 __global__ __launch_bounds__(RED_BLOCK) void bn_tanh_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
@@ -1666,6 +1730,25 @@ extern "C" int fs2_bn_tanh_fwd(const void* x, int dtype, const float* mean, cons
         hipLaunchKernelGGL((bn_tanh_fwd_k<T, NG>), grid, block, 0, st, (const T*)x, mean, rstd, gamma, beta, (T*)y, M, C, p, rng, site);
     }); } });
     FS2_CHECK_LAUNCH("fs2_bn_tanh_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_bn_stats_tanh_fwd(const void* x, int dtype, const float* sums, float count, const float* count_dev, float eps,
+                                     float momentum, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                     float* running_mean, float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float p,
+                                     const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_bn_stats_tanh_fwd", C, 1024); CHECK_DT("fs2_bn_stats_tanh_fwd", dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_bn_stats_tanh_fwd: dropout needs rng");
+    FS2_REQUIRE(sums && mean && rstd && (count > 0.f || count_dev != nullptr), "fs2_bn_stats_tanh_fwd: need sums, mean, rstd and a row count");
+    FS2_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "fs2_bn_stats_tanh_fwd: running_mean and running_var come together");
+    FS2_REQUIRE(M > 0, "fs2_bn_stats_tanh_fwd: no rows");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(C, NG, { if constexpr (NG <= 4) { T_DISPATCH(dtype, T, {
+        hipLaunchKernelGGL((bn_stats_tanh_fwd_k<T, NG>), grid, block, 0, st, (const T*)x, sums, count, count_dev, eps, momentum, gamma, beta,
+                           (T*)y, mean, rstd, running_mean, running_var, num_batches_tracked, M, C, p, rng, site);
+    }); } });
+    FS2_CHECK_LAUNCH("fs2_bn_stats_tanh_fwd");
     return FS2_OK;
 }
 

@@ -128,6 +128,7 @@ SIGNATURES = {
     "fs2_colstats": [_P, _I, _L, _I, _P, _P],
     "fs2_bn_finalize": [_P, _F, _P, _F, _F, _P, _P, _P, _P, _P, _I, _P],
     "fs2_bn_tanh_fwd": [_P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
+    "fs2_bn_stats_tanh_fwd": [_P, _I, _P, _F, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
     "fs2_bn_tanh_bwd_reduce": [_P, _P, _I, _P, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P],
     "fs2_bn_tanh_bwd_apply": [_P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _L, _I, _F, _P, _U32, _P, _P],
     "fs2_softmax_rect_fwd": [_P, _P, _I, _P, _I, _I, _I, _I, _I, _L, _I, _F, _P, _U32, _P],
@@ -1476,6 +1477,19 @@ def bn_tanh_fwd(x, mean, rstd, gamma, beta, p=0.0, rng=None, site=0):
     _check(lib().fs2_bn_tanh_fwd(_p(_c(x)), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(y), x.numel() // C, C, p,
                                  _rng_ptr(rng, p), site, _stream()), "fs2_bn_tanh_fwd")
     return y
+
+
+def bn_stats_tanh_fwd(x, sums, count, eps, momentum, running_mean, running_var, num_batches_tracked, gamma, beta, p=0.0, rng=None,
+                      site=0, count_dev=None):
+    """bn_finalize + bn_tanh_fwd in one launch -> (y, mean, rstd)"""
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    _check(lib().fs2_bn_stats_tanh_fwd(_p(_c(x)), _dt(x), _p(sums), float(count), _p(count_dev), eps, momentum, _p(gamma), _p(beta), _p(y),
+                                       _p(mean), _p(rstd), _p(running_mean), _p(running_var), _p(num_batches_tracked), x.numel() // C, C, p,
+                                       _rng_ptr(rng, p), site, _stream()), "fs2_bn_stats_tanh_fwd")
+    return y, mean, rstd
 
 
 def bn_tanh_bwd_reduce(dy, x, mean, rstd, gamma, beta, red, p=0.0, rng=None, site=0):
