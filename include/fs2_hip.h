@@ -218,6 +218,17 @@ int fs2_pe_add_fwd(const void* a, int a_dtype, const float* pe, const float* alp
 int fs2_pe_add_bwd(const float* dout, const float* pe, void* da, int da_dtype, float* dalpha, int B, int t, int d,
                    float p, const uint64_t* rng, uint32_t site, float* dcolsum, void* stream);
 
+/* The head of an FFT stack in one row pass each way: x = dropout(a + alpha * pe[t]) (fp32, the residual stream) and y = LayerNorm(x)
+ * (Models/modules.py:107-111, then norm_1 of the first layer, Models/layers.py:31); with ids != NULL row r of `a` is table row ids[r]
+ * (nn.Embedding, Models/encoder.py:55,84; fp32 table).  Backward: LayerNorm backward of dy (+ ds, the residual stream's gradient, may
+ * be NULL), then the positional encoder's: da, dalpha += sum(da * pe), dcolsum (may be NULL) += column sums of da, dgamma / dbeta. */
+int fs2_pe_add_ln_fwd(const void* a, int a_dtype, const int64_t* ids, const float* pe, const float* alpha, const float* gamma,
+                      const float* beta, float* x, void* y, int y_dtype, float* mean, float* rstd, int B, int t, int d, float eps,
+                      float p, const uint64_t* rng, uint32_t site, void* stream);
+int fs2_ln_pe_add_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean, const float* rstd,
+                      const float* ds, const float* pe, void* da, int da_dtype, float* dgamma, float* dbeta, float* dalpha,
+                      float* dcolsum, int B, int t, int d, float p, const uint64_t* rng, uint32_t site, void* stream);
+
 /* dcolsum (may be NULL) on the backward entry points below: dcolsum[c] += sum over rows of the gradient tensor the
  * call writes (dx / da / g) -- the bias gradient of the layer that produced the forward input, fused here so the
  * tensor is not read a second time.                                                                             */

@@ -270,6 +270,20 @@ def pe_add_bwd(dout, pe, da_dtype, dalpha, p, rng, site, need_da=True, dcolsum=N
     return g.to(da_dtype) if need_da else None
 
 
+def pe_add_ln_fwd(a, pe, alpha, gamma, beta, out_dtype, p, rng, site, ids=None, eps=1e-5):
+    """the head of an FFT stack: nn.Embedding (ids given; Models/encoder.py:55,84), PositionalEncoder (Models/modules.py:107-111) and
+    norm_1 of the first layer (Models/layers.py:31), composed from the primitives of each"""
+    a0 = embedding_fwd(ids, a, torch.float32) if ids is not None else a
+    x = pe_add_fwd(a0, pe, alpha, p, rng, site)
+    y, mean, rstd = layernorm_fwd(x, gamma, beta, out_dtype, eps)
+    return x, y, mean, rstd
+
+
+def ln_pe_add_bwd(dy, x, gamma, mean, rstd, ds, pe, da_dtype, dgamma, dbeta, dalpha, p, rng, site, dcolsum=None):
+    dx = layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None if ds is None else ds.clone())
+    return pe_add_bwd(dx, pe, da_dtype, dalpha, p, rng, site, dcolsum=dcolsum)
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm family
 def _ln(x, gamma, beta, eps):
     mu = x.mean(-1, keepdim=True)

@@ -955,6 +955,40 @@ def test_ln_linear1_fused_equals_two_kernels(ops, dtype, p, d):
     assert torch.all(res["fused"][0].cpu()[~mask] == 0)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("emb", [False, True])
+@pytest.mark.parametrize("B,t,d", [(3, 37, 256), (2, 5, 32), (4, 130, 512)])
+def test_stack_head_one_pass_each_way(ops, dtype, p, emb, B, t, d):
+    """embedding gather / input activations + positional encoder + first LayerNorm in one row pass, and its backward (LayerNorm backward
+    + residual gradient + positional encoder backward), against the composition of the single-step oracle primitives"""
+    V = 41
+    table, a = rnd(V, d, seed=1), rnd(B, t, d, dtype=dtype, seed=2)
+    ids = torch.from_numpy(np.random.default_rng(3).integers(0, V, size=(B, t)))
+    pe, alpha = rnd(200, d, seed=4), torch.tensor([0.7])
+    gm, bt = 1 + 0.1 * rnd(d, seed=5), 0.1 * rnd(d, seed=6)
+    dy, ds = rnd(B, t, d, dtype=dtype, seed=7), rnd(B, t, d, seed=8)
+    out = {}
+    for o, dev in ((ops, "cuda"), (P, "cpu")):
+        mv = (lambda x_: x_.cuda()) if dev == "cuda" else (lambda x_: x_.clone())
+        rng = o.Rng(11, dev)
+        z = lambda *s_: torch.zeros(*s_, dtype=torch.float32, device=dev)
+        if emb:
+            x, y, mean, rstd = o.pe_add_ln_fwd(mv(table), mv(pe), mv(alpha), mv(gm), mv(bt), dtype, p, rng, 17, ids=mv(ids))
+        else:
+            x, y, mean, rstd = o.pe_add_ln_fwd(mv(a), mv(pe), mv(alpha), mv(gm), mv(bt), dtype, p, rng, 17)
+        dg, db, dal, dcs = z(d) + 0.5, z(d) - 0.25, z(1) + 2.0, z(d) + 1.0
+        da = o.ln_pe_add_bwd(mv(dy), x, mv(gm), mean, rstd, mv(ds), mv(pe), torch.float32 if emb else dtype, dg, db, dal, p, rng, 17,
+                             dcolsum=None if emb else dcs)
+        da_nods = o.ln_pe_add_bwd(mv(dy), x, mv(gm), mean, rstd, None, mv(pe), dtype, z(d), z(d), z(1), p, rng, 17)
+        out[dev] = (x, y, mean, rstd, da, dg, db, dal, dcs, da_nods)
+    names = ("x", "y", "mean", "rstd", "da", "dgamma", "dbeta", "dalpha", "dcolsum", "da without ds")
+    for i, (u, v) in enumerate(zip(out["cuda"], out["cpu"])):
+        red = i in (5, 6, 7, 8)
+        close(u, v, f"stack head {names[i]}", rtol=2e-3 if red else tol(u.dtype)["rtol"], atol=(2e-2 * (B * t) ** 0.5 if red else tol(u.dtype, k=2)["atol"]))
+    assert out["cuda"][0].dtype == torch.float32 and out["cuda"][1].dtype == dtype
+
+
 @pytest.mark.parametrize("B,L,T,d", [(48, 128, 925, 256), (3, 1, 7, 8), (2, 2100, 300, 16), (5, 70, 33, 64), (2, 64, 32, 256)])
 def test_length_regulator_one_launch_and_two_launch_forms(ops, B, L, T, d):
     """the scan + gather launch (L <= 2048: the utterance's prefix sums live in LDS) and the scan / gather pair behind it: frames, padding

@@ -41,6 +41,15 @@ def fwd_bwd(model, hp, batch):
     return out, total, parts
 
 
+def knife_edge_l1_terms(name, g, batch, eps=5e-6):
+    """L1 terms of a fixture whose REFERENCE prediction sits within eps of its target: d|pred - target|/dpred = sign(pred - target) of
+    such an element follows the last bit of the forward, and every gradient moves with it by O(1 / #elements).  `opt_ss1` holds one
+    (mel_after[2, 17, 44], 8e-7 from its target): a change of forward rounding that flips it fails the gradient checks of that fixture
+    without being wrong (round 4: the fused stack-head forward in fp32).  Reported in the failure message, not hidden."""
+    mel = batch[1].cpu().numpy()
+    return {n: int((np.abs(g[f"out.{n}"] - mel) < eps).sum()) for n in ("mel_before", "mel_after")}
+
+
 @pytest.mark.parametrize("name", ["tiny", "small", *OPTIONS])
 def test_fp32_forward_backward_vs_reference_golden(name):
     model, hp, g = product_model(name, amp=False, device="cuda")
@@ -63,9 +72,11 @@ def test_fp32_forward_backward_vs_reference_golden(name):
         assert abs(v.item() - ref) <= 2e-5 * max(1.0, abs(ref)), (k, v.item(), ref)
     assert abs(total.item() - float(g["loss.total"])) <= 2e-5 * float(g["loss.total"])
     gsq = 0.0
+    knife = knife_edge_l1_terms(name, g, CONFIGS[name]["batch"]())
     for k, p in model.named_parameters():
         assert p.grad is not None, k
-        check_digest(p.grad, g[f"graddig.{k}"], rtol=2e-3, atol=2e-5, what=f"grad {k}")
+        check_digest(p.grad, g[f"graddig.{k}"], rtol=2e-3, atol=2e-5,
+                     what=f"grad {k} (L1 terms of this fixture within 5e-6 of their target -- their gradient sign follows the forward's last bit: {knife})")
         gsq += float((p.grad.double() ** 2).sum())
     assert abs(gsq ** 0.5 - float(g["grad_global_norm"])) <= 1e-3 * float(g["grad_global_norm"])
     assert float(model.encoder.embed.weight.grad[0].abs().sum()) == 0.0

@@ -363,14 +363,28 @@ class EncoderStackFunction(torch.autograd.Function):
         km = key_mask.reshape(B, t).contiguous()
         sv = {}
 
-        if enc.embedding:
-            a0 = ops.embedding_fwd(src, enc.embed.weight.detach(), torch.float32)              # encoder.py:84
-        else:
-            a0 = ops.linear(src.reshape(M, -1), rt.w_fwd(enc.embed.weight), enc.embed.bias.detach()).view(B, t, d)
+        # embedding (encoder.py:84) / input Linear, positional encoder (modules.py:107-111) and norm_1 of the first layer (layers.py:31).
+        # bf16 (throughput) mode: the gather, the add + dropout and the LayerNorm are ONE row pass (x = the fp32 residual stream,
+        # h = LN(x)).  The exact-fp32 (parity) mode keeps the separate launches: the fused pass rounds 1/sqrt(var) differently in the last
+        # place, and the reference fixture `opt_ss1` holds one L1 term whose prediction sits 8e-7 from its target -- sign(pred - target)
+        # of that element, and with it every gradient by 1e-4 .. 4e-3, follows the last bit of the decoder's forward (found in round 4:
+        # two golden tests failed with the fused forward in fp32 and pass without).
         pe = enc.pe.table(dev)
-        x = ops.pe_add_fwd(a0, pe, enc.pe.alpha.detach(), p, rng, enc.pe.site)                  # modules.py:107-111
         n1 = enc.layers[0].norm_1
-        h, mean0, rstd0 = ops.layernorm_fwd(x, n1.weight.detach(), n1.bias.detach(), T)         # layers.py:31
+        fused_head = T == torch.bfloat16
+        if enc.embedding and fused_head:
+            x, h, mean0, rstd0 = ops.pe_add_ln_fwd(enc.embed.weight.detach(), pe, enc.pe.alpha.detach(), n1.weight.detach(), n1.bias.detach(), T,
+                                                   p, rng, enc.pe.site, ids=src)
+        else:
+            if enc.embedding:
+                a0 = ops.embedding_fwd(src, enc.embed.weight.detach(), torch.float32)          # encoder.py:84
+            else:
+                a0 = ops.linear(src.reshape(M, -1), rt.w_fwd(enc.embed.weight), enc.embed.bias.detach()).view(B, t, d)
+            if fused_head:
+                x, h, mean0, rstd0 = ops.pe_add_ln_fwd(a0, pe, enc.pe.alpha.detach(), n1.weight.detach(), n1.bias.detach(), T, p, rng, enc.pe.site)
+            else:
+                x = ops.pe_add_fwd(a0, pe, enc.pe.alpha.detach(), p, rng, enc.pe.site)          # modules.py:107-111
+                h, mean0, rstd0 = ops.layernorm_fwd(x, n1.weight.detach(), n1.bias.detach(), T) # layers.py:31
         sv["x0"], sv["mean0"], sv["rstd0"] = x, mean0, rstd0
 
         # hp.return_attn = False: the maps are not wanted -> flash kernels, no (t x t) tensor in HBM; the Philox counters are
@@ -556,15 +570,15 @@ class EncoderStackFunction(torch.autograd.Function):
                                       + list(nn_.parameters())))
 
         n1 = enc.layers[0].norm_1
-        dx0 = ops.layernorm_bwd(dh, sv["x0"], n1.weight.detach(), sv["mean0"], sv["rstd0"], grad_of(n1.weight),
-                                grad_of(n1.bias), dx=dx)
+        # backward of the stack's head in one row pass: norm_1 of the first layer (+ the residual stream's gradient), then the positional encoder
         pe = enc.pe.table(dev)
+        da0 = ops.ln_pe_add_bwd(dh, sv["x0"], n1.weight.detach(), sv["mean0"], sv["rstd0"], dx, pe, torch.float32 if enc.embedding else T,
+                                grad_of(n1.weight), grad_of(n1.bias), grad_of(enc.pe.alpha), p, rng, enc.pe.site,
+                                dcolsum=None if enc.embedding else grad_of(enc.embed.bias))
         if enc.embedding:
-            da0 = ops.pe_add_bwd(dx0, pe, torch.float32, grad_of(enc.pe.alpha), p, rng, enc.pe.site)
             ops.embedding_bwd(src, da0, grad_of(enc.embed.weight), padding_idx=0)
             dsrc = None
         else:
-            da0 = ops.pe_add_bwd(dx0, pe, T, grad_of(enc.pe.alpha), p, rng, enc.pe.site, dcolsum=grad_of(enc.embed.bias))
             _linear_wgrad(rt, da0.view(M, d), src.reshape(M, -1), enc.embed, bias_done=True)
             dsrc = ops.linear(da0.view(M, d), rt.w_dgrad(enc.embed.weight)).view(src.shape)
         first = [enc.pe.alpha] + list(enc.embed.parameters()) + list(n1.parameters())

@@ -964,6 +964,119 @@ __global__ __launch_bounds__(RED_BLOCK) void pe_add_bwd_k(const float* __restric
     if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
 }
 
+// ================================================================ head of an FFT stack: x = dropout(a + alpha pe[t]);  y = LN(x)
+// (Models/modules.py:107-111 followed by the first layer's norm_1, Models/layers.py:31) in one row pass each way -- with ids != NULL
+// the rows of `a` are gathered from the embedding table (nn.Embedding, Models/encoder.py:55,84): three launches of the encoder's
+// forward become one.  x is stored in fp32 (the residual stream), y in the compute dtype, mean / rstd for the backward pass.
+template <typename TA, typename TY, int NG>
+__global__ __launch_bounds__(ROW_BLOCK) void pe_add_ln_fwd_k(const TA* __restrict__ a, const int64_t* __restrict__ ids,
+        const float* __restrict__ pe, const float* __restrict__ alpha, const float* __restrict__ gamma, const float* __restrict__ beta,
+        float* __restrict__ x, TY* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int64_t M, int t, int d, float eps,
+        float p, const uint64_t* rng, uint32_t site) {
+    const DropCtx dc = drop_ctx(rng, site, p);
+    const float al = alpha[0];
+    float4 gm[NG], bt[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm);
+        row_load<NG, float>(beta, d, lane, bt);
+    }
+    ROW_LOOP(M) {
+        const int pos = (int)(row % t);
+        const int64_t src = ids != nullptr ? ids[row] : row;
+        float4 v[NG], pv[NG];
+        row_load<NG, TA>(a + src * d, d, lane, v);
+        row_load<NG, float>(pe + (int64_t)pos * d, d, lane, pv);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            v[g] = add4(v[g], scale4(pv[g], al));
+            if (dc.on && GCOL(g) < d) v[g] = mul4(v[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+        }
+        row_store<NG, float>(x + row * d, d, lane, v);
+        float mu, rs;
+        row_stats<NG>(v, d, lane, eps, mu, rs);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float4 o;
+            o.x = (v[g].x - mu) * rs * gm[g].x + bt[g].x; o.y = (v[g].y - mu) * rs * gm[g].y + bt[g].y;
+            o.z = (v[g].z - mu) * rs * gm[g].z + bt[g].z; o.w = (v[g].w - mu) * rs * gm[g].w + bt[g].w;
+            v[g] = o;
+        }
+        row_store<NG, TY>(y + row * d, d, lane, v);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+// backward of the same: LayerNorm backward of dy (+ the residual stream's gradient ds), then the positional encoder's: da = the
+// gradient of `a` (dropout replayed), dalpha += sum da pe, dcolsum (optional) += column sums of da, dgamma / dbeta of the norm.
+template <typename TDY, typename TDA, int NG>
+__global__ __launch_bounds__(RED_BLOCK) void ln_pe_add_bwd_k(const TDY* __restrict__ dy, const float* __restrict__ x,
+        const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ ds,
+        const float* __restrict__ pe, TDA* __restrict__ da, float* __restrict__ dgamma, float* __restrict__ dbeta,
+        float* __restrict__ dalpha, float* __restrict__ dcolsum, int64_t M, int t, int d, float p, const uint64_t* rng, uint32_t site) {
+    __shared__ __attribute__((aligned(16))) float red[RED_WAVES * NG * 256];
+    const DropCtx dc = drop_ctx(rng, site, p);
+    float4 gm[NG], ag[NG], ab[NG], ac[NG];
+    {
+        const int lane = threadIdx.x & 63;
+        row_load<NG, float>(gamma, d, lane, gm);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ag[g] = ab[g] = ac[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float invd = 1.f / (float)d;
+    float acc = 0.f;
+    RED_LOOP(M) {
+        const int pos = (int)(row % t);
+        float4 g_[NG], xv[NG], old[NG], pv[NG];
+        row_load<NG, TDY>(dy + row * d, d, lane, g_);
+        row_load<NG, float>(x + row * d, d, lane, xv);
+        if (ds != nullptr) row_load<NG, float>(ds + row * d, d, lane, old);
+        row_load<NG, float>(pe + (int64_t)pos * d, d, lane, pv);
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (GCOL(g) < d) {
+                float4 xh = make_float4((xv[g].x - mu) * rs, (xv[g].y - mu) * rs, (xv[g].z - mu) * rs, (xv[g].w - mu) * rs);
+                ag[g] = add4(ag[g], mul4(g_[g], xh));
+                ab[g] = add4(ab[g], g_[g]);
+                float4 dg = mul4(g_[g], gm[g]);
+                c1 += sum4(dg);
+                c2 += sum4(mul4(dg, xh));
+                g_[g] = dg;   // dy * gamma
+                xv[g] = xh;
+            }
+        }
+        c1 = wave_sum(c1) * invd;
+        c2 = wave_sum(c2) * invd;
+        float4 o[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            o[g].x = rs * (g_[g].x - c1 - xv[g].x * c2); o[g].y = rs * (g_[g].y - c1 - xv[g].y * c2);
+            o[g].z = rs * (g_[g].z - c1 - xv[g].z * c2); o[g].w = rs * (g_[g].w - c1 - xv[g].w * c2);
+            if (ds != nullptr) o[g] = add4(o[g], old[g]);
+            if (GCOL(g) >= d) o[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dc.on && GCOL(g) < d) o[g] = mul4(o[g], drop_scale4(dc, (uint64_t)(row * d + GCOL(g)) >> 2));
+            acc += sum4(mul4(o[g], pv[g]));
+            ac[g] = add4(ac[g], o[g]);
+        }
+        row_store<NG, TDA>(da + row * d, d, lane, o);
+    }
+    flush_channel_sums<NG>(ag, dgamma, d, red);
+    flush_channel_sums<NG>(ab, dbeta, d, red);
+    if (dcolsum != nullptr) flush_channel_sums<NG>(ac, dcolsum, d, red);
+    // one atomic per BLOCK on the single dalpha word
+    acc = wave_sum(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tsum = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tsum += red[w];
+        atomicAdd(dalpha, tsum);
+    }
+}
+
 // ================================================================ Linear(d -> 1) + masked_fill(0)
 template <typename T, int NG>
 __global__ __launch_bounds__(ROW_BLOCK) void linear1_fwd_k(const T* __restrict__ x, const float* __restrict__ w,
@@ -1621,6 +1734,43 @@ extern "C" int fs2_pe_add_fwd(const void* a, int a_dtype, const float* pe, const
         hipLaunchKernelGGL((pe_add_fwd_k<T, NG>), grid, block, 0, st, (const T*)a, pe, alpha, out, M, t, d, p, rng, site);
     }); } });
     FS2_CHECK_LAUNCH("fs2_pe_add_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_pe_add_ln_fwd(const void* a, int a_dtype, const int64_t* ids, const float* pe, const float* alpha, const float* gamma,
+                                 const float* beta, float* x, void* y, int y_dtype, float* mean, float* rstd, int B, int t, int d,
+                                 float eps, float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_pe_add_ln_fwd", d, 1024); CHECK_DT("fs2_pe_add_ln_fwd", a_dtype); CHECK_DT("fs2_pe_add_ln_fwd", y_dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_pe_add_ln_fwd: dropout needs rng");
+    FS2_REQUIRE(a && pe && alpha && gamma && beta && x && y && mean && rstd, "fs2_pe_add_ln_fwd: null operand");
+    FS2_REQUIRE(ids == nullptr || a_dtype == FS2_F32, "fs2_pe_add_ln_fwd: the embedding table is fp32");
+    const int64_t M = (int64_t)B * t;
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(row_grid(M)), block(ROW_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(a_dtype, TA, { T_DISPATCH(y_dtype, TY, {
+        hipLaunchKernelGGL((pe_add_ln_fwd_k<TA, TY, NG>), grid, block, 0, st, (const TA*)a, ids, pe, alpha, gamma, beta, x, (TY*)y, mean, rstd,
+                           M, t, d, eps, p, rng, site);
+    }); }); } });
+    FS2_CHECK_LAUNCH("fs2_pe_add_ln_fwd");
+    return FS2_OK;
+}
+
+extern "C" int fs2_ln_pe_add_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                 const float* ds, const float* pe, void* da, int da_dtype, float* dgamma, float* dbeta, float* dalpha,
+                                 float* dcolsum, int B, int t, int d, float p, const uint64_t* rng, uint32_t site, void* stream) {
+    CHECK_ROW("fs2_ln_pe_add_bwd", d, 1024); CHECK_DT("fs2_ln_pe_add_bwd", dy_dtype); CHECK_DT("fs2_ln_pe_add_bwd", da_dtype);
+    FS2_REQUIRE(p == 0.f || rng != nullptr, "fs2_ln_pe_add_bwd: dropout needs rng");
+    FS2_REQUIRE(dy && x && gamma && mean && rstd && pe && da && dgamma && dbeta && dalpha, "fs2_ln_pe_add_bwd: null operand");
+    const int64_t M = (int64_t)B * t;
+    if (M <= 0) return FS2_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(red_grid(M)), block(RED_BLOCK);
+    NG_DISPATCH(d, NG, { if constexpr (NG <= 4) { T_DISPATCH(dy_dtype, TDY, { T_DISPATCH(da_dtype, TDA, {
+        hipLaunchKernelGGL((ln_pe_add_bwd_k<TDY, TDA, NG>), grid, block, 0, st, (const TDY*)dy, x, gamma, mean, rstd, ds, pe, (TDA*)da, dgamma,
+                           dbeta, dalpha, dcolsum, M, t, d, p, rng, site);
+    }); }); } });
+    FS2_CHECK_LAUNCH("fs2_ln_pe_add_bwd");
     return FS2_OK;
 }
 

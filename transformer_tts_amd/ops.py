@@ -88,6 +88,8 @@ SIGNATURES = {
     "fs2_embedding_bwd": [_P, _P, _I, _P, _L, _I, _L, _P],
     "fs2_pe_add_fwd": [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_pe_add_bwd": [_P, _P, _P, _I, _P, _I, _I, _I, _F, _P, _U32, _P, _P],
+    "fs2_pe_add_ln_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _F, _P, _U32, _P],
+    "fs2_ln_pe_add_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_layernorm_fwd": [_P, _I, _P, _P, _P, _I, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
     "fs2_layernorm_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _L, _I, _F, _P, _U32, _I, _I, _P, _P],
     "fs2_add_ln_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _I, _F, _F, _P, _U32, _P],
@@ -980,6 +982,36 @@ def pe_add_bwd(dout, pe, da_dtype, dalpha, p, rng, site, need_da=True, dcolsum=N
 
 
 # ------------------------------------------------------------------------------------------------ LayerNorm family
+def pe_add_ln_fwd(a, pe, alpha, gamma, beta, out_dtype, p, rng, site, ids=None, eps=1e-5):
+    """x = dropout(a + alpha pe[t]) (fp32), y = LayerNorm(x) (out_dtype) in one pass -> (x, y, mean, rstd); ids (B, t) int64: the rows
+    of `a` (then the fp32 embedding table) are gathered by id"""
+    if ids is not None:
+        B, t = ids.shape
+        d = a.shape[1]
+        assert a.dtype == torch.float32 and ids.dtype == torch.int64
+        ids = _c(ids)
+    else:
+        B, t, d = a.shape
+    x = torch.empty((B, t, d), dtype=torch.float32, device=a.device)
+    y = torch.empty((B, t, d), dtype=out_dtype, device=a.device)
+    mean = torch.empty(B * t, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(B * t, dtype=torch.float32, device=a.device)
+    _check(lib().fs2_pe_add_ln_fwd(_p(_c(a)), _dt(a), _p(ids), _p(pe), _p(alpha), _p(gamma), _p(beta), _p(x), _p(y), _dt(y), _p(mean), _p(rstd),
+                                   B, t, d, eps, p, _rng_ptr(rng, p), site, _stream()), "fs2_pe_add_ln_fwd")
+    return x, y, mean, rstd
+
+
+def ln_pe_add_bwd(dy, x, gamma, mean, rstd, ds, pe, da_dtype, dgamma, dbeta, dalpha, p, rng, site, dcolsum=None):
+    """backward of pe_add_ln_fwd: da = gradient of `a` (da_dtype); dgamma / dbeta / dalpha / dcolsum are added to; ds (fp32, may be None):
+    the gradient that reaches x through the residual stream"""
+    B, t, d = x.shape
+    da = torch.empty((B, t, d), dtype=da_dtype, device=x.device)
+    _check(lib().fs2_ln_pe_add_bwd(_p(_c(dy)), _dt(dy), _p(_c(x)), _p(gamma), _p(mean), _p(rstd), _p(None if ds is None else _c(ds)), _p(pe), _p(da),
+                                   _dt(da), _p(dgamma), _p(dbeta), _p(dalpha), _p(dcolsum), B, t, d, p, _rng_ptr(rng, p), site, _stream()),
+           "fs2_ln_pe_add_bwd")
+    return da
+
+
 def layernorm_fwd(x, gamma, beta, out_dtype, eps=1e-5, p=0.0, rng=None, site=0):
     d = x.shape[-1]
     M = x.numel() // d
