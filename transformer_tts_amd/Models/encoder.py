@@ -1,7 +1,7 @@
 """``Encoder`` -- the FFT stack used as FastSpeech2's encoder and decoder (reference: Models/encoder.py:31-112)."""
 import torch.nn as nn
 
-from .functional import EncoderStackFunction, Runtime
+from .functional import EncoderStackFunction, Runtime, module_params
 from .layers import EncoderLayer
 from .modules import PositionalEncoder
 
@@ -32,5 +32,5 @@ class Encoder(nn.Module):
         """src: (B,t) int64 ids (embedding=True) or (B,t,vocab) activations; mask: (B,1,t) bool key mask.
         Returns (LayerNorm(x_N) in the compute dtype, attention maps (B,N,H,t,t) -- post-dropout as in the
         reference, Models/modules.py:19-21)."""
-        out, attn = EncoderStackFunction.apply(self, src, mask, *self.parameters())
+        out, attn = EncoderStackFunction.apply(self, src, mask, *module_params(self))
         return out, (attn if self.rt.return_attn else None)

@@ -284,6 +284,12 @@ def announce_list(owner, key, build):
     return lst
 
 
+def module_params(owner):
+    """owner.parameters() as a list built once (the parameter OBJECTS of a module stay for its lifetime: optim.ParamArena and
+    load_state_dict write through .data): the generator walks every submodule at every call, ~0.3 ms of host time per eager step"""
+    return announce_list(owner, "__params__", owner.parameters)
+
+
 def fp8_bwd(fn):
     """marks a hand-written backward for the fp8 operand mode: row-major products launched inside it quantise their A operand
     (a gradient) to e5m2 instead of e4m3 (ops.FP8_MODE)"""
@@ -581,8 +587,7 @@ class EncoderStackFunction(torch.autograd.Function):
         else:
             _linear_wgrad(rt, da0.view(M, d), src.reshape(M, -1), enc.embed, bias_done=True)
             dsrc = ops.linear(da0.view(M, d), rt.w_dgrad(enc.embed.weight)).view(src.shape)
-        first = [enc.pe.alpha] + list(enc.embed.parameters()) + list(n1.parameters())
-        rt.announce(first)
+        rt.announce(announce_list(enc, "first", lambda: [enc.pe.alpha] + list(enc.embed.parameters()) + list(n1.parameters())))
         rt.side_join()
         return (None, dsrc, None) + (None,) * (len(ctx.needs_input_grad) - 3)
 

@@ -3,7 +3,7 @@ import copy
 
 import torch.nn as nn
 
-from .functional import PostNetFunction, Runtime, next_site
+from .functional import PostNetFunction, Runtime, module_params, next_site
 
 
 class PostConvNet(nn.Module):
@@ -33,4 +33,4 @@ class PostConvNet(nn.Module):
             from .functional_ar import postnet_update_statistics
             postnet_update_statistics(self, input_)
             return input_
-        return PostNetFunction.apply(self, input_, *self.parameters())
+        return PostNetFunction.apply(self, input_, *module_params(self))

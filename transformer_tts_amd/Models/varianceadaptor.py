@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .functional import (BucketEmbedAddFunction, LengthRegulatorFunction, Runtime, VariancePredictorFunction,
+from .functional import (BucketEmbedAddFunction, LengthRegulatorFunction, Runtime, VariancePredictorFunction, module_params,
                          next_site)
 
 
@@ -30,7 +30,7 @@ class VariancePredictor(nn.Module):
     def forward(self, encoder_output, mask, chain=False):
         """chain=True: returns (prediction, alias of encoder_output) -- the caller hands the alias to the next reader of the sequence
         (VariancePredictorFunction: the gradient fan-in then happens inside this predictor's last data-gradient product)."""
-        return VariancePredictorFunction.apply(self, encoder_output, mask, bool(chain), *self.parameters())
+        return VariancePredictorFunction.apply(self, encoder_output, mask, bool(chain), *module_params(self))
 
 
 class LengthRegulator(nn.Module):
