@@ -225,6 +225,8 @@ def run_training(hp):
         step = train_loop(model, optimizer, step, epoch, hp, dataloader, max(1, int(getattr(hp, "log_every", 1))), stepper)
         print("EPOCH {} end".format(epoch + 1))
         print(f"elapsed time {time.time() - start_time}")
+    from .train_fastspeech2 import unsettle_gc
+    unsettle_gc()           # (train_loop froze the run's long-lived objects out of the garbage collector's generations)
     return step
 
 

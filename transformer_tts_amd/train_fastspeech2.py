@@ -171,6 +171,13 @@ def settle_gc(force=False):
     gc.freeze()
 
 
+def unsettle_gc():
+    """undo settle_gc at the end of a run"""
+    if _GC_SETTLED[0]:
+        _GC_SETTLED[0] = False
+        gc.unfreeze()
+
+
 def _dist_alive():
     return dist.is_available() and dist.is_initialized()
 
@@ -480,7 +487,10 @@ def run_training(rank, args, hp, port=None):
     else:
         start_epoch, step = 0, 1
     print("params = {0:.2f}M".format(sum(p.numel() for p in model.parameters()) / 1000 / 1000))
-    train_epoch(model, optimizer, step, start_epoch, args, hp, rank)
+    try:
+        train_epoch(model, optimizer, step, start_epoch, args, hp, rank)
+    finally:
+        unsettle_gc()       # (a process that goes on after the run -- tests, notebooks -- gets the ordinary collector back)
 
 
 def main(argv=None):
