@@ -21,7 +21,7 @@ import time
 import torch
 from torch.utils.data import DataLoader
 
-from .Models.functional import l1_loss
+from .Models.functional import l1_loss, l1_loss_multi  # noqa: F401  (l1_loss: part of the module surface the tests import)
 from .Models.functional_ar import bce_with_logits
 from .Models.transformer import Transformer
 from .optim import FusedAdam
@@ -32,9 +32,19 @@ from .datasets import datasets_transformer as datasets
 DEVICE = torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
+_NOPEAK = {}
+
+
 def nopeak_mask(size, device=None):
-    """reference train.py:26-36: (1, size, size) boolean lower-triangular (diagonal included) mask."""
-    return torch.tril(torch.ones((1, size, size), dtype=torch.bool, device=device or DEVICE))
+    """reference train.py:26-36: (1, size, size) boolean lower-triangular (diagonal included) mask; built once per (size, device)
+    (callers only read it: create_masks combines it with the padding mask into a new tensor)."""
+    key = (int(size), str(device or DEVICE))
+    m = _NOPEAK.get(key)
+    if m is None:
+        if len(_NOPEAK) >= 64:
+            _NOPEAK.clear()
+        m = _NOPEAK[key] = torch.tril(torch.ones((1, size, size), dtype=torch.bool, device=device or DEVICE))
+    return m
 
 
 def create_masks(src_pos, trg_pos, src_pad=0, trg_pad=0):
@@ -69,10 +79,12 @@ def compute_losses(hp, outputs, mel, stop_token):
         raise ValueError(f"decoder output {tuple(outputs_prenet.shape)} does not cover the target frames {tuple(target.shape)}: the "
                          f"padded mel length ({mel.shape[1]}) must be a multiple of hp.reduction_rate ({r}) -- batches must come from "
                          "datasets_transformer.collate_fn (go frame + round-up), not from the FastSpeech2 reader")
-    parts = {"mel": l1_loss(outputs_prenet, target), "post_mel": l1_loss(outputs_postnet, target),
+    # the two L1 terms and their sum from one loss launch (+ its finishing block) each way; the stop-token term is added as the
+    # reference adds it: (mel + post_mel) + token
+    (l_mel, l_post), l_both = l1_loss_multi([(outputs_prenet, target, False), (outputs_postnet, target, False)])
+    parts = {"mel": l_mel, "post_mel": l_post,
              "token": bce_with_logits(outputs_stop_token, stop_token[:, r:].contiguous(), float(hp.positive_weight))}
-    loss = parts["mel"] + parts["post_mel"]
-    loss = loss + parts["token"]
+    loss = l_both + parts["token"]
     return loss, parts
 
 
