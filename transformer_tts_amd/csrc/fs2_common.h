@@ -65,11 +65,23 @@ template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 template <typename T> __device__ __forceinline__ void store4(T* p, float4 v);
-template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// (FS2_NT_STORES: measurement build -- the row kernels' output stores carry the nontemporal hint, profiles/r04_h_nt_stores.txt)
+template <> __device__ __forceinline__ void store4<float>(float* p, float4 v) {
+#ifdef FS2_NT_STORES
+    typedef float __attribute__((ext_vector_type(4))) f32x4nt;
+    __builtin_nontemporal_store(f32x4nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4nt*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float4 v) {
     bf16x4 o;
     o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+#ifdef FS2_NT_STORES
+    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p));
+#else
     *reinterpret_cast<bf16x4*>(p) = o;
+#endif
 }
 
 // ---------------------------------------------------------------- workgroup barrier for LDS hand-offs
