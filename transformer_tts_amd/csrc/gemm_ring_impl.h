@@ -199,7 +199,12 @@ __global__ __launch_bounds__(1024, 4) void fs2_gemm_ring_kernel(const FS2Gemm p,
                 }
                 // (voffset must be an int expression: an unsigned one makes the host-side instantiation of the kernel template fail
                 //  silently -- no stub, undefined symbol when the library is loaded)
+                // (FS2_RING_NT_A: measurement build -- the activation rows, which one workgroup reads once, carry the nontemporal hint)
+#ifdef FS2_RING_NT_A
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)v, sA, 0, 2);
+#else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(base + 1024 * NW * i), 16, (int)v, sA, 0, 0);
+#endif
             }
         }
 #pragma unroll
