@@ -162,7 +162,7 @@ def settle_gc(force=False):
     lists, the first captured graphs): collect what the set-up left behind and FREEZE the survivors (gc.freeze: they move to a permanent
     generation the collector never walks again).  Without it every full collection of the cyclic garbage a training step produces (the
     autograd contexts of the hand-written Functions: ~10 young collections per 64 steps) also traverses all of those: 58 ms measured
-    (`gpurun_ab.py`, round 4), during which the launch thread enqueues nothing -- one such pause inside a 100-step window reads as
+    (`profiles/r04_f_gc_settle.txt`, round 4), during which the launch thread enqueues nothing -- one such pause inside a 100-step window reads as
     +0.3-0.6 ms per step, and the eager launch path (6 ms of host time per 7.2 ms step) falls behind the GPU for the steps after it."""
     if _GC_SETTLED[0] and not force:
         return
