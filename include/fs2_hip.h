@@ -379,10 +379,10 @@ int64_t fs2_flash_attn_keep_words(int B, int H, int t);
  * (one scan per stack instead of one per workgroup), or NULL: every workgroup scans its mask row itself, rows in batch order. */
 int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, int32_t* info, void* stream);
 /* The reference's create_masks for the FastSpeech2 task (train_fastspeech2.py:55-82: mask = pos != pad on the (B, t) int64 positions the
- * collate function made) and the row bounds / ranking above in ONE launch: mask[b][j] = pos[b][j] != pad (bytes 0 / 1), info as
+ * collate function made; row stride ld >= t elements) and the row bounds / ranking above in ONE launch: mask[b][j] = pos[b][j] != pad (bytes 0 / 1), info as
  * fs2_flash_attn_mask_info writes it.  B <= 1024.  ticket: one 32-bit word, zero-filled ONCE by the caller (the launch leaves it zero
  * again), used by one stream at a time. */
-int fs2_pad_mask_info(const int64_t* pos, int64_t pad, int B, int t, uint8_t* mask, int32_t* info, uint32_t* ticket, void* stream);
+int fs2_pad_mask_info(const int64_t* pos, int64_t ld, int64_t pad, int B, int t, uint8_t* mask, int32_t* info, uint32_t* ticket, void* stream);
 int fs2_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t row_stride, int64_t batch_stride, int head_stride,
                        const uint8_t* key_mask, const int32_t* key_info, void* o_out, int64_t o_row_stride, int64_t o_batch_stride,
                        float* stats, uint16_t* keep_bits, int pregenerated, int64_t p_batch_stride, int B, int H, int t, int tp, float alpha,

@@ -523,6 +523,10 @@ def test_pad_mask_info_is_create_masks_plus_mask_info(ops, B, t, pad):
     s, m = create_masks(pos.cuda(), pos.cuda(), task="fastspeech2", src_pad=pad, trg_pad=pad)
     assert s.shape == (B, 1, t) and torch.equal(s.cpu(), want.unsqueeze(-2)) and torch.equal(m.cpu(), want.unsqueeze(-2))
     assert torch.equal(s._fs2_kinfo.cpu(), ref)
+    if t > 1:       # a row-strided view (the autoregressive trainer's pos_mel[:, :-1]) is read in place
+        sub = pos.cuda()[:, :-1]
+        mask2, info2 = ops.pad_mask_info(sub, pad)
+        assert torch.equal(mask2.cpu(), want[:, :-1]) and torch.equal(info2.cpu(), ops.flash_mask_info(want[:, :-1].contiguous().cuda()).cpu())
 
 
 def _oracle_attention(qkv, dO, km, t, p, seed, site, NL=2, layer=1):

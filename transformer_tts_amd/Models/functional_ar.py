@@ -40,6 +40,7 @@ class DecoderStackFunction(torch.autograd.Function):
         M, Me = B * t, B * L
         tp, Lp = _tp(t), _tp(L)
         scale = 1.0 / math.sqrt(dk)
+        src_km_in, trg_km_in = src_km, trg_km
         src_km = src_km.reshape(B, L).contiguous()
         trg_km = trg_km.reshape(B, t).contiguous()
         e2 = e.reshape(Me, d)
@@ -72,7 +73,12 @@ class DecoderStackFunction(torch.autograd.Function):
             stats2 = torch.empty((N, B, H, t, 2), dtype=torch.float32, device=dev)
             keep1 = torch.empty((N, ops.flash_attn_keep_words_rect(B, H, t, t)), dtype=torch.int16, device=dev) if p_att > 0 else None
             keep2 = torch.empty((N, ops.flash_attn_keep_words_rect(B, H, t, L)), dtype=torch.int16, device=dev) if p_att > 0 else None
-            kinfo_trg, kinfo_src = ops.flash_mask_info(trg_km), ops.flash_mask_info(src_km)
+            # (train.create_masks leaves the row bounds / ranking of both key masks with them: no scan launches here then)
+            kinfo_trg, kinfo_src = getattr(trg_km_in, "_fs2_kinfo", None), getattr(src_km_in, "_fs2_kinfo", None)
+            if kinfo_trg is None or kinfo_trg.shape != (B, 3) or kinfo_trg.device != dev:
+                kinfo_trg = ops.flash_mask_info(trg_km)
+            if kinfo_src is None or kinfo_src.shape != (B, 3) or kinfo_src.device != dev:
+                kinfo_src = ops.flash_mask_info(src_km)
         else:
             attn1 = torch.empty((B, N, H, t, tp), dtype=T, device=dev)
             attn1_drop = torch.empty_like(attn1) if p_att > 0 else attn1

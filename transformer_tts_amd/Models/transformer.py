@@ -54,6 +54,8 @@ class Transformer(nn.Module):
         # the kernels apply the no-peak part themselves: only the key padding of the frames is passed on.  The last query row
         # of pad & no-peak is the padding mask itself.
         trg_key_mask = trg_mask[:, -1, :] if trg_mask.dim() == 3 else trg_mask
+        if getattr(trg_mask, "_fs2_kinfo", None) is not None:       # (train.create_masks: row bounds / ranking of the frame padding mask)
+            trg_key_mask._fs2_kinfo = trg_mask._fs2_kinfo
         if getattr(self.rt, "check_masks", False):
             T = trg_mask.shape[-1]
             tri = torch.tril(torch.ones(T, T, dtype=torch.bool, device=trg_mask.device))

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void flash_order_k(int B, int32_t* __restrict_
 // the collate function) and the two kernels above in ONE launch: block b compares and scans row b (all of a row's loads in flight at
 // once), the block that takes the last ticket (a persistent word, zero before and after every launch) ranks the rows.
 constexpr int INFO_MAXB = 1024;
-__global__ __launch_bounds__(256) void pad_mask_info_k(const int64_t* __restrict__ pos, const int64_t pad, uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(256) void pad_mask_info_k(const int64_t* __restrict__ pos, const int64_t ld, const int64_t pad, uint8_t* __restrict__ mask,
                                                        const int B, const int t, int32_t* __restrict__ info, unsigned* __restrict__ ticket) {
     __shared__ int red[2];
     __shared__ int kx[INFO_MAXB];
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void pad_mask_info_k(const int64_t* __restrict
     __syncthreads();
     int first = t, lastk = 0;
     for (int j = threadIdx.x; j < t; j += 256) {
-        const bool on = pos[(int64_t)b * t + j] != pad;
+        const bool on = pos[(int64_t)b * ld + j] != pad;
         mask[(int64_t)b * t + j] = on ? 1 : 0;
         if (on) lastk = max(lastk, j + 1);
         else first = min(first, j);
@@ -1160,10 +1160,10 @@ extern "C" int fs2_flash_attn_mask_info(const uint8_t* key_mask, int B, int t, i
     return FS2_OK;
 }
 
-extern "C" int fs2_pad_mask_info(const int64_t* pos, int64_t pad, int B, int t, uint8_t* mask, int32_t* info, uint32_t* ticket, void* stream) {
-    FS2_REQUIRE(pos && mask && info && ticket && B > 0 && B <= INFO_MAXB && t > 0 && t <= MASK_MAX,
+extern "C" int fs2_pad_mask_info(const int64_t* pos, int64_t ld, int64_t pad, int B, int t, uint8_t* mask, int32_t* info, uint32_t* ticket, void* stream) {
+    FS2_REQUIRE(pos && mask && info && ticket && B > 0 && B <= INFO_MAXB && t > 0 && t <= MASK_MAX && ld >= t,
                 "fs2_pad_mask_info: need pos, mask, info, ticket, 0 < B <= %d and 0 < t <= %d (B=%d t=%d)", INFO_MAXB, MASK_MAX, B, t);
-    hipLaunchKernelGGL(pad_mask_info_k, dim3(B), dim3(256), 0, (hipStream_t)stream, pos, pad, mask, B, t, info, ticket);
+    hipLaunchKernelGGL(pad_mask_info_k, dim3(B), dim3(256), 0, (hipStream_t)stream, pos, ld, pad, mask, B, t, info, ticket);
     FS2_CHECK_LAUNCH("fs2_pad_mask_info");
     return FS2_OK;
 }

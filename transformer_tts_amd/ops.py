@@ -114,7 +114,7 @@ SIGNATURES = {
     "fs2_flash_attention_bwd": [ctypes.POINTER(FS2FlashAttn), _P],
     "fs2_flash_attention_probs": [ctypes.POINTER(FS2FlashAttn), _P, _L, _P],
     "fs2_flash_attn_mask_info": [_P, _I, _I, _P, _P],
-    "fs2_pad_mask_info": [_P, _L, _I, _I, _P, _P, _P, _P],
+    "fs2_pad_mask_info": [_P, _L, _L, _I, _I, _P, _P, _P, _P],
     "fs2_flash_attn_fwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _P, _I, _L, _I, _I, _I, _I, _F, _F, _P, _U32, _P],
     "fs2_flash_attn_keep_bits": [_P, _L, _I, _I, _I, _I, _F, _P, _U32, _P],
     "fs2_flash_attn_bwd": [_P, _P, _P, _L, _L, _I, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _I, _F,
@@ -1285,14 +1285,15 @@ def pad_mask_info(pos, pad=0):
     """create_masks of the FastSpeech2 task (reference train_fastspeech2.py:55-82) and flash_mask_info in ONE launch:
     pos (B, t) int64 -> (mask (B, t) bool = pos != pad, info (B, 3) int32 as flash_mask_info returns it)"""
     assert pos.dtype == torch.int64 and pos.dim() == 2
-    pos = _c(pos)
     B, t = pos.shape
+    if pos.stride(1) != 1 or (B > 1 and pos.stride(0) < t):
+        pos = pos.contiguous()      # (rows of a row-strided view -- pos_mel[:, :-1] of the autoregressive trainer -- are read in place)
     mask = torch.empty((B, t), dtype=torch.bool, device=pos.device)
     info = torch.empty((B, 3), dtype=torch.int32, device=pos.device)
     tk = _PAD_TICKET.get(pos.device)
     if tk is None:      # the ticket word of the launch's last-block-ranks-the-rows step: zero once, the kernel leaves it zero
         tk = _PAD_TICKET[pos.device] = torch.zeros(4, dtype=torch.int32, device=pos.device)
-    _check(lib().fs2_pad_mask_info(_p(pos), int(pad), B, t, _p(mask), _p(info), _p(tk), _stream()), "fs2_pad_mask_info")
+    _check(lib().fs2_pad_mask_info(_p(pos), int(pos.stride(0)) if B > 1 else t, int(pad), B, t, _p(mask), _p(info), _p(tk), _stream()), "fs2_pad_mask_info")
     return mask, info
 
 

@@ -49,10 +49,13 @@ def nopeak_mask(size, device=None):
 
 def create_masks(src_pos, trg_pos, src_pad=0, trg_pad=0):
     """reference train.py:38-58."""
-    src_mask = (src_pos != src_pad).unsqueeze(-2)
+    from .train_fastspeech2 import _pad_mask      # (pos != pad).unsqueeze(-2); on the GPU one launch that also leaves the attention
+    src_mask = _pad_mask(src_pos, src_pad)         #  kernels' row bounds / ranking with the mask (`_fs2_kinfo`)
     if trg_pos is not None:
-        trg_mask = (trg_pos != trg_pad).unsqueeze(-2)
-        trg_mask = trg_mask & nopeak_mask(trg_pos.size(1), trg_pos.device)
+        pad_mask = _pad_mask(trg_pos, trg_pad)
+        trg_mask = pad_mask & nopeak_mask(trg_pos.size(1), trg_pos.device)
+        if getattr(pad_mask, "_fs2_kinfo", None) is not None:
+            trg_mask._fs2_kinfo = pad_mask._fs2_kinfo       # (of the frame padding; the kernels apply the no-peak part themselves)
     else:
         trg_mask = None
     return src_mask, trg_mask
