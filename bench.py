@@ -497,8 +497,12 @@ def shapes_leg(args, model, opt, hp, dev, BATCH):
         before = dict(graphed.stats)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in order:
+        for n_done, i in enumerate(order):
             graphed(step, batches[i]); step += 1
+            if os.environ.get("FS2_SHAPES_MEM") and n_done % 20 == 19:
+                st = torch.cuda.memory_stats()
+                print(f"epoch {ep + 1} step {n_done + 1}: allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB, reserved "
+                      f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB, graphs {len(graphed.graphs)}", file=sys.stderr, flush=True)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         epochs.append({"epoch": ep + 1, "ms_per_step": round(dt * 1e3 / len(order), 3),

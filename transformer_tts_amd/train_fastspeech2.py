@@ -191,15 +191,16 @@ class GraphedTrainStep:
     First occurrence of a shape runs eagerly (allocator warm-up), the second is captured, later ones replay.
     Padding is semantically live in this model (BatchNorm statistics and the L1 losses include padded
     positions), so batches are never padded to a common shape -- one graph per (B, L_pad, T_pad).
-    At most `max_graphs` graphs are kept (a corpus batched by a frame budget, reference datasets_fastspeech2.py:749-813, produces
-    hundreds of shapes; the graphs share one memory pool, so an evicted graph's activations are reused by the next capture).  When the
+    At most `max_graphs` graphs are kept (256: a corpus batched by a frame budget, reference datasets_fastspeech2.py:749-813, produces
+    hundreds of shapes; the graphs share one memory pool -- a capture reuses what the captures before it freed -- and a capture costs
+    7-16 ms once the garbage collector is settled, so a shape is worth capturing when it comes round a second time).  When the
     cache is full, policy "frequency" (default) captures a shape only if it has been seen clearly more often (by max(2, 25 %)) than the
     least recently replayed cached shape (which it then evicts); otherwise the step is launched eagerly -- the eager launch path runs at the replay speed
     ("Dynamic shapes"), while a capture costs tens of milliseconds, so a shape set larger than the cache must not
     be re-captured in a cycle.  Policy "lru" (the round-4a behaviour, FS2_GRAPH_POLICY=lru): always capture, evict the least recently
     replayed."""
 
-    def __init__(self, model, optimizer, hp, max_graphs=64, eager_fallback=False, body=None, inputs=None, eager=None, set_lr=None,
+    def __init__(self, model, optimizer, hp, max_graphs=256, eager_fallback=False, body=None, inputs=None, eager=None, set_lr=None,
                  policy=None):
         """body / inputs / eager / set_lr: the device part of a step, the batch entries it reads, the eager step and the learning-rate rule
         of ANOTHER trainer of this package (transformer_tts_amd.train: the autoregressive model); default: this module's"""
@@ -280,6 +281,12 @@ class GraphedTrainStep:
                 return self.eager(self.model, self.optimizer, step, d, self.hp)
             if gc_on:
                 gc.enable()
+            # Keep the VALUES the replays rewrite, not the autograd graph behind them: the hand-written Functions hold their activations
+            # as plain attributes of their contexts, so a `loss` that still carries its grad_fn pins every activation of the captured
+            # step in the graph pool -- 2 GiB per configs[1] graph, 128 GiB for 64 graphs (measured, round 4).  Detached, the capture's
+            # intermediates go back to the shared pool and the next capture reuses them (graphs replay one after the other).
+            loss = loss.detach()
+            parts = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in parts.items()}
             entry = self.graphs[key] = (g, static, loss, parts)
             self.last_used[key] = self.tick
             self.stats["captured"] += 1
