@@ -332,3 +332,37 @@ def test_eager_steps_do_not_accumulate_device_memory():
             seen.append(torch.cuda.memory_allocated())
     assert len(set(seen)) == 1, seen
     assert len(model.rt._keep) == 0
+
+
+def test_captured_graphs_do_not_pin_the_activations_of_their_step():
+    """a graph entry keeps the values a replay rewrites (loss, parts), not the autograd graph of the captured step: the device memory
+    a further captured shape costs is a fraction of one step's activation footprint (it used to be the whole footprint -- 2 GiB per
+    configs[1] graph, out of memory at ~140 graphs: profiles/r04_h_graph_memory.txt)"""
+    from transformer_tts_amd.Models import functional
+    from transformer_tts_amd.optim import FusedAdam
+    from transformer_tts_amd.train_fastspeech2 import GraphedTrainStep, train_step
+    full = batch_to(CONFIGS["small"]["batch"](), "cuda")
+    assert full[0].shape[0] >= 4
+    shapes = [tuple(x[:k] if torch.is_tensor(x) else x for x in full) for k in (4, 3, 2)]
+    functional._site_counter[0] = 9700
+    model, hp, _ = product_model("small", amp=True, dropout=0.1, device="cuda")
+    opt = FusedAdam(model)
+    train_step(model, opt, 4000, shapes[0], hp)                 # caches, workspaces
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    train_step(model, opt, 4001, shapes[0], hp)
+    torch.cuda.synchronize()
+    footprint = torch.cuda.max_memory_allocated() - base        # what one step of the LARGEST of the shapes needs at its peak
+    assert footprint > 0
+    stepper = GraphedTrainStep(model, opt, hp)
+    after = []
+    for i, b in enumerate(shapes):
+        stepper(4002 + 2 * i, b)                                # first sight: eager
+        loss, parts, _ = stepper(4003 + 2 * i, b)               # second sight: captured + replayed
+        torch.cuda.synchronize()
+        assert loss.grad_fn is None and all(v.grad_fn is None for v in parts.values())
+        after.append(torch.cuda.memory_allocated())
+    assert stepper.stats["captured"] == 3
+    per_graph = (after[-1] - after[0]) / 2
+    assert per_graph < 0.25 * footprint, (per_graph, footprint, after)
