@@ -165,6 +165,9 @@ int fs2_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
 /* dst (dst_dtype) = a + b, both fp32, n elements: the two gradient terms that reach the post-net's mel_pred (reference
  * Models/postnets.py:67,74-75: mel_pred feeds the loss directly and the convolution stack) as one operand. */
 int fs2_add_cast(const float* a, const float* b, void* dst, int dst_dtype, int64_t n, void* stream);
+/* n <= 8 device-to-device copies of nbytes[i] bytes each in ONE launch (host arrays of device pointers): the input tensors of a step
+ * into the static buffers of its captured hipGraph (train_fastspeech2.GraphedTrainStep), one launch instead of one per tensor. */
+int fs2_copy_batched(const void* const* src, void* const* dst, const int64_t* nbytes, int n, void* stream);
 /* All weight shadows of a model in ONE launch: `table` is a DEVICE array of n descriptors. */
 typedef struct FS2CastDesc {
     const float* src;

@@ -1019,6 +1019,18 @@ def test_colsum_narrow_and_wide(ops, dtype, M, N, ld):
     close(a, b, f"colsum {M}x{N}", rtol=1e-4, atol=2e-4 * M ** 0.5)
 
 
+def test_copy_batched(ops):
+    """several device-to-device copies in one launch: mixed dtypes and sizes, unaligned views, empty tensors, more than 8 pairs"""
+    g = np.random.default_rng(0)
+    srcs = [torch.from_numpy(g.integers(0, 100, size=n)).cuda() for n in (1, 7, 4096, 48 * 925)] + \
+           [rnd(48 * 925 * 80, seed=1).cuda(), rnd(33, seed=2).cuda()[1:], torch.zeros(0).cuda(), rnd(5, 7, dtype=torch.bfloat16, seed=3).cuda()] + \
+           [rnd(1000 + i, seed=10 + i).cuda() for i in range(3)]
+    dsts = [torch.empty_like(s_) if s_.is_contiguous() else torch.empty(s_.shape, dtype=s_.dtype, device="cuda") for s_ in srcs]
+    ops.copy_batched(dsts, [s_.contiguous() if not s_.is_contiguous() else s_ for s_ in srcs])
+    for d_, s_ in zip(dsts, srcs):
+        assert torch.equal(d_, s_)
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 1027, 44400 * 80])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_add_cast(ops, n, dtype):

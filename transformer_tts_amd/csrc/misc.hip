@@ -1112,6 +1112,38 @@ extern "C" int fs2_zero(void* ptr, int64_t nbytes, void* stream) {
     FS2_CHECK_LAUNCH("fs2_zero");
     return FS2_OK;
 }
+// up to 8 device-to-device copies in one launch (the seven input tensors of a step into the static buffers of its captured graph:
+// seven copy launches of the runtime otherwise); blockIdx.y = copy, 16-byte chunks + byte tail
+struct CopyItems { const unsigned char* src[8]; unsigned char* dst[8]; int64_t n[8]; };
+__global__ __launch_bounds__(256) void copy_batched_k(const CopyItems it) {
+    const unsigned char* src = it.src[blockIdx.y];
+    unsigned char* dst = it.dst[blockIdx.y];
+    const int64_t n = it.n[blockIdx.y];
+    int64_t done = 0;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const int64_t n16 = n >> 4;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+            reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+        done = n16 << 4;
+    }
+    for (int64_t i = done + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int fs2_copy_batched(const void* const* src, void* const* dst, const int64_t* nbytes, int n, void* stream) {
+    FS2_REQUIRE(src && dst && nbytes && n > 0 && n <= 8, "fs2_copy_batched: 1..8 copies");
+    CopyItems it = {};
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        FS2_REQUIRE(nbytes[i] >= 0 && (nbytes[i] == 0 || (src[i] && dst[i])), "fs2_copy_batched: bad copy %d", i);
+        it.src[i] = static_cast<const unsigned char*>(src[i]); it.dst[i] = static_cast<unsigned char*>(dst[i]); it.n[i] = nbytes[i];
+        most = nbytes[i] > most ? nbytes[i] : most;
+    }
+    if (most == 0) return FS2_OK;
+    int64_t blocks = (most / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    hipLaunchKernelGGL(copy_batched_k, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, it);
+    FS2_CHECK_LAUNCH("fs2_copy_batched");
+    return FS2_OK;
+}
 extern "C" int fs2_rng_advance(uint64_t* rng, void* stream) {
     hipLaunchKernelGGL(rng_advance_k, dim3(1), dim3(1), 0, (hipStream_t)stream, rng);
     FS2_CHECK_LAUNCH("fs2_rng_advance");

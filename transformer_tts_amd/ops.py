@@ -80,6 +80,7 @@ SIGNATURES = {
     "fs2_permute_add": [_P, _P, _I, _I, _I, _I, _P],
     "fs2_cast": [_P, _I, _P, _I, _L, _P],
     "fs2_add_cast": [_P, _P, _P, _I, _L, _P],
+    "fs2_copy_batched": [_P, _P, _P, _I, _P],
     "fs2_cast_permute_batched": [_P, _I, _I, _P],
     "fs2_onehot": [_P, _P, _I, _L, _I, _P],
     "fs2_colsum_segmented": [_P, _I, _L, _I, _L, _P, _I, _L, _P],
@@ -891,6 +892,20 @@ def add_cast(a, b, dtype):
     out = torch.empty(a.shape, dtype=dtype, device=a.device)
     _check(lib().fs2_add_cast(_p(_c(a)), _p(_c(b)), _p(out), _dt(out), a.numel(), _stream()), "fs2_add_cast")
     return out
+
+
+def copy_batched(dsts, srcs):
+    """dsts[i].copy_(srcs[i]) for up to 8 pairs of contiguous device tensors of equal dtype and size per launch"""
+    for k in range(0, len(dsts), 8):
+        d, s = dsts[k:k + 8], srcs[k:k + 8]
+        n = len(d)
+        for a, b in zip(d, s):
+            assert a.dtype == b.dtype and a.numel() == b.numel() and a.is_contiguous() and b.is_contiguous() and a.device == b.device
+        sp = (ctypes.c_void_p * n)(*[_p(t) for t in s])
+        dp = (ctypes.c_void_p * n)(*[_p(t) for t in d])
+        nb = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in d])
+        _check(lib().fs2_copy_batched(ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p), ctypes.cast(nb, ctypes.c_void_p), n,
+                                      _stream()), "fs2_copy_batched")
 
 
 def zero(t):

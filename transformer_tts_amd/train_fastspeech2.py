@@ -294,8 +294,12 @@ class GraphedTrainStep:
         self.stats["replayed"] += 1
         self.optimizer.host_update()
         g, static, loss, parts = entry
-        for dst, src in zip(static, tensors):
-            dst.copy_(src, non_blocking=True)
+        if all(src.is_cuda and src.is_contiguous() and src.dtype == dst.dtype and src.device == dst.device for dst, src in zip(static, tensors)):
+            from . import ops
+            ops.copy_batched(static, tensors)           # the step's inputs into the graph's static buffers: one launch, not one per tensor
+        else:
+            for dst, src in zip(static, tensors):
+                dst.copy_(src, non_blocking=True)
         g.replay()
         # the replayed Adam step rewrote the parameters through raw pointers: a forward outside the graph (evaluation or
         # synthesis between training steps) must not reuse weight shadows derived before it
